@@ -1,0 +1,749 @@
+/*
+ * kpx_oracle.c -- CPU restatement (fp64, deterministic) of the KinectPy hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is imported, linked or executed by the
+ * product (kinectpy_amd/, include/, bench.py's timed GPU leg).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's `cpu_baseline` leg may call it, and only as the checker / the reported baseline.
+ *
+ * PARITY STATUS: **parity unpinned** for everything whose arithmetic lives inside Open3D
+ * (voxel_down_sample, remove_statistical_outlier, segment_plane, registration_icp,
+ * estimate_normals).  Open3D is an un-vendored, un-pinned dependency of the reference
+ * (`import open3d as o3d`, /root/reference/preprocessing/registration.py:4, filtering.py:7,
+ * floor_removal.py:4; API usage bounds it to >= 0.12), it is not installed here and the
+ * reference has no tests or golden vectors.  Those functions restate Open3D's published
+ * algorithms ([O3D], recalled) and are anchored on the reference's call sites.  The pure-NumPy
+ * reference functions (load_depth, rgbd_to_pointcloud masks, equation_plane, pcd_above_plane,
+ * kalman_filter, transform_joints) ARE pinned by the known answers captured from the reference
+ * itself (tests/golden/ref_kat.json).
+ *
+ * Storage contract shared with the GPU product (DESIGN.md "arithmetic contract"): clouds are
+ * float32 (N,3) arrays; every decision scalar is computed in fp64 from the promoted values with
+ * the operation order written here (explicit fma(), compiled with -ffp-contract=off), results
+ * are rounded to float32 only where they are stored as cloud coordinates.
+ *
+ * Each function cites the reference file:line it follows.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define KPO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+/* Philox4x32-10 counter RNG (Salmon et al. 2011).  Used for every random draw so that the     */
+/* CPU and GPU RANSACs consume identical streams (the reference's RANSAC is unseeded:          */
+/* floor_removal.py:70).                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+KPO_API void kpo_philox4x32(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+    uint32_t k0 = key_in[0], k1 = key_in[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a1: depth -> XYZ int16 (the `.dat` contract consumed by utils/io.py:15-20).                 */
+/* The reference has no unprojection arithmetic (extractor.py:68-80 shells out to an external  */
+/* binary); this restates the Azure-Kinect-SDK xy-table formula [K4A, recalled]:               */
+/*   x = (int16) floorf(xt * (float)d + 0.5f), y likewise, z = d; invalid (d==0 or NaN table)  */
+/*   -> (0,0,0).  All arithmetic in float32, no contraction.                                   */
+/* ------------------------------------------------------------------------------------------ */
+KPO_API void kpo_xy_table_pinhole(int H, int W, float fx, float fy, float cx, float cy, float *xy)
+{
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) {
+            xy[2 * ((int64_t)v * W + u) + 0] = ((float)u - cx) / fx;
+            xy[2 * ((int64_t)v * W + u) + 1] = ((float)v - cy) / fy;
+        }
+}
+
+KPO_API void kpo_unproject_u16(const uint16_t *depth, const float *xy, int64_t n, int16_t *xyz)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float xt = xy[2 * i], yt = xy[2 * i + 1];
+        uint16_t d = depth[i];
+        if (d != 0 && !isnan(xt) && !isnan(yt)) {
+            float fd = (float)d;
+            float px = xt * fd; px = px + 0.5f;
+            float py = yt * fd; py = py + 0.5f;
+            xyz[3 * i + 0] = (int16_t)(int32_t)floorf(px);
+            xyz[3 * i + 1] = (int16_t)(int32_t)floorf(py);
+            xyz[3 * i + 2] = (int16_t)d;
+        } else {
+            xyz[3 * i + 0] = 0; xyz[3 * i + 1] = 0; xyz[3 * i + 2] = 0;
+        }
+    }
+}
+
+/* np.median over the z column (preprocessing/data.py:170-171): sorts, mean of the two middle  */
+/* values for even n, as float64.                                                               */
+static int cmp_i16(const void *a, const void *b)
+{
+    int16_t x = *(const int16_t *)a, y = *(const int16_t *)b;
+    return (x > y) - (x < y);
+}
+KPO_API double kpo_median_i16(const int16_t *v, int64_t n, int64_t stride)
+{
+    if (n <= 0) return NAN;
+    int16_t *tmp = (int16_t *)malloc((size_t)n * sizeof(int16_t));
+    for (int64_t i = 0; i < n; ++i) tmp[i] = v[i * stride];
+    qsort(tmp, (size_t)n, sizeof(int16_t), cmp_i16);
+    double m = (n & 1) ? (double)tmp[n / 2] : 0.5 * ((double)tmp[n / 2 - 1] + (double)tmp[n / 2]);
+    free(tmp);
+    return m;
+}
+
+/* a3 + a4: utils/io.py:23-43 (keep = x!=0 & y!=0 & z!=0, colours /255) composed with          */
+/* preprocessing/data.py:165-178 (valid_pixels: all three colour channels != 0; valid_depths:  */
+/* z <= median+750 | z <= median-750  ==  z <= median+750).  Order-preserving compaction.      */
+/* gate_hi is median+750 computed by the caller in float64.                                     */
+KPO_API int64_t kpo_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t n,
+                                 int use_color_mask, int use_gate, double gate_hi,
+                                 float *pts, float *col, int32_t *idx)
+{
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int16_t x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        int keep = (x != 0) && (y != 0) && (z != 0);
+        if (use_color_mask && rgb)
+            keep = keep && rgb[3 * i] != 0 && rgb[3 * i + 1] != 0 && rgb[3 * i + 2] != 0;
+        if (use_gate) keep = keep && ((double)z <= gate_hi);
+        if (!keep) continue;
+        if (pts) { pts[3 * k] = (float)x; pts[3 * k + 1] = (float)y; pts[3 * k + 2] = (float)z; }
+        if (col && rgb)
+            for (int c = 0; c < 3; ++c) col[3 * k + c] = (float)((double)rgb[3 * i + c] / 255.0);
+        if (idx) idx[k] = (int32_t)i;
+        ++k;
+    }
+    return k;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a17 / pcd.transform (preprocessing/data.py:48): p' = R p + t.  Contract AC1:                */
+/*   p'_k = fma(R_k0, x, fma(R_k1, y, fma(R_k2, z, t_k)))  in fp64, stored as float32.         */
+/* T is row-major 4x4.                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+static inline void xform3(const double *T, double x, double y, double z, double *o)
+{
+    for (int k = 0; k < 3; ++k)
+        o[k] = fma(T[4 * k + 0], x, fma(T[4 * k + 1], y, fma(T[4 * k + 2], z, T[4 * k + 3])));
+}
+KPO_API void kpo_transform(const float *pts, int64_t n, const double *T, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double o[3];
+        xform3(T, (double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2], o);
+        out[3 * i] = (float)o[0]; out[3 * i + 1] = (float)o[1]; out[3 * i + 2] = (float)o[2];
+    }
+}
+/* normals rotate only (Open3D PointCloud::Transform) */
+KPO_API void kpo_rotate(const float *nrm, int64_t n, const double *T, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double x = nrm[3 * i], y = nrm[3 * i + 1], z = nrm[3 * i + 2];
+        for (int k = 0; k < 3; ++k)
+            out[3 * i + k] = (float)fma(T[4 * k + 0], x, fma(T[4 * k + 1], y, T[4 * k + 2] * z));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a7: [O3D] PointCloud::VoxelDownSample, call sites preprocessing/filtering.py:23,            */
+/* registration.py:8,100,101.  origin = min_bound - v/2; index = floor((p - origin)/v);        */
+/* output = per-voxel mean.  Documented deviation: output order is ascending (ix,iy,iz)        */
+/* (Open3D's is unordered_map order); accumulation order inside a voxel is ascending original  */
+/* index, fp64, sequential.  Normals are averaged then normalised [O3D GetAverageNormal].      */
+/* Returns number of voxels, or -1 (voxel<=0) / -2 (index overflow: > 2^21 cells on an axis).  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { uint64_t key; int64_t idx; } kv_t;
+static int cmp_kv(const void *a, const void *b)
+{
+    const kv_t *x = (const kv_t *)a, *y = (const kv_t *)b;
+    if (x->key != y->key) return (x->key > y->key) - (x->key < y->key);
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+KPO_API int64_t kpo_voxel_downsample(const float *pts, const float *col, const float *nrm,
+                                     int64_t n, double voxel, float *opts, float *ocol,
+                                     float *onrm, int32_t *ocnt)
+{
+    if (!(voxel > 0.0)) return -1;
+    if (n == 0) return 0;
+    double mn[3] = { pts[0], pts[1], pts[2] };
+    for (int64_t i = 1; i < n; ++i)
+        for (int a = 0; a < 3; ++a) { double v = pts[3 * i + a]; if (v < mn[a]) mn[a] = v; }
+    double org[3];
+    for (int a = 0; a < 3; ++a) org[a] = mn[a] - voxel * 0.5;
+    kv_t *kv = (kv_t *)malloc((size_t)n * sizeof(kv_t));
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t key = 0;
+        for (int a = 0; a < 3; ++a) {
+            double r = ((double)pts[3 * i + a] - org[a]) / voxel;
+            double f = floor(r);
+            if (!(f >= 0.0) || f >= 2097152.0) { free(kv); return -2; }
+            key = (key << 21) | (uint64_t)f;
+        }
+        kv[i].key = key; kv[i].idx = i;
+    }
+    qsort(kv, (size_t)n, sizeof(kv_t), cmp_kv);
+    int64_t m = 0, i = 0;
+    while (i < n) {
+        int64_t j = i;
+        double sp[3] = {0, 0, 0}, sc[3] = {0, 0, 0}, sn[3] = {0, 0, 0};
+        while (j < n && kv[j].key == kv[i].key) {
+            int64_t p = kv[j].idx;
+            for (int a = 0; a < 3; ++a) {
+                sp[a] += (double)pts[3 * p + a];
+                if (col) sc[a] += (double)col[3 * p + a];
+                if (nrm) sn[a] += (double)nrm[3 * p + a];
+            }
+            ++j;
+        }
+        double c = (double)(j - i);
+        for (int a = 0; a < 3; ++a) {
+            opts[3 * m + a] = (float)(sp[a] / c);
+            if (col && ocol) ocol[3 * m + a] = (float)(sc[a] / c);
+        }
+        if (nrm && onrm) {
+            double nn = sqrt(fma(sn[2], sn[2], fma(sn[1], sn[1], sn[0] * sn[0])));
+            for (int a = 0; a < 3; ++a) onrm[3 * m + a] = (float)(nn > 0 ? sn[a] / nn : sn[a]);
+        }
+        if (ocnt) ocnt[m] = (int32_t)(j - i);
+        ++m; i = j;
+    }
+    free(kv);
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Uniform grid used to accelerate the exact neighbour searches (stand-in for Open3D's         */
+/* KD-tree: any exact search returns the same neighbour distances).                             */
+/* Contract AC3 (direct squared distance): d2 = fma(dz,dz, fma(dy,dy, dx*dx)), dx = xi - xj.   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    double org[3], h;
+    int dim[3];
+    int64_t ncell;
+    int64_t *start;     /* ncell+1 */
+    int32_t *order;     /* point ids sorted by cell (stable) */
+} grid_t;
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static void grid_build(grid_t *g, const float *pts, int64_t n, double target_per_cell)
+{
+    double mn[3] = { DBL_MAX, DBL_MAX, DBL_MAX }, mx[3] = { -DBL_MAX, -DBL_MAX, -DBL_MAX };
+    for (int64_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            double v = pts[3 * i + a];
+            if (v < mn[a]) mn[a] = v;
+            if (v > mx[a]) mx[a] = v;
+        }
+    double ext[3], vol = 1.0;
+    for (int a = 0; a < 3; ++a) { ext[a] = mx[a] - mn[a]; if (ext[a] < 1e-9) ext[a] = 1e-9; vol *= ext[a]; }
+    /* surfaces, not volumes: size cells from a 2-D density guess as well and take the larger */
+    double h3 = cbrt(vol * target_per_cell / (double)(n > 0 ? n : 1));
+    double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
+    double h2 = sqrt(area * target_per_cell / (double)(n > 0 ? n : 1)) * 0.5;
+    double h = h3 > h2 ? h3 : h2;
+    if (!(h > 0)) h = 1.0;
+    for (;;) {
+        int64_t tot = 1;
+        for (int a = 0; a < 3; ++a) {
+            double d = floor(ext[a] / h) + 1.0;
+            if (d > 2000000.0) d = 2000000.0;
+            g->dim[a] = (int)d; tot *= g->dim[a];
+        }
+        if (tot <= (int64_t)1 << 24) { g->ncell = tot; break; }
+        h *= 1.26;
+    }
+    g->h = h;
+    for (int a = 0; a < 3; ++a) g->org[a] = mn[a];
+    g->start = (int64_t *)calloc((size_t)g->ncell + 1, sizeof(int64_t));
+    g->order = (int32_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+    int64_t *cid = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) {
+        int c[3];
+        for (int a = 0; a < 3; ++a)
+            c[a] = clampi((int)floor(((double)pts[3 * i + a] - g->org[a]) / h), 0, g->dim[a] - 1);
+        cid[i] = ((int64_t)c[0] * g->dim[1] + c[1]) * g->dim[2] + c[2];
+        g->start[cid[i] + 1]++;
+    }
+    for (int64_t c = 0; c < g->ncell; ++c) g->start[c + 1] += g->start[c];
+    int64_t *fill = (int64_t *)malloc((size_t)g->ncell * sizeof(int64_t));
+    memcpy(fill, g->start, (size_t)g->ncell * sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) g->order[fill[cid[i]]++] = (int32_t)i;
+    free(fill); free(cid);
+}
+static void grid_free(grid_t *g) { free(g->start); free(g->order); }
+
+static inline double dist2_direct(double ax, double ay, double az, double bx, double by, double bz)
+{
+    double dx = ax - bx, dy = ay - by, dz = az - bz;
+    return fma(dz, dz, fma(dy, dy, dx * dx));
+}
+
+/* max-heap of (d2, idx) ordered lexicographically: keeps the k smallest pairs */
+typedef struct { double d; int32_t i; } di_t;
+static inline int di_less(di_t a, di_t b) { return a.d < b.d || (a.d == b.d && a.i < b.i); }
+static void heap_push(di_t *h, int *sz, int k, di_t v)
+{
+    if (*sz < k) {
+        int c = (*sz)++;
+        h[c] = v;
+        while (c > 0) { int p = (c - 1) / 2; if (di_less(h[p], h[c])) { di_t t = h[p]; h[p] = h[c]; h[c] = t; c = p; } else break; }
+    } else if (di_less(v, h[0])) {
+        h[0] = v;
+        int c = 0;
+        for (;;) {
+            int l = 2 * c + 1, r = l + 1, b = c;
+            if (l < k && di_less(h[b], h[l])) b = l;
+            if (r < k && di_less(h[b], h[r])) b = r;
+            if (b == c) break;
+            di_t t = h[b]; h[b] = h[c]; h[c] = t; c = b;
+        }
+    }
+}
+static int cmp_di(const void *a, const void *b)
+{
+    di_t x = *(const di_t *)a, y = *(const di_t *)b;
+    return di_less(x, y) ? -1 : (di_less(y, x) ? 1 : 0);
+}
+
+/* exact k nearest (by (d2, idx)) of query q among the gridded points; result sorted ascending.
+ * If r2max >= 0 only points with d2 < r2max are returned ([O3D] SearchHybrid: knn then
+ * lower_bound(radius^2), i.e. strict <).  Returns the number found. */
+static int grid_knn(const grid_t *g, const float *pts, double qx, double qy, double qz,
+                    int k, double r2max, di_t *heap)
+{
+    int c[3];
+    double q[3] = { qx, qy, qz };
+    for (int a = 0; a < 3; ++a) c[a] = clampi((int)floor((q[a] - g->org[a]) / g->h), 0, g->dim[a] - 1);
+    int sz = 0;
+    int maxr = g->dim[0] > g->dim[1] ? g->dim[0] : g->dim[1];
+    if (g->dim[2] > maxr) maxr = g->dim[2];
+    for (int r = 0; r <= maxr; ++r) {
+        /* after rings 0..r-1 every point with distance < dcov is known, where dcov is the
+         * distance from q to the boundary of the covered cube (clamped queries: use cell box) */
+        if (r > 0) {
+            double dcov = DBL_MAX;
+            for (int a = 0; a < 3; ++a) {
+                double lo = g->org[a] + (double)(c[a] - (r - 1)) * g->h;
+                double hi = g->org[a] + (double)(c[a] + r) * g->h;
+                double dl = q[a] - lo, dh = hi - q[a];
+                if (c[a] - (r - 1) <= 0) dl = DBL_MAX;            /* grid edge: nothing beyond */
+                if (c[a] + r >= g->dim[a]) dh = DBL_MAX;
+                if (dl < dcov) dcov = dl;
+                if (dh < dcov) dcov = dh;
+            }
+            if (dcov == DBL_MAX) break;                           /* whole grid covered */
+            if (dcov < 0) dcov = 0;
+            double cov2 = dcov * dcov * (1.0 - 1e-12);
+            if (sz == k && heap[0].d < cov2) break;
+            if (r2max >= 0 && cov2 >= r2max) break;
+        }
+        int x0 = c[0] - r, x1 = c[0] + r, y0 = c[1] - r, y1 = c[1] + r, z0 = c[2] - r, z1 = c[2] + r;
+        for (int x = x0 < 0 ? 0 : x0; x <= (x1 >= g->dim[0] ? g->dim[0] - 1 : x1); ++x)
+            for (int y = y0 < 0 ? 0 : y0; y <= (y1 >= g->dim[1] ? g->dim[1] - 1 : y1); ++y) {
+                int shell_xy = (x == x0 || x == x1 || y == y0 || y == y1);
+                for (int z = z0 < 0 ? 0 : z0; z <= (z1 >= g->dim[2] ? g->dim[2] - 1 : z1); ++z) {
+                    if (!shell_xy && z != z0 && z != z1) continue;
+                    int64_t cell = ((int64_t)x * g->dim[1] + y) * g->dim[2] + z;
+                    for (int64_t s = g->start[cell]; s < g->start[cell + 1]; ++s) {
+                        int32_t j = g->order[s];
+                        double d = dist2_direct(qx, qy, qz, pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]);
+                        if (r2max >= 0 && !(d < r2max)) continue;
+                        di_t v = { d, j };
+                        heap_push(heap, &sz, k, v);
+                    }
+                }
+            }
+    }
+    qsort(heap, (size_t)sz, sizeof(di_t), cmp_di);
+    return sz;
+}
+
+/* a8: [O3D] PointCloud::RemoveStatisticalOutliers, call sites filtering.py:24 (200, 3.0),
+ * floor_removal.py:73 (50, 0.30), utils/processing.py:309.
+ *   avg_i  = (sum_{ascending} sqrt(d2_j)) / k'   over the k' = min(k, N) nearest incl. itself
+ *   mean   = (sum of avg_i with avg_i > 0) / N ;  std = sqrt(sum_{avg_i>0}(avg_i-mean)^2 / (N-1))
+ *   keep   = avg_i > 0 && avg_i < mean + std_ratio*std ; indices ascending.
+ * stats[0..2] = mean, std, threshold.  Returns kept count, -1 on invalid arguments.
+ * brute != 0 uses the O(N^2) scan (validation of the grid search). */
+KPO_API int64_t kpo_sor(const float *pts, int64_t n, int k, double std_ratio, int brute,
+                        int32_t *keep_idx, double *stats, double *avg_out)
+{
+    if (k < 1 || !(std_ratio > 0.0)) return -1;
+    if (n == 0) return 0;
+    int kk = (int64_t)k < n ? k : (int)n;
+    double *avg = avg_out ? avg_out : (double *)malloc((size_t)n * sizeof(double));
+    grid_t g;
+    if (!brute) grid_build(&g, pts, n, (double)kk * 0.5 + 1.0);
+#pragma omp parallel
+    {
+        di_t *heap = (di_t *)malloc((size_t)kk * sizeof(di_t));
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t i = 0; i < n; ++i) {
+            double qx = pts[3 * i], qy = pts[3 * i + 1], qz = pts[3 * i + 2];
+            int sz = 0;
+            if (brute) {
+                for (int64_t j = 0; j < n; ++j) {
+                    di_t v = { dist2_direct(qx, qy, qz, pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]), (int32_t)j };
+                    heap_push(heap, &sz, kk, v);
+                }
+                qsort(heap, (size_t)sz, sizeof(di_t), cmp_di);
+            } else {
+                sz = grid_knn(&g, pts, qx, qy, qz, kk, -1.0, heap);
+            }
+            double s = 0.0;
+            for (int t = 0; t < sz; ++t) s += sqrt(heap[t].d);
+            avg[i] = sz > 0 ? s / (double)sz : -1.0;
+        }
+        free(heap);
+    }
+    if (!brute) grid_free(&g);
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; ++i) if (avg[i] > 0) sum += avg[i];
+    double mean = sum / (double)n;
+    double sq = 0.0;
+    for (int64_t i = 0; i < n; ++i) if (avg[i] > 0) sq += (avg[i] - mean) * (avg[i] - mean);
+    double sd = sqrt(sq / (double)(n - 1));
+    double thr = mean + std_ratio * sd;
+    if (stats) { stats[0] = mean; stats[1] = sd; stats[2] = thr; }
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (avg[i] > 0 && avg[i] < thr) { if (keep_idx) keep_idx[cnt] = (int32_t)i; ++cnt; }
+    if (!avg_out) free(avg);
+    return cnt;
+}
+
+/* [O3D] KDTreeFlann::SearchHybrid(radius, max_nn) for every point of the cloud against itself
+ * (estimate_normals, preprocessing/registration.py:9-13).  nbr: n*max_nn indices ascending by
+ * (d2, idx); cnt: number found.  */
+KPO_API int kpo_hybrid_knn(const float *pts, int64_t n, double radius, int max_nn,
+                           int32_t *nbr, int32_t *cnt)
+{
+    if (max_nn < 1 || !(radius > 0)) return -1;
+    if (n == 0) return 0;
+    int kk = (int64_t)max_nn < n ? max_nn : (int)n;
+    grid_t g;
+    grid_build(&g, pts, n, 8.0);
+    double r2 = radius * radius;
+#pragma omp parallel
+    {
+        di_t *heap = (di_t *)malloc((size_t)kk * sizeof(di_t));
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t i = 0; i < n; ++i) {
+            int sz = grid_knn(&g, pts, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], kk, r2, heap);
+            cnt[i] = sz;
+            for (int t = 0; t < sz; ++t) nbr[i * max_nn + t] = heap[t].i;
+            for (int t = sz; t < max_nn; ++t) nbr[i * max_nn + t] = -1;
+        }
+        free(heap);
+    }
+    grid_free(&g);
+    return 0;
+}
+
+/* [O3D] utility::ComputeCovariance over the hybrid neighbourhood (cumulant form):
+ *   c[0..8] = mean of x,y,z,xx,xy,xz,yy,yz,zz (sequential, neighbour order), then
+ *   cov = E[ab] - E[a]E[b].  Output 6 doubles per point: xx,xy,xz,yy,yz,zz; cnt<3 -> zeros. */
+KPO_API void kpo_covariances(const float *pts, int64_t n, const int32_t *nbr, const int32_t *cnt,
+                             int max_nn, double *cov6)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double c[9] = {0};
+        int m = cnt[i];
+        if (m < 3) { for (int a = 0; a < 6; ++a) cov6[6 * i + a] = 0.0; continue; }
+        for (int t = 0; t < m; ++t) {
+            int32_t j = nbr[i * max_nn + t];
+            double x = pts[3 * j], y = pts[3 * j + 1], z = pts[3 * j + 2];
+            c[0] += x; c[1] += y; c[2] += z;
+            c[3] += x * x; c[4] += x * y; c[5] += x * z;
+            c[6] += y * y; c[7] += y * z; c[8] += z * z;
+        }
+        for (int a = 0; a < 9; ++a) c[a] /= (double)m;
+        cov6[6 * i + 0] = c[3] - c[0] * c[0];
+        cov6[6 * i + 1] = c[4] - c[0] * c[1];
+        cov6[6 * i + 2] = c[5] - c[0] * c[2];
+        cov6[6 * i + 3] = c[6] - c[1] * c[1];
+        cov6[6 * i + 4] = c[7] - c[1] * c[2];
+        cov6[6 * i + 5] = c[8] - c[2] * c[2];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a21: [O3D] PointCloud::SegmentPlane (floor_removal.py:70: thr 30, ransac_n 30, 2000 iters). */
+/* Sampling (ours, seeded; the reference's is unseeded): hypothesis h draws u32 values from     */
+/* Philox(ctr=(block,h,0,0), key=(seed_lo,seed_hi)), four per block, index = (u*n)>>32,         */
+/* duplicates rejected, until ransac_n distinct indices.                                        */
+/* Plane: n==3 triangle normal, else the determinant least-squares fit (Appendix A).            */
+/* Score: dist = |fma(a,x, fma(b,y, fma(c,z, d)))| ; inlier if dist < thr ; error = sum(dist)   */
+/*        (in index order); fitness = count/N ; rmse = error/sqrt(count) [O3D quirk, recalled]. */
+/* Best: higher fitness, tie -> lower rmse.  Early exit [O3D >= 0.16]: after an improvement     */
+/*        break_iteration = min(log(1-p)/log(1-fitness^n), iters) (0 if fitness == 1);          */
+/*        iterations with index > break_iteration are skipped.                                  */
+/* Final: inliers of the best plane (ascending), plane re-fitted to them.                       */
+/* ------------------------------------------------------------------------------------------ */
+static void plane_from_points(const float *pts, const int32_t *ids, int64_t m, double pl[4])
+{
+    pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
+    if (m < 3) return;
+    double cx = 0, cy = 0, cz = 0;
+    for (int64_t t = 0; t < m; ++t) { int64_t j = ids ? ids[t] : t; cx += pts[3 * j]; cy += pts[3 * j + 1]; cz += pts[3 * j + 2]; }
+    cx /= (double)m; cy /= (double)m; cz /= (double)m;
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    for (int64_t t = 0; t < m; ++t) {
+        int64_t j = ids ? ids[t] : t;
+        double rx = pts[3 * j] - cx, ry = pts[3 * j + 1] - cy, rz = pts[3 * j + 2] - cz;
+        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+    }
+    double det_x = yy * zz - yz * yz, det_y = xx * zz - xz * xz, det_z = xx * yy - xy * xy;
+    double a, b, c;
+    if (det_x > det_y && det_x > det_z) { a = det_x; b = xz * yz - xy * zz; c = xy * yz - xz * yy; }
+    else if (det_y > det_z)             { a = xz * yz - xy * zz; b = det_y; c = xy * xz - yz * xx; }
+    else                                { a = xy * yz - xz * yy; b = xy * xz - yz * xx; c = det_z; }
+    double nn = sqrt(a * a + b * b + c * c);
+    if (nn == 0.0) return;
+    a /= nn; b /= nn; c /= nn;
+    pl[0] = a; pl[1] = b; pl[2] = c; pl[3] = -(a * cx + b * cy + c * cz);
+}
+static void plane_from_triangle(const float *pts, const int32_t *ids, double pl[4])
+{
+    const float *p0 = pts + 3 * ids[0], *p1 = pts + 3 * ids[1], *p2 = pts + 3 * ids[2];
+    double e0[3], e1[3];
+    for (int a = 0; a < 3; ++a) { e0[a] = (double)p1[a] - p0[a]; e1[a] = (double)p2[a] - p0[a]; }
+    double a = e0[1] * e1[2] - e0[2] * e1[1], b = e0[2] * e1[0] - e0[0] * e1[2], c = e0[0] * e1[1] - e0[1] * e1[0];
+    double nn = sqrt(a * a + b * b + c * c);
+    pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
+    if (nn == 0.0) return;
+    a /= nn; b /= nn; c /= nn;
+    pl[0] = a; pl[1] = b; pl[2] = c; pl[3] = -(a * p0[0] + b * p0[1] + c * p0[2]);
+}
+KPO_API void kpo_ransac_sample(int64_t n, int ransac_n, uint64_t seed, uint32_t h, int32_t *ids)
+{
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    int got = 0;
+    for (uint32_t blk = 0; got < ransac_n; ++blk) {
+        uint32_t ctr[4] = { blk, h, 0u, 0u }, out[4];
+        kpo_philox4x32(ctr, key, out);
+        for (int w = 0; w < 4 && got < ransac_n; ++w) {
+            int32_t id = (int32_t)(((uint64_t)out[w] * (uint64_t)n) >> 32);
+            int dup = 0;
+            for (int t = 0; t < got; ++t) if (ids[t] == id) { dup = 1; break; }
+            if (!dup) ids[got++] = id;
+        }
+    }
+}
+KPO_API void kpo_plane_fit(const float *pts, const int32_t *ids, int64_t m, double pl[4])
+{
+    if (m == 3 && ids) plane_from_triangle(pts, ids, pl); else plane_from_points(pts, ids, m, pl);
+}
+static inline double plane_dist(const double pl[4], const float *p)
+{
+    return fabs(fma(pl[0], (double)p[0], fma(pl[1], (double)p[1], fma(pl[2], (double)p[2], pl[3]))));
+}
+/* per-hypothesis table hyp[h*6 + {a,b,c,d,count,error}] is optional (debug / GPU cross-check) */
+KPO_API int kpo_segment_plane(const float *pts, int64_t n, double thr, int ransac_n, int iters,
+                              double probability, uint64_t seed, double plane[4],
+                              int32_t *inl_idx, int64_t *inl_count, double *hyp)
+{
+    if (ransac_n < 3 || n < ransac_n || !(probability > 0.0) || probability > 1.0) return -1;
+    double best_fit = 0.0, best_rmse = 0.0, best_pl[4] = {0, 0, 0, 0};
+    double break_it = DBL_MAX;
+    int32_t *ids = (int32_t *)malloc((size_t)ransac_n * sizeof(int32_t));
+    for (int it = 0; it < iters; ++it) {
+        if ((double)it > break_it && !hyp) break;
+        double pl[4];
+        kpo_ransac_sample(n, ransac_n, seed, (uint32_t)it, ids);
+        if (ransac_n == 3) plane_from_triangle(pts, ids, pl); else plane_from_points(pts, ids, ransac_n, pl);
+        int zero = (pl[0] == 0 && pl[1] == 0 && pl[2] == 0 && pl[3] == 0);
+        int64_t cnt = 0; double err = 0.0;
+        if (!zero) {
+            int64_t c = 0; double e = 0.0;
+#pragma omp parallel for reduction(+ : c) schedule(static)
+            for (int64_t i = 0; i < n; ++i) if (plane_dist(pl, pts + 3 * i) < thr) ++c;
+            cnt = c;
+            /* error summed sequentially in index order (the defined order) */
+            if (cnt) for (int64_t i = 0; i < n; ++i) { double d = plane_dist(pl, pts + 3 * i); if (d < thr) e += d; }
+            err = e;
+        }
+        if (hyp) { for (int a = 0; a < 4; ++a) hyp[6 * it + a] = pl[a]; hyp[6 * it + 4] = (double)cnt; hyp[6 * it + 5] = err; }
+        if ((double)it > break_it || zero) continue;
+        double fit = cnt ? (double)cnt / (double)n : 0.0;
+        double rmse = cnt ? err / sqrt((double)cnt) : 0.0;
+        if (fit > best_fit || (fit == best_fit && rmse < best_rmse)) {
+            best_fit = fit; best_rmse = rmse; memcpy(best_pl, pl, sizeof(pl));
+            if (fit < 1.0) {
+                double b = log(1.0 - probability) / log(1.0 - pow(fit, (double)ransac_n));
+                break_it = b < (double)iters ? b : (double)iters;
+                break_it = floor(break_it);              /* size_t truncation in [O3D] */
+            } else break_it = 0.0;
+        }
+    }
+    free(ids);
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) if (plane_dist(best_pl, pts + 3 * i) < thr) inl_idx[k++] = (int32_t)i;
+    *inl_count = k;
+    plane_from_points(pts, inl_idx, k, plane);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a14/a16: correspondence search of [O3D] registration_icp                                    */
+/* (manual_pointcloud_registration.py:96-98, preprocessing/registration.py:78-84).             */
+/* Source point i is first transformed by T (AC1, fp64, not rounded).  Nearest target under     */
+/* contract AC2:  m_ij = fma(1, |t_j|^2, fma(s_z,-2t_z, fma(s_y,-2t_y, s_x*(-2t_x))))           */
+/* (= d^2 - |s|^2: the K=4 augmented inner product evaluated as a k-ordered fma chain, which   */
+/* is what the f64 MFMA computes), |t|^2 = fma(tx,tx, fma(ty,ty, tz*tz)); argmin, ties ->      */
+/* lowest j.  The reported d2 is the direct form AC3 of the chosen pair.                        */
+/* ------------------------------------------------------------------------------------------ */
+static inline double nn_metric(const double s[3], const float *t)
+{
+    double tx = t[0], ty = t[1], tz = t[2];
+    double t2 = fma(tx, tx, fma(ty, ty, tz * tz));
+    double m = s[0] * (-2.0 * tx);
+    m = fma(s[1], -2.0 * ty, m);
+    m = fma(s[2], -2.0 * tz, m);
+    m = fma(1.0, t2, m);
+    return m;
+}
+KPO_API int kpo_nn_brute(const float *src, int64_t n, const double *T, const float *tgt, int64_t m,
+                         int32_t *idx, double *d2, double *metric)
+{
+    if (m <= 0) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double s[3];
+        xform3(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], s);
+        double best = DBL_MAX; int64_t bj = 0;
+        for (int64_t j = 0; j < m; ++j) {
+            double v = nn_metric(s, tgt + 3 * j);
+            if (v < best) { best = v; bj = j; }
+        }
+        idx[i] = (int32_t)bj;
+        if (metric) metric[i] = best;
+        d2[i] = dist2_direct(s[0], s[1], s[2], tgt[3 * bj], tgt[3 * bj + 1], tgt[3 * bj + 2]);
+    }
+    return 0;
+}
+/* Same answer through the grid: ring search on the direct distance with a safety margin, the
+ * AC2 metric decides among everything within the margin of the best. */
+KPO_API int kpo_nn_grid(const float *src, int64_t n, const double *T, const float *tgt, int64_t m,
+                        int32_t *idx, double *d2, double *metric)
+{
+    if (m <= 0) return -1;
+    grid_t g;
+    grid_build(&g, tgt, m, 4.0);
+    int maxr = g.dim[0] > g.dim[1] ? g.dim[0] : g.dim[1];
+    if (g.dim[2] > maxr) maxr = g.dim[2];
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; ++i) {
+        double s[3];
+        xform3(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], s);
+        int c[3];
+        double outside2 = 0.0;          /* squared distance from s to the grid box (clamped query) */
+        for (int a = 0; a < 3; ++a) {
+            double r = floor((s[a] - g.org[a]) / g.h);
+            if (r < 0) { double o = g.org[a] - s[a]; outside2 += o * o; c[a] = 0; }
+            else if (r > g.dim[a] - 1) { double o = s[a] - (g.org[a] + g.dim[a] * g.h); if (o > 0) outside2 += o * o; c[a] = g.dim[a] - 1; }
+            else c[a] = (int)r;
+        }
+        double bestm = DBL_MAX, bestd = DBL_MAX; int64_t bj = -1;
+        for (int r = 0; r <= maxr; ++r) {
+            if (r > 0 && bj >= 0) {
+                double dcov = DBL_MAX;
+                for (int a = 0; a < 3; ++a) {
+                    double lo = g.org[a] + (double)(c[a] - (r - 1)) * g.h;
+                    double hi = g.org[a] + (double)(c[a] + r) * g.h;
+                    double dl = s[a] - lo, dh = hi - s[a];
+                    if (c[a] - (r - 1) <= 0) dl = DBL_MAX;
+                    if (c[a] + r >= g.dim[a]) dh = DBL_MAX;
+                    if (dl < dcov) dcov = dl;
+                    if (dh < dcov) dcov = dh;
+                }
+                if (dcov == DBL_MAX) break;
+                if (dcov > 0 && bestd * (1.0 + 1e-9) + 1e-9 < dcov * dcov) break;
+            }
+            int x0 = c[0] - r, x1 = c[0] + r, y0 = c[1] - r, y1 = c[1] + r, z0 = c[2] - r, z1 = c[2] + r;
+            for (int x = x0 < 0 ? 0 : x0; x <= (x1 >= g.dim[0] ? g.dim[0] - 1 : x1); ++x)
+                for (int y = y0 < 0 ? 0 : y0; y <= (y1 >= g.dim[1] ? g.dim[1] - 1 : y1); ++y) {
+                    int shell_xy = (x == x0 || x == x1 || y == y0 || y == y1);
+                    for (int z = z0 < 0 ? 0 : z0; z <= (z1 >= g.dim[2] ? g.dim[2] - 1 : z1); ++z) {
+                        if (!shell_xy && z != z0 && z != z1) continue;
+                        int64_t cell = ((int64_t)x * g.dim[1] + y) * g.dim[2] + z;
+                        for (int64_t q = g.start[cell]; q < g.start[cell + 1]; ++q) {
+                            int32_t j = g.order[q];
+                            double v = nn_metric(s, tgt + 3 * j);
+                            if (v < bestm || (v == bestm && j < bj)) {
+                                bestm = v; bj = j;
+                                bestd = dist2_direct(s[0], s[1], s[2], tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]);
+                            }
+                        }
+                    }
+                }
+        }
+        (void)outside2;
+        idx[i] = (int32_t)bj;
+        if (metric) metric[i] = bestm;
+        d2[i] = bestd;
+    }
+    grid_free(&g);
+    return 0;
+}
+
+/* ICP accumulations for one iteration, given the correspondences (idx, d2) of the transformed
+ * source: valid pair iff d2 < max_dist^2 ([O3D] SearchHybrid strict <).
+ * out[0]=count, out[1]=sum d2, out[2..4]=sum s, out[5..7]=sum t, out[8..16]=sum t s^T (row-major,
+ * rows = target component)  -> Umeyama needs Sigma = E[t s^T] - mu_t mu_s^T.
+ * If tn (target normals) != NULL also the point-to-plane normal equations:
+ * out[17..37] = upper triangle of J^T J (6x6 row-major upper), out[38..43] = J^T r,
+ * with r = (s - t).n, J = [s x n, n]  ([O3D] TransformationEstimationPointToPlane). */
+KPO_API void kpo_icp_accumulate(const float *src, int64_t n, const double *T, const float *tgt,
+                                const float *tn, const int32_t *idx, const double *d2,
+                                double max_dist, double *out)
+{
+    for (int a = 0; a < 44; ++a) out[a] = 0.0;
+    double md2 = max_dist * max_dist;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!(d2[i] < md2)) continue;
+        double s[3];
+        xform3(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], s);
+        const float *t = tgt + 3 * (int64_t)idx[i];
+        out[0] += 1.0; out[1] += d2[i];
+        for (int a = 0; a < 3; ++a) { out[2 + a] += s[a]; out[5 + a] += (double)t[a]; }
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) out[8 + 3 * a + b] += (double)t[a] * s[b];
+        if (tn) {
+            const float *nf = tn + 3 * (int64_t)idx[i];
+            double nx = nf[0], ny = nf[1], nz = nf[2];
+            double r = (s[0] - t[0]) * nx + (s[1] - t[1]) * ny + (s[2] - t[2]) * nz;
+            double J[6] = { s[1] * nz - s[2] * ny, s[2] * nx - s[0] * nz, s[0] * ny - s[1] * nx, nx, ny, nz };
+            int q = 17;
+            for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) out[q++] += J[a] * J[b];
+            for (int a = 0; a < 6; ++a) out[38 + a] += J[a] * r;
+        }
+    }
+}
+
+KPO_API int kpo_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,405 @@
+"""ctypes + NumPy front end of the CPU oracle (TEST INFRASTRUCTURE ONLY -- see kpx_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY STATUS: parity unpinned for the Open3D-internal algorithms (no golden vectors exist in the
+reference); the NumPy-only reference functions are pinned by tests/golden/ref_kat.json.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libkpx_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "kpx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.kpo_median_i16.restype = C.c_double
+        _lib.kpo_rgbd_compact.restype = C.c_int64
+        _lib.kpo_voxel_downsample.restype = C.c_int64
+        _lib.kpo_sor.restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+def philox4x32(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    o = np.zeros(4, dtype=np.uint32)
+    lib().kpo_philox4x32(_p(c), _p(k), _p(o))
+    return o
+
+
+def xy_table_pinhole(H, W, fx, fy, cx, cy):
+    xy = np.zeros((H * W, 2), dtype=np.float32)
+    lib().kpo_xy_table_pinhole(C.c_int(H), C.c_int(W), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                               C.c_float(cy), _p(xy))
+    return xy
+
+
+def unproject_u16(depth, xy):
+    depth = np.ascontiguousarray(depth, dtype=np.uint16).reshape(-1)
+    xy = _f32(xy).reshape(-1, 2)
+    out = np.zeros((depth.size, 3), dtype=np.int16)
+    lib().kpo_unproject_u16(_p(depth), _p(xy), C.c_int64(depth.size), _p(out))
+    return out
+
+
+def median_z(xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.int16).reshape(-1, 3)
+    z = np.ascontiguousarray(xyz[:, 2])
+    return float(lib().kpo_median_i16(_p(z), C.c_int64(z.size), C.c_int64(1)))
+
+
+def rgbd_compact(xyz, rgb=None, use_color_mask=False, use_gate=False, gate_hi=0.0):
+    """a3 (+a4 when the flags are set).  Returns points f32 (K,3), colours f32 (K,3)|None, idx i32 (K)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.int16).reshape(-1, 3)
+    n = xyz.shape[0]
+    if rgb is not None:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+    pts = np.zeros((n, 3), dtype=np.float32)
+    col = np.zeros((n, 3), dtype=np.float32) if rgb is not None else None
+    idx = np.zeros(n, dtype=np.int32)
+    k = lib().kpo_rgbd_compact(_p(xyz), _p(rgb), C.c_int64(n), C.c_int(int(use_color_mask)),
+                               C.c_int(int(use_gate)), C.c_double(gate_hi), _p(pts), _p(col), _p(idx))
+    return pts[:k].copy(), (col[:k].copy() if col is not None else None), idx[:k].copy()
+
+
+def transform(pts, T):
+    pts = _f32(pts).reshape(-1, 3)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    out = np.empty_like(pts)
+    lib().kpo_transform(_p(pts), C.c_int64(pts.shape[0]), _p(T), _p(out))
+    return out
+
+
+def rotate(nrm, T):
+    nrm = _f32(nrm).reshape(-1, 3)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    out = np.empty_like(nrm)
+    lib().kpo_rotate(_p(nrm), C.c_int64(nrm.shape[0]), _p(T), _p(out))
+    return out
+
+
+def voxel_downsample(pts, voxel, col=None, nrm=None, return_counts=False):
+    pts = _f32(pts).reshape(-1, 3)
+    n = pts.shape[0]
+    col = _f32(col).reshape(-1, 3) if col is not None else None
+    nrm = _f32(nrm).reshape(-1, 3) if nrm is not None else None
+    op = np.zeros((max(n, 1), 3), dtype=np.float32)
+    oc = np.zeros((max(n, 1), 3), dtype=np.float32) if col is not None else None
+    on = np.zeros((max(n, 1), 3), dtype=np.float32) if nrm is not None else None
+    cnt = np.zeros(max(n, 1), dtype=np.int32)
+    m = lib().kpo_voxel_downsample(_p(pts), _p(col), _p(nrm), C.c_int64(n), C.c_double(voxel), _p(op),
+                                   _p(oc), _p(on), _p(cnt))
+    if m == -1:
+        raise RuntimeError("voxel_size <= 0")
+    if m == -2:
+        raise RuntimeError("voxel_size is too small")
+    res = [op[:m].copy(), oc[:m].copy() if oc is not None else None, on[:m].copy() if on is not None else None]
+    if return_counts:
+        res.append(cnt[:m].copy())
+    return tuple(res)
+
+
+def sor(pts, nb_neighbors, std_ratio, brute=False):
+    """a8.  Returns keep_idx i32 (K), (mean, std, thr), avg f64 (N)."""
+    pts = _f32(pts).reshape(-1, 3)
+    n = pts.shape[0]
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    st = np.zeros(3, dtype=np.float64)
+    avg = np.zeros(max(n, 1), dtype=np.float64)
+    k = lib().kpo_sor(_p(pts), C.c_int64(n), C.c_int(nb_neighbors), C.c_double(std_ratio), C.c_int(int(brute)),
+                      _p(idx), _p(st), _p(avg))
+    if k < 0:
+        raise RuntimeError("invalid nb_neighbors / std_ratio")
+    return idx[:k].copy(), tuple(st.tolist()), avg[:n].copy()
+
+
+def hybrid_knn(pts, radius, max_nn):
+    pts = _f32(pts).reshape(-1, 3)
+    n = pts.shape[0]
+    nbr = np.full((n, max_nn), -1, dtype=np.int32)
+    cnt = np.zeros(n, dtype=np.int32)
+    rc = lib().kpo_hybrid_knn(_p(pts), C.c_int64(n), C.c_double(radius), C.c_int(max_nn), _p(nbr), _p(cnt))
+    if rc:
+        raise RuntimeError("invalid radius / max_nn")
+    return nbr, cnt
+
+
+def covariances(pts, nbr, cnt):
+    pts = _f32(pts).reshape(-1, 3)
+    n = pts.shape[0]
+    cov = np.zeros((n, 6), dtype=np.float64)
+    lib().kpo_covariances(_p(pts), C.c_int64(n), _p(nbr), _p(cnt), C.c_int(nbr.shape[1]), _p(cov))
+    return cov
+
+
+def estimate_normals(pts, radius, max_nn):
+    """[O3D] estimate_normals(KDTreeSearchParamHybrid) (registration.py:9-13): eigenvector of the
+    smallest eigenvalue of the neighbourhood covariance; < 3 neighbours -> (0,0,1).  Sign is
+    implementation-defined: compare up to sign.  Returns normals f64 (N,3), cov (N,6), cnt."""
+    nbr, cnt = hybrid_knn(pts, radius, max_nn)
+    cov = covariances(pts, nbr, cnt)
+    A = np.zeros((cov.shape[0], 3, 3))
+    A[:, 0, 0], A[:, 0, 1], A[:, 0, 2] = cov[:, 0], cov[:, 1], cov[:, 2]
+    A[:, 1, 0], A[:, 1, 1], A[:, 1, 2] = cov[:, 1], cov[:, 3], cov[:, 4]
+    A[:, 2, 0], A[:, 2, 1], A[:, 2, 2] = cov[:, 2], cov[:, 4], cov[:, 5]
+    w, v = np.linalg.eigh(A)
+    nrm = v[:, :, 0].copy()
+    nrm[cnt < 3] = [0.0, 0.0, 1.0]
+    return nrm, cov, cnt
+
+
+def ransac_sample(n, ransac_n, seed, h):
+    ids = np.zeros(ransac_n, dtype=np.int32)
+    lib().kpo_ransac_sample(C.c_int64(n), C.c_int(ransac_n), C.c_uint64(seed), C.c_uint32(h), _p(ids))
+    return ids
+
+
+def plane_fit(pts, ids=None):
+    pts = _f32(pts).reshape(-1, 3)
+    pl = np.zeros(4)
+    if ids is not None:
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lib().kpo_plane_fit(_p(pts), _p(ids), C.c_int64(ids.size), _p(pl))
+    else:
+        lib().kpo_plane_fit(_p(pts), None, C.c_int64(pts.shape[0]), _p(pl))
+    return pl
+
+
+def segment_plane(pts, distance_threshold, ransac_n, num_iterations, probability=0.99999999, seed=0,
+                  return_hypotheses=False):
+    """a21.  Returns plane f64 (4,), inlier idx i32 (K,) [, hyp (iters,6)]."""
+    pts = _f32(pts).reshape(-1, 3)
+    n = pts.shape[0]
+    plane = np.zeros(4)
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    cnt = C.c_int64(0)
+    hyp = np.zeros((num_iterations, 6)) if return_hypotheses else None
+    rc = lib().kpo_segment_plane(_p(pts), C.c_int64(n), C.c_double(distance_threshold), C.c_int(ransac_n),
+                                 C.c_int(num_iterations), C.c_double(probability), C.c_uint64(seed), _p(plane),
+                                 _p(idx), C.byref(cnt), _p(hyp))
+    if rc:
+        raise RuntimeError("invalid segment_plane arguments")
+    if return_hypotheses:
+        return plane, idx[:cnt.value].copy(), hyp
+    return plane, idx[:cnt.value].copy()
+
+
+def nn(src, T, tgt, grid=False):
+    """Correspondence search of one ICP iteration.  Returns idx i32 (N), d2 f64 (N), metric f64 (N)."""
+    src = _f32(src).reshape(-1, 3)
+    tgt = _f32(tgt).reshape(-1, 3)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    n = src.shape[0]
+    idx = np.zeros(n, dtype=np.int32)
+    d2 = np.zeros(n)
+    met = np.zeros(n)
+    fn = lib().kpo_nn_grid if grid else lib().kpo_nn_brute
+    rc = fn(_p(src), C.c_int64(n), _p(T), _p(tgt), C.c_int64(tgt.shape[0]), _p(idx), _p(d2), _p(met))
+    if rc:
+        raise RuntimeError("empty target")
+    return idx, d2, met
+
+
+def icp_accumulate(src, T, tgt, idx, d2, max_dist, tgt_normals=None):
+    src = _f32(src).reshape(-1, 3)
+    tgt = _f32(tgt).reshape(-1, 3)
+    tn = _f32(tgt_normals).reshape(-1, 3) if tgt_normals is not None else None
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    out = np.zeros(44)
+    lib().kpo_icp_accumulate(_p(src), C.c_int64(src.shape[0]), _p(T), _p(tgt), _p(tn), _p(idx), _p(d2),
+                             C.c_double(max_dist), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def kabsch_from_sums(acc):
+    """[O3D] TransformationEstimationPointToPoint(with_scaling=False) == Eigen::umeyama without
+    scale (manual_pointcloud_registration.py:90-91): Sigma = E[t s^T] - mu_t mu_s^T,
+    R = U diag(1,1,sign(det U det V)) V^T, t = mu_t - R mu_s."""
+    n = acc[0]
+    if n < 1:
+        return np.eye(4)
+    mu_s = acc[2:5] / n
+    mu_t = acc[5:8] / n
+    sigma = acc[8:17].reshape(3, 3) / n - np.outer(mu_t, mu_s)
+    U, _, Vt = np.linalg.svd(sigma)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = mu_t - R @ mu_s
+    return T
+
+
+def kabsch(src_pts, tgt_pts):
+    """Umeyama on explicit pairs (compute_transformation with a correspondence list)."""
+    s = np.asarray(src_pts, dtype=np.float64)
+    t = np.asarray(tgt_pts, dtype=np.float64)
+    acc = np.zeros(44)
+    acc[0] = len(s)
+    acc[2:5] = s.sum(0)
+    acc[5:8] = t.sum(0)
+    acc[8:17] = (t.T @ s).reshape(-1)
+    return kabsch_from_sums(acc)
+
+
+def _rot_zyx(a, b, g):
+    ca, sa, cb, sb, cg, sg = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(g), np.sin(g)
+    Rx = np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
+    Ry = np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+    Rz = np.array([[cg, -sg, 0], [sg, cg, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def p2plane_from_sums(acc):
+    """[O3D] TransformationEstimationPointToPlane (registration.py:83): solve (J^T J) x = -J^T r,
+    T = [Rz(x2) Ry(x1) Rx(x0) | x3..5]."""
+    if acc[0] < 1:
+        return np.eye(4)
+    A = np.zeros((6, 6))
+    q = 17
+    for a in range(6):
+        for b in range(a, 6):
+            A[a, b] = A[b, a] = acc[q]
+            q += 1
+    rhs = -acc[38:44]
+    try:
+        x = np.linalg.solve(A, rhs)
+    except np.linalg.LinAlgError:
+        return np.eye(4)
+    T = np.eye(4)
+    T[:3, :3] = _rot_zyx(x[0], x[1], x[2])
+    T[:3, 3] = x[3:6]
+    return T
+
+
+def registration_icp(src, tgt, max_dist, init=None, mode="p2p", tgt_normals=None, max_iteration=30,
+                     relative_fitness=1e-6, relative_rmse=1e-6, grid=True, trace=None):
+    """[O3D] registration_icp loop.  The transformed source is always
+    T_acc . src_original in fp64 (contract AC1).  Returns T, fitness, rmse, iterations.
+    trace (list) receives (T_used, idx, d2) per correspondence search."""
+    src = _f32(src).reshape(-1, 3)
+    tgt = _f32(tgt).reshape(-1, 3)
+    T = np.eye(4) if init is None else np.array(init, dtype=np.float64).reshape(4, 4)
+    n = src.shape[0]
+
+    def search(Tc):
+        idx, d2, _ = nn(src, Tc, tgt, grid=grid)
+        acc = icp_accumulate(src, Tc, tgt, idx, d2, max_dist, tgt_normals if mode == "p2plane" else None)
+        if trace is not None:
+            trace.append((Tc.copy(), idx, d2))
+        cnt = acc[0]
+        fit = cnt / n if n else 0.0
+        rmse = np.sqrt(acc[1] / cnt) if cnt else 0.0
+        return acc, fit, rmse
+
+    acc, fit, rmse = search(T)
+    it = 0
+    for it in range(1, max_iteration + 1):
+        upd = kabsch_from_sums(acc) if mode == "p2p" else p2plane_from_sums(acc)
+        T = upd @ T
+        acc, nfit, nrmse = search(T)
+        done = abs(fit - nfit) < relative_fitness and abs(rmse - nrmse) < relative_rmse
+        fit, rmse = nfit, nrmse
+        if done:
+            break
+    return T, fit, rmse, it
+
+
+# ------------------------------------------------------------------------------------------------
+# NumPy-only reference functions (pinned by tests/golden/ref_kat.json)
+def equation_plane(p1, p2, p3):
+    """floor_removal.py:21-36"""
+    x1, y1, z1 = p1
+    x2, y2, z2 = p2
+    x3, y3, z3 = p3
+    a1, b1, c1 = x2 - x1, y2 - y1, z2 - z1
+    a2, b2, c2 = x3 - x1, y3 - y1, z3 - z1
+    a = b1 * c2 - b2 * c1
+    b = a2 * c1 - a1 * c2
+    c = a1 * b2 - b1 * a2
+    d = -a * x1 - b * y1 - c * z1
+    return a, b, c, d
+
+
+def halfspace_keep_idx(a, b, c, d, pts):
+    """floor_removal.py:39-51: keeps points whose plane value is < 0 (label 0)."""
+    p = np.asarray(pts, dtype=np.float64)
+    val = a * p[:, 0] + b * p[:, 1] + c * p[:, 2] + d
+    return np.flatnonzero(~(val >= 0)).astype(np.int32)
+
+
+def kalman_filter(joint_vals, ri=10, qi=10, fi=1 / 30, hi=1):
+    """preprocessing/filtering.py:98-129"""
+    x = np.asarray(joint_vals, dtype=np.float64)
+    Pi = np.identity(3)
+    Fi, Ri, Qi, Hi = fi * np.identity(3), ri * np.identity(3), qi * np.identity(3), hi * np.identity(3)
+    xh = x[0]
+    out = [xh]
+    for i in range(1, len(x)):
+        xd = Fi @ xh
+        Pd = Fi @ Pi @ Fi.T + Qi
+        K = Pd @ Hi.T @ np.linalg.inv(Hi @ Pd @ Hi.T + Ri)
+        xh = xd + K @ (x[i] - Hi @ xd)
+        Pi = (np.identity(3) - K @ Hi) @ Pd
+        out.append(xh)
+    return np.array(out)
+
+
+def transform_joints(vals, T):
+    """utils/processing.py:357-383 / extractor.py:109-116: (F,J,3) @ inv(R) + t"""
+    v = np.asarray(vals, dtype=np.float64)
+    T = np.asarray(T, dtype=np.float64)
+    j = v.shape[1] // 3
+    return (v.reshape(v.shape[0], j, 3) @ np.linalg.inv(T[:3, :3]) + T[:3, 3]).reshape(v.shape[0], j * 3)
+
+
+def floor_removal(pts, slab=200.0, thr=30.0, ransac_n=30, iters=2000, seed=0, sor_k=50, sor_ratio=0.30,
+                  probability=0.99999999):
+    """floor_removal.py:61-73 on a float32 cloud.  Returns (points, dict of intermediates)."""
+    pts = _f32(pts).reshape(-1, 3)
+    y = pts[:, 1].astype(np.float64)
+    cut = y.max() - slab
+    lower = np.flatnonzero(y >= cut).astype(np.int32)
+    upper = np.flatnonzero(y < cut).astype(np.int32)
+    floor = pts[lower]
+    plane, inl = segment_plane(floor, thr, ransac_n, iters, probability, seed)
+    keep = np.ones(len(floor), dtype=bool)
+    keep[inl] = False
+    merged = np.concatenate([floor[keep], pts[upper]], axis=0)
+    kidx, stats, _ = sor(merged, sor_k, sor_ratio)
+    return merged[kidx], {"lower": lower, "upper": upper, "plane": plane, "inliers": inl, "merged": merged,
+                          "sor_idx": kidx, "sor_stats": stats}
+
+
+def num_threads():
+    return int(lib().kpo_num_threads())
