@@ -1,0 +1,179 @@
+/*
+ * kinectpx.h -- C ABI of libkinectpx.so: the MI355X (gfx950) hot path behind KinectPy's
+ * preprocessing.{extractor,filtering,registration} and floor_removal module APIs.
+ *
+ * The reference (tiborcamargo/KinectPy) is pure Python: it has no FFI layer; its "operators" are
+ * module functions that call Open3D.  Each entry point below names the reference interface it
+ * replaces (file:line under the reference root) -- the ctypes stubs a maintainer would add are in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name starts with `h_`; the caller owns all memory
+ *    (torch-ROCm tensors in the Python host); the library never allocates user-visible memory;
+ *  - scratch comes from a caller-provided workspace `ws` of at least `kpx_*_workspace_bytes()` bytes,
+ *    256-byte aligned;
+ *  - clouds are float32 (N,3) row-major ("xyz xyz ..."), colours/normals likewise; index arrays are
+ *    int32; rigid transforms are float64 row-major 4x4 (the reference's .npy interchange format,
+ *    preprocessing/data.py:158-160);
+ *  - outputs of data-dependent length are written into worst-case-sized buffers and their length
+ *    into a device int32 (`d_count`);
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream)
+ *    and returns 0 or a negative kpx_status; `kpx_last_error()` (thread-local) has the message;
+ *  - no C++ exception crosses this boundary.
+ */
+#ifndef KINECTPX_H
+#define KINECTPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPX_VERSION 100
+
+typedef enum {
+    KPX_OK = 0,
+    KPX_ERR_INVALID = -1,     /* invalid argument (Open3D raises RuntimeError / ValueError here) */
+    KPX_ERR_WORKSPACE = -2,   /* workspace too small */
+    KPX_ERR_RANGE = -3,       /* value out of the supported range (e.g. voxel index overflow) */
+    KPX_ERR_HIP = -4          /* a HIP runtime call failed */
+} kpx_status;
+
+const char *kpx_last_error(void);
+int kpx_version(void);
+
+/* ---- extract stage -------------------------------------------------------------------------- */
+
+/* a1: depth -> XYZ int16 millimetres, the `<ts>_depth.dat` layout that utils/io.py:15-20
+ * (load_depth) reads and that preprocessing/extractor.py:68-80 obtains from an external binary.
+ * xyz[i] = (floorf(xt*d+0.5f), floorf(yt*d+0.5f), d), (0,0,0) when d==0 or the table entry is NaN.
+ * depth: u16 [frames*n_px]; xy_table: f32 [n_px*2] shared by all frames; xyz: i16 [frames*n_px*3]. */
+int kpx_unproject_u16(const uint16_t *depth, const float *xy_table, int64_t n_px, int32_t frames,
+                      int16_t *xyz, void *stream);
+
+/* a4: np.median of the z column (preprocessing/data.py:170-171), exact, per frame.
+ * v: i16 values with `stride` elements between consecutive samples (3 for the z column of an
+ * (N,3) .dat array, 1 for a raw depth frame); d_median: f64 [frames]. */
+size_t kpx_median_workspace_bytes(int32_t frames);
+int kpx_median_i16(const int16_t *v, int64_t n, int64_t stride, int32_t frames, double *d_median,
+                   void *ws, size_t ws_bytes, void *stream);
+
+/* a3 + a4: utils/io.py:23-43 rgbd_to_pointcloud (keep = x!=0 & y!=0 & z!=0, colours/255) composed
+ * with preprocessing/data.py:165-178 (_transform_filtered_image_to_pointcloud: all colour
+ * channels != 0, z <= median + gate).  Order-preserving compaction, per frame.
+ * rgb may be NULL (no colours, no colour mask).  flags: bit0 = colour mask, bit1 = depth gate
+ * (needs d_median).  Outputs per frame f at offset f*n: pts f32 [n*3], col f32 [n*3] (optional),
+ * idx i32 [n] (optional, source pixel index), d_count i32 [frames]. */
+#define KPX_COMPACT_COLOR_MASK 1
+#define KPX_COMPACT_DEPTH_GATE 2
+size_t kpx_compact_workspace_bytes(int64_t n, int32_t frames);
+int kpx_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t n, int32_t frames, int32_t flags,
+                     const double *d_median, double gate, float *pts, float *col, int32_t *idx,
+                     int32_t *d_count, void *ws, size_t ws_bytes, void *stream);
+
+/* Fused a1+a3+a4 for the streaming pipeline: u16 depth (+ xy table, + optional rgb) straight to the
+ * compacted float32 cloud, never materialising the int16 XYZ image.  Same outputs as
+ * kpx_rgbd_compact; the median is taken over the raw depth (== the z column). */
+size_t kpx_depth_to_cloud_workspace_bytes(int64_t n_px, int32_t frames);
+int kpx_depth_to_cloud(const uint16_t *depth, const float *xy_table, const uint8_t *rgb, int64_t n_px,
+                       int32_t frames, int32_t flags, double gate, float *pts, float *col, int32_t *idx,
+                       int32_t *d_count, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- container operations (Open3D surface used by the path) ------------------ */
+
+/* a17: pcd.transform(T) (preprocessing/data.py:48) -- out = R p + t (fp64 fma chain, stored f32).
+ * normals (optional, in place rotation only).  in == out allowed. */
+int kpx_transform(const float *pts, int64_t n, const double *h_T, float *out, void *stream);
+int kpx_rotate(const float *nrm, int64_t n, const double *h_T, float *out, void *stream);
+/* a5: align_skeletons / transform_joints (preprocessing/extractor.py:113-116,
+ * utils/processing.py:357-383): out = x @ inv(R) + t on f64 (rows,3) joints; h_A = inv(R) row-major 3x3. */
+int kpx_joints_affine_f64(const double *x, int64_t rows, const double *h_A, const double *h_t, double *out,
+                          void *stream);
+
+/* select_by_index (floor_removal.py:50,69,71,72): gather of up to three (n,3) f32 attributes.
+ * invert == 0: out[k] = in[idx[k]] for k < n_idx (idx taken in the given order).
+ * invert != 0: ascending complement of idx; d_count receives its length. */
+size_t kpx_select_workspace_bytes(int64_t n);
+int kpx_select_by_index(const float *a0, const float *a1, const float *a2, int64_t n, const int32_t *idx,
+                        int64_t n_idx, int32_t invert, float *o0, float *o1, float *o2, int32_t *d_count,
+                        void *ws, size_t ws_bytes, void *stream);
+
+/* a19: pcd_above_plane (floor_removal.py:39-51): indices of points with a x + b y + c z + d < 0
+ * (evaluated left to right in fp64, as the reference's Python loop). */
+int kpx_halfspace_select(const float *pts, int64_t n, const double *h_plane, int32_t *idx, int32_t *d_count,
+                         void *ws, size_t ws_bytes, void *stream);
+/* floor_removal.py:64-66: y >= max(y) - slab  -> lower indices, y < max(y) - slab -> upper indices. */
+int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t *lower_idx, int32_t *d_lower,
+                   int32_t *upper_idx, int32_t *d_upper, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- filter stage ------------------------------------------------------------------------------ */
+
+/* a7: PointCloud.voxel_down_sample(v) (preprocessing/filtering.py:23, registration.py:8,100,101).
+ * origin = min_bound - v/2, index = floor((p-origin)/v), per-voxel mean of points / colours /
+ * normals (normals renormalised).  Output order: ascending (ix,iy,iz) (documented deviation from
+ * Open3D's hash order).  col/nrm and their outputs may be NULL. */
+size_t kpx_voxel_workspace_bytes(int64_t n);
+int kpx_voxel_downsample(const float *pts, const float *col, const float *nrm, int64_t n, double voxel,
+                         float *opts, float *ocol, float *onrm, int32_t *d_count, void *ws, size_t ws_bytes,
+                         void *stream);
+
+/* a8: PointCloud.remove_statistical_outlier(nb_neighbors, std_ratio) (filtering.py:24,
+ * floor_removal.py:73, utils/processing.py:309).  keep_idx ascending, d_count = kept,
+ * d_stats f64 [3] = (mean, std, threshold), d_avg f64 [n] (optional) = per-point mean kNN distance.
+ * nb_neighbors <= KPX_SOR_MAX_K. */
+#define KPX_SOR_MAX_K 288
+size_t kpx_sor_workspace_bytes(int64_t n, int32_t nb_neighbors);
+int kpx_sor(const float *pts, int64_t n, int32_t nb_neighbors, double std_ratio, int32_t *keep_idx,
+            int32_t *d_count, double *d_stats, double *d_avg, void *ws, size_t ws_bytes, void *stream);
+
+/* estimate_normals(KDTreeSearchParamHybrid(radius, max_nn)) (preprocessing/registration.py:9-13):
+ * neighbours = up to max_nn nearest with d2 < radius^2; < 3 neighbours -> (0,0,1); else the
+ * eigenvector of the smallest eigenvalue of the neighbourhood covariance.  max_nn <= 128. */
+#define KPX_NORMALS_MAX_NN 128
+size_t kpx_normals_workspace_bytes(int64_t n, int32_t max_nn);
+int kpx_estimate_normals(const float *pts, int64_t n, double radius, int32_t max_nn, float *normals,
+                         void *ws, size_t ws_bytes, void *stream);
+
+/* a21: PointCloud.segment_plane(distance_threshold, ransac_n, num_iterations) (floor_removal.py:70).
+ * Seeded (Philox4x32-10) so results are reproducible; the reference's is unseeded.
+ * d_plane f64 [4], inlier_idx ascending, d_count = #inliers. */
+size_t kpx_segment_plane_workspace_bytes(int64_t n, int32_t ransac_n, int32_t num_iterations);
+int kpx_segment_plane(const float *pts, int64_t n, double distance_threshold, int32_t ransac_n,
+                      int32_t num_iterations, double probability, uint64_t seed, double *d_plane,
+                      int32_t *inlier_idx, int32_t *d_count, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- register stage ---------------------------------------------------------------------------- */
+
+/* One correspondence search of registration_icp (manual_pointcloud_registration.py:96-98,
+ * preprocessing/registration.py:78-84): for every source point transformed by d_T (device f64 [16]),
+ * the nearest target point -- an fp64 MFMA distance GEMM (K=4 augmented form) with a fused running
+ * argmin.  idx i32 [n], d2 f64 [n] (direct squared distance of the chosen pair). */
+size_t kpx_nn_workspace_bytes(int64_t n_src, int64_t n_tgt);
+int kpx_nn_search(const float *src, int64_t n_src, const float *tgt, int64_t n_tgt, const double *d_T,
+                  int32_t *idx, double *d2, void *ws, size_t ws_bytes, void *stream);
+
+/* TransformationEstimationPointToPoint().compute_transformation(src, tgt, corr)
+ * (manual_pointcloud_registration.py:90-91): Umeyama/Kabsch without scale on explicit pairs.
+ * corr i32 [n_corr*2] = (source index, target index); d_T f64 [16]. */
+size_t kpx_kabsch_workspace_bytes(int64_t n_corr);
+int kpx_kabsch(const float *src, const float *tgt, const int32_t *corr, int64_t n_corr, double *d_T, void *ws,
+               size_t ws_bytes, void *stream);
+
+/* registration_icp(source, target, max_dist, init, estimation, criteria) -- the whole loop runs on
+ * the device without host synchronisation.  mode 0 = point-to-point (Kabsch, a16), 1 = point-to-plane
+ * (needs tgt_normals, a14).  h_init: f64 [16] host.  d_result f64 [20]: T (16), fitness, inlier_rmse,
+ * iterations done, correspondence count.  idx/d2 (optional) receive the last correspondence set. */
+#define KPX_ICP_POINT_TO_POINT 0
+#define KPX_ICP_POINT_TO_PLANE 1
+size_t kpx_icp_workspace_bytes(int64_t n_src, int64_t n_tgt);
+int kpx_icp(const float *src, int64_t n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
+            double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness,
+            double relative_rmse, double *d_result, int32_t *idx, double *d2, void *ws, size_t ws_bytes,
+            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KINECTPX_H */

@@ -1,0 +1,121 @@
+"""ctypes binding of libkinectpx.so (include/kinectpx.h).
+
+The library is the product: if it is missing, or no MI355X is visible, the functions here raise --
+there is no CPU fallback.  PyTorch-ROCm tensors are used only as the device-memory container
+(allocation, streams); every computation is a call into the C ABI.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libkinectpx.so")
+
+_i64, _i32, _f64, _u64, _vp, _sz = C.c_int64, C.c_int32, C.c_double, C.c_uint64, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/kinectpx.h one to one
+SIGNATURES = {
+    "kpx_last_error": (C.c_char_p, []),
+    "kpx_version": (C.c_int, []),
+    "kpx_unproject_u16": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "kpx_median_workspace_bytes": (_sz, [_i32]),
+    "kpx_median_i16": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "kpx_compact_workspace_bytes": (_sz, [_i64, _i32]),
+    "kpx_rgbd_compact": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_depth_to_cloud_workspace_bytes": (_sz, [_i64, _i32]),
+    "kpx_depth_to_cloud": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_transform": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "kpx_rotate": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "kpx_joints_affine_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "kpx_select_workspace_bytes": (_sz, [_i64]),
+    "kpx_select_by_index": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_halfspace_select": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_slab_split": (C.c_int, [_vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_voxel_workspace_bytes": (_sz, [_i64]),
+    "kpx_voxel_downsample": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_sor_workspace_bytes": (_sz, [_i64, _i32]),
+    "kpx_sor": (C.c_int, [_vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_normals_workspace_bytes": (_sz, [_i64, _i32]),
+    "kpx_estimate_normals": (C.c_int, [_vp, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
+    "kpx_segment_plane_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "kpx_segment_plane": (C.c_int, [_vp, _i64, _f64, _i32, _i32, _f64, _u64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_nn_workspace_bytes": (_sz, [_i64, _i64]),
+    "kpx_nn_search": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_kabsch_workspace_bytes": (_sz, [_i64]),
+    "kpx_kabsch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "kpx_icp_workspace_bytes": (_sz, [_i64, _i64]),
+    "kpx_icp": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _f64, _vp, _i32, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class KinectPxError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (torch is imported first so both share one libamdhip64)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise KinectPxError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C kinectpy_amd/csrc).  There is no CPU fallback.")
+        lib = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    """kpx_status -> Python exception (SURVEY 8b error conventions: Open3D raises RuntimeError for
+    invalid arguments; ValueError-like conditions map to the same class here)."""
+    if rc != 0:
+        msg = load().kpx_last_error().decode() or f"kpx error {rc}"
+        raise KinectPxError(msg)
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise KinectPxError("no ROCm device visible: the kinectpx hot path runs on MI355X only (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "kinectpx needs contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def hptr(a):
+    """host numpy float64 array -> pointer"""
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Workspace:
+    """Grow-only device scratch buffer owned by the caller side (one per thread of use)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = int(nbytes)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device())
+        return C.c_void_p(self.buf.data_ptr()), C.c_size_t(self.buf.numel())
+
+
+_ws = Workspace()
+
+
+def workspace(nbytes):
+    return _ws.get(nbytes)

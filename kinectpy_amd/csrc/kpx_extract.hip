@@ -1,0 +1,323 @@
+// kpx_extract.hip -- extract stage: depth -> XYZ int16, exact median, mask + gate + compaction.
+// Reference: preprocessing/extractor.py:68-80 (external unprojection, `.dat` contract),
+// utils/io.py:15-43, preprocessing/data.py:165-178.  All HBM-streaming kernels.
+#include <stdarg.h>
+
+#include "kpx_common.h"
+
+namespace kpx {
+
+thread_local char g_err[512] = "";
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1 unproject: 8 pixels per thread.  Reads 16 B of depth + 64 B of table, writes 48 B of int16 xyz.
+// Arithmetic contract: float32, x = floorf(xt*d + 0.5f) with separate multiply and add.
+__device__ __forceinline__ void unproject1(uint16_t d, float xt, float yt, int16_t &x, int16_t &y, int16_t &z)
+{
+    if (d != 0 && !__builtin_isnan(xt) && !__builtin_isnan(yt)) {
+        float fd = (float)d;
+        float px = __fmul_rn(xt, fd);
+        px = __fadd_rn(px, 0.5f);
+        float py = __fmul_rn(yt, fd);
+        py = __fadd_rn(py, 0.5f);
+        x = (int16_t)(int)floorf(px);
+        y = (int16_t)(int)floorf(py);
+        z = (int16_t)d;
+    } else {
+        x = 0; y = 0; z = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void unproject_vec8_kernel(const uint16_t *__restrict__ depth,
+                                                             const float *__restrict__ xy, int64_t n_px,
+                                                             int16_t *__restrict__ xyz)
+{
+    const int frame = blockIdx.y;
+    const int64_t groups = n_px >> 3;
+    const uint16_t *dp = depth + (int64_t)frame * n_px;
+    int16_t *op = xyz + (int64_t)frame * n_px * 3;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        uint4 dv = *reinterpret_cast<const uint4 *>(dp + g * 8);
+        const float4 *tp = reinterpret_cast<const float4 *>(xy + g * 16);
+        float4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+        uint16_t d[8] = { (uint16_t)(dv.x & 0xffff), (uint16_t)(dv.x >> 16), (uint16_t)(dv.y & 0xffff), (uint16_t)(dv.y >> 16),
+                          (uint16_t)(dv.z & 0xffff), (uint16_t)(dv.z >> 16), (uint16_t)(dv.w & 0xffff), (uint16_t)(dv.w >> 16) };
+        float xt[8] = { t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z };
+        float yt[8] = { t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w };
+        union { int16_t s[24]; uint4 v[3]; } o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) unproject1(d[k], xt[k], yt[k], o.s[3 * k], o.s[3 * k + 1], o.s[3 * k + 2]);
+        uint4 *dst = reinterpret_cast<uint4 *>(op + g * 24);
+        dst[0] = o.v[0]; dst[1] = o.v[1]; dst[2] = o.v[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void unproject_scalar_kernel(const uint16_t *__restrict__ depth,
+                                                               const float *__restrict__ xy, int64_t n_px,
+                                                               int64_t first, int16_t *__restrict__ xyz)
+{
+    const int frame = blockIdx.y;
+    for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += (int64_t)gridDim.x * blockDim.x) {
+        int16_t x, y, z;
+        unproject1(depth[(int64_t)frame * n_px + i], xy[2 * i], xy[2 * i + 1], x, y, z);
+        int16_t *o = xyz + ((int64_t)frame * n_px + i) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4 exact median by two 8-bit radix-histogram passes (order key = v ^ 0x8000).
+struct MedianSel {
+    int32_t bin_a, bin_b;       // top-byte bins of the two middle ranks
+    int64_t rank_a, rank_b;     // ranks inside those bins
+};
+
+__global__ __launch_bounds__(256) void median_hist_kernel(const int16_t *__restrict__ v, int64_t n, int64_t stride,
+                                                          int64_t frame_stride, const MedianSel *__restrict__ sel,
+                                                          uint32_t *__restrict__ hist /* [frames][2][256] */, int pass)
+{
+    __shared__ uint32_t h[2][256];
+    const int frame = blockIdx.y;
+    h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
+    __syncthreads();
+    const int16_t *p = v + (int64_t)frame * frame_stride;
+    int ba = 0, bb = 0;
+    if (pass == 1) { ba = sel[frame].bin_a; bb = sel[frame].bin_b; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t key = ((uint32_t)(uint16_t)p[i * stride]) ^ 0x8000u;
+        if (pass == 0) {
+            atomicAdd(&h[0][key >> 8], 1u);
+        } else {
+            int top = (int)(key >> 8);
+            if (top == ba) atomicAdd(&h[0][key & 255u], 1u);
+            if (top == bb) atomicAdd(&h[1][key & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *g = hist + (int64_t)frame * 512;
+    if (h[0][threadIdx.x]) atomicAdd(&g[threadIdx.x], h[0][threadIdx.x]);
+    if (pass == 1 && h[1][threadIdx.x]) atomicAdd(&g[256 + threadIdx.x], h[1][threadIdx.x]);
+}
+
+// one block (256 threads) per frame; finds the bin holding a rank by a serial walk (256 bins)
+__global__ __launch_bounds__(64) void median_select_kernel(uint32_t *__restrict__ hist, int64_t n, MedianSel *sel,
+                                                           double *d_median, int pass)
+{
+    const int frame = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    uint32_t *g = hist + (int64_t)frame * 512;
+    if (pass == 0) {
+        int64_t ra = (n - 1) / 2, rb = n / 2;
+        MedianSel s;
+        int64_t cum = 0;
+        s.bin_a = s.bin_b = 255; s.rank_a = s.rank_b = 0;
+        bool fa = false, fb = false;
+        for (int b = 0; b < 256; ++b) {
+            int64_t c = g[b];
+            if (!fa && ra < cum + c) { s.bin_a = b; s.rank_a = ra - cum; fa = true; }
+            if (!fb && rb < cum + c) { s.bin_b = b; s.rank_b = rb - cum; fb = true; }
+            cum += c;
+            g[b] = 0;                       // reused by pass 1
+        }
+        sel[frame] = s;
+    } else {
+        MedianSel s = sel[frame];
+        int va = 0, vb = 0;
+        int64_t cum = 0;
+        bool fa = false;
+        for (int b = 0; b < 256; ++b) { int64_t c = g[b]; if (!fa && s.rank_a < cum + c) { va = b; fa = true; } cum += c; }
+        cum = 0;
+        bool fb = false;
+        for (int b = 0; b < 256; ++b) { int64_t c = g[256 + b]; if (!fb && s.rank_b < cum + c) { vb = b; fb = true; } cum += c; }
+        int ka = ((s.bin_a << 8) | va) ^ 0x8000, kb = ((s.bin_b << 8) | vb) ^ 0x8000;
+        double a = (double)(int16_t)(uint16_t)ka, b = (double)(int16_t)(uint16_t)kb;
+        d_median[frame] = 0.5 * (a + b);
+    }
+}
+
+static int median_impl(const int16_t *v, int64_t n, int64_t stride, int64_t frame_stride, int32_t frames,
+                       double *d_median, Arena &a, hipStream_t st)
+{
+    uint32_t *hist = a.get<uint32_t>((size_t)frames * 512);
+    MedianSel *sel = a.get<MedianSel>((size_t)frames);
+    if (a.dry) return KPX_OK;
+    KPX_ARENA_CHECK(a);
+    KPX_HIP(hipMemsetAsync(hist, 0, (size_t)frames * 512 * sizeof(uint32_t), st));
+    int bx = (int)(cdiv(n, 256 * 16) < 1 ? 1 : (cdiv(n, 256 * 16) > 512 ? 512 : cdiv(n, 256 * 16)));
+    dim3 grid(bx, frames);
+    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 0);
+    hipLaunchKernelGGL(median_select_kernel, dim3(frames), dim3(64), 0, st, hist, n, sel, d_median, 0);
+    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 1);
+    hipLaunchKernelGGL(median_select_kernel, dim3(frames), dim3(64), 0, st, hist, n, sel, d_median, 1);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a3 + a4 compaction functors
+struct XyzPred {
+    const int16_t *xyz; const uint8_t *rgb; const double *median; int64_t n; int flags; double gate;
+    __device__ bool operator()(int64_t i, int f) const
+    {
+        const int16_t *p = xyz + ((int64_t)f * n + i) * 3;
+        int16_t x = p[0], y = p[1], z = p[2];
+        bool keep = (x != 0) & (y != 0) & (z != 0);
+        if ((flags & KPX_COMPACT_COLOR_MASK) && rgb) {
+            const uint8_t *c = rgb + ((int64_t)f * n + i) * 3;
+            keep = keep & (c[0] != 0) & (c[1] != 0) & (c[2] != 0);
+        }
+        if (flags & KPX_COMPACT_DEPTH_GATE) keep = keep & ((double)z <= median[f] + gate);
+        return keep;
+    }
+};
+struct XyzEmit {
+    const int16_t *xyz; const uint8_t *rgb; int64_t n; float *pts; float *col; int32_t *idx;
+    __device__ void operator()(int64_t i, int f, int32_t dst) const
+    {
+        const int16_t *p = xyz + ((int64_t)f * n + i) * 3;
+        int64_t o = ((int64_t)f * n + dst) * 3;
+        pts[o] = (float)p[0]; pts[o + 1] = (float)p[1]; pts[o + 2] = (float)p[2];
+        if (col && rgb) {
+            const uint8_t *c = rgb + ((int64_t)f * n + i) * 3;
+            col[o] = (float)((double)c[0] / 255.0); col[o + 1] = (float)((double)c[1] / 255.0); col[o + 2] = (float)((double)c[2] / 255.0);
+        }
+        if (idx) idx[(int64_t)f * n + dst] = (int32_t)i;
+    }
+};
+
+// fused depth -> cloud functors (never materialise the int16 image)
+struct DepthPred {
+    const uint16_t *depth; const float *xy; const uint8_t *rgb; const double *median; int64_t n; int flags; double gate;
+    __device__ bool operator()(int64_t i, int f) const
+    {
+        int16_t x, y, z;
+        unproject1(depth[(int64_t)f * n + i], xy[2 * i], xy[2 * i + 1], x, y, z);
+        bool keep = (x != 0) & (y != 0) & (z != 0);
+        if ((flags & KPX_COMPACT_COLOR_MASK) && rgb) {
+            const uint8_t *c = rgb + ((int64_t)f * n + i) * 3;
+            keep = keep & (c[0] != 0) & (c[1] != 0) & (c[2] != 0);
+        }
+        if (flags & KPX_COMPACT_DEPTH_GATE) keep = keep & ((double)z <= median[f] + gate);
+        return keep;
+    }
+};
+struct DepthEmit {
+    const uint16_t *depth; const float *xy; const uint8_t *rgb; int64_t n; float *pts; float *col; int32_t *idx;
+    __device__ void operator()(int64_t i, int f, int32_t dst) const
+    {
+        int16_t x, y, z;
+        unproject1(depth[(int64_t)f * n + i], xy[2 * i], xy[2 * i + 1], x, y, z);
+        int64_t o = ((int64_t)f * n + dst) * 3;
+        pts[o] = (float)x; pts[o + 1] = (float)y; pts[o + 2] = (float)z;
+        if (col && rgb) {
+            const uint8_t *c = rgb + ((int64_t)f * n + i) * 3;
+            col[o] = (float)((double)c[0] / 255.0); col[o + 1] = (float)((double)c[1] / 255.0); col[o + 2] = (float)((double)c[2] / 255.0);
+        }
+        if (idx) idx[(int64_t)f * n + dst] = (int32_t)i;
+    }
+};
+
+}  // namespace kpx
+
+using namespace kpx;
+
+KPX_EXPORT const char *kpx_last_error(void) { return g_err; }
+KPX_EXPORT int kpx_version(void) { return KPX_VERSION; }
+
+KPX_EXPORT int kpx_unproject_u16(const uint16_t *depth, const float *xy, int64_t n_px, int32_t frames, int16_t *xyz,
+                                 void *stream)
+{
+    KPX_REQUIRE(n_px >= 0 && frames >= 0, "kpx_unproject_u16: negative size");
+    if (n_px == 0 || frames == 0) return KPX_OK;
+    KPX_REQUIRE(depth && xy && xyz, "kpx_unproject_u16: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    bool vec = (n_px % 8 == 0) && (((uintptr_t)depth | (uintptr_t)xy | (uintptr_t)xyz) % 16 == 0);
+    if (vec) {
+        int64_t groups = n_px / 8;
+        int bx = (int)(cdiv(groups, 256) > 2048 ? 2048 : cdiv(groups, 256));
+        hipLaunchKernelGGL(unproject_vec8_kernel, dim3(bx, frames), dim3(256), 0, st, depth, xy, n_px, xyz);
+    } else {
+        int bx = (int)(cdiv(n_px, 256) > 4096 ? 4096 : cdiv(n_px, 256));
+        hipLaunchKernelGGL(unproject_scalar_kernel, dim3(bx, frames), dim3(256), 0, st, depth, xy, n_px, (int64_t)0, xyz);
+    }
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+KPX_EXPORT size_t kpx_median_workspace_bytes(int32_t frames)
+{
+    Arena a(nullptr, 0);
+    median_impl(nullptr, 0, 1, 0, frames < 1 ? 1 : frames, nullptr, a, nullptr);
+    return a.off;
+}
+KPX_EXPORT int kpx_median_i16(const int16_t *v, int64_t n, int64_t stride, int32_t frames, double *d_median, void *ws,
+                              size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n > 0 && stride > 0 && frames > 0, "kpx_median_i16: empty input");
+    KPX_REQUIRE(v && d_median && ws, "kpx_median_i16: null pointer");
+    Arena a(ws, ws_bytes);
+    return median_impl(v, n, stride, n * stride, frames, d_median, a, (hipStream_t)stream);
+}
+
+KPX_EXPORT size_t kpx_compact_workspace_bytes(int64_t n, int32_t frames)
+{
+    Arena a(nullptr, 0);
+    a.get<int32_t>((size_t)(frames < 1 ? 1 : frames) * compact_tiles(n));
+    return a.off;
+}
+KPX_EXPORT int kpx_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t n, int32_t frames, int32_t flags,
+                                const double *d_median, double gate, float *pts, float *col, int32_t *idx,
+                                int32_t *d_count, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n >= 0 && frames > 0, "kpx_rgbd_compact: bad size");
+    KPX_REQUIRE(xyz && pts && d_count && ws, "kpx_rgbd_compact: null pointer");
+    KPX_REQUIRE(!(flags & KPX_COMPACT_DEPTH_GATE) || d_median, "kpx_rgbd_compact: depth gate needs d_median");
+    KPX_REQUIRE(n < ((int64_t)1 << 31), "kpx_rgbd_compact: frame too large");
+    Arena a(ws, ws_bytes);
+    int32_t *counts = a.get<int32_t>((size_t)frames * compact_tiles(n));
+    KPX_ARENA_CHECK(a);
+    XyzPred pred{ xyz, rgb, d_median, n, flags, gate };
+    XyzEmit emit{ xyz, rgb, n, pts, col, idx };
+    return compact(pred, emit, n, frames, counts, d_count, (hipStream_t)stream);
+}
+
+static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uint8_t *rgb, int64_t n, int32_t frames,
+                               int32_t flags, double gate, float *pts, float *col, int32_t *idx, int32_t *d_count,
+                               Arena &a, hipStream_t st)
+{
+    int32_t *counts = a.get<int32_t>((size_t)frames * compact_tiles(n));
+    double *med = a.get<double>((size_t)frames);
+    int rc = KPX_OK;
+    if (flags & KPX_COMPACT_DEPTH_GATE || a.dry)
+        rc = median_impl(reinterpret_cast<const int16_t *>(depth), n, 1, n, frames, med, a, st);
+    if (a.dry || rc) return rc;
+    KPX_ARENA_CHECK(a);
+    DepthPred pred{ depth, xy, rgb, med, n, flags, gate };
+    DepthEmit emit{ depth, xy, rgb, n, pts, col, idx };
+    return compact(pred, emit, n, frames, counts, d_count, st);
+}
+KPX_EXPORT size_t kpx_depth_to_cloud_workspace_bytes(int64_t n_px, int32_t frames)
+{
+    Arena a(nullptr, 0);
+    depth_to_cloud_impl(nullptr, nullptr, nullptr, n_px, frames < 1 ? 1 : frames, KPX_COMPACT_DEPTH_GATE, 0, nullptr,
+                        nullptr, nullptr, nullptr, a, nullptr);
+    return a.off;
+}
+KPX_EXPORT int kpx_depth_to_cloud(const uint16_t *depth, const float *xy, const uint8_t *rgb, int64_t n_px,
+                                  int32_t frames, int32_t flags, double gate, float *pts, float *col, int32_t *idx,
+                                  int32_t *d_count, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n_px > 0 && frames > 0, "kpx_depth_to_cloud: bad size");
+    KPX_REQUIRE(depth && xy && pts && d_count && ws, "kpx_depth_to_cloud: null pointer");
+    KPX_REQUIRE(n_px < ((int64_t)1 << 31), "kpx_depth_to_cloud: frame too large");
+    Arena a(ws, ws_bytes);
+    return depth_to_cloud_impl(depth, xy, rgb, n_px, frames, flags, gate, pts, col, idx, d_count, a, (hipStream_t)stream);
+}

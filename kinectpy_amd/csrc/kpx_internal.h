@@ -1,0 +1,31 @@
+// kpx_internal.h -- functions shared between the translation units of libkinectpx.so.
+#pragma once
+#include "kpx_common.h"
+
+namespace kpx {
+
+// Per-axis min / max of a float32 (n,3) cloud as doubles: d_bbox6 = (minx,miny,minz,maxx,maxy,maxz).
+// Exact (min/max need no rounding).  Scratch: bbox_partials_count(n) * 6 doubles.
+constexpr int kBboxBlocks = 1024;
+int bbox_f32(const float *pts, int64_t n, double *d_bbox6, double *ws_partials, hipStream_t st);
+
+// ---- uniform grid over a cloud (exact neighbour searches: SOR, normals) --------------------------
+struct GridParams {
+    double org[3];
+    double h;
+    int32_t dim[3];
+    int32_t ncell;
+};
+constexpr int32_t kGridMaxCells = 1 << 22;
+
+struct Grid {
+    GridParams *params;      // device
+    uint32_t *cell_start;    // device [kGridMaxCells + 1]
+    float *sorted_pts;       // device [n*3] points in cell order
+    int32_t *sorted_idx;     // device [n] original index of each sorted point
+};
+// Carves a Grid out of the arena (dry arenas only count bytes) and, when real, builds it on `st`.
+// target_per_cell: desired mean occupancy of non-empty cells.
+int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Grid *g, hipStream_t st);
+
+}  // namespace kpx

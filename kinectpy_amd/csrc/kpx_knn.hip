@@ -1,0 +1,406 @@
+// kpx_knn.hip -- exact neighbour searches on a uniform grid:
+//   a8  PointCloud.remove_statistical_outlier (filtering.py:24, floor_removal.py:73, utils/processing.py:309)
+//       estimate_normals(KDTreeSearchParamHybrid) (preprocessing/registration.py:9-13)
+// One thread per query walks Chebyshev rings of cells around its own cell and keeps the k smallest
+// squared distances in a per-thread max-heap held in LDS (layout [slot][thread]: bank-conflict free
+// when the threads of a wave touch the same slot).  The search is exact: a ring loop stops only once
+// the k-th best distance is below the distance to the boundary of the covered cube.
+// Squared distance (contract AC3): d2 = fma(dz,dz, fma(dy,dy, dx*dx)), differences in fp64.
+#include <hipcub/hipcub.hpp>
+
+#include "kpx_internal.h"
+#include "kpx_linalg.h"
+
+namespace kpx {
+
+// ---- grid construction ------------------------------------------------------------------------------
+__global__ void grid_params_kernel(const double *__restrict__ bbox, int64_t n, double target, GridParams *gp)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    double ext[3], vol = 1.0;
+    for (int a = 0; a < 3; ++a) { ext[a] = bbox[3 + a] - bbox[a]; if (!(ext[a] > 1e-9)) ext[a] = 1e-9; vol *= ext[a]; }
+    double nn = (double)(n > 0 ? n : 1);
+    double h3 = cbrt(vol * target / nn);
+    double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
+    double h2 = sqrt(area * target / nn) * 0.5;           // clouds are surfaces: size cells by area too
+    double h = h3 > h2 ? h3 : h2;
+    if (!(h > 0.0)) h = 1.0;
+    int dim[3];
+    for (;;) {
+        double tot = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            double d = floor(ext[a] / h) + 1.0;
+            if (d > 1000000.0) d = 1000000.0;
+            dim[a] = (int)d; tot *= d;
+        }
+        if (tot <= (double)kGridMaxCells) break;
+        h *= 1.26;
+    }
+    gp->h = h;
+    for (int a = 0; a < 3; ++a) { gp->org[a] = bbox[a]; gp->dim[a] = dim[a]; }
+    gp->ncell = dim[0] * dim[1] * dim[2];
+}
+
+__device__ __forceinline__ int cell_coord(double v, double org, double h, int dim)
+{
+    int c = (int)floor((v - org) / h);
+    return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+__global__ __launch_bounds__(256) void grid_cell_kernel(const float *__restrict__ pts, int64_t n, const GridParams *__restrict__ gp,
+                                                        uint32_t *__restrict__ keys, int32_t *__restrict__ vals,
+                                                        uint32_t *__restrict__ cell_count)
+{
+    const GridParams g = *gp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int cx = cell_coord(pts[3 * i], g.org[0], g.h, g.dim[0]);
+        int cy = cell_coord(pts[3 * i + 1], g.org[1], g.h, g.dim[1]);
+        int cz = cell_coord(pts[3 * i + 2], g.org[2], g.h, g.dim[2]);
+        uint32_t cell = (uint32_t)((cx * g.dim[1] + cy) * g.dim[2] + cz);
+        keys[i] = cell;
+        vals[i] = (int32_t)i;
+        atomicAdd(&cell_count[cell], 1u);
+    }
+}
+__global__ __launch_bounds__(256) void grid_gather_kernel(const float *__restrict__ pts, int64_t n, const int32_t *__restrict__ order,
+                                                          float *__restrict__ sorted_pts)
+{
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = order[s];
+        sorted_pts[3 * s] = pts[3 * i]; sorted_pts[3 * s + 1] = pts[3 * i + 1]; sorted_pts[3 * s + 2] = pts[3 * i + 2];
+    }
+}
+
+int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Grid *g, hipStream_t st)
+{
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    g->params = a.get<GridParams>(1);
+    uint32_t *count = a.get<uint32_t>((size_t)kGridMaxCells + 1);
+    g->cell_start = a.get<uint32_t>((size_t)kGridMaxCells + 1);
+    g->sorted_pts = a.get<float>(nn * 3);
+    g->sorted_idx = a.get<int32_t>(nn);
+    uint32_t *keys_in = a.get<uint32_t>(nn), *keys_out = a.get<uint32_t>(nn);
+    int32_t *vals_in = a.get<int32_t>(nn);
+    double *part = a.get<double>((size_t)kBboxBlocks * 6 + 8);
+    size_t sort_bytes = 0, scan_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, (int)nn, 0, 22, st);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, count, g->cell_start, kGridMaxCells + 1, st);
+    char *tmp = a.get<char>(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
+    if (a.dry) return KPX_OK;
+    KPX_ARENA_CHECK(a);
+    double *bbox = part + (size_t)kBboxBlocks * 6;
+    int rc = bbox_f32(pts, n, bbox, part, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(1), 0, st, bbox, n, target_per_cell, g->params);
+    KPX_HIP(hipMemsetAsync(count, 0, ((size_t)kGridMaxCells + 1) * sizeof(uint32_t), st));
+    int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->params, keys_in, vals_in, count);
+    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, (int)n, 0, 22, st));
+    KPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, count, g->cell_start, kGridMaxCells + 1, st));
+    hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->sorted_idx, g->sorted_pts);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+// ---- per-thread max-heaps in LDS ---------------------------------------------------------------------
+// values only (SOR): slot e of this thread lives at h[e * stride]
+struct HeapD {
+    double *h; int stride, k, sz;
+    __device__ bool full() const { return sz == k; }
+    __device__ double worst() const { return h[0]; }
+    __device__ void push(double d, int)
+    {
+        if (sz < k) {
+            int c = sz++;
+            while (c > 0) {
+                int p = (c - 1) >> 1;
+                double hp = h[p * stride];
+                if (hp < d) { h[c * stride] = hp; c = p; } else break;
+            }
+            h[c * stride] = d;
+        } else if (d < h[0]) {
+            int c = 0;
+            for (;;) {
+                int l = 2 * c + 1, r = l + 1;
+                if (l >= k) break;
+                double hl = h[l * stride];
+                int b = l; double hb = hl;
+                if (r < k) { double hr = h[r * stride]; if (hr > hl) { b = r; hb = hr; } }
+                if (hb > d) { h[c * stride] = hb; c = b; } else break;
+            }
+            h[c * stride] = d;
+        }
+    }
+};
+// (d2, idx) pairs ordered lexicographically (normals: the neighbour identities matter)
+struct HeapDI {
+    double *h; int32_t *ix; int stride, k, sz;
+    __device__ bool full() const { return sz == k; }
+    __device__ double worst() const { return h[0]; }
+    static __device__ bool less(double a, int32_t ai, double b, int32_t bi) { return a < b || (a == b && ai < bi); }
+    __device__ void push(double d, int j)
+    {
+        if (sz < k) {
+            int c = sz++;
+            while (c > 0) {
+                int p = (c - 1) >> 1;
+                double hp = h[p * stride]; int32_t ip = ix[p * stride];
+                if (less(hp, ip, d, j)) { h[c * stride] = hp; ix[c * stride] = ip; c = p; } else break;
+            }
+            h[c * stride] = d; ix[c * stride] = j;
+        } else if (less(d, j, h[0], ix[0])) {
+            int c = 0;
+            for (;;) {
+                int l = 2 * c + 1, r = l + 1;
+                if (l >= k) break;
+                int b = l; double hb = h[l * stride]; int32_t ib = ix[l * stride];
+                if (r < k) { double hr = h[r * stride]; int32_t ir = ix[r * stride]; if (less(hb, ib, hr, ir)) { b = r; hb = hr; ib = ir; } }
+                if (less(d, j, hb, ib)) { h[c * stride] = hb; ix[c * stride] = ib; c = b; } else break;
+            }
+            h[c * stride] = d; ix[c * stride] = j;
+        }
+    }
+};
+
+// Ring walk.  r2max < 0: plain kNN; otherwise only candidates with d2 < r2max ([O3D] SearchHybrid).
+template <class Heap>
+__device__ __forceinline__ void grid_knn_scan(const GridParams &g, const uint32_t *__restrict__ cell_start,
+                                              const float *__restrict__ spts, const int32_t *__restrict__ sidx, double qx,
+                                              double qy, double qz, double r2max, Heap &heap)
+{
+    const double q[3] = { qx, qy, qz };
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = cell_coord(q[a], g.org[a], g.h, g.dim[a]);
+    int maxr = g.dim[0] > g.dim[1] ? g.dim[0] : g.dim[1];
+    if (g.dim[2] > maxr) maxr = g.dim[2];
+    for (int r = 0; r <= maxr; ++r) {
+        if (r > 0) {
+            double dcov = INFINITY;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double lo = g.org[a] + (double)(c[a] - (r - 1)) * g.h;
+                double hi = g.org[a] + (double)(c[a] + r) * g.h;
+                double dl = (c[a] - (r - 1) <= 0) ? INFINITY : q[a] - lo;
+                double dh = (c[a] + r >= g.dim[a]) ? INFINITY : hi - q[a];
+                dcov = fmin(dcov, fmin(dl, dh));
+            }
+            if (dcov == INFINITY) break;
+            if (dcov < 0.0) dcov = 0.0;
+            double cov2 = dcov * dcov * (1.0 - 1e-12);
+            if (heap.full() && heap.worst() < cov2) break;
+            if (r2max >= 0.0 && cov2 >= r2max) break;
+        }
+        const int x0 = c[0] - r, x1 = c[0] + r, y0 = c[1] - r, y1 = c[1] + r, z0 = c[2] - r, z1 = c[2] + r;
+        const int xa = x0 < 0 ? 0 : x0, xb = x1 >= g.dim[0] ? g.dim[0] - 1 : x1;
+        const int ya = y0 < 0 ? 0 : y0, yb = y1 >= g.dim[1] ? g.dim[1] - 1 : y1;
+        const int za = z0 < 0 ? 0 : z0, zb = z1 >= g.dim[2] ? g.dim[2] - 1 : z1;
+        for (int x = xa; x <= xb; ++x)
+            for (int y = ya; y <= yb; ++y) {
+                const bool shell_xy = (x == x0) | (x == x1) | (y == y0) | (y == y1);
+                const int64_t col = ((int64_t)x * g.dim[1] + y) * g.dim[2];
+                // cells of one (x,y) column are contiguous in the sorted order
+                for (int part = 0; part < 2; ++part) {
+                    int zs, ze;
+                    if (shell_xy) { if (part) break; zs = za; ze = zb; }
+                    else {
+                        if (part == 0) { if (z0 < 0) continue; zs = ze = z0; }
+                        else { if (z1 >= g.dim[2] || r == 0) continue; zs = ze = z1; }
+                    }
+                    uint32_t s0 = cell_start[col + zs], s1 = cell_start[col + ze + 1];
+                    for (uint32_t s = s0; s < s1; ++s) {
+                        double dx = qx - (double)spts[3 * s], dy = qy - (double)spts[3 * s + 1], dz = qz - (double)spts[3 * s + 2];
+                        double d = fma(dz, dz, fma(dy, dy, dx * dx));
+                        if (r2max >= 0.0 && !(d < r2max)) continue;
+                        heap.push(d, sidx ? sidx[s] : 0);
+                    }
+                }
+            }
+    }
+}
+
+// ---- a8 SOR ------------------------------------------------------------------------------------------
+__global__ void sor_knn_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
+                               const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t n, int k,
+                               double *__restrict__ avg)
+{
+    extern __shared__ __align__(16) double lds[];
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const GridParams g = *gp;
+    HeapD heap{ lds + threadIdx.x, (int)blockDim.x, k, 0 };
+    grid_knn_scan(g, cell_start, spts, (const int32_t *)nullptr, (double)spts[3 * s], (double)spts[3 * s + 1],
+                  (double)spts[3 * s + 2], -1.0, heap);
+    double sum = 0.0;
+    for (int e = 0; e < heap.sz; ++e) sum += sqrt(heap.h[e * heap.stride]);
+    avg[sidx[s]] = heap.sz > 0 ? sum / (double)heap.sz : -1.0;
+}
+
+// mean / std exactly as [O3D]: mean = sum(avg>0)/n ; std = sqrt(sum_{avg>0}(avg-mean)^2/(n-1))
+__global__ __launch_bounds__(256) void sor_sum_kernel(const double *__restrict__ avg, int64_t n, const double *__restrict__ stats,
+                                                      int pass, double *__restrict__ part)
+{
+    __shared__ double sh[4];
+    double mean = pass ? stats[0] : 0.0, acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = avg[i];
+        if (v > 0.0) acc += pass ? (v - mean) * (v - mean) : v;
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ void sor_final_kernel(const double *__restrict__ part, int nb, int64_t n, double std_ratio, int pass, double *stats)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[b];
+    if (pass == 0) stats[0] = s / (double)n;
+    else { stats[1] = sqrt(s / (double)(n - 1)); stats[2] = stats[0] + std_ratio * stats[1]; }
+}
+struct SorPred {
+    const double *avg; const double *stats;
+    __device__ bool operator()(int64_t i, int) const { double v = avg[i]; return v > 0.0 && v < stats[2]; }
+};
+struct IdxEmit {
+    int32_t *idx;
+    __device__ void operator()(int64_t i, int, int32_t dst) const { idx[dst] = (int32_t)i; }
+};
+
+static int sor_block_threads(int k)
+{
+    // k * threads * 8 B of LDS per block; keep >= 2 blocks per CU where k allows
+    if (k <= 32) return 256;
+    if (k <= 80) return 128;
+    return 64;
+}
+
+static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_t *keep_idx, int32_t *d_count, double *d_stats,
+                    double *d_avg, Arena &a, hipStream_t st)
+{
+    Grid g;
+    int kk = (int64_t)k < n ? k : (int)(n > 0 ? n : 1);
+    int rc = grid_build(pts, n, (double)kk * 0.5 + 1.0, a, &g, st);
+    if (rc) return rc;
+    double *avg = a.get<double>((size_t)(n > 0 ? n : 1));
+    double *part = a.get<double>(1024);
+    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    if (a.dry) return KPX_OK;
+    KPX_ARENA_CHECK(a);
+    if (d_avg) avg = d_avg;
+    const int threads = sor_block_threads(kk);
+    const size_t lds = (size_t)kk * threads * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KPX_HIP(hipFuncSetAttribute((const void *)sor_knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sor_knn_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g.params, g.cell_start,
+                       g.sorted_pts, g.sorted_idx, n, kk, avg);
+    int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(sor_sum_kernel, dim3(nb), dim3(256), 0, st, avg, n, d_stats, pass, part);
+        hipLaunchKernelGGL(sor_final_kernel, dim3(1), dim3(1), 0, st, part, nb, n, std_ratio, pass, d_stats);
+    }
+    KPX_LAUNCH_CHECK();
+    return compact(SorPred{ avg, d_stats }, IdxEmit{ keep_idx }, n, 1, counts, d_count, st);
+}
+
+// ---- estimate_normals ---------------------------------------------------------------------------------
+__global__ void normals_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
+                               const float *__restrict__ spts, const int32_t *__restrict__ sidx, const float *__restrict__ pts,
+                               int64_t n, int k, double r2, float *__restrict__ normals)
+{
+    extern __shared__ __align__(16) double lds[];
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const GridParams g = *gp;
+    int32_t *ilds = reinterpret_cast<int32_t *>(lds + (size_t)k * blockDim.x);
+    HeapDI heap{ lds + threadIdx.x, ilds + threadIdx.x, (int)blockDim.x, k, 0 };
+    grid_knn_scan(g, cell_start, spts, sidx, (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2], r2, heap);
+    const int64_t me = sidx[s];
+    double nx = 0.0, ny = 0.0, nz = 1.0;
+    if (heap.sz >= 3) {
+        double c[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int e = 0; e < heap.sz; ++e) {
+            int64_t j = heap.ix[e * heap.stride];
+            double x = pts[3 * j], y = pts[3 * j + 1], z = pts[3 * j + 2];
+            c[0] += x; c[1] += y; c[2] += z;
+            c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
+        }
+        const double m = (double)heap.sz;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) c[q] /= m;
+        double cov[6] = { c[3] - c[0] * c[0], c[4] - c[0] * c[1], c[5] - c[0] * c[2],
+                          c[6] - c[1] * c[1], c[7] - c[1] * c[2], c[8] - c[2] * c[2] };
+        double w[3], V[9];
+        sym3_eigen(cov, w, V);
+        nx = V[0]; ny = V[3]; nz = V[6];                       // eigenvector of the smallest eigenvalue
+        double nn = sqrt(nx * nx + ny * ny + nz * nz);
+        if (nn > 0.0) { nx /= nn; ny /= nn; nz /= nn; } else { nx = 0.0; ny = 0.0; nz = 1.0; }
+    }
+    normals[3 * me] = (float)nx; normals[3 * me + 1] = (float)ny; normals[3 * me + 2] = (float)nz;
+}
+
+static int normals_impl(const float *pts, int64_t n, double radius, int max_nn, float *normals, Arena &a, hipStream_t st)
+{
+    Grid g;
+    int kk = (int64_t)max_nn < n ? max_nn : (int)(n > 0 ? n : 1);
+    int rc = grid_build(pts, n, 8.0, a, &g, st);
+    if (rc) return rc;
+    if (a.dry) return KPX_OK;
+    KPX_ARENA_CHECK(a);
+    const int threads = kk <= 48 ? 128 : 64;
+    const size_t lds = (size_t)kk * threads * (sizeof(double) + sizeof(int32_t));
+    static bool attr_set = false;
+    if (!attr_set) {
+        KPX_HIP(hipFuncSetAttribute((const void *)normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(normals_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g.params, g.cell_start,
+                       g.sorted_pts, g.sorted_idx, pts, n, kk, radius * radius, normals);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+}  // namespace kpx
+
+using namespace kpx;
+
+KPX_EXPORT size_t kpx_sor_workspace_bytes(int64_t n, int32_t nb_neighbors)
+{
+    Arena a(nullptr, 0);
+    sor_impl(nullptr, n, nb_neighbors < 1 ? 1 : nb_neighbors, 1.0, nullptr, nullptr, nullptr, nullptr, a, nullptr);
+    return a.off;
+}
+KPX_EXPORT int kpx_sor(const float *pts, int64_t n, int32_t nb_neighbors, double std_ratio, int32_t *keep_idx,
+                       int32_t *d_count, double *d_stats, double *d_avg, void *ws, size_t ws_bytes, void *stream)
+{
+    // [O3D] "Illegal input parameters, the number of neighbors and standard deviation ratio must be positive"
+    KPX_REQUIRE(nb_neighbors >= 1 && std_ratio > 0.0, "remove_statistical_outlier: nb_neighbors and std_ratio must be positive");
+    KPX_REQUIRE(nb_neighbors <= KPX_SOR_MAX_K, "remove_statistical_outlier: nb_neighbors > %d is not supported", KPX_SOR_MAX_K);
+    KPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "kpx_sor: bad size");
+    KPX_REQUIRE(d_count && d_stats && ws, "kpx_sor: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { KPX_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return KPX_OK; }
+    KPX_REQUIRE(pts && keep_idx, "kpx_sor: null pointer");
+    Arena a(ws, ws_bytes);
+    return sor_impl(pts, n, nb_neighbors, std_ratio, keep_idx, d_count, d_stats, d_avg, a, st);
+}
+
+KPX_EXPORT size_t kpx_normals_workspace_bytes(int64_t n, int32_t max_nn)
+{
+    Arena a(nullptr, 0);
+    normals_impl(nullptr, n, 1.0, max_nn < 1 ? 1 : max_nn, nullptr, a, nullptr);
+    return a.off;
+}
+KPX_EXPORT int kpx_estimate_normals(const float *pts, int64_t n, double radius, int32_t max_nn, float *normals, void *ws,
+                                    size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(radius > 0.0 && max_nn >= 1, "estimate_normals: radius and max_nn must be positive");
+    KPX_REQUIRE(max_nn <= KPX_NORMALS_MAX_NN, "estimate_normals: max_nn > %d is not supported", KPX_NORMALS_MAX_NN);
+    KPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "kpx_estimate_normals: bad size");
+    if (n == 0) return KPX_OK;
+    KPX_REQUIRE(pts && normals && ws, "kpx_estimate_normals: null pointer");
+    Arena a(ws, ws_bytes);
+    return normals_impl(pts, n, radius, max_nn, normals, a, (hipStream_t)stream);
+}

@@ -1,0 +1,274 @@
+// kpx_misc.hip -- container operations of the Open3D surface the path touches:
+// transform, select_by_index, half-space select, slab split, bounding box.  HBM-streaming.
+#include "kpx_internal.h"
+
+namespace kpx {
+
+struct Affine { double m[12]; };   // rows of [R | t]
+
+// AC1: p'_k = fma(R_k0, x, fma(R_k1, y, fma(R_k2, z, t_k)))
+__device__ __forceinline__ void xform3(const Affine &A, double x, double y, double z, double o[3])
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = fma(A.m[4 * k], x, fma(A.m[4 * k + 1], y, fma(A.m[4 * k + 2], z, A.m[4 * k + 3])));
+}
+
+// 4 points (48 B) per thread when aligned; rotate_only drops t and uses R_k2*z as the chain seed
+template <bool ROT_ONLY>
+__global__ __launch_bounds__(256) void transform_kernel(const float *__restrict__ in, int64_t n, Affine A,
+                                                        float *__restrict__ out, int vec)
+{
+    if (vec) {
+        const int64_t groups = n >> 2;
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+            const float4 *src = reinterpret_cast<const float4 *>(in + g * 12);
+            float4 a = src[0], b = src[1], c = src[2];
+            float v[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+            float r[12];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                double x = v[3 * p], y = v[3 * p + 1], z = v[3 * p + 2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double o = ROT_ONLY ? fma(A.m[4 * k], x, fma(A.m[4 * k + 1], y, A.m[4 * k + 2] * z))
+                                        : fma(A.m[4 * k], x, fma(A.m[4 * k + 1], y, fma(A.m[4 * k + 2], z, A.m[4 * k + 3])));
+                    r[3 * p + k] = (float)o;
+                }
+            }
+            float4 *dst = reinterpret_cast<float4 *>(out + g * 12);
+            dst[0] = make_float4(r[0], r[1], r[2], r[3]);
+            dst[1] = make_float4(r[4], r[5], r[6], r[7]);
+            dst[2] = make_float4(r[8], r[9], r[10], r[11]);
+        }
+    }
+    const int64_t first = vec ? (n & ~(int64_t)3) : 0;
+    for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double o = ROT_ONLY ? fma(A.m[4 * k], x, fma(A.m[4 * k + 1], y, A.m[4 * k + 2] * z))
+                                : fma(A.m[4 * k], x, fma(A.m[4 * k + 1], y, fma(A.m[4 * k + 2], z, A.m[4 * k + 3])));
+            out[3 * i + k] = (float)o;
+        }
+    }
+}
+
+// out = x @ A + t on f64 rows of 3 (align_skeletons): o_c = (x0*A0c + x1*A1c) + x2*A2c, then + t_c
+__global__ __launch_bounds__(256) void joints_affine_kernel(const double *__restrict__ x, int64_t rows, Affine A,
+                                                            double *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        double a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[3 * i + k] = ((a * A.m[k] + b * A.m[3 + k]) + c * A.m[6 + k]) + A.m[9 + k];
+    }
+}
+
+// ---- bounding box --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restrict__ pts, int64_t n, double *__restrict__ part)
+{
+    __shared__ float sh[6][4];
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { float v = pts[3 * i + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+    if (lane_id() == 0)
+        for (int a = 0; a < 3; ++a) { sh[a][wave_id()] = mn[a]; sh[3 + a][wave_id()] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[threadIdx.x][w]) : fmaxf(v, sh[threadIdx.x][w]);
+        part[(int64_t)blockIdx.x * 6 + threadIdx.x] = (double)v;
+    }
+}
+__global__ __launch_bounds__(64) void bbox_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ bbox)
+{
+    if (threadIdx.x < 6) {
+        double v = part[threadIdx.x];
+        for (int b = 1; b < nb; ++b) { double t = part[(int64_t)b * 6 + threadIdx.x]; v = threadIdx.x < 3 ? fmin(v, t) : fmax(v, t); }
+        bbox[threadIdx.x] = v;
+    }
+}
+int bbox_f32(const float *pts, int64_t n, double *d_bbox6, double *ws_partials, hipStream_t st)
+{
+    int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > kBboxBlocks ? kBboxBlocks : cdiv(n, 256 * 8)));
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, st, pts, n, ws_partials);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, ws_partials, nb, d_bbox6);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+// ---- select_by_index -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather3_kernel(const float *__restrict__ a0, const float *__restrict__ a1,
+                                                      const float *__restrict__ a2, const int32_t *__restrict__ idx,
+                                                      int64_t n_idx, float *__restrict__ o0, float *__restrict__ o1,
+                                                      float *__restrict__ o2)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_idx; k += (int64_t)gridDim.x * blockDim.x) {
+        int64_t s = idx[k];
+        if (a0) { o0[3 * k] = a0[3 * s]; o0[3 * k + 1] = a0[3 * s + 1]; o0[3 * k + 2] = a0[3 * s + 2]; }
+        if (a1) { o1[3 * k] = a1[3 * s]; o1[3 * k + 1] = a1[3 * s + 1]; o1[3 * k + 2] = a1[3 * s + 2]; }
+        if (a2) { o2[3 * k] = a2[3 * s]; o2[3 * k + 1] = a2[3 * s + 1]; o2[3 * k + 2] = a2[3 * s + 2]; }
+    }
+}
+__global__ __launch_bounds__(256) void mark_kernel(const int32_t *__restrict__ idx, int64_t n_idx, int64_t n, uint8_t *__restrict__ flag)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_idx; k += (int64_t)gridDim.x * blockDim.x) {
+        int64_t s = idx[k];
+        if (s >= 0 && s < n) flag[s] = 1;
+    }
+}
+struct UnmarkedPred {
+    const uint8_t *flag;
+    __device__ bool operator()(int64_t i, int) const { return flag[i] == 0; }
+};
+struct Gather3Emit {
+    const float *a0, *a1, *a2; float *o0, *o1, *o2;
+    __device__ void operator()(int64_t i, int, int32_t dst) const
+    {
+        int64_t d = dst;
+        if (a0) { o0[3 * d] = a0[3 * i]; o0[3 * d + 1] = a0[3 * i + 1]; o0[3 * d + 2] = a0[3 * i + 2]; }
+        if (a1) { o1[3 * d] = a1[3 * i]; o1[3 * d + 1] = a1[3 * i + 1]; o1[3 * d + 2] = a1[3 * i + 2]; }
+        if (a2) { o2[3 * d] = a2[3 * i]; o2[3 * d + 1] = a2[3 * i + 1]; o2[3 * d + 2] = a2[3 * i + 2]; }
+    }
+};
+
+// ---- half-space / slab ------------------------------------------------------------------------------
+struct HalfspacePred {
+    const float *pts; double a, b, c, d;
+    __device__ bool operator()(int64_t i, int) const
+    {
+        double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        double v = ((a * x + b * y) + c * z) + d;     // floor_removal.py:43, left to right
+        return !(v >= 0.0);
+    }
+};
+struct IndexEmit {
+    int32_t *idx;
+    __device__ void operator()(int64_t i, int, int32_t dst) const { idx[dst] = (int32_t)i; }
+};
+struct SlabPred {
+    const float *pts; const double *bbox; double slab; int lower;
+    __device__ bool operator()(int64_t i, int) const
+    {
+        double cut = bbox[4] - slab;                  // y.max() - 200 (floor_removal.py:65-66)
+        double y = pts[3 * i + 1];
+        return lower ? (y >= cut) : (y < cut);
+    }
+};
+
+static Affine affine_from(const double *T)
+{
+    Affine A;
+    for (int k = 0; k < 3; ++k) for (int c = 0; c < 4; ++c) A.m[4 * k + c] = T[4 * k + c];
+    return A;
+}
+static int grid_for(int64_t work, int per_block, int cap = 4096)
+{
+    int64_t b = cdiv(work > 0 ? work : 1, per_block);
+    return (int)(b > cap ? cap : b);
+}
+
+}  // namespace kpx
+
+using namespace kpx;
+
+KPX_EXPORT int kpx_transform(const float *pts, int64_t n, const double *h_T, float *out, void *stream)
+{
+    KPX_REQUIRE(n >= 0, "kpx_transform: negative size");
+    if (n == 0) return KPX_OK;
+    KPX_REQUIRE(pts && h_T && out, "kpx_transform: null pointer");
+    int vec = (((uintptr_t)pts | (uintptr_t)out) % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(transform_kernel<false>, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, pts, n,
+                       affine_from(h_T), out, vec);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+KPX_EXPORT int kpx_rotate(const float *nrm, int64_t n, const double *h_T, float *out, void *stream)
+{
+    KPX_REQUIRE(n >= 0, "kpx_rotate: negative size");
+    if (n == 0) return KPX_OK;
+    KPX_REQUIRE(nrm && h_T && out, "kpx_rotate: null pointer");
+    int vec = (((uintptr_t)nrm | (uintptr_t)out) % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(transform_kernel<true>, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, nrm, n,
+                       affine_from(h_T), out, vec);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+KPX_EXPORT int kpx_joints_affine_f64(const double *x, int64_t rows, const double *h_A, const double *h_t, double *out,
+                                     void *stream)
+{
+    KPX_REQUIRE(rows >= 0, "kpx_joints_affine_f64: negative size");
+    if (rows == 0) return KPX_OK;
+    KPX_REQUIRE(x && h_A && h_t && out, "kpx_joints_affine_f64: null pointer");
+    Affine A;
+    for (int k = 0; k < 9; ++k) A.m[k] = h_A[k];
+    for (int k = 0; k < 3; ++k) A.m[9 + k] = h_t[k];
+    hipLaunchKernelGGL(joints_affine_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, A, out);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+KPX_EXPORT size_t kpx_select_workspace_bytes(int64_t n)
+{
+    Arena a(nullptr, 0);
+    a.get<uint8_t>((size_t)(n > 0 ? n : 1));
+    a.get<int32_t>((size_t)compact_tiles(n));
+    a.get<double>((size_t)kBboxBlocks * 6 + 8);
+    return a.off;
+}
+KPX_EXPORT int kpx_select_by_index(const float *a0, const float *a1, const float *a2, int64_t n, const int32_t *idx,
+                                   int64_t n_idx, int32_t invert, float *o0, float *o1, float *o2, int32_t *d_count,
+                                   void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n >= 0 && n_idx >= 0, "kpx_select_by_index: negative size");
+    KPX_REQUIRE(n_idx == 0 || idx, "kpx_select_by_index: null index array");
+    hipStream_t st = (hipStream_t)stream;
+    if (!invert) {
+        if (n_idx)
+            hipLaunchKernelGGL(gather3_kernel, dim3(grid_for(n_idx, 256)), dim3(256), 0, st, a0, a1, a2, idx, n_idx, o0, o1, o2);
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
+    KPX_REQUIRE(ws && d_count, "kpx_select_by_index: invert needs workspace and d_count");
+    Arena a(ws, ws_bytes);
+    uint8_t *flag = a.get<uint8_t>((size_t)(n > 0 ? n : 1));
+    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    KPX_ARENA_CHECK(a);
+    KPX_HIP(hipMemsetAsync(flag, 0, (size_t)(n > 0 ? n : 1), st));
+    if (n_idx) hipLaunchKernelGGL(mark_kernel, dim3(grid_for(n_idx, 256)), dim3(256), 0, st, idx, n_idx, n, flag);
+    return compact(UnmarkedPred{ flag }, Gather3Emit{ a0, a1, a2, o0, o1, o2 }, n, 1, counts, d_count, st);
+}
+
+KPX_EXPORT int kpx_halfspace_select(const float *pts, int64_t n, const double *h_plane, int32_t *idx, int32_t *d_count,
+                                    void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n >= 0 && h_plane && idx && d_count && ws, "kpx_halfspace_select: bad arguments");
+    Arena a(ws, ws_bytes);
+    a.get<uint8_t>((size_t)(n > 0 ? n : 1));
+    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    KPX_ARENA_CHECK(a);
+    return compact(HalfspacePred{ pts, h_plane[0], h_plane[1], h_plane[2], h_plane[3] }, IndexEmit{ idx }, n, 1, counts,
+                   d_count, (hipStream_t)stream);
+}
+
+KPX_EXPORT int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t *lower_idx, int32_t *d_lower,
+                              int32_t *upper_idx, int32_t *d_upper, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n > 0 && pts && lower_idx && upper_idx && d_lower && d_upper && ws, "kpx_slab_split: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    a.get<uint8_t>((size_t)n);
+    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    double *part = a.get<double>((size_t)kBboxBlocks * 6 + 8);
+    KPX_ARENA_CHECK(a);
+    double *bbox = part + (size_t)kBboxBlocks * 6;
+    int rc = bbox_f32(pts, n, bbox, part, st);
+    if (rc) return rc;
+    rc = compact(SlabPred{ pts, bbox, slab, 1 }, IndexEmit{ lower_idx }, n, 1, counts, d_lower, st);
+    if (rc) return rc;
+    return compact(SlabPred{ pts, bbox, slab, 0 }, IndexEmit{ upper_idx }, n, 1, counts, d_upper, st);
+}

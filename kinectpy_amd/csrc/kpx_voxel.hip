@@ -1,0 +1,129 @@
+// kpx_voxel.hip -- a7: PointCloud.voxel_down_sample (preprocessing/filtering.py:23,
+// preprocessing/registration.py:8,100,101).
+//   origin = min_bound - v/2 ; index = floor((p - origin)/v)   (fp64, identical to the oracle)
+//   63-bit key (21 bits per axis), stable radix sort of (key, point id), one thread per voxel sums
+//   its points in ascending original index (fp64, sequential) -> bit-exact means.
+// Output order: ascending (ix,iy,iz).
+#include <hipcub/hipcub.hpp>
+
+#include "kpx_internal.h"
+
+namespace kpx {
+
+__global__ __launch_bounds__(256) void voxel_key_kernel(const float *__restrict__ pts, int64_t n, const double *__restrict__ bbox,
+                                                        double voxel, uint64_t *__restrict__ keys, int32_t *__restrict__ vals,
+                                                        int32_t *__restrict__ err)
+{
+    const double ox = bbox[0] - voxel * 0.5, oy = bbox[1] - voxel * 0.5, oz = bbox[2] - voxel * 0.5;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double fx = floor(((double)pts[3 * i] - ox) / voxel);
+        double fy = floor(((double)pts[3 * i + 1] - oy) / voxel);
+        double fz = floor(((double)pts[3 * i + 2] - oz) / voxel);
+        bool bad = !(fx >= 0.0) || !(fy >= 0.0) || !(fz >= 0.0) || fx >= 2097152.0 || fy >= 2097152.0 || fz >= 2097152.0;
+        if (bad) { *err = 1; fx = fy = fz = 0.0; }
+        keys[i] = ((uint64_t)fx << 42) | ((uint64_t)fy << 21) | (uint64_t)fz;
+        vals[i] = (int32_t)i;
+    }
+}
+
+struct HeadPred {
+    const uint64_t *keys;
+    __device__ bool operator()(int64_t s, int) const { return s == 0 || keys[s] != keys[s - 1]; }
+};
+struct HeadEmit {
+    int32_t *seg_start;
+    __device__ void operator()(int64_t s, int, int32_t dst) const { seg_start[dst] = (int32_t)s; }
+};
+
+__global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict__ pts, const float *__restrict__ col,
+                                                         const float *__restrict__ nrm, int64_t n,
+                                                         const int32_t *__restrict__ vals, const int32_t *__restrict__ seg_start,
+                                                         int32_t *__restrict__ d_count, const int32_t *__restrict__ err,
+                                                         float *__restrict__ opts, float *__restrict__ ocol, float *__restrict__ onrm)
+{
+    const int32_t m_total = *d_count;
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < m_total; m += (int64_t)gridDim.x * blockDim.x) {
+        int64_t s0 = seg_start[m], s1 = (m + 1 < m_total) ? seg_start[m + 1] : n;
+        double sp[3] = { 0, 0, 0 }, sc[3] = { 0, 0, 0 }, sn[3] = { 0, 0, 0 };
+        for (int64_t s = s0; s < s1; ++s) {
+            int64_t p = vals[s];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                sp[a] += (double)pts[3 * p + a];
+                if (col) sc[a] += (double)col[3 * p + a];
+                if (nrm) sn[a] += (double)nrm[3 * p + a];
+            }
+        }
+        double c = (double)(s1 - s0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            opts[3 * m + a] = (float)(sp[a] / c);
+            if (col && ocol) ocol[3 * m + a] = (float)(sc[a] / c);
+        }
+        if (nrm && onrm) {
+            double nn = sqrt(fma(sn[2], sn[2], fma(sn[1], sn[1], sn[0] * sn[0])));
+#pragma unroll
+            for (int a = 0; a < 3; ++a) onrm[3 * m + a] = (float)(nn > 0 ? sn[a] / nn : sn[a]);
+        }
+    }
+}
+// index overflow is reported through the count word (host sees KPX_ERR_RANGE when it reads it)
+__global__ void voxel_flag_error_kernel(const int32_t *err, int32_t *d_count)
+{
+    if (*err) *d_count = KPX_ERR_RANGE;
+}
+
+static int voxel_impl(const float *pts, const float *col, const float *nrm, int64_t n, double voxel, float *opts,
+                      float *ocol, float *onrm, int32_t *d_count, Arena &a, hipStream_t st)
+{
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    uint64_t *keys_in = a.get<uint64_t>(nn), *keys_out = a.get<uint64_t>(nn);
+    int32_t *vals_in = a.get<int32_t>(nn), *vals_out = a.get<int32_t>(nn);
+    int32_t *seg_start = a.get<int32_t>(nn);
+    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    double *part = a.get<double>((size_t)kBboxBlocks * 6 + 8);
+    int32_t *err = a.get<int32_t>(1);
+    size_t sort_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, vals_out, (int)nn, 0, 63, st);
+    char *sort_tmp = a.get<char>(sort_bytes);
+    if (a.dry) return KPX_OK;
+    KPX_ARENA_CHECK(a);
+    double *bbox = part + (size_t)kBboxBlocks * 6;
+    int rc = bbox_f32(pts, n, bbox, part, st);
+    if (rc) return rc;
+    KPX_HIP(hipMemsetAsync(err, 0, sizeof(int32_t), st));
+    int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
+    hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(256), 0, st, pts, n, bbox, voxel, keys_in, vals_in, err);
+    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
+    rc = compact(HeadPred{ keys_out }, HeadEmit{ seg_start }, n, 1, counts, d_count, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(voxel_mean_kernel, dim3(nb), dim3(256), 0, st, pts, col, nrm, n, vals_out, seg_start, d_count, err, opts,
+                       ocol, onrm);
+    hipLaunchKernelGGL(voxel_flag_error_kernel, dim3(1), dim3(1), 0, st, err, d_count);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+}  // namespace kpx
+
+using namespace kpx;
+
+KPX_EXPORT size_t kpx_voxel_workspace_bytes(int64_t n)
+{
+    Arena a(nullptr, 0);
+    voxel_impl(nullptr, nullptr, nullptr, n, 1.0, nullptr, nullptr, nullptr, nullptr, a, nullptr);
+    return a.off;
+}
+KPX_EXPORT int kpx_voxel_downsample(const float *pts, const float *col, const float *nrm, int64_t n, double voxel,
+                                    float *opts, float *ocol, float *onrm, int32_t *d_count, void *ws, size_t ws_bytes,
+                                    void *stream)
+{
+    KPX_REQUIRE(voxel > 0.0, "voxel_size <= 0");                       // [O3D] raises here
+    KPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "kpx_voxel_downsample: bad size");
+    KPX_REQUIRE(d_count && ws, "kpx_voxel_downsample: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { KPX_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return KPX_OK; }
+    KPX_REQUIRE(pts && opts, "kpx_voxel_downsample: null pointer");
+    Arena a(ws, ws_bytes);
+    return voxel_impl(pts, col, nrm, n, voxel, opts, ocol, onrm, d_count, a, st);
+}

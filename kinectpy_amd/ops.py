@@ -1,0 +1,302 @@
+"""Tensor-level operators: one thin function per C-ABI entry point of libkinectpx.so.
+
+Inputs/outputs are torch-ROCm tensors (device memory containers).  Functions that produce a
+data-dependent number of rows read the device count (one host sync) and return trimmed views.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+GATE_MM = 750.0          # preprocessing/data.py:170-171
+FLAG_COLOR_MASK = 1
+FLAG_DEPTH_GATE = 2
+
+
+def _dev(x, dtype):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=L.device(), dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(L.device()).contiguous()
+
+
+def _count(t):
+    """Device count word(s) -> Python ints; negative values are kpx_status codes raised by kernels."""
+    v = t.cpu().tolist()
+    for c in v:
+        if c < 0:
+            raise L.KinectPxError("voxel_size is too small" if c == -3 else f"kpx device error {c}")
+    return v
+
+
+def _T(T):
+    T = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4))
+    return T
+
+
+# ---- extract --------------------------------------------------------------------------------------
+def unproject_u16(depth, xy_table, frames=1):
+    """a1.  depth u16 [frames*n_px], xy f32 [n_px*2] -> int16 [frames, n_px, 3]."""
+    lib = L.load()
+    depth = _dev(depth, torch.uint16).reshape(-1)
+    xy = _dev(xy_table, torch.float32).reshape(-1)
+    n_px = xy.numel() // 2
+    assert depth.numel() == frames * n_px
+    out = torch.empty((frames, n_px, 3), dtype=torch.int16, device=depth.device)
+    L.check(lib.kpx_unproject_u16(L.ptr(depth), L.ptr(xy), n_px, frames, L.ptr(out), L.stream_ptr()))
+    return out
+
+
+def median_i16(v, n, stride, frames=1):
+    lib = L.load()
+    out = torch.empty(frames, dtype=torch.float64, device=v.device)
+    ws, wsz = L.workspace(lib.kpx_median_workspace_bytes(frames))
+    L.check(lib.kpx_median_i16(L.ptr(v), n, stride, frames, L.ptr(out), ws, wsz, L.stream_ptr()))
+    return out
+
+
+def rgbd_compact(xyz, rgb=None, frames=1, color_mask=False, depth_gate=False, gate=GATE_MM, want_idx=True):
+    """a3 (+a4).  xyz int16 [frames, n, 3]; rgb u8 [frames, n, 3] or None.
+    Returns per-frame lists (points f32 (K,3), colours f32 (K,3)|None, idx i32 (K)|None)."""
+    lib = L.load()
+    xyz = _dev(xyz, torch.int16).reshape(frames, -1, 3)
+    n = xyz.shape[1]
+    rgb_t = _dev(rgb, torch.uint8).reshape(frames, n, 3) if rgb is not None else None
+    dev = xyz.device
+    flags = (FLAG_COLOR_MASK if (color_mask and rgb is not None) else 0) | (FLAG_DEPTH_GATE if depth_gate else 0)
+    med = median_i16(xyz.reshape(-1)[2:], n, 3, frames) if depth_gate else None   # z column, frame stride 3n
+    pts = torch.empty((frames, n, 3), dtype=torch.float32, device=dev)
+    col = torch.empty((frames, n, 3), dtype=torch.float32, device=dev) if rgb_t is not None else None
+    idx = torch.empty((frames, n), dtype=torch.int32, device=dev) if want_idx else None
+    cnt = torch.empty(frames, dtype=torch.int32, device=dev)
+    ws, wsz = L.workspace(lib.kpx_compact_workspace_bytes(n, frames))
+    L.check(lib.kpx_rgbd_compact(L.ptr(xyz), L.ptr(rgb_t), n, frames, flags, L.ptr(med), float(gate), L.ptr(pts),
+                                 L.ptr(col), L.ptr(idx), L.ptr(cnt), ws, wsz, L.stream_ptr()))
+    ks = _count(cnt)
+    return [(pts[f, :k], col[f, :k] if col is not None else None, idx[f, :k] if idx is not None else None)
+            for f, k in enumerate(ks)]
+
+
+def depth_to_cloud(depth, xy_table, rgb=None, frames=1, color_mask=False, depth_gate=False, gate=GATE_MM,
+                   want_idx=False, sync=True):
+    """Fused a1+a3+a4.  Returns per-frame (points, colours|None, idx|None) or, with sync=False,
+    the padded buffers and the device count tensor."""
+    lib = L.load()
+    depth = _dev(depth, torch.uint16).reshape(frames, -1)
+    n = depth.shape[1]
+    xy = _dev(xy_table, torch.float32).reshape(-1)
+    rgb_t = _dev(rgb, torch.uint8).reshape(frames, n, 3) if rgb is not None else None
+    dev = depth.device
+    flags = (FLAG_COLOR_MASK if (color_mask and rgb is not None) else 0) | (FLAG_DEPTH_GATE if depth_gate else 0)
+    pts = torch.empty((frames, n, 3), dtype=torch.float32, device=dev)
+    col = torch.empty((frames, n, 3), dtype=torch.float32, device=dev) if rgb_t is not None else None
+    idx = torch.empty((frames, n), dtype=torch.int32, device=dev) if want_idx else None
+    cnt = torch.empty(frames, dtype=torch.int32, device=dev)
+    ws, wsz = L.workspace(lib.kpx_depth_to_cloud_workspace_bytes(n, frames))
+    L.check(lib.kpx_depth_to_cloud(L.ptr(depth), L.ptr(xy), L.ptr(rgb_t), n, frames, flags, float(gate), L.ptr(pts),
+                                   L.ptr(col), L.ptr(idx), L.ptr(cnt), ws, wsz, L.stream_ptr()))
+    if not sync:
+        return pts, col, idx, cnt
+    ks = _count(cnt)
+    return [(pts[f, :k], col[f, :k] if col is not None else None, idx[f, :k] if idx is not None else None)
+            for f, k in enumerate(ks)]
+
+
+# ---- container ops ----------------------------------------------------------------------------------
+def transform(pts, T, out=None):
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    out = torch.empty_like(pts) if out is None else out
+    T = _T(T)
+    L.check(lib.kpx_transform(L.ptr(pts), pts.shape[0], L.hptr(T), L.ptr(out), L.stream_ptr()))
+    return out
+
+
+def rotate(nrm, T, out=None):
+    lib = L.load()
+    nrm = _dev(nrm, torch.float32).reshape(-1, 3)
+    out = torch.empty_like(nrm) if out is None else out
+    T = _T(T)
+    L.check(lib.kpx_rotate(L.ptr(nrm), nrm.shape[0], L.hptr(T), L.ptr(out), L.stream_ptr()))
+    return out
+
+
+def joints_affine(x, A, t):
+    """a5: x (rows,3) f64 @ A (3,3) + t"""
+    lib = L.load()
+    x = _dev(x, torch.float64).reshape(-1, 3)
+    out = torch.empty_like(x)
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(3, 3)
+    t = np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+    L.check(lib.kpx_joints_affine_f64(L.ptr(x), x.shape[0], L.hptr(A), L.hptr(t), L.ptr(out), L.stream_ptr()))
+    return out
+
+
+def select_by_index(attrs, idx, invert=False):
+    """attrs: list of up to three (n,3) f32 tensors (None allowed).  Returns list of selected tensors."""
+    lib = L.load()
+    attrs = list(attrs) + [None] * (3 - len(attrs))
+    ref = next(a for a in attrs if a is not None)
+    n = ref.shape[0]
+    idx = _dev(idx, torch.int32).reshape(-1)
+    k = idx.numel()
+    if k and n:
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= n:
+            raise L.KinectPxError("select_by_index: index out of range")
+    m = n if invert else k
+    outs = [torch.empty((m, 3), dtype=torch.float32, device=ref.device) if a is not None else None for a in attrs]
+    cnt = torch.zeros(1, dtype=torch.int32, device=ref.device)
+    ws, wsz = L.workspace(lib.kpx_select_workspace_bytes(n))
+    L.check(lib.kpx_select_by_index(L.ptr(attrs[0]), L.ptr(attrs[1]), L.ptr(attrs[2]), n, L.ptr(idx), k, int(invert),
+                                    L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(cnt), ws, wsz,
+                                    L.stream_ptr()))
+    if invert:
+        m = _count(cnt)[0]
+        outs = [o[:m] if o is not None else None for o in outs]
+    return outs
+
+
+def halfspace_select(pts, plane):
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=pts.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=pts.device)
+    pl = np.ascontiguousarray(plane, dtype=np.float64).reshape(4)
+    ws, wsz = L.workspace(lib.kpx_select_workspace_bytes(n))
+    L.check(lib.kpx_halfspace_select(L.ptr(pts), n, L.hptr(pl), L.ptr(idx), L.ptr(cnt), ws, wsz, L.stream_ptr()))
+    return idx[:_count(cnt)[0]]
+
+
+def slab_split(pts, slab):
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    lo = torch.empty(n, dtype=torch.int32, device=pts.device)
+    up = torch.empty(n, dtype=torch.int32, device=pts.device)
+    cnt = torch.zeros(2, dtype=torch.int32, device=pts.device)
+    ws, wsz = L.workspace(lib.kpx_select_workspace_bytes(n))
+    L.check(lib.kpx_slab_split(L.ptr(pts), n, float(slab), L.ptr(lo), C.c_void_p(cnt.data_ptr()), L.ptr(up),
+                               C.c_void_p(cnt.data_ptr() + 4), ws, wsz, L.stream_ptr()))
+    c = _count(cnt)
+    return lo[:c[0]], up[:c[1]]
+
+
+# ---- filters ----------------------------------------------------------------------------------------
+def voxel_downsample(pts, voxel, col=None, nrm=None):
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    col = _dev(col, torch.float32).reshape(-1, 3) if col is not None else None
+    nrm = _dev(nrm, torch.float32).reshape(-1, 3) if nrm is not None else None
+    dev = pts.device
+    op = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
+    oc = torch.empty_like(op) if col is not None else None
+    on = torch.empty_like(op) if nrm is not None else None
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws, wsz = L.workspace(lib.kpx_voxel_workspace_bytes(n))
+    L.check(lib.kpx_voxel_downsample(L.ptr(pts), L.ptr(col), L.ptr(nrm), n, float(voxel), L.ptr(op), L.ptr(oc),
+                                     L.ptr(on), L.ptr(cnt), ws, wsz, L.stream_ptr()))
+    m = _count(cnt)[0]
+    return op[:m], (oc[:m] if oc is not None else None), (on[:m] if on is not None else None)
+
+
+def sor(pts, nb_neighbors, std_ratio, want_avg=False):
+    """a8.  Returns keep_idx i32 (K), stats f64 (3) [mean, std, thr] (device), avg f64 (N)|None."""
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    dev = pts.device
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    avg = torch.empty(max(n, 1), dtype=torch.float64, device=dev) if want_avg else None
+    ws, wsz = L.workspace(lib.kpx_sor_workspace_bytes(n, int(nb_neighbors)))
+    L.check(lib.kpx_sor(L.ptr(pts), n, int(nb_neighbors), float(std_ratio), L.ptr(idx), L.ptr(cnt), L.ptr(stats),
+                        L.ptr(avg), ws, wsz, L.stream_ptr()))
+    k = _count(cnt)[0]
+    return idx[:k], stats, (avg[:n] if avg is not None else None)
+
+
+def estimate_normals(pts, radius, max_nn):
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    ws, wsz = L.workspace(lib.kpx_normals_workspace_bytes(n, int(max_nn)))
+    L.check(lib.kpx_estimate_normals(L.ptr(pts), n, float(radius), int(max_nn), L.ptr(out), ws, wsz, L.stream_ptr()))
+    return out
+
+
+def segment_plane(pts, distance_threshold, ransac_n, num_iterations, probability=0.99999999, seed=0):
+    """a21.  Returns plane (numpy f64 (4,)), inlier idx i32 (K) device tensor."""
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    dev = pts.device
+    plane = torch.zeros(4, dtype=torch.float64, device=dev)
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws, wsz = L.workspace(lib.kpx_segment_plane_workspace_bytes(n, int(ransac_n), int(num_iterations)))
+    L.check(lib.kpx_segment_plane(L.ptr(pts), n, float(distance_threshold), int(ransac_n), int(num_iterations),
+                                  float(probability), C.c_uint64(int(seed)), L.ptr(plane), L.ptr(idx), L.ptr(cnt), ws,
+                                  wsz, L.stream_ptr()))
+    k = _count(cnt)[0]
+    return plane.cpu().numpy(), idx[:k]
+
+
+# ---- registration -----------------------------------------------------------------------------------
+def nn_search(src, tgt, T=None):
+    """One correspondence search.  Returns idx i32 (N), d2 f64 (N)."""
+    lib = L.load()
+    src = _dev(src, torch.float32).reshape(-1, 3)
+    tgt = _dev(tgt, torch.float32).reshape(-1, 3)
+    dev = src.device
+    Td = torch.as_tensor(_T(np.eye(4) if T is None else T)).to(dev)
+    n, m = src.shape[0], tgt.shape[0]
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    d2 = torch.empty(n, dtype=torch.float64, device=dev)
+    ws, wsz = L.workspace(lib.kpx_nn_workspace_bytes(n, m))
+    L.check(lib.kpx_nn_search(L.ptr(src), n, L.ptr(tgt), m, L.ptr(Td), L.ptr(idx), L.ptr(d2), ws, wsz, L.stream_ptr()))
+    return idx, d2
+
+
+def kabsch(src, tgt, corr):
+    lib = L.load()
+    src = _dev(src, torch.float32).reshape(-1, 3)
+    tgt = _dev(tgt, torch.float32).reshape(-1, 3)
+    corr = _dev(corr, torch.int32).reshape(-1, 2)
+    T = torch.zeros(16, dtype=torch.float64, device=src.device)
+    ws, wsz = L.workspace(lib.kpx_kabsch_workspace_bytes(corr.shape[0]))
+    L.check(lib.kpx_kabsch(L.ptr(src), L.ptr(tgt), L.ptr(corr), corr.shape[0], L.ptr(T), ws, wsz, L.stream_ptr()))
+    return T.cpu().numpy().reshape(4, 4)
+
+
+def icp(src, tgt, max_dist, init=None, mode="p2p", tgt_normals=None, max_iteration=30, relative_fitness=1e-6,
+        relative_rmse=1e-6, want_corr=False):
+    """registration_icp.  Returns dict(transformation, fitness, inlier_rmse, iterations, count[, idx, d2])."""
+    lib = L.load()
+    src = _dev(src, torch.float32).reshape(-1, 3)
+    tgt = _dev(tgt, torch.float32).reshape(-1, 3)
+    dev = src.device
+    n, m = src.shape[0], tgt.shape[0]
+    tn = _dev(tgt_normals, torch.float32).reshape(-1, 3) if tgt_normals is not None else None
+    md = {"p2p": 0, "p2plane": 1}[mode]
+    if md == 1 and tn is None:
+        raise L.KinectPxError("TransformationEstimationPointToPlane requires target normals")
+    res = torch.zeros(20, dtype=torch.float64, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev) if want_corr else None
+    d2 = torch.empty(n, dtype=torch.float64, device=dev) if want_corr else None
+    init = _T(np.eye(4) if init is None else init)
+    ws, wsz = L.workspace(lib.kpx_icp_workspace_bytes(n, m))
+    L.check(lib.kpx_icp(L.ptr(src), n, L.ptr(tgt), L.ptr(tn), m, float(max_dist), L.hptr(init), md, int(max_iteration),
+                        float(relative_fitness), float(relative_rmse), L.ptr(res), L.ptr(idx), L.ptr(d2), ws, wsz,
+                        L.stream_ptr()))
+    r = res.cpu().numpy()
+    out = {"transformation": r[:16].reshape(4, 4).copy(), "fitness": float(r[16]), "inlier_rmse": float(r[17]),
+           "iterations": int(r[18]), "count": int(r[19])}
+    if want_corr:
+        out["idx"], out["d2"] = idx, d2
+    return out
