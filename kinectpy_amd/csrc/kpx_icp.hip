@@ -1,0 +1,480 @@
+// kpx_icp.hip -- register stage: registration_icp (preprocessing/registration.py:78-84 point-to-plane,
+// manual_pointcloud_registration.py:90-98 point-to-point + Kabsch from picked pairs).
+//
+// Correspondence search = all-pairs nearest neighbour as an fp64 MFMA distance GEMM in the K=4 augmented
+// form (contract AC2):
+//     A[i] = (s_x, s_y, s_z, 1)            s = T . src_i       (fp64 fma chain, contract AC1)
+//     B[j] = (-2t_x, -2t_y, -2t_z, |t|^2)  |t|^2 = fma(tx,tx, fma(ty,ty, tz*tz))
+//     m_ij = A[i] . B[j] = d_ij^2 - |s_i|^2   -> argmin_j, ties to the lowest j
+// v_mfma_f64_16x16x4_f64 produces a 16x16 tile of m per instruction; the running (min, argmin) is fused
+// behind it in registers, the N x M matrix is never materialised.  Block = 4 waves x 64 rows; the B
+// stream is staged through LDS (double buffered) and shared by the 4 waves; the column range is split
+// over gridDim.y to fill the 256 CUs, a second kernel merges the splits (ascending, strict <), computes
+// the direct squared distance (AC3) of the chosen pair and accumulates the sums the update needs.
+// The whole ICP loop runs without host synchronisation: a one-thread kernel solves the 3x3 (Kabsch) or
+// 6x6 (point-to-plane) system, updates T and raises `done`; later launches see it and return.
+#include "kpx_internal.h"
+#include "kpx_linalg.h"
+
+namespace kpx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRT = 4;                       // 16-row tiles per wave (the sweep below is written for 4)
+constexpr int kWaves = 4;
+constexpr int kRowsPerBlock = kWaves * kRT * 16;   // 256
+constexpr int kCT = 32;                      // 16-column tiles per LDS stage (16 KiB)
+constexpr int kStageDoubles = kCT * 64;
+constexpr double kSentinel = 1e300;
+constexpr int kAcc = 44;                     // accumulator layout of the oracle's kpo_icp_accumulate
+
+struct IcpState {
+    double T[16];
+    double fitness, rmse;
+    double count;
+    int32_t iter, done;
+};
+
+// ---- target preparation: B tiles, element (k, j) of tile t at B[t*64 + k*16 + j] ----------------------
+__global__ __launch_bounds__(256) void nn_prep_kernel(const float *__restrict__ tgt, int64_t m, int64_t tiles_pad, double *__restrict__ B)
+{
+    const int64_t total = tiles_pad * 16;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = kSentinel;
+        if (j < m) {
+            double tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
+            b0 = -2.0 * tx; b1 = -2.0 * ty; b2 = -2.0 * tz;
+            b3 = fma(tx, tx, fma(ty, ty, tz * tz));
+        }
+        double *o = B + (j >> 4) * 64 + (j & 15);
+        o[0] = b0; o[16] = b1; o[32] = b2; o[48] = b3;
+    }
+}
+
+// ---- the MFMA nearest-neighbour sweep ------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void nn_mfma_kernel(const float *__restrict__ src, int64_t n, const double *__restrict__ B,
+                                                         int32_t tiles_per_split, const double *__restrict__ T,
+                                                         const int32_t *__restrict__ done, double *__restrict__ part_val,
+                                                         int32_t *__restrict__ part_idx)
+{
+    if (done && *done) return;
+    __shared__ __align__(16) double lds[2][kStageDoubles];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row_base = (int64_t)blockIdx.x * kRowsPerBlock + (int64_t)wave * (kRT * 16);
+    const int split = blockIdx.y;
+    const int64_t t0 = (int64_t)split * tiles_per_split;
+    const int nstages = tiles_per_split / kCT;
+
+    // A operands: lane holds component k = lane>>4 of row (lane&15) of each of its row tiles
+    const int kcomp = lane >> 4;
+    double a[kRT];
+    {
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 1.0;
+        if (kcomp < 3) { r0 = T[4 * kcomp]; r1 = T[4 * kcomp + 1]; r2 = T[4 * kcomp + 2]; r3 = T[4 * kcomp + 3]; }
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) {
+            int64_t row = row_base + rt * 16 + (lane & 15);
+            double v = 0.0;
+            if (row < n) {
+                double x = src[3 * row], y = src[3 * row + 1], z = src[3 * row + 2];
+                v = kcomp < 3 ? fma(r0, x, fma(r1, y, fma(r2, z, r3))) : 1.0;
+            }
+            a[rt] = v;
+        }
+    }
+    double best[kRT][4];
+    int32_t btile[kRT][4];
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { best[rt][r] = INFINITY; btile[rt][r] = 0; }
+
+    // B stream: global -> LDS by LDS-DMA (1 KiB per wave-instruction, 16 pieces per 16 KiB stage)
+    const double *gB = B + t0 * 64;
+    auto stage_load = [&](int stage, int buf) {
+        const double *g = gB + (int64_t)stage * kStageDoubles;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave * 4 + q;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + piece * 128 + lane * 2),
+                                             (__attribute__((address_space(3))) void *)(&lds[buf][piece * 128]), 16, 0, 0);
+        }
+    };
+    stage_load(0, 0);
+    __syncthreads();
+
+    const d4 zero = { 0.0, 0.0, 0.0, 0.0 };
+#define KPX_NN_UPDATE(ACC, RT, TG)                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
+        const bool lt = ACC[r] < best[RT][r];                                                      \
+        best[RT][r] = lt ? ACC[r] : best[RT][r];                                                   \
+        btile[RT][r] = lt ? (TG) : btile[RT][r];                                                   \
+    }
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstages) stage_load(st + 1, buf ^ 1);
+        const double *lb = lds[buf] + lane;
+        const int32_t tile0 = (int32_t)t0 + st * kCT;
+        // software pipeline: the four MFMAs of tile ct+1 are issued before the selects of tile ct
+        double b = lb[0];
+        d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b, zero, 0, 0, 0);
+        d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b, zero, 0, 0, 0);
+        d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b, zero, 0, 0, 0);
+        d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b, zero, 0, 0, 0);
+#pragma unroll 4
+        for (int ct = 0; ct < kCT; ++ct) {
+            const int32_t tg = tile0 + ct;
+            d4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+            if (ct + 1 < kCT) {
+                b = lb[(ct + 1) * 64];
+                n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b, zero, 0, 0, 0);
+                n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b, zero, 0, 0, 0);
+                n2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b, zero, 0, 0, 0);
+                n3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b, zero, 0, 0, 0);
+            }
+            KPX_NN_UPDATE(c0, 0, tg) KPX_NN_UPDATE(c1, 1, tg) KPX_NN_UPDATE(c2, 2, tg) KPX_NN_UPDATE(c3, 3, tg)
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+        __syncthreads();
+    }
+#undef KPX_NN_UPDATE
+
+    // reduce over the 16 lanes that hold the same rows (lexicographic (value, column) minimum)
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = best[rt][r];
+            int32_t c = btile[rt][r] * 16 + (lane & 15);
+#pragma unroll
+            for (int msk = 1; msk < 16; msk <<= 1) {
+                double ov = __shfl_xor(v, msk, 64);
+                int32_t oc = __shfl_xor(c, msk, 64);
+                bool take = ov < v || (ov == v && oc < c);
+                v = take ? ov : v;
+                c = take ? oc : c;
+            }
+            int64_t row = row_base + rt * 16 + (lane >> 4) + 4 * r;
+            if ((lane & 15) == 0 && row < n) {
+                part_val[(int64_t)split * n + row] = v;
+                part_idx[(int64_t)split * n + row] = c;
+            }
+        }
+}
+
+// ---- merge splits, direct distance, accumulation ---------------------------------------------------------
+// mode: -1 = correspondences only, 0 = point-to-point sums, 1 = + point-to-plane normal equations
+__global__ __launch_bounds__(256) void nn_merge_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+                                                       const float *__restrict__ tn, const double *__restrict__ T,
+                                                       const int32_t *__restrict__ done, const double *__restrict__ part_val,
+                                                       const int32_t *__restrict__ part_idx, int splits, double max_d2, int mode,
+                                                       int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
+                                                       double *__restrict__ part_acc)
+{
+    if (done && *done) return;
+    __shared__ double sh[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[kAcc];
+#pragma unroll
+    for (int q = 0; q < kAcc; ++q) acc[q] = 0.0;
+    if (i < n) {
+        double bv = part_val[i];
+        int32_t bj = part_idx[i];
+        for (int s = 1; s < splits; ++s) {
+            double v = part_val[(int64_t)s * n + i];
+            if (v < bv) { bv = v; bj = part_idx[(int64_t)s * n + i]; }
+        }
+        double x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+        double s[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] = fma(T[4 * k], x, fma(T[4 * k + 1], y, fma(T[4 * k + 2], z, T[4 * k + 3])));
+        const float *tp = tgt + 3 * (int64_t)bj;
+        double t[3] = { (double)tp[0], (double)tp[1], (double)tp[2] };
+        double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
+        double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+        if (idx_out) idx_out[i] = bj;
+        if (d2_out) d2_out[i] = d2;
+        if (mode >= 0 && d2 < max_d2) {
+            acc[0] = 1.0; acc[1] = d2;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { acc[2 + k] = s[k]; acc[5 + k] = t[k]; }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[8 + 3 * p + q] = t[p] * s[q];
+            if (mode == 1) {
+                const float *np_ = tn + 3 * (int64_t)bj;
+                double nx = np_[0], ny = np_[1], nz = np_[2];
+                double r = (s[0] - t[0]) * nx + (s[1] - t[1]) * ny + (s[2] - t[2]) * nz;
+                double J[6] = { s[1] * nz - s[2] * ny, s[2] * nx - s[0] * nz, s[0] * ny - s[1] * nx, nx, ny, nz };
+                int q = 17;
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int c = p; c < 6; ++c) acc[q++] = J[p] * J[c];
+#pragma unroll
+                for (int p = 0; p < 6; ++p) acc[38 + p] = J[p] * r;
+            }
+        }
+    }
+    if (mode < 0) return;
+    const int nacc = mode == 1 ? kAcc : 17;
+    for (int q = 0; q < nacc; ++q) {
+        double v = block_sum(acc[q], sh);
+        if (threadIdx.x == 0) part_acc[(int64_t)blockIdx.x * kAcc + q] = v;
+    }
+}
+
+// ---- update step ------------------------------------------------------------------------------------------
+__device__ void mat4_mul(const double A[16], const double B[16], double C[16])
+{
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double v = 0.0;
+            for (int k = 0; k < 4; ++k) v += A[4 * r + k] * B[4 * k + c];
+            C[4 * r + c] = v;
+        }
+}
+// Umeyama / Kabsch without scale from the sums (Eigen::umeyama, with_scaling = false)
+__device__ void update_p2p(const double *acc, double U[16])
+{
+    for (int k = 0; k < 16; ++k) U[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    double cnt = acc[0];
+    if (cnt < 1.0) return;
+    double mu_s[3], mu_t[3], S[9], R[9];
+    for (int k = 0; k < 3; ++k) { mu_s[k] = acc[2 + k] / cnt; mu_t[k] = acc[5 + k] / cnt; }
+    for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) S[3 * p + q] = acc[8 + 3 * p + q] / cnt - mu_t[p] * mu_s[q];
+    kabsch_rotation(S, R);
+    for (int p = 0; p < 3; ++p) {
+        for (int q = 0; q < 3; ++q) U[4 * p + q] = R[3 * p + q];
+        U[4 * p + 3] = mu_t[p] - (R[3 * p] * mu_s[0] + R[3 * p + 1] * mu_s[1] + R[3 * p + 2] * mu_s[2]);
+    }
+}
+// point-to-plane: (J^T J) x = -J^T r ; T = [Rz(x2) Ry(x1) Rx(x0) | x3..5]
+__device__ void update_p2plane(const double *acc, double U[16])
+{
+    for (int k = 0; k < 16; ++k) U[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (acc[0] < 1.0) return;
+    double A[36], b[6], x[6];
+    int q = 17;
+    for (int p = 0; p < 6; ++p) for (int c = p; c < 6; ++c) { A[6 * p + c] = acc[q]; A[6 * c + p] = acc[q]; ++q; }
+    for (int p = 0; p < 6; ++p) b[p] = -acc[38 + p];
+    if (!solve6_ldlt(A, b, x)) return;
+    double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+    // Rz(g) Ry(b) Rx(a)
+    U[0] = cg * cb; U[1] = cg * sb * sa - sg * ca; U[2] = cg * sb * ca + sg * sa; U[3] = x[3];
+    U[4] = sg * cb; U[5] = sg * sb * sa + cg * ca; U[6] = sg * sb * ca - cg * sa; U[7] = x[4];
+    U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
+}
+
+// one wave: lanes sum the accumulator columns over blocks (fixed order), lane 0 does the algebra.
+// k = index of the correspondence search just finished (0 = the initial one).
+__global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ part_acc, int nblocks, int64_t n, int mode, int k,
+                                                       int max_iter, double rel_fit, double rel_rmse, IcpState *st,
+                                                       double *__restrict__ result)
+{
+    if (st->done) return;
+    __shared__ double acc[kAcc];
+    const int nacc = mode == 1 ? kAcc : 17;
+    if ((int)threadIdx.x < kAcc) {
+        double s = 0.0;
+        if ((int)threadIdx.x < nacc) for (int b = 0; b < nblocks; ++b) s += part_acc[(int64_t)b * kAcc + threadIdx.x];
+        acc[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x) return;
+    double cnt = acc[0];
+    double fit = (n > 0 && cnt > 0) ? cnt / (double)n : 0.0;
+    double rmse = cnt > 0 ? sqrt(acc[1] / cnt) : 0.0;
+    bool done = false;
+    if (k >= 1 && fabs(st->fitness - fit) < rel_fit && fabs(st->rmse - rmse) < rel_rmse) done = true;
+    st->fitness = fit; st->rmse = rmse; st->count = cnt; st->iter = k;
+    if (k >= max_iter) done = true;
+    if (!done) {
+        double U[16], Tn[16];
+        if (mode == 1) update_p2plane(acc, U); else update_p2p(acc, U);
+        mat4_mul(U, st->T, Tn);
+        for (int q = 0; q < 16; ++q) st->T[q] = Tn[q];
+    }
+    if (done) st->done = 1;
+    for (int q = 0; q < 16; ++q) result[q] = st->T[q];
+    result[16] = fit; result[17] = rmse; result[18] = (double)k; result[19] = cnt;
+}
+
+__global__ void icp_init_kernel(IcpState *st, const double *__restrict__ T0)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    for (int q = 0; q < 16; ++q) st->T[q] = T0[q];
+    st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0;
+}
+
+// ---- explicit-pair Kabsch (compute_transformation with a correspondence list) ------------------------------
+__global__ __launch_bounds__(256) void pairs_acc_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
+                                                        const int32_t *__restrict__ corr, int64_t nc, double *__restrict__ part_acc)
+{
+    __shared__ double sh[4];
+    double acc[17];
+#pragma unroll
+    for (int q = 0; q < 17; ++q) acc[q] = 0.0;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+        const float *sp = src + 3 * (int64_t)corr[2 * c], *tp = tgt + 3 * (int64_t)corr[2 * c + 1];
+        double s[3] = { (double)sp[0], (double)sp[1], (double)sp[2] }, t[3] = { (double)tp[0], (double)tp[1], (double)tp[2] };
+        acc[0] += 1.0;
+        for (int k = 0; k < 3; ++k) { acc[2 + k] += s[k]; acc[5 + k] += t[k]; }
+        for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) acc[8 + 3 * p + q] += t[p] * s[q];
+    }
+    for (int q = 0; q < 17; ++q) {
+        double v = block_sum(acc[q], sh);
+        if (threadIdx.x == 0) part_acc[(int64_t)blockIdx.x * kAcc + q] = v;
+    }
+}
+__global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restrict__ part_acc, int nblocks, double *__restrict__ T)
+{
+    __shared__ double acc[17];
+    if (threadIdx.x < 17) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += part_acc[(int64_t)b * kAcc + threadIdx.x];
+        acc[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x) return;
+    double U[16];
+    update_p2p(acc, U);
+    for (int q = 0; q < 16; ++q) T[q] = U[q];
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+struct NnPlan {
+    int64_t tiles_pad;
+    int32_t tiles_per_split, splits, row_blocks;
+};
+static NnPlan nn_plan(int64_t n, int64_t m)
+{
+    NnPlan p;
+    int64_t tiles = cdiv(m > 0 ? m : 1, 16);
+    int64_t stages = cdiv(tiles, kCT);
+    p.row_blocks = (int32_t)cdiv(n > 0 ? n : 1, kRowsPerBlock);
+    int64_t want = cdiv(2048, p.row_blocks);            // aim for >= ~2048 workgroups (8 per CU)
+    if (want > stages) want = stages;
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    int64_t stages_per_split = cdiv(stages, want);
+    p.splits = (int32_t)cdiv(stages, stages_per_split);
+    p.tiles_per_split = (int32_t)(stages_per_split * kCT);
+    p.tiles_pad = (int64_t)p.splits * p.tiles_per_split;
+    return p;
+}
+
+struct NnBuffers {
+    double *B, *part_val, *part_acc;
+    int32_t *part_idx;
+    IcpState *state;
+    double *T0;
+};
+static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
+{
+    b->B = a.get<double>((size_t)p.tiles_pad * 64);
+    b->part_val = a.get<double>((size_t)p.splits * (size_t)(n > 0 ? n : 1));
+    b->part_idx = a.get<int32_t>((size_t)p.splits * (size_t)(n > 0 ? n : 1));
+    b->part_acc = a.get<double>((size_t)p.row_blocks * kAcc);
+    b->state = a.get<IcpState>(1);
+    b->T0 = a.get<double>(16);
+}
+
+static int nn_launch(const float *src, int64_t n, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b,
+                     const double *T, const int32_t *done, double max_d2, int mode, int32_t *idx, double *d2, hipStream_t st)
+{
+    hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), dim3(256), 0, st, src, n, b.B, p.tiles_per_split, T, done,
+                       b.part_val, b.part_idx);
+    hipLaunchKernelGGL(nn_merge_kernel, dim3(p.row_blocks), dim3(256), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
+                       p.splits, max_d2, mode, idx, d2, b.part_acc);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+}  // namespace kpx
+
+using namespace kpx;
+
+KPX_EXPORT size_t kpx_nn_workspace_bytes(int64_t n_src, int64_t n_tgt)
+{
+    Arena a(nullptr, 0);
+    NnBuffers b;
+    nn_carve(a, n_src, n_tgt, nn_plan(n_src, n_tgt), &b);
+    return a.off;
+}
+KPX_EXPORT int kpx_nn_search(const float *src, int64_t n_src, const float *tgt, int64_t n_tgt, const double *d_T, int32_t *idx,
+                             double *d2, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n_src >= 0 && n_tgt >= 1, "kpx_nn_search: empty target");
+    KPX_REQUIRE(n_src < ((int64_t)1 << 31) && n_tgt < ((int64_t)1 << 31) - 1024, "kpx_nn_search: cloud too large");
+    if (n_src == 0) return KPX_OK;
+    KPX_REQUIRE(src && tgt && d_T && idx && d2 && ws, "kpx_nn_search: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    NnPlan p = nn_plan(n_src, n_tgt);
+    NnBuffers b;
+    nn_carve(a, n_src, n_tgt, p, &b);
+    KPX_ARENA_CHECK(a);
+    hipLaunchKernelGGL(nn_prep_kernel, dim3((unsigned)(cdiv(p.tiles_pad * 16, 256) > 2048 ? 2048 : cdiv(p.tiles_pad * 16, 256))),
+                       dim3(256), 0, st, tgt, n_tgt, p.tiles_pad, b.B);
+    return nn_launch(src, n_src, tgt, nullptr, p, b, d_T, nullptr, 0.0, -1, idx, d2, st);
+}
+
+KPX_EXPORT size_t kpx_kabsch_workspace_bytes(int64_t n_corr)
+{
+    Arena a(nullptr, 0);
+    a.get<double>((size_t)256 * kAcc);
+    return a.off;
+}
+KPX_EXPORT int kpx_kabsch(const float *src, const float *tgt, const int32_t *corr, int64_t n_corr, double *d_T, void *ws,
+                          size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n_corr >= 0 && d_T && ws, "kpx_kabsch: bad arguments");
+    KPX_REQUIRE(n_corr == 0 || (src && tgt && corr), "kpx_kabsch: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    double *part = a.get<double>((size_t)256 * kAcc);
+    KPX_ARENA_CHECK(a);
+    int nb = (int)(cdiv(n_corr > 0 ? n_corr : 1, 256) > 256 ? 256 : cdiv(n_corr > 0 ? n_corr : 1, 256));
+    hipLaunchKernelGGL(pairs_acc_kernel, dim3(nb), dim3(256), 0, st, src, tgt, corr, n_corr, part);
+    hipLaunchKernelGGL(pairs_solve_kernel, dim3(1), dim3(64), 0, st, part, nb, d_T);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+KPX_EXPORT size_t kpx_icp_workspace_bytes(int64_t n_src, int64_t n_tgt)
+{
+    return kpx_nn_workspace_bytes(n_src, n_tgt);
+}
+KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
+                       double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness,
+                       double relative_rmse, double *d_result, int32_t *idx, double *d2, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(mode == KPX_ICP_POINT_TO_POINT || mode == KPX_ICP_POINT_TO_PLANE, "kpx_icp: unknown estimation mode");
+    KPX_REQUIRE(mode != KPX_ICP_POINT_TO_PLANE || tgt_normals,
+                "TransformationEstimationPointToPlane and TransformationEstimationColoredICP require pre-computed normal vectors for target PointCloud.");
+    KPX_REQUIRE(max_dist > 0.0, "Invalid max_correspondence_distance.");          // [O3D]
+    KPX_REQUIRE(n_src >= 1 && n_tgt >= 1 && max_iteration >= 0, "kpx_icp: empty cloud");
+    KPX_REQUIRE(n_src < ((int64_t)1 << 31) && n_tgt < ((int64_t)1 << 31) - 1024, "kpx_icp: cloud too large");
+    KPX_REQUIRE(src && tgt && h_init && d_result && ws, "kpx_icp: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    NnPlan p = nn_plan(n_src, n_tgt);
+    NnBuffers b;
+    nn_carve(a, n_src, n_tgt, p, &b);
+    KPX_ARENA_CHECK(a);
+    KPX_HIP(hipMemcpyAsync(b.T0, h_init, 16 * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, b.state, b.T0);
+    hipLaunchKernelGGL(nn_prep_kernel, dim3((unsigned)(cdiv(p.tiles_pad * 16, 256) > 2048 ? 2048 : cdiv(p.tiles_pad * 16, 256))),
+                       dim3(256), 0, st, tgt, n_tgt, p.tiles_pad, b.B);
+    const double md2 = max_dist * max_dist;
+    for (int k = 0; k <= max_iteration; ++k) {
+        int rc = nn_launch(src, n_src, tgt, tgt_normals, p, b, b.state->T, &b.state->done, md2, mode, idx, d2, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, st, b.part_acc, p.row_blocks, n_src, mode, k, max_iteration,
+                           relative_fitness, relative_rmse, b.state, d_result);
+    }
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
