@@ -26,7 +26,7 @@ constexpr int kRowsPerBlock = kWaves * kRT * 16;   // 256
 constexpr int kCT = 32;                      // 16-column tiles per LDS stage (16 KiB)
 constexpr int kStageDoubles = kCT * 64;
 constexpr double kSentinel = 1e300;
-constexpr int kAcc = 44;                     // accumulator layout of the oracle's kpo_icp_accumulate
+constexpr int kAcc = 44;                     // accumulator slots: count, sum d2, sum s, sum t, sum t s^T, J^T J (21), J^T r (6)
 
 struct IcpState {
     double T[16];

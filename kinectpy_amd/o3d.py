@@ -1,0 +1,90 @@
+"""Open3D-shaped namespace over the kinectpx hot path, so that KinectPy code written as
+`import open3d as o3d` keeps working with `from kinectpy_amd import o3d` for the calls on the
+path.  Anything off the path (visualisation, FPFH global registration this round)
+raises NotImplementedError loudly instead of silently computing on the CPU.
+"""
+import types
+
+import numpy as np
+
+from . import ops
+from .geometry import (KDTreeSearchParamHybrid, KDTreeSearchParamKNN, PointCloud, Vector2iVector, Vector3dVector)
+from . import pcd_io
+
+
+class ICPConvergenceCriteria:
+    def __init__(self, relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30):
+        self.relative_fitness, self.relative_rmse, self.max_iteration = relative_fitness, relative_rmse, max_iteration
+
+
+class RegistrationResult:
+    def __init__(self, transformation=None, fitness=0.0, inlier_rmse=0.0, correspondence_set=None):
+        self.transformation = np.eye(4) if transformation is None else transformation
+        self.fitness, self.inlier_rmse = fitness, inlier_rmse
+        self.correspondence_set = correspondence_set if correspondence_set is not None else np.zeros((0, 2), np.int32)
+
+    def __repr__(self):
+        return (f"RegistrationResult with fitness={self.fitness:e}, inlier_rmse={self.inlier_rmse:e}, "
+                f"and correspondence_set size of {len(self.correspondence_set)}")
+
+
+class TransformationEstimationPointToPoint:
+    mode = "p2p"
+
+    def __init__(self, with_scaling=False):
+        if with_scaling:
+            raise NotImplementedError("with_scaling=True is not on the KinectPy path (registration.py:53 passes False)")
+        self.with_scaling = False
+
+    def compute_transformation(self, source, target, corres):
+        """manual_pointcloud_registration.py:90-91: Umeyama/Kabsch on picked pairs"""
+        return ops.kabsch(source._pts, target._pts, np.asarray(corres, dtype=np.int32))
+
+
+class TransformationEstimationPointToPlane:
+    mode = "p2plane"
+
+
+def registration_icp(source, target, max_correspondence_distance, init=None, estimation_method=None, criteria=None):
+    """manual_pointcloud_registration.py:96-98, preprocessing/registration.py:78-84"""
+    est = estimation_method if estimation_method is not None else TransformationEstimationPointToPoint()
+    crit = criteria if criteria is not None else ICPConvergenceCriteria()
+    if max_correspondence_distance <= 0:
+        raise RuntimeError("Invalid max_correspondence_distance.")
+    tn = None
+    if est.mode == "p2plane":
+        if not target.has_normals():
+            raise RuntimeError("TransformationEstimationPointToPlane and TransformationEstimationColoredICP "
+                               "require pre-computed normal vectors for target PointCloud.")
+        tn = target._nrm
+    r = ops.icp(source._pts, target._pts, float(max_correspondence_distance), init, est.mode, tn, crit.max_iteration,
+                crit.relative_fitness, crit.relative_rmse, want_corr=True)
+    idx, d2 = r["idx"].cpu().numpy(), r["d2"].cpu().numpy()
+    ok = d2 < float(max_correspondence_distance) ** 2
+    corr = np.stack([np.flatnonzero(ok).astype(np.int32), idx[ok]], 1)
+    return RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], corr)
+
+
+def _off_path(name):
+    def f(*a, **k):
+        raise NotImplementedError(f"{name} is outside the round-1 hot path of kinectpy_amd (SURVEY.md 8f); "
+                                  "there is no CPU fallback")
+    return f
+
+
+geometry = types.SimpleNamespace(PointCloud=PointCloud, KDTreeSearchParamHybrid=KDTreeSearchParamHybrid,
+                                 KDTreeSearchParamKNN=KDTreeSearchParamKNN)
+utility = types.SimpleNamespace(Vector3dVector=Vector3dVector, Vector2iVector=Vector2iVector)
+io = types.SimpleNamespace(read_point_cloud=pcd_io.read_point_cloud, write_point_cloud=pcd_io.write_point_cloud)
+pipelines = types.SimpleNamespace(registration=types.SimpleNamespace(
+    registration_icp=registration_icp,
+    ICPConvergenceCriteria=ICPConvergenceCriteria,
+    RegistrationResult=RegistrationResult,
+    TransformationEstimationPointToPoint=TransformationEstimationPointToPoint,
+    TransformationEstimationPointToPlane=TransformationEstimationPointToPlane,
+    compute_fpfh_feature=_off_path("compute_fpfh_feature"),
+    registration_ransac_based_on_feature_matching=_off_path("registration_ransac_based_on_feature_matching"),
+    registration_colored_icp=_off_path("registration_colored_icp"),
+))
+visualization = types.SimpleNamespace(VisualizerWithEditing=_off_path("VisualizerWithEditing"),
+                                      draw_geometries=_off_path("draw_geometries"))

@@ -1,0 +1,51 @@
+"""Drop-in for KinectPy's preprocessing/registration.py (reference lines 7-114)."""
+import copy
+
+import numpy as np
+
+from .. import o3d
+
+
+def preprocess_point_cloud(pcd, voxel_size, normals_nn=30, fpfh_nn=100, with_fpfh=True):
+    """registration.py:7-21: voxel down-sample, normals (radius 2v), FPFH (radius 5v).
+    FPFH is a next-row component: with_fpfh=True raises until it lands."""
+    pcd_down = pcd.voxel_down_sample(voxel_size)
+    pcd_down.estimate_normals(o3d.geometry.KDTreeSearchParamHybrid(radius=voxel_size * 2, max_nn=normals_nn))
+    pcd_fpfh = None
+    if with_fpfh:
+        pcd_fpfh = o3d.pipelines.registration.compute_fpfh_feature(
+            pcd_down, o3d.geometry.KDTreeSearchParamHybrid(radius=voxel_size * 5, max_nn=fpfh_nn))
+    return pcd_down, pcd_fpfh
+
+
+def prepare_dataset(pcd_master, pcd_sub, voxel_size, normals_nn=40, fpfh_nn=40, with_fpfh=True):
+    """registration.py:24-29: source = sub, target = master."""
+    source, target = copy.deepcopy(pcd_sub), copy.deepcopy(pcd_master)
+    source_down, source_fpfh = preprocess_point_cloud(source, voxel_size, normals_nn, fpfh_nn, with_fpfh)
+    target_down, target_fpfh = preprocess_point_cloud(target, voxel_size, normals_nn, fpfh_nn, with_fpfh)
+    return source, target, source_down, target_down, source_fpfh, target_fpfh
+
+
+def execute_global_registration(pcd_master, pcd_sub, voxel_size: int = 35, ransac_n_trials: int = 15) -> np.ndarray:
+    """registration.py:32-62 (FPFH feature-matching RANSAC).  Next-row component."""
+    raise NotImplementedError("execute_global_registration (FPFH + RANSAC) is the next row after the hot path "
+                              "(SURVEY.md 8f); pass an initial transformation to execute_point_to_plane_registration")
+
+
+def execute_point_to_plane_registration(pcd_master, pcd_sub, initial_transformation: np.ndarray,
+                                        voxel_size: int = 35) -> np.ndarray:
+    """registration.py:65-86.  The reference names master `source` and sub `target` and then calls
+    prepare_dataset(source, target), which swaps them back: the effective call is
+    registration_icp(sub_down, master_down, 100, init, PointToPlane) and the result maps sub -> master."""
+    source, target = copy.deepcopy(pcd_master), copy.deepcopy(pcd_sub)
+    threshold = 100
+    _, _, source_down, target_down, _, _ = prepare_dataset(source, target, voxel_size, with_fpfh=False)
+    reg = o3d.pipelines.registration.registration_icp(
+        source_down, target_down, threshold, initial_transformation,
+        o3d.pipelines.registration.TransformationEstimationPointToPlane())
+    return reg.transformation
+
+
+def execute_colored_ICP_registration(pcd_master, pcd_sub, initial_transformation):
+    """registration.py:89-114: unused by the reference's pipeline and defective there."""
+    raise NotImplementedError("coloured ICP is unused by KinectPy's pipeline (SURVEY.md 8f rank 4)")

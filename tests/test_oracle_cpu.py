@@ -1,0 +1,153 @@
+"""CPU suite: the oracle against the reference's known answers (tests/golden/ref_kat.json, captured by
+tests/golden/make_ref_kat.py from the reference's NumPy-only functions) and against independent exact
+implementations (scipy cKDTree, numpy SVD, brute force)."""
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from kinectpy_amd.utils import synth
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kat.json")))
+
+
+def test_equation_plane_kat(oracle):
+    for c in KAT["equation_plane"]:
+        assert np.allclose(oracle.equation_plane(*c["p"]), c["abcd"], rtol=0, atol=0)
+
+
+def test_pcd_above_plane_kat(oracle):
+    for c in KAT["pcd_above_plane"]:
+        idx = oracle.halfspace_keep_idx(*c["abcd"], np.array(c["pts"]))
+        assert idx.tolist() == np.array(c["idx"]).reshape(-1).tolist() and c["invert"] is False
+        assert np.array(c["idx"]).ndim == 2 and np.array(c["idx"]).shape[1] == 1     # (K,1) argwhere shape
+
+
+def test_kalman_kat(oracle):
+    for c in KAT["kalman_filter"]:
+        assert np.array_equal(oracle.kalman_filter(np.array(c["x"]), **c["kw"]), np.array(c["y"]))
+
+
+def test_transform_joints_kat(oracle):
+    for c in KAT["transform_joints"]:
+        assert np.allclose(oracle.transform_joints(np.array(c["x"]), np.array(c["T"])), np.array(c["y"]), rtol=1e-15, atol=1e-12)
+
+
+def test_mask_gate_compact_kat(oracle):
+    """a3+a4 restatement against the reference's own NumPy masks (data.py:165-178 + utils/io.py:36)."""
+    for c in KAT["mask_gate_compact"]:
+        depth = np.array(c["depth"], dtype=np.int16)
+        color = np.array(c["color"], dtype=np.uint8)
+        med = oracle.median_z(depth)
+        assert med == c["median"]
+        pts, col, idx = oracle.rgbd_compact(depth, color, True, True, med + 750.0)
+        assert np.array_equal(pts.astype(np.float64), np.array(c["final_points"]).reshape(-1, 3))
+        assert np.allclose(col.astype(np.float64), np.array(c["final_colors"]).reshape(-1, 3), atol=6e-8)
+        # the intermediate the reference hands to rgbd_to_pointcloud
+        gate = (depth[:, 2] <= med + 750) & (color != 0).all(1)
+        assert np.array_equal(depth[gate], np.array(c["after_gate_depth"], dtype=np.int16).reshape(-1, 3))
+
+
+def test_load_depth_kat():
+    assert KAT["load_depth"][0]["equal"] and KAT["load_depth"][0]["dtype"] == "int16"
+
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors, philox4x32-10
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, out in kats:
+        assert tuple(int(v) for v in oracle.philox4x32(ctr, key)) == out
+
+
+def test_median_matches_numpy(oracle):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 7, 1000, 1001):
+        xyz = rng.integers(-32768, 32767, size=(n, 3)).astype(np.int16)
+        assert oracle.median_z(xyz) == float(np.median(xyz[:, 2]))
+
+
+def test_unproject_matches_numpy(oracle):
+    xy = synth.xy_table()
+    dep = synth.render_depth(xy=xy)
+    xyz = oracle.unproject_u16(dep, xy)
+    ok = (dep > 0) & ~np.isnan(xy[:, 0])
+    x = np.floor(xy[:, 0] * dep.astype(np.float32) + np.float32(0.5))
+    assert np.array_equal(xyz[ok, 0], x[ok].astype(np.int16)) and np.array_equal(xyz[ok, 2], dep[ok].astype(np.int16))
+    assert not xyz[~ok].any()
+
+
+def test_voxel_matches_numpy(oracle, base_cloud):
+    p = base_cloud[::7]
+    v = 35.0
+    org = p.astype(np.float64).min(0) - v / 2
+    key = np.floor((p.astype(np.float64) - org) / v).astype(np.int64)
+    order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))
+    ks = key[order]
+    heads = np.flatnonzero(np.r_[True, (ks[1:] != ks[:-1]).any(1)])
+    means = np.add.reduceat(p[order].astype(np.float64), heads) / np.diff(np.r_[heads, len(p)])[:, None]
+    got, _, _, cnt = oracle.voxel_downsample(p, v, return_counts=True)
+    assert len(got) == len(heads) and cnt.sum() == len(p)
+    assert np.allclose(got, means.astype(np.float32), rtol=0, atol=1e-3)
+    with pytest.raises(RuntimeError):
+        oracle.voxel_downsample(p, 0.0)
+
+
+def test_sor_grid_equals_brute_and_scipy(oracle, base_cloud):
+    rng = np.random.default_rng(0)
+    p = base_cloud[rng.choice(len(base_cloud), 4000, replace=False)]
+    for k, r in [(20, 2.0), (50, 0.3), (200, 3.0)]:
+        i1, s1, a1 = oracle.sor(p, k, r, brute=True)
+        i2, s2, a2 = oracle.sor(p, k, r, brute=False)
+        assert np.array_equal(i1, i2) and np.array_equal(a1, a2) and s1 == s2
+        d, _ = cKDTree(p.astype(np.float64)).query(p.astype(np.float64), k=k)
+        assert np.abs(d.mean(1) - a1).max() < 1e-10
+        thr = a1[a1 > 0].sum() / len(p) + r * np.sqrt(((a1 - s1[0]) ** 2).sum() / (len(p) - 1))
+        assert abs(thr - s1[2]) < 1e-9
+
+
+def test_nn_grid_equals_brute_and_scipy(oracle, base_cloud):
+    src, tgt, T = synth.icp_pair(6000, base_cloud)
+    for M in (np.eye(4), np.linalg.inv(T)):
+        ib, db, mb = oracle.nn(src, M, tgt, grid=False)
+        ig, dg, mg = oracle.nn(src, M, tgt, grid=True)
+        assert np.array_equal(ib, ig) and np.array_equal(db, dg) and np.array_equal(mb, mg)
+        s = oracle.transform(src, M).astype(np.float64)      # float32-rounded: only for the loose check
+        dd, ii = cKDTree(tgt.astype(np.float64)).query(s)
+        assert np.abs(np.sqrt(db) - dd).max() < 1e-2
+
+
+def test_segment_plane_recovers_floor(oracle):
+    c3 = synth.filter_cloud(60000)
+    fl = c3[c3[:, 1] >= c3[:, 1].max() - 200]
+    plane, inl, hyp = oracle.segment_plane(fl, 30.0, 30, 300, seed=7, return_hypotheses=True)
+    assert abs(abs(plane[1]) - 1) < 1e-3 and abs(abs(plane[3]) - 900) < 2
+    assert len(inl) > 0.9 * len(fl) and (np.diff(inl) > 0).all()
+    # sampling: distinct indices, deterministic
+    ids = oracle.ransac_sample(len(fl), 30, 7, 5)
+    assert len(set(ids.tolist())) == 30 and np.array_equal(ids, oracle.ransac_sample(len(fl), 30, 7, 5))
+    with pytest.raises(RuntimeError):
+        oracle.segment_plane(fl[:10], 30.0, 30, 10)
+
+
+def test_kabsch_and_icp_recover_transform(oracle, base_cloud):
+    rng = np.random.default_rng(5)
+    T = synth.t_star()
+    s = rng.normal(scale=300, size=(50, 3))
+    t = s @ T[:3, :3].T + T[:3, 3]
+    assert np.abs(oracle.kabsch(s, t) - T).max() < 1e-9
+    src, tgt, Tgt = synth.icp_pair(8000, base_cloud)
+    nrm = oracle.estimate_normals(tgt, 70.0, 40)[0].astype(np.float32)
+    Tr, fit, rmse, it = oracle.registration_icp(src, tgt, 100.0, mode="p2plane", tgt_normals=nrm)
+    assert it < 30 and fit > 0.99 and np.abs(Tr[:3, :3] - Tgt[:3, :3]).max() < 2e-3 and np.abs(Tr[:3, 3] - Tgt[:3, 3]).max() < 3.0
+
+
+def test_normals_of_a_plane(oracle):
+    rng = np.random.default_rng(1)
+    p = np.stack([rng.uniform(0, 500, 3000), rng.uniform(0, 500, 3000), np.full(3000, 100.0)], 1).astype(np.float32)
+    n, cov, cnt = oracle.estimate_normals(p, 70.0, 40)
+    assert np.allclose(np.abs(n[cnt >= 3, 2]), 1.0, atol=1e-9)

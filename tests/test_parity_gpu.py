@@ -1,0 +1,428 @@
+"""GPU suite (-m gpu): the HIP path through the C ABI against the CPU oracle on the same seeded inputs.
+Bar: bit-exact for integer / index outputs and for floats produced in a defined operation order
+(compaction, voxel means, transforms, NN distances); stated tolerances where a parallel reduction
+reorders a floating-point sum (SOR statistics, plane re-fit, ICP transform)."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from kinectpy_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kat.json")))
+
+TOL_STATS = 1e-11      # relative, SOR mean/std/threshold (reduction order)
+TOL_PLANE = 1e-10      # absolute, re-fitted plane coefficients (unit normal; d in mm)
+TOL_T = 1e-8           # absolute, ICP 4x4 (rotation entries / mm)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from kinectpy_amd import ops as o
+    return o
+
+
+def npy(t):
+    return t.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------- extract
+def test_unproject_bit_exact(ops, oracle):
+    xy = synth.xy_table()
+    dep = synth.render_depth(xy=xy)
+    assert np.array_equal(npy(ops.unproject_u16(dep, xy))[0], oracle.unproject_u16(dep, xy))
+    # scalar path (size not a multiple of 8), extreme depths, NaN table entries
+    rng = np.random.default_rng(0)
+    n = 1003
+    d = rng.integers(0, 65535, n).astype(np.uint16)
+    d[:5] = [0, 1, 65535, 32767, 32768]
+    t = rng.normal(scale=0.6, size=(n, 2)).astype(np.float32)
+    t[7] = np.nan
+    assert np.array_equal(npy(ops.unproject_u16(d, t))[0], oracle.unproject_u16(d, t))
+    # batched frames share the table
+    deps = np.stack([synth.render_depth(seed=s, xy=xy) for s in (3, 4)])
+    got = npy(ops.unproject_u16(deps, xy, 2))
+    for f in range(2):
+        assert np.array_equal(got[f], oracle.unproject_u16(deps[f], xy))
+
+
+def test_median_exact(ops):
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 3, 1000, 1001, 368640):
+        v = rng.integers(-32768, 32767, size=(3, n, 3)).astype(np.int16)
+        if n > 10:
+            v[1, :, 2] = 1234                 # constant column
+            v[2, : n // 2, 2] = -5            # two clusters -> even-n mean of different values
+            v[2, n // 2:, 2] = 6
+        t = torch.as_tensor(v).cuda()
+        got = npy(ops.median_i16(t.reshape(-1)[2:], n, 3, 3))
+        assert got.tolist() == [float(np.median(v[f, :, 2])) for f in range(3)]
+
+
+@pytest.mark.parametrize("cm,dg", [(False, False), (True, False), (False, True), (True, True)])
+def test_compact_bit_exact(ops, oracle, cm, dg):
+    xy = synth.xy_table()
+    dep = synth.render_depth(xy=xy)
+    rgb = synth.person_mask_rgb(dep)
+    xyz = oracle.unproject_u16(dep, xy)
+    (p, c, i), = ops.rgbd_compact(xyz, rgb, 1, cm, dg)
+    rp, rc, ri = oracle.rgbd_compact(xyz, rgb, cm, dg, oracle.median_z(xyz) + 750.0)
+    assert np.array_equal(npy(p), rp) and np.array_equal(npy(c), rc) and np.array_equal(npy(i), ri)
+
+
+def test_compact_reference_kat(ops):
+    """the reference's own NumPy masks (captured by tests/golden/make_ref_kat.py)"""
+    from kinectpy_amd.preprocessing.data import transform_filtered_image_to_pointcloud
+    for c in KAT["mask_gate_compact"]:
+        pcd = transform_filtered_image_to_pointcloud(np.array(c["color"], np.uint8), np.array(c["depth"], np.int16))
+        assert np.array_equal(np.asarray(pcd.points), np.array(c["final_points"]).reshape(-1, 3))
+        assert np.allclose(np.asarray(pcd.colors), np.array(c["final_colors"]).reshape(-1, 3), atol=6e-8)
+
+
+def test_fused_depth_to_cloud_batched_and_edge_cases(ops, oracle):
+    xy = synth.xy_table()
+    deps = np.stack([synth.render_depth(seed=s, xy=xy) for s in (1, 2, 3)] + [np.zeros(576 * 640, np.uint16)])
+    rgbs = np.stack([synth.person_mask_rgb(d) for d in deps])
+    res = ops.depth_to_cloud(deps, xy, rgbs, 4, True, True, want_idx=True)
+    for f in range(4):
+        r = oracle.unproject_u16(deps[f], xy)
+        rp, rc, ri = oracle.rgbd_compact(r, rgbs[f], True, True, oracle.median_z(r) + 750.0)
+        p, c, i = res[f]
+        assert np.array_equal(npy(p), rp) and np.array_equal(npy(c), rc) and np.array_equal(npy(i), ri)
+    assert res[3][0].shape[0] == 0           # empty frame -> empty cloud
+    # no colours, no gate, ragged size
+    d = deps[0][:5001]
+    (p, c, i), = ops.depth_to_cloud(d, xy[:5001], None, 1, False, False, want_idx=True)
+    rp, _, ri = oracle.rgbd_compact(oracle.unproject_u16(d, xy[:5001]))
+    assert c is None and np.array_equal(npy(p), rp) and np.array_equal(npy(i), ri)
+
+
+# ------------------------------------------------------------------------------------------- container
+def test_transform_rotate_bit_exact(ops, oracle, base_cloud):
+    T = synth.t_star()
+    for n in (0, 1, 5, 4096, len(base_cloud)):
+        assert np.array_equal(npy(ops.transform(base_cloud[:n], T)), oracle.transform(base_cloud[:n], T))
+    nrm = np.random.default_rng(0).normal(size=(1001, 3)).astype(np.float32)
+    assert np.array_equal(npy(ops.rotate(nrm, T)), oracle.rotate(nrm, T))
+    t = torch.as_tensor(base_cloud[:1000].copy()).cuda()       # in place
+    ops.transform(t, T, out=t)
+    assert np.array_equal(npy(t), oracle.transform(base_cloud[:1000], T))
+
+
+def test_joints_affine_reference_kat():
+    from kinectpy_amd.preprocessing.extractor import transform_joint_rows
+    for c in KAT["transform_joints"]:
+        got = transform_joint_rows(np.array(c["x"]), np.array(c["T"]))
+        assert np.allclose(got, np.array(c["y"]), rtol=1e-15, atol=1e-12)
+
+
+def test_select_halfspace_slab(ops, oracle, base_cloud):
+    from kinectpy_amd.geometry import PointCloud
+    from kinectpy_amd.floor_removal import pcd_above_plane
+    rng = np.random.default_rng(1)
+    idx = rng.choice(len(base_cloud), 1000, replace=False)
+    pc = PointCloud(base_cloud)
+    pc.colors = rng.random(base_cloud.shape)
+    col32 = npy(pc._col)
+    sel = pc.select_by_index(idx.reshape(-1, 1))                     # (K,1) argwhere-style
+    assert np.array_equal(npy(sel._pts), base_cloud[idx]) and np.array_equal(npy(sel._col), col32[idx])
+    inv = pc.select_by_index(idx, invert=True)
+    m = np.ones(len(base_cloud), bool)
+    m[idx] = False
+    assert np.array_equal(npy(inv._pts), base_cloud[m]) and np.array_equal(npy(inv._col), col32[m])
+    assert pc.select_by_index([]).points.__len__() == 0
+    assert len(pc.select_by_index([], invert=True).points) == len(base_cloud)
+    lo, up = ops.slab_split(base_cloud, 200.0)
+    y = base_cloud[:, 1].astype(np.float64)
+    assert np.array_equal(npy(lo), np.flatnonzero(y >= y.max() - 200)) and np.array_equal(npy(up), np.flatnonzero(y < y.max() - 200))
+    pl = [0.1, -0.9, 0.2, 300.0]
+    assert np.array_equal(npy(ops.halfspace_select(base_cloud, pl)), oracle.halfspace_keep_idx(*pl, base_cloud))
+    for c in KAT["pcd_above_plane"]:                                    # reference KAT2
+        kept = pcd_above_plane(*c["abcd"], PointCloud(np.array(c["pts"])))
+        want = np.array(c["pts"], dtype=np.float64)[np.array(c["idx"]).reshape(-1)]
+        assert np.array_equal(np.asarray(kept.points), want.astype(np.float32).astype(np.float64))   # float32 storage
+
+
+# ---------------------------------------------------------------------------------------------- filters
+@pytest.mark.parametrize("voxel", [0.02, 10.0, 35.0, 500.0])
+def test_voxel_bit_exact(ops, oracle, base_cloud, voxel):
+    rng = np.random.default_rng(0)
+    col = rng.random(base_cloud.shape).astype(np.float32)
+    nrm = rng.normal(size=base_cloud.shape).astype(np.float32)
+    gp, gc, gn = ops.voxel_downsample(base_cloud, voxel, col, nrm)
+    rp, rc, rn = oracle.voxel_downsample(base_cloud, voxel, col, nrm)
+    assert np.array_equal(npy(gp), rp) and np.array_equal(npy(gc), rc) and np.array_equal(npy(gn), rn)
+
+
+def test_voxel_edge_cases(ops, oracle):
+    from kinectpy_amd._lib import KinectPxError
+    one = np.array([[1.0, 2.0, 3.0]], np.float32)
+    assert np.array_equal(npy(ops.voxel_downsample(one, 5.0)[0]), one)
+    dup = np.repeat(one, 17, 0)
+    assert np.array_equal(npy(ops.voxel_downsample(dup, 5.0)[0]), one)
+    assert ops.voxel_downsample(np.zeros((0, 3), np.float32), 5.0)[0].shape[0] == 0
+    with pytest.raises(KinectPxError, match="voxel_size"):
+        ops.voxel_downsample(one, 0.0)
+    far = np.array([[0, 0, 0], [1e7, 0, 0]], np.float32)
+    with pytest.raises(KinectPxError, match="too small"):
+        ops.voxel_downsample(far, 0.001)
+    with pytest.raises(RuntimeError):
+        oracle.voxel_downsample(far, 0.001)
+
+
+@pytest.mark.parametrize("n,k,ratio", [(5000, 20, 2.0), (60000, 20, 2.0), (20000, 50, 0.3), (20000, 200, 3.0),
+                                       (17, 20, 1.0), (2, 5, 1.0), (300, 288, 1.5)])
+def test_sor_indices_bit_exact(ops, oracle, base_cloud, n, k, ratio):
+    rng = np.random.default_rng(n + k)
+    p = base_cloud[rng.choice(len(base_cloud), n, replace=False)]
+    gi, gs, ga = ops.sor(p, k, ratio, want_avg=True)
+    ri, rs, ra = oracle.sor(p, k, ratio)
+    assert np.array_equal(npy(gi), ri)
+    assert np.allclose(npy(ga), ra, rtol=1e-14, atol=0)
+    if n > 2:
+        assert np.allclose(npy(gs), rs, rtol=TOL_STATS, atol=0)
+
+
+def test_sor_duplicates_and_errors(ops, oracle):
+    from kinectpy_amd._lib import KinectPxError
+    rng = np.random.default_rng(3)
+    p = rng.normal(scale=100, size=(2000, 3)).astype(np.float32)
+    p[:40] = p[0]                 # 40 coincident points: avg distance 0 for k <= 40 -> dropped (avg > 0 test)
+    gi, _, ga = ops.sor(p, 20, 2.0, want_avg=True)
+    ri, _, ra = oracle.sor(p, 20, 2.0)
+    assert np.array_equal(npy(gi), ri) and (npy(ga)[:40] == 0).all() and not np.isin(np.arange(40), ri).any()
+    for bad in [(0, 1.0), (5, 0.0), (5, -1.0), (289, 1.0)]:
+        with pytest.raises(KinectPxError):
+            ops.sor(p, *bad)
+
+
+def test_normals_up_to_sign(ops, oracle, base_cloud):
+    rng = np.random.default_rng(2)
+    p = base_cloud[rng.choice(len(base_cloud), 30000, replace=False)]
+    gn = npy(ops.estimate_normals(p, 70.0, 40)).astype(np.float64)
+    rn, cov, cnt = oracle.estimate_normals(p, 70.0, 40)
+    A = np.zeros((len(p), 3, 3))
+    A[:, 0, 0], A[:, 1, 1], A[:, 2, 2] = cov[:, 0], cov[:, 3], cov[:, 5]
+    A[:, 0, 1] = A[:, 1, 0] = cov[:, 1]
+    A[:, 0, 2] = A[:, 2, 0] = cov[:, 2]
+    A[:, 1, 2] = A[:, 2, 1] = cov[:, 4]
+    w = np.linalg.eigvalsh(A)
+    well = (cnt >= 3) & ((w[:, 1] - w[:, 0]) > 1e-3 * np.maximum(w[:, 2], 1e-30))
+    assert well.mean() > 0.95
+    assert (np.abs((gn * rn).sum(1))[well] > 1 - 1e-6).all()          # float32 storage of a unit vector
+    assert np.allclose(gn[cnt < 3], [0, 0, 1])
+
+
+@pytest.mark.parametrize("n,rn,iters,prob,seed", [(50000, 30, 2000, 0.99999999, 7), (50000, 3, 500, 0.99999999, 1),
+                                                  (400000, 30, 2000, 0.99999999, 7), (20000, 30, 200, 1.0, 11),
+                                                  (100, 30, 50, 0.9, 2)])
+def test_segment_plane_inliers_bit_exact(ops, oracle, n, rn, iters, prob, seed):
+    c3 = synth.filter_cloud(1_000_000 if n > 100000 else 200_000)
+    fl = c3[c3[:, 1] >= c3[:, 1].max() - 200][:n]
+    gpl, gidx = ops.segment_plane(fl, 30.0, rn, iters, prob, seed)
+    rpl, ridx = oracle.segment_plane(fl, 30.0, rn, iters, prob, seed)
+    assert np.array_equal(npy(gidx), ridx)
+    assert np.abs(gpl - rpl).max() < TOL_PLANE
+
+
+# ------------------------------------------------------------------------------------------- registration
+@pytest.mark.parametrize("n,m", [(20000, 20000), (1000, 777), (333, 5000), (5, 1), (64, 17), (4097, 16)])
+def test_nn_bit_exact(ops, oracle, base_cloud, n, m):
+    src, tgt, T = synth.icp_pair(max(n, m), base_cloud)
+    src, tgt = src[:n], tgt[:m]
+    for M in (np.eye(4), np.linalg.inv(T)):
+        gi, gd = ops.nn_search(src, tgt, M)
+        ri, rd, _ = oracle.nn(src, M, tgt, grid=(n * m > 1e6))
+        assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd)
+
+
+def test_nn_ties_go_to_the_lowest_index(ops, oracle):
+    """integer-grid data (raw Kinect XYZ is int16): exact ties, exact arithmetic in both forms"""
+    rng = np.random.default_rng(4)
+    tgt = rng.integers(-50, 50, size=(3000, 3)).astype(np.float32)
+    tgt[1500:] = tgt[:1500]                    # every target point twice
+    src = rng.integers(-50, 50, size=(2000, 3)).astype(np.float32)
+    gi, gd = ops.nn_search(src, tgt, np.eye(4))
+    ri, rd, _ = oracle.nn(src, np.eye(4), tgt)
+    assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd) and (ri < 1500).all()
+
+
+@pytest.mark.parametrize("mode", ["p2p", "p2plane"])
+def test_icp_matches_oracle(ops, oracle, base_cloud, mode):
+    src, tgt, T = synth.icp_pair(20000, base_cloud)
+    tn = oracle.estimate_normals(tgt, 70.0, 40)[0].astype(np.float32) if mode == "p2plane" else None
+    g = ops.icp(src, tgt, 100.0, None, mode, tn, want_corr=True)
+    trace = []
+    rT, rf, rr, rit = oracle.registration_icp(src, tgt, 100.0, None, mode, tn, trace=trace)
+    assert g["iterations"] == rit and g["fitness"] == rf
+    assert abs(g["inlier_rmse"] - rr) < 1e-9 * max(rr, 1)
+    assert np.abs(g["transformation"] - rT).max() < TOL_T
+    # correspondence search is bit-exact at every iteration when both sides use the same transform
+    for Tk, idx, d2 in trace[:: max(1, len(trace) // 6)]:
+        gi, gd = ops.nn_search(src, tgt, Tk)
+        assert np.array_equal(npy(gi), idx) and np.array_equal(npy(gd), d2)
+    if mode == "p2plane":
+        assert np.abs(g["transformation"][:3, 3] - T[:3, 3]).max() < 3.0       # recovers the ground truth
+
+
+def test_kabsch_pairs(ops, oracle, base_cloud):
+    src, tgt, T = synth.icp_pair(5000, base_cloud)
+    rng = np.random.default_rng(0)
+    corr = np.stack([rng.choice(5000, 300, replace=False), rng.choice(5000, 300, replace=False)], 1).astype(np.int32)
+    assert np.abs(ops.kabsch(src, tgt, corr) - oracle.kabsch(src[corr[:, 0]], tgt[corr[:, 1]])).max() < 1e-9
+    s = rng.normal(scale=300, size=(3, 3)).astype(np.float32)        # minimum of 3 picked pairs
+    t = oracle.transform(s, T)
+    got = ops.kabsch(s, t, np.stack([np.arange(3), np.arange(3)], 1))
+    assert np.abs(got - T).max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------- module-level APIs
+def test_filter_outliers_and_remove_floor_chain(oracle):
+    from kinectpy_amd.floor_removal import remove_floor
+    from kinectpy_amd.geometry import PointCloud
+    from kinectpy_amd.preprocessing.filtering import filter_outliers
+    c3 = synth.filter_cloud(200_000)
+    pcd = PointCloud(c3)
+    before = np.asarray(pcd.points).copy()
+    out = filter_outliers(pcd, nb_neighbors=20, std_ratio=2.0, voxel_size=10)
+    assert np.array_equal(np.asarray(pcd.points), before)                    # input not mutated (deepcopy)
+    vp, _, _ = oracle.voxel_downsample(c3, 10.0)
+    keep, _, _ = oracle.sor(vp, 20, 2.0)
+    assert np.array_equal(npy(out._pts), vp[keep])
+    fl = remove_floor(out, seed=7)
+    want, info = oracle.floor_removal(vp[keep], seed=7)
+    assert np.array_equal(npy(fl._pts), want)
+    assert len(want) < 0.7 * len(keep)                                        # the floor is gone
+
+
+def test_default_filter_outliers_on_mm_data(oracle):
+    """reference defaults (voxel 0.02 on millimetre data, k=200, ratio 3): every point its own voxel"""
+    from kinectpy_amd.geometry import PointCloud
+    from kinectpy_amd.preprocessing.filtering import filter_outliers
+    p = synth.filter_cloud(30_000)
+    out = filter_outliers(PointCloud(p))
+    vp, _, _ = oracle.voxel_downsample(p, 0.02)
+    keep, _, _ = oracle.sor(vp, 200, 3.0)
+    assert np.array_equal(npy(out._pts), vp[keep])
+
+
+def test_point_to_plane_registration_api(oracle):
+    from kinectpy_amd.geometry import PointCloud
+    from kinectpy_amd.preprocessing.registration import execute_point_to_plane_registration, execute_global_registration
+    E0, E1 = synth.camera_pose(0, 8), synth.camera_pose(1, 8)
+    xy = synth.xy_table()
+    clouds = []
+    for E, seed in ((E0, 100), (E1, 101)):
+        dep = synth.render_depth(E, seed=seed, xy=xy)
+        pts, _, _ = oracle.rgbd_compact(oracle.unproject_u16(dep, xy))
+        clouds.append(pts)
+    T_true = np.linalg.inv(E0) @ E1                       # sub -> master
+    a = np.deg2rad(2.0)
+    pert = np.eye(4)
+    pert[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    pert[:3, 3] = [30, -20, 25]
+    init = pert @ T_true
+    master, sub = PointCloud(clouds[0]), PointCloud(clouds[1])
+    T = execute_point_to_plane_registration(master, sub, init)
+    # oracle: same call sequence (voxel 35, normals r=70 nn=40 on the master, ICP threshold 100)
+    sd, _, _ = oracle.voxel_downsample(clouds[1], 35.0)
+    md, _, _ = oracle.voxel_downsample(clouds[0], 35.0)
+    mn = oracle.estimate_normals(md, 70.0, 40)[0].astype(np.float32)
+    from kinectpy_amd import o3d
+    mn_gpu = np.asarray(PointCloud(md).estimate_normals(o3d.geometry.KDTreeSearchParamHybrid(70.0, 40)).normals).astype(np.float32)
+    oT, _, _, _ = oracle.registration_icp(sd, md, 100.0, init, "p2plane", mn_gpu)
+    assert np.abs(T - oT).max() < 1e-6
+    assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < 15 and np.abs(T[:3, :3] - T_true[:3, :3]).max() < 5e-3
+    assert (np.abs((mn * mn_gpu.astype(np.float64)).sum(1)) > 0.999).mean() > 0.95
+    with pytest.raises(NotImplementedError):
+        execute_global_registration(master, sub)
+
+
+def test_data_processor_frame(oracle):
+    from kinectpy_amd.preprocessing.data import DataProcessor
+    xy = synth.xy_table()
+    S = 2
+    Es = [synth.camera_pose(i, 8) for i in range(S)]
+    deps = [synth.render_depth(E, seed=200 + i, xy=xy) for i, E in enumerate(Es)]
+    xyzs = [oracle.unproject_u16(d, xy) for d in deps]
+    rgbs = [synth.person_mask_rgb(d, E) for d, E in zip(deps, Es)]
+    Ts = [np.linalg.inv(Es[0]) @ Es[i] for i in range(1, S)]
+    dp = DataProcessor(S)
+    dp.registration_transformations = Ts
+    fused = dp.process_frame(rgbs, xyzs)
+    parts, cols = [], []
+    for i in range(S):
+        p, c, _ = oracle.rgbd_compact(xyzs[i], rgbs[i], True, True, oracle.median_z(xyzs[i]) + 750.0)
+        parts.append(p if i == 0 else oracle.transform(p, Ts[i - 1]))
+        cols.append(c)
+    allp, allc = np.concatenate(parts), np.concatenate(cols)
+    vp, vc, _ = oracle.voxel_downsample(allp, 0.02, allc)
+    keep, _, _ = oracle.sor(vp, 200, 3.0)
+    assert np.array_equal(npy(fused._pts), vp[keep]) and np.array_equal(npy(fused._col), vc[keep])
+    assert len(keep) > 1000
+
+
+def test_pcd_io_round_trip(tmp_path):
+    from kinectpy_amd import o3d
+    rng = np.random.default_rng(0)
+    pcd = o3d.geometry.PointCloud(rng.normal(scale=1000, size=(500, 3)))
+    pcd.colors = rng.integers(0, 256, size=(500, 3)) / 255.0
+    fp = str(tmp_path / "a.pcd")
+    o3d.io.write_point_cloud(fp, pcd)
+    back = o3d.io.read_point_cloud(fp)
+    assert np.array_equal(np.asarray(back.points), np.asarray(pcd.points))
+    assert np.allclose(np.asarray(back.colors), np.asarray(pcd.colors), atol=1e-6)
+    both = pcd + back
+    assert len(both.points) == 1000 and both.has_colors()
+    c = copy.deepcopy(pcd)
+    c.transform(synth.t_star())
+    assert not np.array_equal(np.asarray(c.points), np.asarray(pcd.points))
+
+
+def test_extract_writes_dat_files(tmp_path, oracle):
+    from kinectpy_amd.preprocessing.extractor import MKVFilesProcessing
+    from kinectpy_amd.utils.io import load_depth
+    xy = synth.xy_table()
+    frames = [(1000 + 33 * i, synth.render_depth(seed=i, xy=xy)) for i in range(3)]
+    m = MKVFilesProcessing(["a.mkv"], [str(tmp_path / "master_1")], frame_source=lambda fp: (xy, iter(frames)))
+    m.extract(pointcloud=True, batch=2)
+    for ts, d in frames:
+        got = load_depth(str(tmp_path / "master_1" / "depths" / str(ts)))
+        assert np.array_equal(got, oracle.unproject_u16(d, xy))
+
+
+# ----------------------------------------------------------------------------- BASELINE.json full sizes
+def test_full_size_icp_pair_nn(ops, oracle, base_cloud):
+    """config 2: 100k x 100k correspondence search, bit-exact against the (grid-accelerated) oracle"""
+    src, tgt, T = synth.icp_pair(100_000, base_cloud)
+    gi, gd = ops.nn_search(src, tgt, np.eye(4))
+    ri, rd, _ = oracle.nn(src, np.eye(4), tgt, grid=True)
+    assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd)
+    # size-independent properties: the reported distance is the distance of the reported pair, and no
+    # sampled target is closer
+    s64, t64 = src.astype(np.float64), tgt.astype(np.float64)
+    assert np.allclose(((s64 - t64[npy(gi)]) ** 2).sum(1), npy(gd), rtol=1e-12)
+    probe = np.random.default_rng(0).choice(len(tgt), 64, replace=False)
+    assert (((s64[:, None, :] - t64[probe][None]) ** 2).sum(2).min(1) >= npy(gd) * (1 - 1e-12)).all()
+
+
+def test_full_size_filter_chain(ops, oracle):
+    """config 3: 1M points, voxel 10 mm -> SOR(20, 2.0) -> slab -> RANSAC plane(30,30,2000,seed 7)"""
+    c3 = synth.filter_cloud(1_000_000)
+    vp, _, _ = ops.voxel_downsample(c3, 10.0)
+    rv, _, _, cnt = oracle.voxel_downsample(c3, 10.0, return_counts=True)
+    assert np.array_equal(npy(vp), rv) and cnt.sum() == len(c3)
+    gi, gs, _ = ops.sor(vp, 20, 2.0)
+    ri, rs, _ = oracle.sor(rv, 20, 2.0)
+    assert np.array_equal(npy(gi), ri) and np.allclose(npy(gs), rs, rtol=TOL_STATS)
+    cloud = rv[ri]
+    lo, up = ops.slab_split(cloud, 200.0)
+    floor = cloud[npy(lo)]
+    gpl, gidx = ops.segment_plane(floor, 30.0, 30, 2000, seed=7)
+    rpl, ridx = oracle.segment_plane(floor, 30.0, 30, 2000, seed=7)
+    assert np.array_equal(npy(gidx), ridx) and np.abs(gpl - rpl).max() < TOL_PLANE
+    assert abs(abs(gpl[1]) - 1) < 1e-4 and abs(abs(gpl[3]) - 900) < 3.0       # it is the floor
