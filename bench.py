@@ -1,0 +1,190 @@
+"""bench.py -- Mpoints/s end-to-end (unproject + filter + ICP) on synthetic multi-Kinect frames.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one synchronised frame set of the sensors a GPU owns
+(BASELINE.json configs[3]: a 4-sensor frame, 640x576 u16 depth + person-mask colour per sensor, already
+resident in HBM):  depth -> masked/gated compacted clouds (a1-a4)  ->  every sub sensor registered
+onto the group master exactly as execute_point_to_plane_registration does (voxel 35 -> normals ->
+point-to-plane ICP, threshold 100, <= 30 iterations; a11-a14)  ->  transform, fuse, filter_outliers
+(voxel 10 mm + SOR k=20, ratio 2.0; a17, a6-a8).  With N GPUs every rank owns its own 4-sensor group
+(weak scaling: per-GPU work is fixed) and the frame ends with the fuse exchange over RCCL
+(transforms + filtered clouds, kinectpy_amd/parallel.py).
+
+One JSON line is printed by rank 0.  `roofline` is the dominant kernel (the fp64-MFMA nearest-neighbour
+sweep of ICP) timed with HIP events on its own stream inside the timed region (kpx_prof_*);
+`cpu_baseline` is the CPU oracle (oracle/, OpenMP over the host cores) running the same step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PX = 576 * 640
+FP64_MFMA_PEAK_TFLOPS = 78.6          # MI355X dense fp64 matrix peak (vendor figure)
+
+
+def perturb(T, deg=3.0, mm=50.0, seed=0):
+    """initial guess = ground-truth extrinsic perturbed by 3 deg / 50 mm"""
+    rng = np.random.default_rng(seed)
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    a = np.deg2rad(deg)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+    t = rng.normal(size=3)
+    t *= mm / np.linalg.norm(t)
+    P = np.eye(4)
+    P[:3, :3] = R
+    P[:3, 3] = t
+    return P @ T
+
+
+def make_group(rank, world, spg, n_frames):
+    """depth (F, spg, N_PX) u16, rgb (F, spg, N_PX, 3) u8, initial transforms, group->global transform"""
+    from kinectpy_amd.utils import synth
+    total = spg * world
+    xy = synth.xy_table()
+    poses = [synth.camera_pose(rank * spg + i, total) for i in range(spg)]
+    depth = np.zeros((n_frames, spg, N_PX), np.uint16)
+    rgb = np.zeros((n_frames, spg, N_PX, 3), np.uint8)
+    for f in range(n_frames):
+        for i, E in enumerate(poses):
+            d, person = synth.render_depth(E, person_shift=(5.0 * f, 0.0, 0.0), seed=100 + rank * spg + i + 1000 * f, xy=xy,
+                                           return_person=True)
+            depth[f, i] = d
+            rgb[f, i] = synth.mask_rgb(person, seed=7 + i)
+    Einv = np.linalg.inv(poses[0])
+    truth = [Einv @ poses[i] for i in range(1, spg)]                       # sub -> group master
+    inits = [perturb(T, seed=rank * spg + i) for i, T in enumerate(truth)]
+    to_global = np.linalg.inv(synth.camera_pose(0, total)) @ poses[0]      # group master -> global master
+    return xy, depth, rgb, inits, truth, to_global
+
+
+def cpu_step(O, xy, depth, rgb, inits, P):
+    """the same step through the CPU oracle (baseline only)"""
+    S = depth.shape[0]
+    full, masked = [], []
+    for i in range(S):
+        xyz = O.unproject_u16(depth[i], xy)
+        full.append(O.rgbd_compact(xyz)[0])
+        p, c, _ = O.rgbd_compact(xyz, rgb[i], True, True, O.median_z(xyz) + P.gate)
+        masked.append((p, c))
+    downs = [O.voxel_downsample(f, P.reg_voxel)[0] for f in full]
+    tn = O.estimate_normals(downs[0], 2 * P.reg_voxel, P.normals_nn)[0].astype(np.float32)
+    Ts = [np.eye(4)]
+    for i in range(1, S):
+        T, _, _, _ = O.registration_icp(downs[i], downs[0], P.icp_max_dist, inits[i - 1], P.icp_mode, tn,
+                                        P.icp_max_iteration, grid=True)
+        Ts.append(T)
+    pts = np.concatenate([masked[0][0]] + [O.transform(masked[i][0], Ts[i]) for i in range(1, S)])
+    col = np.concatenate([m[1] for m in masked])
+    vp, vc, _ = O.voxel_downsample(pts, P.filt_voxel, col)
+    keep, _, _ = O.sor(vp, P.filt_k, P.filt_ratio)
+    return vp[keep], vc[keep], Ts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sensors-per-gpu", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=2, help="distinct synthetic time frames cycled through")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="0 disables the cpu_baseline leg")
+    ap.add_argument("--check", action="store_true", help="compare one GPU step against the oracle step")
+    args = ap.parse_args()
+
+    import torch
+    from kinectpy_amd import ops, parallel
+    from kinectpy_amd.pipeline import PipelineParams, SensorGroupPipeline
+
+    rank, world, local = parallel.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    spg, F = args.sensors_per_gpu, args.frames
+    P = PipelineParams()
+    xy, depth_h, rgb_h, inits, truth, to_global = make_group(rank, world, spg, F)
+    depth = torch.as_tensor(depth_h).to(dev)
+    rgb = torch.as_tensor(rgb_h).to(dev)
+    pipe = SensorGroupPipeline(xy, inits, P, cloud_capacity=spg * 48 * 1024)
+
+    def step(k):
+        f = k % F
+        out_p, out_c, Ts = pipe.step(depth[f], rgb[f])
+        if world > 1:
+            out_p, out_c, _, _ = pipe.exchange(out_p, out_c, Ts, to_global)
+        return out_p, out_c, Ts
+
+    for k in range(args.warmup):
+        step(k)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    ops.prof_begin(1 << 16)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.prof_end()
+    dt = parallel.allreduce_max(dt, dev)
+
+    if rank != 0:
+        return
+    ms_step = dt / args.steps * 1e3
+    value = world * spg * N_PX * args.steps / dt / 1e6
+    ms, launches, flops = prof["nn_mfma"]
+    roof = None
+    if launches:
+        achieved = flops / (ms * 1e-3) / 1e12
+        roof = {"kernel": "nn_mfma_kernel", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": launches, "avg_launch_us": round(ms / launches * 1e3, 2),
+                "flop_per_launch": round(flops / launches), "share_of_step": round(ms / (dt * 1e3), 3)}
+    other = {k: {"launches": v[1], "avg_us": round(v[0] / max(v[1], 1) * 1e3, 2)} for k, v in prof.items() if k != "nn_mfma"}
+
+    cpu = None
+    if world == 1 and args.cpu_budget_s > 0:
+        from oracle import oracle as O
+        O.build()
+        t_cpu, n_cpu, ref = 0.0, 0, None
+        while t_cpu < args.cpu_budget_s and n_cpu < max(1, F):
+            t1 = time.perf_counter()
+            out = cpu_step(O, xy, depth_h[n_cpu % F], rgb_h[n_cpu % F], inits, P)
+            ref = out if ref is None else ref          # frame 0, used by --check
+            t_cpu += time.perf_counter() - t1
+            n_cpu += 1
+        cpu = {"value": round(spg * N_PX * n_cpu / t_cpu / 1e6, 4), "unit": "Mpoints/s", "cores": O.num_threads(),
+               "kind": "port", "sample": f"{n_cpu} step(s) of the same {spg}-sensor frame workload through the CPU oracle "
+               f"(C/OpenMP restatement, grid-accelerated exact NN), {t_cpu:.1f} s"}
+        if args.check:
+            gp, gc, gT = step(0)
+            terr = np.abs(gT - np.stack(ref[2])).reshape(len(gT), -1).max(1)
+            same = gp.shape[0] == ref[0].shape[0] and np.array_equal(gp.cpu().numpy(), ref[0])
+            close = gp.shape[0] == ref[0].shape[0] and np.abs(gp.cpu().numpy() - ref[0]).max() < 1e-3
+            print(f"# check vs oracle: transform errors {terr}, cloud sizes {gp.shape[0]}/{ref[0].shape[0]}, "
+                  f"identical={same}, within 1e-3 mm={close}", file=sys.stderr)
+    line = {
+        "metric": "Mpoints/sec end-to-end (unproject+filter+ICP), 4-sensor frame", "value": round(value, 3), "unit": "Mpoints/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: 4 synthetic Kinect views (640x576 u16 depth + person mask) per GPU per "
+                               "step: extract -> pairwise point-to-plane ICP onto the group master -> fuse -> voxel+SOR",
+                   "sensors_per_gpu": spg, "pixels_per_step_per_gpu": spg * N_PX, "icp": f"{P.icp_mode}, voxel {P.reg_voxel}, "
+                   f"max_dist {P.icp_max_dist}, <= {P.icp_max_iteration} it", "filter": f"voxel {P.filt_voxel} + SOR({P.filt_k}, {P.filt_ratio})",
+                   "last_step": pipe.last},
+        "roofline": roof, "cpu_baseline": cpu, "kernels": other,
+    }
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -164,14 +164,30 @@ int kpx_kabsch(const float *src, const float *tgt, const int32_t *corr, int64_t 
 /* registration_icp(source, target, max_dist, init, estimation, criteria) -- the whole loop runs on
  * the device without host synchronisation.  mode 0 = point-to-point (Kabsch, a16), 1 = point-to-plane
  * (needs tgt_normals, a14).  h_init: f64 [16] host.  d_result f64 [20]: T (16), fitness, inlier_rmse,
- * iterations done, correspondence count.  idx/d2 (optional) receive the last correspondence set. */
+ * iterations done, correspondence count.  idx/d2 (optional) receive the last correspondence set.
+ * poll_interval == 0: every iteration is enqueued up front and later launches return at once after
+ * convergence (fully asynchronous).  poll_interval = p > 0: the host reads the device `done` flag every
+ * p iterations (one 4-byte copy + stream sync) and stops enqueuing -- no empty launches. */
 #define KPX_ICP_POINT_TO_POINT 0
 #define KPX_ICP_POINT_TO_PLANE 1
 size_t kpx_icp_workspace_bytes(int64_t n_src, int64_t n_tgt);
 int kpx_icp(const float *src, int64_t n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
             double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness,
-            double relative_rmse, double *d_result, int32_t *idx, double *d2, void *ws, size_t ws_bytes,
-            void *stream);
+            double relative_rmse, int32_t poll_interval, double *d_result, int32_t *idx, double *d2, void *ws,
+            size_t ws_bytes, void *stream);
+
+/* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
+/* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it
+ * (capacity = max launches recorded); every launch of a tagged kernel is bracketed by an event pair;
+ * kpx_prof_end synchronises, sums per kernel id and disarms.  h_ms / h_launches / h_work: arrays of
+ * KPX_PROF_KERNELS entries (work = flops for the MFMA kernel, algorithmic bytes for the others). */
+#define KPX_PROF_NN_MFMA 0
+#define KPX_PROF_SOR_KNN 1
+#define KPX_PROF_PLANE_SCORE 2
+#define KPX_PROF_COMPACT 3
+#define KPX_PROF_KERNELS 4
+int kpx_prof_begin(int32_t capacity);
+int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work);
 
 #ifdef __cplusplus
 }

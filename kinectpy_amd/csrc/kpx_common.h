@@ -52,6 +52,14 @@ struct Arena {
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- HIP-event profiler (armed by kpx_prof_begin; a no-op otherwise) ----------------------------
+struct ProfScope {
+    int slot;
+    hipStream_t st;
+    ProfScope(int kernel_id, double work, hipStream_t stream);
+    ~ProfScope();
+};
+
 // ---- device helpers ----------------------------------------------------------------------------
 constexpr int kWave = 64;
 

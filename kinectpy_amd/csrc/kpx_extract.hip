@@ -17,6 +17,28 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// ---- profiler -------------------------------------------------------------------------------------
+static struct {
+    bool on = false;
+    int cap = 0, used = 0;
+    hipEvent_t *e0 = nullptr, *e1 = nullptr;
+    int *kid = nullptr;
+    double *work = nullptr;
+} g_prof;
+
+ProfScope::ProfScope(int kernel_id, double w, hipStream_t stream) : slot(-1), st(stream)
+{
+    if (!g_prof.on || g_prof.used >= g_prof.cap) return;
+    slot = g_prof.used++;
+    g_prof.kid[slot] = kernel_id;
+    g_prof.work[slot] = w;
+    (void)hipEventRecord(g_prof.e0[slot], st);
+}
+ProfScope::~ProfScope()
+{
+    if (slot >= 0) (void)hipEventRecord(g_prof.e1[slot], st);
+}
+
 // ------------------------------------------------------------------------------------------------
 // a1 unproject: 8 pixels per thread.  Reads 16 B of depth + 64 B of table, writes 48 B of int16 xyz.
 // Arithmetic contract: float32, x = floorf(xt*d + 0.5f) with separate multiply and add.
@@ -230,6 +252,37 @@ struct DepthEmit {
 using namespace kpx;
 
 KPX_EXPORT const char *kpx_last_error(void) { return g_err; }
+
+KPX_EXPORT int kpx_prof_begin(int32_t capacity)
+{
+    KPX_REQUIRE(capacity > 0 && capacity <= (1 << 20), "kpx_prof_begin: bad capacity");
+    if (g_prof.cap < capacity) {
+        for (int i = 0; i < g_prof.cap; ++i) { (void)hipEventDestroy(g_prof.e0[i]); (void)hipEventDestroy(g_prof.e1[i]); }
+        delete[] g_prof.e0; delete[] g_prof.e1; delete[] g_prof.kid; delete[] g_prof.work;
+        g_prof.e0 = new hipEvent_t[capacity]; g_prof.e1 = new hipEvent_t[capacity];
+        g_prof.kid = new int[capacity]; g_prof.work = new double[capacity];
+        for (int i = 0; i < capacity; ++i) { KPX_HIP(hipEventCreate(&g_prof.e0[i])); KPX_HIP(hipEventCreate(&g_prof.e1[i])); }
+        g_prof.cap = capacity;
+    }
+    g_prof.used = 0;
+    g_prof.on = true;
+    return KPX_OK;
+}
+KPX_EXPORT int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work)
+{
+    KPX_REQUIRE(h_ms && h_launches && h_work, "kpx_prof_end: null pointer");
+    g_prof.on = false;
+    for (int k = 0; k < KPX_PROF_KERNELS; ++k) { h_ms[k] = 0.0; h_launches[k] = 0; h_work[k] = 0.0; }
+    for (int i = 0; i < g_prof.used; ++i) {
+        KPX_HIP(hipEventSynchronize(g_prof.e1[i]));
+        float ms = 0.f;
+        KPX_HIP(hipEventElapsedTime(&ms, g_prof.e0[i], g_prof.e1[i]));
+        int k = g_prof.kid[i];
+        h_ms[k] += ms; h_launches[k] += 1; h_work[k] += g_prof.work[i];
+    }
+    g_prof.used = 0;
+    return KPX_OK;
+}
 KPX_EXPORT int kpx_version(void) { return KPX_VERSION; }
 
 KPX_EXPORT int kpx_unproject_u16(const uint16_t *depth, const float *xy, int64_t n_px, int32_t frames, int16_t *xyz,
@@ -302,6 +355,8 @@ static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uin
     KPX_ARENA_CHECK(a);
     DepthPred pred{ depth, xy, rgb, med, n, flags, gate };
     DepthEmit emit{ depth, xy, rgb, n, pts, col, idx };
+    // algorithmic input bytes (u16 depth + rgb); outputs depend on the kept count and are added by the caller
+    ProfScope prof(KPX_PROF_COMPACT, (double)frames * (double)n * (2.0 + (rgb ? 3.0 : 0.0)), st);
     return compact(pred, emit, n, frames, counts, d_count, st);
 }
 KPX_EXPORT size_t kpx_depth_to_cloud_workspace_bytes(int64_t n_px, int32_t frames)

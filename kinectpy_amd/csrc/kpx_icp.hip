@@ -345,12 +345,13 @@ __global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restric
 
 // ---- host side ----------------------------------------------------------------------------------------------
 struct NnPlan {
-    int64_t tiles_pad;
+    int64_t tiles_pad, n_src, n_tgt;
     int32_t tiles_per_split, splits, row_blocks;
 };
 static NnPlan nn_plan(int64_t n, int64_t m)
 {
     NnPlan p;
+    p.n_src = n; p.n_tgt = m;
     int64_t tiles = cdiv(m > 0 ? m : 1, 16);
     int64_t stages = cdiv(tiles, kCT);
     p.row_blocks = (int32_t)cdiv(n > 0 ? n : 1, kRowsPerBlock);
@@ -384,8 +385,11 @@ static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers 
 static int nn_launch(const float *src, int64_t n, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b,
                      const double *T, const int32_t *done, double max_d2, int mode, int32_t *idx, double *d2, hipStream_t st)
 {
-    hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), dim3(256), 0, st, src, n, b.B, p.tiles_per_split, T, done,
-                       b.part_val, b.part_idx);
+    {
+        ProfScope prof(KPX_PROF_NN_MFMA, 8.0 * (double)p.n_src * (double)p.n_tgt, st);     // 4 MAC per (source, target) pair
+        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), dim3(256), 0, st, src, n, b.B, p.tiles_per_split, T, done,
+                           b.part_val, b.part_idx);
+    }
     hipLaunchKernelGGL(nn_merge_kernel, dim3(p.row_blocks), dim3(256), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
                        p.splits, max_d2, mode, idx, d2, b.part_acc);
     KPX_LAUNCH_CHECK();
@@ -449,7 +453,8 @@ KPX_EXPORT size_t kpx_icp_workspace_bytes(int64_t n_src, int64_t n_tgt)
 }
 KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
                        double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness,
-                       double relative_rmse, double *d_result, int32_t *idx, double *d2, void *ws, size_t ws_bytes, void *stream)
+                       double relative_rmse, int32_t poll_interval, double *d_result, int32_t *idx, double *d2, void *ws,
+                       size_t ws_bytes, void *stream)
 {
     KPX_REQUIRE(mode == KPX_ICP_POINT_TO_POINT || mode == KPX_ICP_POINT_TO_PLANE, "kpx_icp: unknown estimation mode");
     KPX_REQUIRE(mode != KPX_ICP_POINT_TO_PLANE || tgt_normals,
@@ -474,6 +479,12 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
         if (rc) return rc;
         hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, st, b.part_acc, p.row_blocks, n_src, mode, k, max_iteration,
                            relative_fitness, relative_rmse, b.state, d_result);
+        if (poll_interval > 0 && (k + 1) % poll_interval == 0 && k < max_iteration) {
+            int32_t h_done = 0;
+            KPX_HIP(hipMemcpyAsync(&h_done, &b.state->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            KPX_HIP(hipStreamSynchronize(st));
+            if (h_done) break;
+        }
     }
     KPX_LAUNCH_CHECK();
     return KPX_OK;

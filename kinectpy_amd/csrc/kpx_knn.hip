@@ -294,8 +294,11 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
         KPX_HIP(hipFuncSetAttribute((const void *)sor_knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(sor_knn_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g.params, g.cell_start,
-                       g.sorted_pts, g.sorted_idx, n, kk, avg);
+    {
+        ProfScope prof(KPX_PROF_SOR_KNN, 12.0 * (double)n + 8.0 * (double)n, st);     // read points, write mean distances
+        hipLaunchKernelGGL(sor_knn_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g.params, g.cell_start,
+                           g.sorted_pts, g.sorted_idx, n, kk, avg);
+    }
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
     for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(sor_sum_kernel, dim3(nb), dim3(256), 0, st, avg, n, d_stats, pass, part);

@@ -231,8 +231,11 @@ static int plane_impl(const float *pts, int64_t n, double thr, int ransac_n, int
     if (H > 0) {
         hipLaunchKernelGGL(plane_hyp_kernel, dim3((unsigned)cdiv(H, 64)), dim3(64), 0, st, pts, n, ransac_n, H, (uint32_t)seed,
                            (uint32_t)(seed >> 32), ids, hyp);
-        hipLaunchKernelGGL(plane_score_kernel, dim3((unsigned)cdiv(H, kScoreThreads), chunks), dim3(kScoreThreads), 0, st, pts, n,
-                           chunk, hyp, H, thr, part_cnt, part_err);
+        {
+            ProfScope prof(KPX_PROF_PLANE_SCORE, 12.0 * (double)n, st);      // one algorithmic sweep of the points for all H
+            hipLaunchKernelGGL(plane_score_kernel, dim3((unsigned)cdiv(H, kScoreThreads), chunks), dim3(kScoreThreads), 0, st, pts, n,
+                               chunk, hyp, H, thr, part_cnt, part_err);
+        }
         hipLaunchKernelGGL(plane_reduce_kernel, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, part_cnt, part_err, chunks, H, cnt, err);
     }
     hipLaunchKernelGGL(plane_select_kernel, dim3(1), dim3(1), 0, st, hyp, cnt, err, H, n, ransac_n, probability, best);

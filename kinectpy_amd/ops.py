@@ -275,7 +275,7 @@ def kabsch(src, tgt, corr):
 
 
 def icp(src, tgt, max_dist, init=None, mode="p2p", tgt_normals=None, max_iteration=30, relative_fitness=1e-6,
-        relative_rmse=1e-6, want_corr=False):
+        relative_rmse=1e-6, want_corr=False, poll_interval=1):
     """registration_icp.  Returns dict(transformation, fitness, inlier_rmse, iterations, count[, idx, d2])."""
     lib = L.load()
     src = _dev(src, torch.float32).reshape(-1, 3)
@@ -292,7 +292,7 @@ def icp(src, tgt, max_dist, init=None, mode="p2p", tgt_normals=None, max_iterati
     init = _T(np.eye(4) if init is None else init)
     ws, wsz = L.workspace(lib.kpx_icp_workspace_bytes(n, m))
     L.check(lib.kpx_icp(L.ptr(src), n, L.ptr(tgt), L.ptr(tn), m, float(max_dist), L.hptr(init), md, int(max_iteration),
-                        float(relative_fitness), float(relative_rmse), L.ptr(res), L.ptr(idx), L.ptr(d2), ws, wsz,
+                        float(relative_fitness), float(relative_rmse), int(poll_interval), L.ptr(res), L.ptr(idx), L.ptr(d2), ws, wsz,
                         L.stream_ptr()))
     r = res.cpu().numpy()
     out = {"transformation": r[:16].reshape(4, 4).copy(), "fitness": float(r[16]), "inlier_rmse": float(r[17]),
@@ -300,3 +300,20 @@ def icp(src, tgt, max_dist, init=None, mode="p2p", tgt_normals=None, max_iterati
     if want_corr:
         out["idx"], out["d2"] = idx, d2
     return out
+
+
+# ---- measurement hooks --------------------------------------------------------------------------------
+PROF_KERNELS = ("nn_mfma", "sor_knn", "plane_score", "compact")
+
+
+def prof_begin(capacity=65536):
+    L.check(L.load().kpx_prof_begin(int(capacity)))
+
+
+def prof_end():
+    """-> {kernel: (total_ms, launches, work)}; work = flops (nn_mfma) or algorithmic bytes"""
+    ms = np.zeros(4)
+    cnt = np.zeros(4, dtype=np.int64)
+    work = np.zeros(4)
+    L.check(L.load().kpx_prof_end(L.hptr(ms), cnt.ctypes.data_as(C.c_void_p), L.hptr(work)))
+    return {k: (float(ms[i]), int(cnt[i]), float(work[i])) for i, k in enumerate(PROF_KERNELS)}

@@ -1,0 +1,83 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" for the
+CPU rehearsal in tests).  The path shards by sensor (preprocessing/data.py:96-122 loops the devices with no
+cross-talk); the only exchange is the fuse (data.py:44-58): the rigid transforms (128 B each) and the
+filtered clouds.  Messages are small and latency-bound on xGMI, so each frame uses exactly two
+collectives: an all-gather of a fixed-size header (count + transforms) and an all-gather of the padded
+cloud buffers (direct peer writes; no ring reduction of payload).
+"""
+import os
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str = None) -> Tuple[int, int, int]:
+    """-> (rank, world, local_rank).  Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def shard_sensors(n_sensors: int, rank: int, world: int) -> List[int]:
+    """Contiguous block of sensors owned by `rank` (sensors are dealt as evenly as possible; with fewer
+    GPUs than sensors a rank simply owns several, same code path -- SURVEY.md 8e)."""
+    base, rem = divmod(n_sensors, world)
+    start = rank * base + min(rank, rem)
+    return list(range(start, start + base + (1 if rank < rem else 0)))
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def allgather_header(header: torch.Tensor) -> torch.Tensor:
+    """header: 1-D float64 tensor of equal length on every rank -> (world, len)."""
+    if world_size() == 1:
+        return header[None]
+    out = [torch.empty_like(header) for _ in range(world_size())]
+    dist.all_gather(out, header)
+    return torch.stack(out)
+
+
+def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor):
+    """padded: (cap, C) float32 buffer whose first `count` rows are valid (same cap on every rank);
+    transforms: (k, 4, 4) float64 of this rank's sensors (same k on every rank).
+    Returns (cloud (sum counts, C), all transforms (world*k, 4, 4), counts list)."""
+    k = transforms.shape[0]
+    hdr = torch.cat([torch.tensor([float(count)], dtype=torch.float64, device=padded.device),
+                     transforms.reshape(-1).to(padded.device)])
+    hdrs = allgather_header(hdr)
+    counts = [int(c) for c in hdrs[:, 0].tolist()]
+    all_T = hdrs[:, 1:].reshape(-1, 4, 4)
+    if world_size() == 1:
+        return padded[:count], all_T, counts
+    bufs = [torch.empty_like(padded) for _ in range(world_size())]
+    dist.all_gather(bufs, padded)
+    cloud = torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+    assert all_T.shape[0] == k * world_size()
+    return cloud, all_T, counts
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def allreduce_max(value: float, device) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

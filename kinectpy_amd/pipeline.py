@@ -1,0 +1,82 @@
+"""Per-frame multi-sensor pipeline: the frame loop of the reference's DataProcessor
+(preprocessing/data.py:35-61, 127-161) for one group of sensors held by one GPU:
+
+    extract (depth -> masked, gated, compacted clouds)           a1-a4
+    register each sub sensor onto the group's master (voxel 35 -> normals -> point-to-plane ICP)  a11-a14
+    transform the sub clouds, fuse, filter_outliers                a17, a6-a8
+
+and, across GPUs, the exchange of parallel.py.  Everything on the device goes through kinectpy_amd.ops.
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import ops, parallel
+
+
+@dataclass
+class PipelineParams:
+    reg_voxel: float = 35.0          # preprocessing/registration.py:35,69
+    normals_nn: int = 40             # registration.py:24
+    icp_max_dist: float = 100.0      # registration.py:75
+    icp_mode: str = "p2plane"        # registration.py:83
+    icp_max_iteration: int = 30      # Open3D default criteria
+    filt_voxel: float = 10.0         # BASELINE.json config 3: voxel 1 cm on mm data
+    filt_k: int = 20
+    filt_ratio: float = 2.0
+    gate: float = 750.0              # preprocessing/data.py:170-171
+    poll_interval: int = 1
+
+
+class SensorGroupPipeline:
+    def __init__(self, xy_table, init_transforms: List[np.ndarray], params: Optional[PipelineParams] = None,
+                 cloud_capacity: int = 0):
+        self.p = params or PipelineParams()
+        self.xy = ops._dev(xy_table, torch.float32).reshape(-1)
+        self.init = [np.asarray(T, dtype=np.float64) for T in init_transforms]
+        self.capacity = cloud_capacity
+        self.last = {}
+
+    def step(self, depth: torch.Tensor, rgb: torch.Tensor):
+        """depth (S, n_px) u16, rgb (S, n_px, 3) u8 (background zeroed), both resident on the device.
+        Returns (points (K,3) f32, colours (K,3) f32, transforms (S,4,4) f64 sub->group master)."""
+        p = self.p
+        S = depth.shape[0]
+        full = ops.depth_to_cloud(depth, self.xy, None, S, False, False)                 # registration input
+        masked = ops.depth_to_cloud(depth, self.xy, rgb, S, True, True, gate=p.gate)     # person clouds
+        # -- registration: every sub onto the master, exactly execute_point_to_plane_registration
+        downs = [ops.voxel_downsample(full[i][0], p.reg_voxel)[0] for i in range(S)]
+        tn = ops.estimate_normals(downs[0], 2.0 * p.reg_voxel, p.normals_nn) if p.icp_mode == "p2plane" else None
+        Ts = [np.eye(4)]
+        stats = []
+        for i in range(1, S):
+            r = ops.icp(downs[i], downs[0], p.icp_max_dist, self.init[i - 1], p.icp_mode, tn, p.icp_max_iteration,
+                        poll_interval=p.poll_interval)
+            Ts.append(r["transformation"])
+            stats.append((r["iterations"], r["fitness"], r["inlier_rmse"]))
+        # -- transform + fuse + filter
+        pts = [masked[0][0]] + [ops.transform(masked[i][0], Ts[i]) for i in range(1, S)]
+        fused_p = torch.cat(pts, 0)
+        fused_c = torch.cat([m[1] for m in masked], 0)
+        vp, vc, _ = ops.voxel_downsample(fused_p, p.filt_voxel, fused_c)
+        keep, _, _ = ops.sor(vp, p.filt_k, p.filt_ratio)
+        out_p, out_c, _ = ops.select_by_index([vp, vc], keep)
+        self.last = {"icp": stats, "n_down": [int(d.shape[0]) for d in downs], "n_masked": [int(m[0].shape[0]) for m in masked],
+                     "n_fused": int(fused_p.shape[0]), "n_out": int(out_p.shape[0])}
+        return out_p, out_c, np.stack(Ts)
+
+    def exchange(self, out_p, out_c, Ts, to_global: np.ndarray):
+        """Fuse across GPUs: clouds are moved into the global master frame with `to_global` (group master ->
+        global master, from calibration) and all-gathered together with the composed transforms."""
+        if self.capacity <= 0:
+            raise ValueError("cloud_capacity must be set for multi-GPU exchange")
+        gp = ops.transform(out_p, to_global) if not np.allclose(to_global, np.eye(4)) else out_p
+        buf = torch.zeros((self.capacity, 6), dtype=torch.float32, device=out_p.device)
+        k = min(int(gp.shape[0]), self.capacity)
+        buf[:k, :3] = gp[:k]
+        buf[:k, 3:] = out_c[:k]
+        comp = torch.as_tensor(np.stack([to_global @ T for T in Ts]))
+        cloud, all_T, counts = parallel.allgather_clouds(buf, k, comp)
+        return cloud[:, :3], cloud[:, 3:], all_T, counts

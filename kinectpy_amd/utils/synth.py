@@ -51,9 +51,9 @@ def camera_pose(i, n_cams, radius=2500.0):
 
 
 def render_depth(E=None, person_shift=(0.0, 0.0, 0.0), seed=20250202, noise=2.0, drop=0.10, xy=None,
-                 max_depth=6000.0):
+                 max_depth=6000.0, return_person=False):
     """Ray-casts the scene from camera pose E (camera->world).  Returns uint16 (H*W,) depth in mm
-    (camera-frame z), 0 = invalid."""
+    (camera-frame z), 0 = invalid; with return_person also the boolean "ray hit the person" mask."""
     rng = np.random.default_rng(seed)
     if E is None:
         E = camera_pose(0, 1, 2000.0)
@@ -78,6 +78,7 @@ def render_depth(E=None, person_shift=(0.0, 0.0, 0.0), seed=20250202, noise=2.0,
         inside = (np.abs(p[:, 0]) <= ROOM + 1) & (np.abs(p[:, 2]) <= ROOM + 1) & (p[:, 1] <= FLOOR_Y + 1) & (p[:, 1] >= -2500)
         t[~inside] = np.inf
         t_best = np.minimum(t_best, t)
+    t_room = t_best.copy()
     for c, r in _PERSON:
         c = np.array(c) + np.array(person_shift)
         r = np.array(r)
@@ -95,7 +96,19 @@ def render_depth(E=None, person_shift=(0.0, 0.0, 0.0), seed=20250202, noise=2.0,
     z = t_best + rng.normal(scale=noise, size=len(xy))
     bad = ~np.isfinite(t_best) | (z <= 250) | (z >= max_depth) | ~valid | (rng.random(len(xy)) < drop)
     z[bad] = 0
-    return np.round(z).astype(np.uint16)
+    dep = np.round(z).astype(np.uint16)
+    if return_person:
+        return dep, (t_best < t_room) & (dep > 0)
+    return dep
+
+
+def mask_rgb(person, seed=7):
+    """uint8 (H*W,3) colour image with the background zeroed the way Filtering.apply_segmentation leaves
+    it (all-channels-zero == background, preprocessing/data.py:169); stand-in for Mask R-CNN."""
+    rng = np.random.default_rng(seed)
+    rgb = rng.integers(1, 256, size=(person.size, 3), dtype=np.uint8)
+    rgb[~person] = 0
+    return rgb
 
 
 def person_mask_rgb(depth, E=None, seed=7):

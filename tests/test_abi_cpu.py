@@ -49,10 +49,10 @@ def test_version_and_error_channel(lib):
     assert rc == -1 and b"at least" in lib.kpx_last_error()
     init = np.eye(4)
     rc = lib.kpx_icp(None, 5, None, None, 5, C.c_double(1.0), init.ctypes.data_as(C.c_void_p), 1, 30, C.c_double(1e-6),
-                     C.c_double(1e-6), None, None, None, None, 0, None)
+                     C.c_double(1e-6), 0, None, None, None, None, 0, None)
     assert rc == -1 and b"normal" in lib.kpx_last_error()
     rc = lib.kpx_icp(None, 5, None, None, 5, C.c_double(-1.0), init.ctypes.data_as(C.c_void_p), 0, 30, C.c_double(1e-6),
-                     C.c_double(1e-6), None, None, None, None, 0, None)
+                     C.c_double(1e-6), 0, None, None, None, None, 0, None)
     assert rc == -1 and b"max_correspondence_distance" in lib.kpx_last_error()
 
 
