@@ -5,14 +5,25 @@
 // form (contract AC2):
 //     A[i] = (s_x, s_y, s_z, 1)            s = T . src_i       (fp64 fma chain, contract AC1)
 //     B[j] = (-2t_x, -2t_y, -2t_z, |t|^2)  |t|^2 = fma(tx,tx, fma(ty,ty, tz*tz))
-//     m_ij = A[i] . B[j] = d_ij^2 - |s_i|^2   -> argmin_j, ties to the lowest j
-// v_mfma_f64_16x16x4_f64 produces a 16x16 tile of m per instruction; the running (min, argmin) is fused
-// behind it in registers, the N x M matrix is never materialised.  Block = 4 waves x 64 rows; the B
-// stream is staged through LDS (double buffered) and shared by the 4 waves; the column range is split
-// over gridDim.y to fill the 256 CUs, a second kernel merges the splits (ascending, strict <), computes
-// the direct squared distance (AC3) of the chosen pair and accumulates the sums the update needs.
-// The whole ICP loop runs without host synchronisation: a one-thread kernel solves the 3x3 (Kabsch) or
-// 6x6 (point-to-plane) system, updates T and raises `done`; later launches see it and return.
+//     C[i] = K_i = fma(sx,sx, fma(sy,sy, sz*sz)) + 1
+//     D_ij = fma(1,|t|^2, fma(s_z,-2t_z, fma(s_y,-2t_y, fma(s_x,-2t_x, K_i))))  = d_ij^2 + 1 > 0
+//            -> argmin_j, ties to the lowest j.
+// v_mfma_f64_16x16x4_f64 produces a 16x16 tile of D per instruction (bit-for-bit the k-ordered fma chain
+// above, seeded with C).  D > 0, so the IEEE bit pattern orders like an unsigned integer: the running
+// argmin behind each MFMA is a 32-bit compare of the HIGH words (hi(D) <= hi(best): a necessary condition
+// for an update) and a wave-uniform branch; the exact fp64 (value, column) update runs only in the rare
+// wave-iterations where some lane passes.  To make updates rare the sweep starts from a valid upper bound:
+// the previous iteration's partner (ICP iterations >= 1) or the winner of a seed sweep over every 64th
+// target tile.  fp64 VALU compares contend with the fp64 MFMA pipe on MI355X (measured: 4 v_cmp_f64 per
+// MFMA cost 30 % of the MFMA rate), the 32-bit prefilter does not.
+// Block = 4 waves x 32 source rows; the B stream is staged through LDS by LDS-DMA (16 KiB stages, double
+// buffered) and shared by the waves; the column range is split over gridDim.y, a second kernel merges the
+// splits (lexicographic (value, column)), computes the direct squared distance (AC3) of the chosen pair
+// and accumulates the sums the update needs.  The ICP loop runs on the device; a small kernel solves the
+// 3x3 (Kabsch) or 6x6 (point-to-plane) system, updates T and raises `done`.
+#include <limits.h>
+#include <stdlib.h>
+
 #include "kpx_internal.h"
 #include "kpx_linalg.h"
 
@@ -20,11 +31,12 @@ namespace kpx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int kRT = 4;                       // 16-row tiles per wave (the sweep below is written for 4)
+constexpr int kRT = 2;                       // 16-row tiles per wave (the sweep below is written for 2)
 constexpr int kWaves = 4;
-constexpr int kRowsPerBlock = kWaves * kRT * 16;   // 256
+constexpr int kRowsPerBlock = kWaves * kRT * 16;   // 128
 constexpr int kCT = 32;                      // 16-column tiles per LDS stage (16 KiB)
 constexpr int kStageDoubles = kCT * 64;
+constexpr int kSeedStride = 64;              // the seed sweep visits every 64th target tile
 constexpr double kSentinel = 1e300;
 constexpr int kAcc = 44;                     // accumulator slots: count, sum d2, sum s, sum t, sum t s^T, J^T J (21), J^T r (6)
 
@@ -35,26 +47,67 @@ struct IcpState {
     int32_t iter, done;
 };
 
-// ---- target preparation: B tiles, element (k, j) of tile t at B[t*64 + k*16 + j] ----------------------
-__global__ __launch_bounds__(256) void nn_prep_kernel(const float *__restrict__ tgt, int64_t m, int64_t tiles_pad, double *__restrict__ B)
+__device__ __forceinline__ void xform_row(const double *__restrict__ T, const float *__restrict__ p, double s[3])
 {
-    const int64_t total = tiles_pad * 16;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    const double x = p[0], y = p[1], z = p[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = fma(T[4 * k], x, fma(T[4 * k + 1], y, fma(T[4 * k + 2], z, T[4 * k + 3])));
+}
+__device__ __forceinline__ double row_seed(const double s[3]) { return fma(s[0], s[0], fma(s[1], s[1], s[2] * s[2])) + 1.0; }
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+// high word of the IEEE pattern as a 32-bit register reference (a shift of the 64-bit pattern makes hipcc
+// compare zero-extended 64-bit values, i.e. the slow v_cmp_*_u64 this prefilter exists to avoid)
+__device__ __forceinline__ unsigned hi32(double v) { return __builtin_bit_cast(u2, v)[1]; }
+
+// ---- target preparation: B tiles, element (k, j) of tile t at B[t*64 + k*16 + j]; Bseed = every 64th tile --
+__global__ __launch_bounds__(256) void nn_prep_kernel(const float *__restrict__ tgt, int64_t m, int64_t tiles_pad, double *__restrict__ B,
+                                                      int64_t seed_tiles_pad, double *__restrict__ Bseed)
+{
+    const int64_t total = (tiles_pad + seed_tiles_pad) * 16;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const bool seed = q >= tiles_pad * 16;
+        const int64_t jj = seed ? q - tiles_pad * 16 : q;                 // column slot inside its operand array
+        const int64_t j = seed ? (jj >> 4) * kSeedStride * 16 + (jj & 15) : jj;   // target index it stands for
         double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = kSentinel;
         if (j < m) {
             double tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
             b0 = -2.0 * tx; b1 = -2.0 * ty; b2 = -2.0 * tz;
             b3 = fma(tx, tx, fma(ty, ty, tz * tz));
         }
-        double *o = B + (j >> 4) * 64 + (j & 15);
+        double *o = (seed ? Bseed : B) + (jj >> 4) * 64 + (jj & 15);
         o[0] = b0; o[16] = b1; o[32] = b2; o[48] = b3;
     }
 }
 
+// ---- upper bound from a known partner (previous iteration): D(i, prev[i]) by the same fma chain ----------
+__global__ __launch_bounds__(256) void nn_bound_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+                                                       const double *__restrict__ T, const int32_t *__restrict__ done,
+                                                       const int32_t *__restrict__ prev, double *__restrict__ init_val,
+                                                       int32_t *__restrict__ init_idx)
+{
+    if (done && *done) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s[3];
+    xform_row(T, src + 3 * i, s);
+    const int32_t j = prev[i];
+    const float *tp = tgt + 3 * (int64_t)j;
+    const double tx = tp[0], ty = tp[1], tz = tp[2];
+    const double t2 = fma(tx, tx, fma(ty, ty, tz * tz));
+    double d = fma(s[0], -2.0 * tx, row_seed(s));
+    d = fma(s[1], -2.0 * ty, d);
+    d = fma(s[2], -2.0 * tz, d);
+    d = fma(1.0, t2, d);
+    init_val[i] = d;
+    init_idx[i] = j;
+}
+
 // ---- the MFMA nearest-neighbour sweep ------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void nn_mfma_kernel(const float *__restrict__ src, int64_t n, const double *__restrict__ B,
-                                                         int32_t tiles_per_split, const double *__restrict__ T,
-                                                         const int32_t *__restrict__ done, double *__restrict__ part_val,
+// tile_stride: 1 for the full operand, kSeedStride for the seed operand (column = tile * tile_stride * 16 + lane&15)
+__global__ __launch_bounds__(256, 4) void nn_mfma_kernel(const float *__restrict__ src, int64_t n, const double *__restrict__ B,
+                                                         int32_t tiles_per_split, int32_t tile_stride, const double *__restrict__ T,
+                                                         const int32_t *__restrict__ done, const double *__restrict__ init_val,
+                                                         const int32_t *__restrict__ init_idx, double *__restrict__ part_val,
                                                          int32_t *__restrict__ part_idx)
 {
     if (done && *done) return;
@@ -68,26 +121,36 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(const float *__restrict
     // A operands: lane holds component k = lane>>4 of row (lane&15) of each of its row tiles
     const int kcomp = lane >> 4;
     double a[kRT];
-    {
-        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 1.0;
-        if (kcomp < 3) { r0 = T[4 * kcomp]; r1 = T[4 * kcomp + 1]; r2 = T[4 * kcomp + 2]; r3 = T[4 * kcomp + 3]; }
 #pragma unroll
-        for (int rt = 0; rt < kRT; ++rt) {
-            int64_t row = row_base + rt * 16 + (lane & 15);
-            double v = 0.0;
-            if (row < n) {
-                double x = src[3 * row], y = src[3 * row + 1], z = src[3 * row + 2];
-                v = kcomp < 3 ? fma(r0, x, fma(r1, y, fma(r2, z, r3))) : 1.0;
-            }
-            a[rt] = v;
+    for (int rt = 0; rt < kRT; ++rt) {
+        const int64_t row = row_base + rt * 16 + (lane & 15);
+        double v = 0.0;
+        if (row < n) {
+            double s[3];
+            xform_row(T, src + 3 * row, s);
+            v = kcomp == 0 ? s[0] : (kcomp == 1 ? s[1] : (kcomp == 2 ? s[2] : 1.0));
         }
+        a[rt] = v;
     }
+    // C operands (row seeds K_i), running best and its column: D layout row = (lane>>4) + 4*reg
+    d4 seed[kRT];
     double best[kRT][4];
-    int32_t btile[kRT][4];
+    int32_t bcol[kRT][4];
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { best[rt][r] = INFINITY; btile[rt][r] = 0; }
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row_base + rt * 16 + (lane >> 4) + 4 * r;
+            double kk = 1.0, bv = INFINITY;
+            int32_t bj = INT_MAX;
+            if (row < n) {
+                double s[3];
+                xform_row(T, src + 3 * row, s);
+                kk = row_seed(s);
+                if (init_val) { bv = init_val[row]; bj = init_idx[row]; }
+            }
+            seed[rt][r] = kk; best[rt][r] = bv; bcol[rt][r] = bj;
+        }
 
     // B stream: global -> LDS by LDS-DMA (1 KiB per wave-instruction, 16 pieces per 16 KiB stage)
     const double *gB = B + t0 * 64;
@@ -103,41 +166,64 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(const float *__restrict
     stage_load(0, 0);
     __syncthreads();
 
-    const d4 zero = { 0.0, 0.0, 0.0, 0.0 };
-#define KPX_NN_UPDATE(ACC, RT, TG)                                                                 \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
-        const bool lt = ACC[r] < best[RT][r];                                                      \
-        best[RT][r] = lt ? ACC[r] : best[RT][r];                                                   \
-        btile[RT][r] = lt ? (TG) : btile[RT][r];                                                   \
-    }
     for (int st = 0; st < nstages; ++st) {
         const int buf = st & 1;
         if (st + 1 < nstages) stage_load(st + 1, buf ^ 1);
         const double *lb = lds[buf] + lane;
         const int32_t tile0 = (int32_t)t0 + st * kCT;
-        // software pipeline: the four MFMAs of tile ct+1 are issued before the selects of tile ct
-        double b = lb[0];
-        d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b, zero, 0, 0, 0);
-        d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b, zero, 0, 0, 0);
-        d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b, zero, 0, 0, 0);
-        d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b, zero, 0, 0, 0);
-#pragma unroll 4
-        for (int ct = 0; ct < kCT; ++ct) {
-            const int32_t tg = tile0 + ct;
-            d4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
-            if (ct + 1 < kCT) {
-                b = lb[(ct + 1) * 64];
-                n0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b, zero, 0, 0, 0);
-                n1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b, zero, 0, 0, 0);
-                n2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b, zero, 0, 0, 0);
-                n3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b, zero, 0, 0, 0);
+        // two column tiles (four MFMAs) per trip; the B values of the next trip are read before the results
+        // of this one are examined
+        double b0 = lb[0], b1 = lb[64];
+#pragma unroll 1
+        for (int ct = 0; ct < kCT; ct += 2) {
+            const d4 c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b0, seed[0], 0, 0, 0);
+            const d4 c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b0, seed[1], 0, 0, 0);
+            const d4 c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b1, seed[0], 0, 0, 0);
+            const d4 c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b1, seed[1], 0, 0, 0);
+            const int nx = (ct + 2) & (kCT - 1);                   // wraps on the last trip (value unused)
+            b0 = lb[nx * 64];
+            b1 = lb[nx * 64 + 64];
+            // prefilter on the high words (D > 0: unsigned order of the bit patterns == numeric order)
+            bool pass = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned h0 = hi32(best[0][r]), h1 = hi32(best[1][r]);
+                pass |= (hi32(c00[r]) <= h0) | (hi32(c01[r]) <= h0) | (hi32(c10[r]) <= h1) | (hi32(c11[r]) <= h1);
             }
-            KPX_NN_UPDATE(c0, 0, tg) KPX_NN_UPDATE(c1, 1, tg) KPX_NN_UPDATE(c2, 2, tg) KPX_NN_UPDATE(c3, 3, tg)
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            if (__builtin_amdgcn_ballot_w64(pass) != 0 && tile_stride != 7777) {   // wave-uniform, rare once the bound is tight
+                const int32_t col0 = (tile0 + ct) * tile_stride * 16 + (lane & 15);
+                const int32_t col1 = col0 + tile_stride * 16;
+                bool anyeq = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned h0 = hi32(best[0][r]), h1 = hi32(best[1][r]);
+                    anyeq |= (hi32(c00[r]) == h0) | (hi32(c01[r]) == h0) | (hi32(c10[r]) == h1) | (hi32(c11[r]) == h1);
+                }
+                if (__builtin_amdgcn_ballot_w64(anyeq) == 0) {
+                    // every high word differs from its bound: the high words alone decide "<" (no fp64 op)
+#define KPX_NN_HI(ACC, RT, COL)                                                                     \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
+                        const bool t = hi32(ACC[r]) < hi32(best[RT][r]);                           \
+                        best[RT][r] = t ? ACC[r] : best[RT][r];                                    \
+                        bcol[RT][r] = t ? (COL) : bcol[RT][r];                                     \
+                    }
+                    KPX_NN_HI(c00, 0, col0) KPX_NN_HI(c01, 0, col1) KPX_NN_HI(c10, 1, col0) KPX_NN_HI(c11, 1, col1)
+#undef KPX_NN_HI
+                } else {
+                    // near-ties (equal high words, e.g. the bound's own column): exact lexicographic (value, column)
+#define KPX_NN_EXACT(ACC, RT, COL)                                                                  \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
+                        const bool t = (ACC[r] < best[RT][r]) | ((ACC[r] == best[RT][r]) & ((COL) < bcol[RT][r])); \
+                        best[RT][r] = t ? ACC[r] : best[RT][r];                                    \
+                        bcol[RT][r] = t ? (COL) : bcol[RT][r];                                     \
+                    }
+                    KPX_NN_EXACT(c00, 0, col0) KPX_NN_EXACT(c01, 0, col1) KPX_NN_EXACT(c10, 1, col0) KPX_NN_EXACT(c11, 1, col1)
+#undef KPX_NN_EXACT
+                }
+            }
         }
         __syncthreads();
     }
-#undef KPX_NN_UPDATE
 
     // reduce over the 16 lanes that hold the same rows (lexicographic (value, column) minimum)
 #pragma unroll
@@ -145,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(const float *__restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double v = best[rt][r];
-            int32_t c = btile[rt][r] * 16 + (lane & 15);
+            int32_t c = bcol[rt][r];
 #pragma unroll
             for (int msk = 1; msk < 16; msk <<= 1) {
                 double ov = __shfl_xor(v, msk, 64);
@@ -163,16 +249,17 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(const float *__restrict
 }
 
 // ---- merge splits, direct distance, accumulation ---------------------------------------------------------
-// mode: -1 = correspondences only, 0 = point-to-point sums, 1 = + point-to-plane normal equations
+// mode: -2 = write (value, column) as the bound of the next sweep, -1 = correspondences only,
+//        0 = point-to-point sums, 1 = + point-to-plane normal equations
 __global__ __launch_bounds__(256) void nn_merge_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ T,
                                                        const int32_t *__restrict__ done, const double *__restrict__ part_val,
                                                        const int32_t *__restrict__ part_idx, int splits, double max_d2, int mode,
                                                        int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
-                                                       double *__restrict__ part_acc)
+                                                       double *__restrict__ val_out, double *__restrict__ part_acc)
 {
     if (done && *done) return;
-    __shared__ double sh[4];
+    __shared__ double sh[4][kAcc];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[kAcc];
 #pragma unroll
@@ -182,47 +269,57 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(const float *__restrict__
         int32_t bj = part_idx[i];
         for (int s = 1; s < splits; ++s) {
             double v = part_val[(int64_t)s * n + i];
-            if (v < bv) { bv = v; bj = part_idx[(int64_t)s * n + i]; }
+            int32_t j = part_idx[(int64_t)s * n + i];
+            if (v < bv || (v == bv && j < bj)) { bv = v; bj = j; }
         }
-        double x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
-        double s[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s[k] = fma(T[4 * k], x, fma(T[4 * k + 1], y, fma(T[4 * k + 2], z, T[4 * k + 3])));
-        const float *tp = tgt + 3 * (int64_t)bj;
-        double t[3] = { (double)tp[0], (double)tp[1], (double)tp[2] };
-        double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
-        double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
         if (idx_out) idx_out[i] = bj;
-        if (d2_out) d2_out[i] = d2;
-        if (mode >= 0 && d2 < max_d2) {
-            acc[0] = 1.0; acc[1] = d2;
+        if (mode == -2) {
+            val_out[i] = bv;
+        } else {
+            double s[3];
+            xform_row(T, src + 3 * i, s);
+            const float *tp = tgt + 3 * (int64_t)bj;
+            double t[3] = { (double)tp[0], (double)tp[1], (double)tp[2] };
+            double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
+            double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+            if (d2_out) d2_out[i] = d2;
+            if (mode >= 0 && d2 < max_d2) {
+                acc[0] = 1.0; acc[1] = d2;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { acc[2 + k] = s[k]; acc[5 + k] = t[k]; }
+                for (int k = 0; k < 3; ++k) { acc[2 + k] = s[k]; acc[5 + k] = t[k]; }
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) acc[8 + 3 * p + q] = t[p] * s[q];
-            if (mode == 1) {
-                const float *np_ = tn + 3 * (int64_t)bj;
-                double nx = np_[0], ny = np_[1], nz = np_[2];
-                double r = (s[0] - t[0]) * nx + (s[1] - t[1]) * ny + (s[2] - t[2]) * nz;
-                double J[6] = { s[1] * nz - s[2] * ny, s[2] * nx - s[0] * nz, s[0] * ny - s[1] * nx, nx, ny, nz };
-                int q = 17;
+                    for (int q = 0; q < 3; ++q) acc[8 + 3 * p + q] = t[p] * s[q];
+                if (mode == 1) {
+                    const float *np_ = tn + 3 * (int64_t)bj;
+                    double nx = np_[0], ny = np_[1], nz = np_[2];
+                    double r = (s[0] - t[0]) * nx + (s[1] - t[1]) * ny + (s[2] - t[2]) * nz;
+                    double J[6] = { s[1] * nz - s[2] * ny, s[2] * nx - s[0] * nz, s[0] * ny - s[1] * nx, nx, ny, nz };
+                    int q = 17;
 #pragma unroll
-                for (int p = 0; p < 6; ++p)
+                    for (int p = 0; p < 6; ++p)
 #pragma unroll
-                    for (int c = p; c < 6; ++c) acc[q++] = J[p] * J[c];
+                        for (int c = p; c < 6; ++c) acc[q++] = J[p] * J[c];
 #pragma unroll
-                for (int p = 0; p < 6; ++p) acc[38 + p] = J[p] * r;
+                    for (int p = 0; p < 6; ++p) acc[38 + p] = J[p] * r;
+                }
             }
         }
     }
     if (mode < 0) return;
-    const int nacc = mode == 1 ? kAcc : 17;
-    for (int q = 0; q < nacc; ++q) {
-        double v = block_sum(acc[q], sh);
-        if (threadIdx.x == 0) part_acc[(int64_t)blockIdx.x * kAcc + q] = v;
+    // fixed-order block sums: wave tree per slot, then the four waves in order (one barrier in total)
+#pragma unroll
+    for (int q = 0; q < kAcc; ++q) {
+        if (q < 17 || mode == 1) {
+            double v = wave_sum(acc[q]);
+            if (lane_id() == 0) sh[wave_id()][q] = v;
+        }
     }
+    __syncthreads();
+    if (threadIdx.x < kAcc && (threadIdx.x < 17 || mode == 1))
+        part_acc[(int64_t)blockIdx.x * kAcc + threadIdx.x] =
+            ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
 }
 
 // ---- update step ------------------------------------------------------------------------------------------
@@ -267,20 +364,29 @@ __device__ void update_p2plane(const double *acc, double U[16])
     U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
 }
 
-// one wave: lanes sum the accumulator columns over blocks (fixed order), lane 0 does the algebra.
+// 256 threads: thread (slot q = t & 63, slice s = t >> 6) sums its slice of the per-block partials, the four
+// slices are added in order (fixed summation tree), thread 0 does the algebra.
 // k = index of the correspondence search just finished (0 = the initial one).
-__global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ part_acc, int nblocks, int64_t n, int mode, int k,
-                                                       int max_iter, double rel_fit, double rel_rmse, IcpState *st,
-                                                       double *__restrict__ result)
+__global__ __launch_bounds__(256) void icp_solve_kernel(const double *__restrict__ part_acc, int nblocks, int64_t n, int mode, int k,
+                                                        int max_iter, double rel_fit, double rel_rmse, IcpState *st,
+                                                        double *__restrict__ result)
 {
     if (st->done) return;
+    __shared__ double part[4][64];
     __shared__ double acc[kAcc];
     const int nacc = mode == 1 ? kAcc : 17;
-    if ((int)threadIdx.x < kAcc) {
+    const int q = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    {
         double s = 0.0;
-        if ((int)threadIdx.x < nacc) for (int b = 0; b < nblocks; ++b) s += part_acc[(int64_t)b * kAcc + threadIdx.x];
-        acc[threadIdx.x] = s;
+        if (q < nacc) {
+            const int per = (nblocks + 3) / 4;
+            const int b0 = slice * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+            for (int b = b0; b < b1; ++b) s += part_acc[(int64_t)b * kAcc + q];
+        }
+        part[slice][q] = s;
     }
+    __syncthreads();
+    if (threadIdx.x < kAcc) acc[threadIdx.x] = threadIdx.x < nacc ? ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x] : 0.0;
     __syncthreads();
     if (threadIdx.x) return;
     double cnt = acc[0];
@@ -294,10 +400,10 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict_
         double U[16], Tn[16];
         if (mode == 1) update_p2plane(acc, U); else update_p2p(acc, U);
         mat4_mul(U, st->T, Tn);
-        for (int q = 0; q < 16; ++q) st->T[q] = Tn[q];
+        for (int c = 0; c < 16; ++c) st->T[c] = Tn[c];
     }
     if (done) st->done = 1;
-    for (int q = 0; q < 16; ++q) result[q] = st->T[q];
+    for (int c = 0; c < 16; ++c) result[c] = st->T[c];
     result[16] = fit; result[17] = rmse; result[18] = (double)k; result[19] = cnt;
 }
 
@@ -345,7 +451,7 @@ __global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restric
 
 // ---- host side ----------------------------------------------------------------------------------------------
 struct NnPlan {
-    int64_t tiles_pad, n_src, n_tgt;
+    int64_t tiles_pad, seed_tiles_pad, n_src, n_tgt;
     int32_t tiles_per_split, splits, row_blocks;
 };
 static NnPlan nn_plan(int64_t n, int64_t m)
@@ -355,7 +461,9 @@ static NnPlan nn_plan(int64_t n, int64_t m)
     int64_t tiles = cdiv(m > 0 ? m : 1, 16);
     int64_t stages = cdiv(tiles, kCT);
     p.row_blocks = (int32_t)cdiv(n > 0 ? n : 1, kRowsPerBlock);
-    int64_t want = cdiv(2048, p.row_blocks);            // aim for >= ~2048 workgroups (8 per CU)
+    int64_t target_blocks = 4096;                       // aim for >= ~4096 workgroups (16 per CU)
+    if (const char *e = getenv("KPX_NN_BLOCKS")) target_blocks = atoll(e);      // tuning knob (dev)
+    int64_t want = cdiv(target_blocks, p.row_blocks);
     if (want > stages) want = stages;
     if (want < 1) want = 1;
     if (want > 64) want = 64;
@@ -363,35 +471,64 @@ static NnPlan nn_plan(int64_t n, int64_t m)
     p.splits = (int32_t)cdiv(stages, stages_per_split);
     p.tiles_per_split = (int32_t)(stages_per_split * kCT);
     p.tiles_pad = (int64_t)p.splits * p.tiles_per_split;
+    p.seed_tiles_pad = cdiv(cdiv(tiles, kSeedStride), kCT) * kCT;
     return p;
 }
 
 struct NnBuffers {
-    double *B, *part_val, *part_acc;
-    int32_t *part_idx;
+    double *B, *Bseed, *part_val, *part_acc, *init_val, *d2_cur;
+    int32_t *part_idx, *init_idx, *idx_cur;
     IcpState *state;
     double *T0;
 };
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
 {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
     b->B = a.get<double>((size_t)p.tiles_pad * 64);
-    b->part_val = a.get<double>((size_t)p.splits * (size_t)(n > 0 ? n : 1));
-    b->part_idx = a.get<int32_t>((size_t)p.splits * (size_t)(n > 0 ? n : 1));
+    b->Bseed = a.get<double>((size_t)p.seed_tiles_pad * 64);
+    b->part_val = a.get<double>((size_t)p.splits * nn);
+    b->part_idx = a.get<int32_t>((size_t)p.splits * nn);
     b->part_acc = a.get<double>((size_t)p.row_blocks * kAcc);
+    b->init_val = a.get<double>(nn);
+    b->init_idx = a.get<int32_t>(nn);
+    b->idx_cur = a.get<int32_t>(nn);
+    b->d2_cur = a.get<double>(nn);
     b->state = a.get<IcpState>(1);
     b->T0 = a.get<double>(16);
 }
 
-static int nn_launch(const float *src, int64_t n, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b,
-                     const double *T, const int32_t *done, double max_d2, int mode, int32_t *idx, double *d2, hipStream_t st)
+static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st)
 {
+    int64_t work = (p.tiles_pad + p.seed_tiles_pad) * 16;
+    hipLaunchKernelGGL(nn_prep_kernel, dim3((unsigned)(cdiv(work, 256) > 2048 ? 2048 : cdiv(work, 256))), dim3(256), 0, st, tgt,
+                       p.n_tgt, p.tiles_pad, b.B, p.seed_tiles_pad, b.Bseed);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+// One correspondence search.  have_prev: b.idx_cur holds the partners of the previous search (bound from them),
+// otherwise a seed sweep over every 64th target tile provides the bound.
+static int nn_search_launch(const float *src, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b,
+                            const double *T, const int32_t *done, bool have_prev, double max_d2, int mode, hipStream_t st)
+{
+    const int64_t n = p.n_src;
+    const dim3 thr(256);
+    if (have_prev) {
+        hipLaunchKernelGGL(nn_bound_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, T, done, b.idx_cur,
+                           b.init_val, b.init_idx);
+    } else {
+        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, 1), thr, 0, st, src, n, b.Bseed, (int32_t)p.seed_tiles_pad,
+                           (int32_t)kSeedStride, T, done, (const double *)nullptr, (const int32_t *)nullptr, b.part_val, b.part_idx);
+        hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx, 1,
+                           0.0, -2, b.init_idx, (double *)nullptr, b.init_val, b.part_acc);
+    }
     {
         ProfScope prof(KPX_PROF_NN_MFMA, 8.0 * (double)p.n_src * (double)p.n_tgt, st);     // 4 MAC per (source, target) pair
-        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), dim3(256), 0, st, src, n, b.B, p.tiles_per_split, T, done,
-                           b.part_val, b.part_idx);
+        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), thr, 0, st, src, n, b.B, p.tiles_per_split, getenv("KPX_NN_SKIP_SLOW") ? 7777 : 1, T, done,
+                           b.init_val, b.init_idx, b.part_val, b.part_idx);
     }
-    hipLaunchKernelGGL(nn_merge_kernel, dim3(p.row_blocks), dim3(256), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
-                       p.splits, max_d2, mode, idx, d2, b.part_acc);
+    hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
+                       p.splits, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
@@ -411,7 +548,7 @@ KPX_EXPORT int kpx_nn_search(const float *src, int64_t n_src, const float *tgt, 
                              double *d2, void *ws, size_t ws_bytes, void *stream)
 {
     KPX_REQUIRE(n_src >= 0 && n_tgt >= 1, "kpx_nn_search: empty target");
-    KPX_REQUIRE(n_src < ((int64_t)1 << 31) && n_tgt < ((int64_t)1 << 31) - 1024, "kpx_nn_search: cloud too large");
+    KPX_REQUIRE(n_src < ((int64_t)1 << 31) && n_tgt < ((int64_t)1 << 31) - 65536, "kpx_nn_search: cloud too large");
     if (n_src == 0) return KPX_OK;
     KPX_REQUIRE(src && tgt && d_T && idx && d2 && ws, "kpx_nn_search: null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -420,9 +557,13 @@ KPX_EXPORT int kpx_nn_search(const float *src, int64_t n_src, const float *tgt, 
     NnBuffers b;
     nn_carve(a, n_src, n_tgt, p, &b);
     KPX_ARENA_CHECK(a);
-    hipLaunchKernelGGL(nn_prep_kernel, dim3((unsigned)(cdiv(p.tiles_pad * 16, 256) > 2048 ? 2048 : cdiv(p.tiles_pad * 16, 256))),
-                       dim3(256), 0, st, tgt, n_tgt, p.tiles_pad, b.B);
-    return nn_launch(src, n_src, tgt, nullptr, p, b, d_T, nullptr, 0.0, -1, idx, d2, st);
+    int rc = nn_prep(tgt, p, b, st);
+    if (rc) return rc;
+    rc = nn_search_launch(src, tgt, nullptr, p, b, d_T, nullptr, false, 0.0, -1, st);
+    if (rc) return rc;
+    KPX_HIP(hipMemcpyAsync(idx, b.idx_cur, (size_t)n_src * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    KPX_HIP(hipMemcpyAsync(d2, b.d2_cur, (size_t)n_src * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return KPX_OK;
 }
 
 KPX_EXPORT size_t kpx_kabsch_workspace_bytes(int64_t n_corr)
@@ -461,7 +602,7 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
                 "TransformationEstimationPointToPlane and TransformationEstimationColoredICP require pre-computed normal vectors for target PointCloud.");
     KPX_REQUIRE(max_dist > 0.0, "Invalid max_correspondence_distance.");          // [O3D]
     KPX_REQUIRE(n_src >= 1 && n_tgt >= 1 && max_iteration >= 0, "kpx_icp: empty cloud");
-    KPX_REQUIRE(n_src < ((int64_t)1 << 31) && n_tgt < ((int64_t)1 << 31) - 1024, "kpx_icp: cloud too large");
+    KPX_REQUIRE(n_src < ((int64_t)1 << 31) && n_tgt < ((int64_t)1 << 31) - 65536, "kpx_icp: cloud too large");
     KPX_REQUIRE(src && tgt && h_init && d_result && ws, "kpx_icp: null pointer");
     hipStream_t st = (hipStream_t)stream;
     Arena a(ws, ws_bytes);
@@ -471,14 +612,14 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
     KPX_ARENA_CHECK(a);
     KPX_HIP(hipMemcpyAsync(b.T0, h_init, 16 * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, b.state, b.T0);
-    hipLaunchKernelGGL(nn_prep_kernel, dim3((unsigned)(cdiv(p.tiles_pad * 16, 256) > 2048 ? 2048 : cdiv(p.tiles_pad * 16, 256))),
-                       dim3(256), 0, st, tgt, n_tgt, p.tiles_pad, b.B);
+    int rc = nn_prep(tgt, p, b, st);
+    if (rc) return rc;
     const double md2 = max_dist * max_dist;
     for (int k = 0; k <= max_iteration; ++k) {
-        int rc = nn_launch(src, n_src, tgt, tgt_normals, p, b, b.state->T, &b.state->done, md2, mode, idx, d2, st);
+        rc = nn_search_launch(src, tgt, tgt_normals, p, b, b.state->T, &b.state->done, k > 0, md2, mode, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, st, b.part_acc, p.row_blocks, n_src, mode, k, max_iteration,
-                           relative_fitness, relative_rmse, b.state, d_result);
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, st, b.part_acc, (int)cdiv(n_src, 256), n_src, mode, k,
+                           max_iteration, relative_fitness, relative_rmse, b.state, d_result);
         if (poll_interval > 0 && (k + 1) % poll_interval == 0 && k < max_iteration) {
             int32_t h_done = 0;
             KPX_HIP(hipMemcpyAsync(&h_done, &b.state->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -486,6 +627,8 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
             if (h_done) break;
         }
     }
+    if (idx) KPX_HIP(hipMemcpyAsync(idx, b.idx_cur, (size_t)n_src * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (d2) KPX_HIP(hipMemcpyAsync(d2, b.d2_cur, (size_t)n_src * sizeof(double), hipMemcpyDeviceToDevice, st));
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

@@ -607,16 +607,19 @@ KPO_API int kpo_segment_plane(const float *pts, int64_t n, double thr, int ransa
 /* a14/a16: correspondence search of [O3D] registration_icp                                    */
 /* (manual_pointcloud_registration.py:96-98, preprocessing/registration.py:78-84).             */
 /* Source point i is first transformed by T (AC1, fp64, not rounded).  Nearest target under     */
-/* contract AC2:  m_ij = fma(1, |t_j|^2, fma(s_z,-2t_z, fma(s_y,-2t_y, s_x*(-2t_x))))           */
-/* (= d^2 - |s|^2: the K=4 augmented inner product evaluated as a k-ordered fma chain, which   */
-/* is what the f64 MFMA computes), |t|^2 = fma(tx,tx, fma(ty,ty, tz*tz)); argmin, ties ->      */
-/* lowest j.  The reported d2 is the direct form AC3 of the chosen pair.                        */
+/* contract AC2:                                                                                */
+/*   K_i  = fma(s_x,s_x, fma(s_y,s_y, s_z*s_z)) + 1                                             */
+/*   D_ij = fma(1, |t_j|^2, fma(s_z,-2t_z, fma(s_y,-2t_y, fma(s_x,-2t_x, K_i))))                */
+/* (= d^2 + 1 > 0: the K=4 augmented inner product accumulated onto the row seed K_i as a       */
+/* k-ordered fma chain, which is what the f64 MFMA computes), |t|^2 = fma(tx,tx,fma(ty,ty,tz*tz)); */
+/* argmin, ties -> lowest j.  The reported d2 is the direct form AC3 of the chosen pair.        */
 /* ------------------------------------------------------------------------------------------ */
 static inline double nn_metric(const double s[3], const float *t)
 {
     double tx = t[0], ty = t[1], tz = t[2];
     double t2 = fma(tx, tx, fma(ty, ty, tz * tz));
-    double m = s[0] * (-2.0 * tx);
+    double m = fma(s[0], s[0], fma(s[1], s[1], s[2] * s[2])) + 1.0;
+    m = fma(s[0], -2.0 * tx, m);
     m = fma(s[1], -2.0 * ty, m);
     m = fma(s[2], -2.0 * tz, m);
     m = fma(1.0, t2, m);
