@@ -22,7 +22,6 @@
 // and accumulates the sums the update needs.  The ICP loop runs on the device; a small kernel solves the
 // 3x3 (Kabsch) or 6x6 (point-to-plane) system, updates T and raises `done`.
 #include <limits.h>
-#include <stdlib.h>
 
 #include "kpx_internal.h"
 #include "kpx_linalg.h"
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(const float *__restrict
                 const unsigned h0 = hi32(best[0][r]), h1 = hi32(best[1][r]);
                 pass |= (hi32(c00[r]) <= h0) | (hi32(c01[r]) <= h0) | (hi32(c10[r]) <= h1) | (hi32(c11[r]) <= h1);
             }
-            if (__builtin_amdgcn_ballot_w64(pass) != 0 && tile_stride != 7777) {   // wave-uniform, rare once the bound is tight
+            if (__builtin_amdgcn_ballot_w64(pass) != 0) {   // wave-uniform, rare once the bound is tight
                 const int32_t col0 = (tile0 + ct) * tile_stride * 16 + (lane & 15);
                 const int32_t col1 = col0 + tile_stride * 16;
                 bool anyeq = false;
@@ -461,9 +460,7 @@ static NnPlan nn_plan(int64_t n, int64_t m)
     int64_t tiles = cdiv(m > 0 ? m : 1, 16);
     int64_t stages = cdiv(tiles, kCT);
     p.row_blocks = (int32_t)cdiv(n > 0 ? n : 1, kRowsPerBlock);
-    int64_t target_blocks = 4096;                       // aim for >= ~4096 workgroups (16 per CU)
-    if (const char *e = getenv("KPX_NN_BLOCKS")) target_blocks = atoll(e);      // tuning knob (dev)
-    int64_t want = cdiv(target_blocks, p.row_blocks);
+    int64_t want = cdiv(4096, p.row_blocks);            // aim for >= ~4096 workgroups (16 per CU, 5 resident)
     if (want > stages) want = stages;
     if (want < 1) want = 1;
     if (want > 64) want = 64;
@@ -524,7 +521,7 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
     }
     {
         ProfScope prof(KPX_PROF_NN_MFMA, 8.0 * (double)p.n_src * (double)p.n_tgt, st);     // 4 MAC per (source, target) pair
-        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), thr, 0, st, src, n, b.B, p.tiles_per_split, getenv("KPX_NN_SKIP_SLOW") ? 7777 : 1, T, done,
+        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), thr, 0, st, src, n, b.B, p.tiles_per_split, 1, T, done,
                            b.init_val, b.init_idx, b.part_val, b.part_idx);
     }
     hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,

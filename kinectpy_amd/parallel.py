@@ -17,17 +17,18 @@ def init_distributed(backend: str = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            backend = os.environ.get("KPX_DIST_BACKEND") or ("nccl" if ndev else "gloo")
+        if ndev:
+            torch.cuda.set_device(local % ndev)      # gloo rehearsal: several ranks may share one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
-    return rank, world, local
+    elif ndev:
+        torch.cuda.set_device(local % ndev)
+    return rank, world, (local % ndev if ndev else local)
 
 
 def shard_sensors(n_sensors: int, rank: int, world: int) -> List[int]:
@@ -42,13 +43,22 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def _all_gather(t: torch.Tensor):
+    """all_gather that stages through the host when the backend is gloo and the tensor lives on a GPU"""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        out = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world_size())]
+        dist.all_gather(out, t.cpu())
+        return [o.to(t.device) for o in out]
+    out = [torch.empty_like(t) for _ in range(world_size())]
+    dist.all_gather(out, t)
+    return out
+
+
 def allgather_header(header: torch.Tensor) -> torch.Tensor:
     """header: 1-D float64 tensor of equal length on every rank -> (world, len)."""
     if world_size() == 1:
         return header[None]
-    out = [torch.empty_like(header) for _ in range(world_size())]
-    dist.all_gather(out, header)
-    return torch.stack(out)
+    return torch.stack(_all_gather(header))
 
 
 def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor):
@@ -63,8 +73,7 @@ def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor)
     all_T = hdrs[:, 1:].reshape(-1, 4, 4)
     if world_size() == 1:
         return padded[:count], all_T, counts
-    bufs = [torch.empty_like(padded) for _ in range(world_size())]
-    dist.all_gather(bufs, padded)
+    bufs = _all_gather(padded)
     cloud = torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
     assert all_T.shape[0] == k * world_size()
     return cloud, all_T, counts
@@ -78,6 +87,6 @@ def barrier():
 def allreduce_max(value: float, device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -1,0 +1,138 @@
+"""Per-operator measurement at BASELINE.json sizes: whole-operator device time from
+HIP events on the launch stream, algorithmic bytes / flops per SURVEY 8d, fraction of the roofline.
+Writes one JSON line per operator (stdout); profiles/rNN/kernels.json keeps the output.
+
+    python tools/bench_kernels.py [--quick]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kinectpy_amd import ops  # noqa: E402
+from kinectpy_amd.utils import synth  # noqa: E402
+
+HBM_PEAK = 8000.0      # GB/s spec (6.3 TB/s measured achievable, MI355X_MICROARCH.md)
+FP64_MFMA_PEAK = 78.6  # TFLOP/s vendor
+N_PX = 576 * 640
+
+
+def timed(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        e0.record()
+        out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts)), out
+
+
+def report(name, ms, nbytes=None, flops=None, **extra):
+    row = {"op": name, "ms": round(ms, 4)}
+    if nbytes is not None:
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        row.update(algorithmic_bytes=int(nbytes), GBps=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK, 4))
+    if flops is not None:
+        tf = flops / (ms * 1e-3) / 1e12
+        row.update(flops=int(flops), TFLOPs=round(tf, 2), frac_fp64_mfma=round(tf / FP64_MFMA_PEAK, 4))
+    row.update(extra)
+    print(json.dumps(row), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    F = 64 if a.quick else 256
+    xy = synth.xy_table()
+    base_d, person = synth.render_depth(xy=xy, return_person=True)
+    rgb1 = synth.mask_rgb(person)
+    depth = torch.as_tensor(np.tile(base_d, (F, 1))).to(dev)
+    rgb = torch.as_tensor(np.tile(rgb1, (F, 1, 1))).to(dev)
+    xyd = torch.as_tensor(xy).to(dev)
+
+    # ---- extract (config 1, batched so the working set exceeds the 256 MiB Infinity Cache)
+    ms, xyz = timed(lambda: ops.unproject_u16(depth, xyd, F))
+    report("unproject_u16 (a1)", ms, F * N_PX * 8, frames=F)
+    ms, res = timed(lambda: ops.depth_to_cloud(depth, xyd, None, F, False, False, sync=False))
+    kept = int(res[3].sum().item())
+    report("depth_to_cloud no colour (a1+a3)", ms, F * N_PX * 2 + kept * 12, frames=F, kept=kept)
+    ms, res = timed(lambda: ops.depth_to_cloud(depth, xyd, rgb, F, True, True, sync=False))
+    kept = int(res[3].sum().item())
+    report("depth_to_cloud mask+gate+colour (a1+a3+a4)", ms, F * N_PX * 5 + kept * 24, frames=F, kept=kept)
+    ms, res = timed(lambda: ops.rgbd_compact(xyz, rgb, F, True, True, want_idx=False))
+    kept = sum(int(r[0].shape[0]) for r in res)
+    report("rgbd_compact from int16 XYZ (a3+a4)", ms, F * N_PX * 9 + kept * 24, frames=F, kept=kept)
+    del depth, rgb, xyz, res
+
+    # ---- container ops
+    n_big = 16_000_000 if a.quick else 64_000_000
+    big = torch.rand((n_big, 3), device=dev) * 3000
+    T = synth.t_star()
+    ms, out = timed(lambda: ops.transform(big, T, out=big))
+    report("transform (a17)", ms, n_big * 24, points=n_big)
+    idx = torch.randperm(n_big, device=dev)[: n_big // 2].to(torch.int32).sort().values
+    ms, _ = timed(lambda: ops.select_by_index([big], idx))
+    report("select_by_index gather", ms, n_big // 2 * (12 + 12 + 4), points=n_big // 2)
+    ms, hs = timed(lambda: ops.halfspace_select(big, [0.1, -0.9, 0.2, 300.0]))
+    report("halfspace_select (a19)", ms, n_big * 12 + int(hs.shape[0]) * 4, points=n_big)
+    del big, idx, out
+
+    # ---- filter chain (config 3)
+    c3 = torch.as_tensor(synth.filter_cloud(1_000_000)).to(dev)
+    col = torch.rand_like(c3)
+    ms, (vp, vc, _) = timed(lambda: ops.voxel_downsample(c3, 10.0, col))
+    report("voxel_down_sample 1M, 10 mm, colours (a7)", ms, 24 * c3.shape[0] + 24 * vp.shape[0], n=int(c3.shape[0]), m=int(vp.shape[0]))
+    ops.prof_begin(64)
+    ms, (keep, stats, _) = timed(lambda: ops.sor(vp, 20, 2.0), reps=3, warm=1)
+    pk = ops.prof_end()["sor_knn"]
+    report("remove_statistical_outlier k=20 (a8)", ms, 12 * vp.shape[0] + 16 * keep.shape[0], n=int(vp.shape[0]), kept=int(keep.shape[0]),
+           knn_kernel_ms=round(pk[0] / max(pk[1], 1), 3))
+    ms, (keep200, _, _) = timed(lambda: ops.sor(vp[:100000].contiguous(), 200, 3.0), reps=2, warm=1)
+    report("remove_statistical_outlier k=200 on 100k (filter_outliers default)", ms, 12 * 100000 + 16 * keep200.shape[0], n=100000)
+    cloud = vp[keep.long()].contiguous()
+    lo, up = ops.slab_split(cloud, 200.0)
+    floor = cloud[lo.long()].contiguous()
+    ops.prof_begin(64)
+    ms, (plane, inl) = timed(lambda: ops.segment_plane(floor, 30.0, 30, 2000, seed=7), reps=3, warm=1)
+    pk = ops.prof_end()["plane_score"]
+    report("segment_plane 30/30/2000 (a21)", ms, 12 * floor.shape[0] * 2 + 4 * inl.shape[0], flops=None, n=int(floor.shape[0]),
+           inliers=int(inl.shape[0]), score_kernel_ms=round(pk[0] / max(pk[1], 1), 3), score_GFLOPs=round(2000 * floor.shape[0] * 8 / (pk[0] / max(pk[1], 1) * 1e-3) / 1e9, 1))
+    ms, nrm = timed(lambda: ops.estimate_normals(vp[:100000].contiguous(), 70.0, 40), reps=3, warm=1)
+    report("estimate_normals r=70 nn=40 on 100k (a11)", ms, 24 * 100000, n=100000)
+
+    # ---- registration (config 2)
+    src, tgt, _ = synth.icp_pair(100_000)
+    s, t = torch.as_tensor(src).to(dev), torch.as_tensor(tgt).to(dev)
+    ops.prof_begin(256)
+    ms, _ = timed(lambda: ops.nn_search(s, t, np.eye(4)), reps=5, warm=1)
+    pk = ops.prof_end()["nn_mfma"]
+    report("nn_search 100k x 100k, cold (seed bound)", ms, flops=8.0 * len(src) * len(tgt), sweep_kernel_ms=round(pk[0] / pk[1], 3),
+           sweep_TFLOPs=round(pk[2] / pk[0] / 1e9, 2))
+    ops.prof_begin(256)
+    ms, r = timed(lambda: ops.icp(s, t, 100.0, None, "p2p", None, 30), reps=2, warm=1)
+    pk = ops.prof_end()["nn_mfma"]
+    report("registration_icp p2p 100k x 100k, 30 it (a16, config 2)", ms, flops=8.0 * len(src) * len(tgt) * (r["iterations"] + 1),
+           iterations=r["iterations"], fitness=round(r["fitness"], 5), sweep_kernel_ms=round(pk[0] / pk[1], 3),
+           sweep_TFLOPs=round(pk[2] / pk[0] / 1e9, 2))
+    tn = ops.estimate_normals(t, 70.0, 40)
+    ops.prof_begin(256)
+    ms, r = timed(lambda: ops.icp(s, t, 100.0, None, "p2plane", tn, 30), reps=2, warm=1)
+    pk = ops.prof_end()["nn_mfma"]
+    report("registration_icp p2plane 100k x 100k (a14)", ms, flops=8.0 * len(src) * len(tgt) * (r["iterations"] + 1),
+           iterations=r["iterations"], fitness=round(r["fitness"], 5), sweep_kernel_ms=round(pk[0] / pk[1], 3),
+           sweep_TFLOPs=round(pk[2] / pk[0] / 1e9, 2))
+
+
+if __name__ == "__main__":
+    main()
