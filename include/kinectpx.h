@@ -176,6 +176,17 @@ int kpx_icp(const float *src, int64_t n_src, const float *tgt, const float *tgt_
             double relative_rmse, int32_t poll_interval, double *d_result, int32_t *idx, double *d2, void *ws,
             size_t ws_bytes, void *stream);
 
+/* Several registrations onto ONE shared target (preprocessing/data.py:144-161 registers every sub device onto
+ * the master cloud).  The target operand is prepared once; the problems' iterations are queued round-robin on
+ * `stream` and each problem's convergence flag is polled through a side stream that waits only for that
+ * problem, so the host round trip is hidden behind the other problems' sweeps (kernels never overlap).
+ * h_src / h_n_src: host arrays of `count` entries; h_init: count x 16; d_results: count x 20 (as kpx_icp). */
+size_t kpx_icp_batch_workspace_bytes(int32_t count, const int64_t *h_n_src, int64_t n_tgt);
+int kpx_icp_batch(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt,
+                  const float *tgt_normals, int64_t n_tgt, double max_dist, const double *h_init, int32_t mode,
+                  int32_t max_iteration, double relative_fitness, double relative_rmse, double *d_results, void *ws,
+                  size_t ws_bytes, void *stream);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it
  * (capacity = max launches recorded); every launch of a tagged kernel is bracketed by an event pair;

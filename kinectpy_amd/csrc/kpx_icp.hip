@@ -478,20 +478,28 @@ struct NnBuffers {
     IcpState *state;
     double *T0;
 };
-static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
+static void nn_carve_target(Arena &a, const NnPlan &p, NnBuffers *b)
 {
-    const size_t nn = (size_t)(n > 0 ? n : 1);
     b->B = a.get<double>((size_t)p.tiles_pad * 64);
     b->Bseed = a.get<double>((size_t)p.seed_tiles_pad * 64);
+}
+static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
+{
+    const size_t nn = (size_t)(n > 0 ? n : 1);
     b->part_val = a.get<double>((size_t)p.splits * nn);
     b->part_idx = a.get<int32_t>((size_t)p.splits * nn);
-    b->part_acc = a.get<double>((size_t)p.row_blocks * kAcc);
+    b->part_acc = a.get<double>((size_t)cdiv((int64_t)nn, 256) * kAcc);
     b->init_val = a.get<double>(nn);
     b->init_idx = a.get<int32_t>(nn);
     b->idx_cur = a.get<int32_t>(nn);
     b->d2_cur = a.get<double>(nn);
     b->state = a.get<IcpState>(1);
     b->T0 = a.get<double>(16);
+}
+static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
+{
+    nn_carve_target(a, p, b);
+    nn_carve_source(a, n, p, b);
 }
 
 static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st)
@@ -626,6 +634,94 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
     }
     if (idx) KPX_HIP(hipMemcpyAsync(idx, b.idx_cur, (size_t)n_src * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     if (d2) KPX_HIP(hipMemcpyAsync(d2, b.d2_cur, (size_t)n_src * sizeof(double), hipMemcpyDeviceToDevice, st));
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+// ---- several registrations onto one shared target, software-pipelined on ONE stream ------------------------------
+// (preprocessing/data.py:144-161 registers every sub device onto the same master cloud.)  The target operand is
+// prepared once.  Iterations of the problems are queued round-robin on the caller's stream; a problem's convergence
+// flag is read back through a side stream that only waits for that problem's last kernel, and its next iteration is
+// queued while the other problems' sweeps are still running -- the GPU never waits for the host round trip, and
+// kernels never overlap (per-launch timings stay those of a solo kernel).
+KPX_EXPORT size_t kpx_icp_batch_workspace_bytes(int32_t count, const int64_t *h_n_src, int64_t n_tgt)
+{
+    Arena a(nullptr, 0);
+    NnBuffers b;
+    if (count < 1 || !h_n_src) return 0;
+    NnPlan tplan = nn_plan(h_n_src[0], n_tgt);          // the shared operand is padded for the largest split plan
+    for (int i = 1; i < count; ++i) { NnPlan q = nn_plan(h_n_src[i], n_tgt); if (q.tiles_pad > tplan.tiles_pad) tplan = q; }
+    nn_carve_target(a, tplan, &b);
+    for (int i = 0; i < count; ++i) nn_carve_source(a, h_n_src[i], nn_plan(h_n_src[i], n_tgt), &b);
+    return a.off;
+}
+KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt,
+                             const float *tgt_normals, int64_t n_tgt, double max_dist, const double *h_init, int32_t mode,
+                             int32_t max_iteration, double relative_fitness, double relative_rmse, double *d_results, void *ws,
+                             size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(count >= 1 && count <= 64 && h_src && h_n_src, "kpx_icp_batch: bad batch");
+    KPX_REQUIRE(mode == KPX_ICP_POINT_TO_POINT || mode == KPX_ICP_POINT_TO_PLANE, "kpx_icp: unknown estimation mode");
+    KPX_REQUIRE(mode != KPX_ICP_POINT_TO_PLANE || tgt_normals,
+                "TransformationEstimationPointToPlane and TransformationEstimationColoredICP require pre-computed normal vectors for target PointCloud.");
+    KPX_REQUIRE(max_dist > 0.0, "Invalid max_correspondence_distance.");
+    KPX_REQUIRE(n_tgt >= 1 && n_tgt < ((int64_t)1 << 31) - 65536 && max_iteration >= 0, "kpx_icp_batch: bad target size");
+    KPX_REQUIRE(tgt && h_init && d_results && ws, "kpx_icp_batch: null pointer");
+    for (int i = 0; i < count; ++i)
+        KPX_REQUIRE(h_src[i] && h_n_src[i] >= 1 && h_n_src[i] < ((int64_t)1 << 31), "kpx_icp_batch: bad source cloud %d", i);
+    hipStream_t st = (hipStream_t)stream;
+    static hipStream_t side = nullptr;                  // library-internal, created once
+    if (!side) KPX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    Arena a(ws, ws_bytes);
+    NnPlan plans[64];
+    NnBuffers bufs[64];
+    NnPlan tplan = nn_plan(h_n_src[0], n_tgt);          // the shared operand is padded for the largest split plan
+    for (int i = 0; i < count; ++i) { plans[i] = nn_plan(h_n_src[i], n_tgt); if (plans[i].tiles_pad > tplan.tiles_pad) tplan = plans[i]; }
+    nn_carve_target(a, tplan, &bufs[0]);
+    for (int i = 0; i < count; ++i) {
+        bufs[i].B = bufs[0].B; bufs[i].Bseed = bufs[0].Bseed;
+        nn_carve_source(a, h_n_src[i], plans[i], &bufs[i]);
+    }
+    KPX_ARENA_CHECK(a);
+    int rc = nn_prep(tgt, tplan, bufs[0], st);
+    if (rc) return rc;
+    hipEvent_t ev[64];
+    for (int i = 0; i < count; ++i) KPX_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    const double md2 = max_dist * max_dist;
+    int iter[64], queue[64], qn = 0;
+    auto launch = [&](int i, int k) -> int {
+        int r = nn_search_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], bufs[i].state->T, &bufs[i].state->done, k > 0, md2,
+                                 mode, st);
+        if (r) return r;
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, st, bufs[i].part_acc, (int)cdiv(h_n_src[i], 256), h_n_src[i], mode, k,
+                           max_iteration, relative_fitness, relative_rmse, bufs[i].state, d_results + 20 * i);
+        KPX_HIP(hipEventRecord(ev[i], st));
+        return KPX_OK;
+    };
+    for (int i = 0; i < count && !rc; ++i) {
+        KPX_HIP(hipMemcpyAsync(bufs[i].T0, h_init + 16 * i, 16 * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, bufs[i].state, bufs[i].T0);
+        iter[i] = 0;
+        rc = launch(i, 0);
+        queue[qn++] = i;
+    }
+    int head = 0;
+    while (!rc && head < qn) {
+        const int i = queue[head % 64];
+        ++head;
+        int32_t h_done = 0;
+        rc = hipStreamWaitEvent(side, ev[i], 0) == hipSuccess ? KPX_OK : fail(KPX_ERR_HIP, "hipStreamWaitEvent failed");
+        if (rc) break;
+        if (hipMemcpyAsync(&h_done, &bufs[i].state->done, sizeof(int32_t), hipMemcpyDeviceToHost, side) != hipSuccess ||
+            hipStreamSynchronize(side) != hipSuccess) { rc = fail(KPX_ERR_HIP, "convergence poll failed"); break; }
+        if (h_done || iter[i] >= max_iteration) continue;
+        ++iter[i];
+        rc = launch(i, iter[i]);
+        queue[qn % 64] = i;
+        ++qn;
+    }
+    for (int i = 0; i < count; ++i) (void)hipEventDestroy(ev[i]);
+    if (rc) return rc;
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

@@ -302,6 +302,32 @@ def icp(src, tgt, max_dist, init=None, mode="p2p", tgt_normals=None, max_iterati
     return out
 
 
+def icp_batch(srcs, tgt, max_dist, inits, mode="p2p", tgt_normals=None, max_iteration=30, relative_fitness=1e-6,
+              relative_rmse=1e-6):
+    """Several registrations onto one shared target, software-pipelined on the current stream.
+    Returns a list of dicts like icp()."""
+    lib = L.load()
+    srcs = [_dev(s, torch.float32).reshape(-1, 3) for s in srcs]
+    tgt = _dev(tgt, torch.float32).reshape(-1, 3)
+    dev = tgt.device
+    cnt, m = len(srcs), tgt.shape[0]
+    tn = _dev(tgt_normals, torch.float32).reshape(-1, 3) if tgt_normals is not None else None
+    md = {"p2p": 0, "p2plane": 1}[mode]
+    if md == 1 and tn is None:
+        raise L.KinectPxError("TransformationEstimationPointToPlane requires target normals")
+    n_arr = np.array([s.shape[0] for s in srcs], dtype=np.int64)
+    p_arr = (C.c_void_p * cnt)(*[s.data_ptr() for s in srcs])
+    init = np.ascontiguousarray(np.stack([_T(np.eye(4) if T is None else T) for T in inits]))
+    res = torch.zeros((cnt, 20), dtype=torch.float64, device=dev)
+    ws, wsz = L.workspace(lib.kpx_icp_batch_workspace_bytes(cnt, n_arr.ctypes.data_as(C.c_void_p), m))
+    L.check(lib.kpx_icp_batch(cnt, C.cast(p_arr, C.c_void_p), n_arr.ctypes.data_as(C.c_void_p), L.ptr(tgt), L.ptr(tn), m,
+                              float(max_dist), L.hptr(init), md, int(max_iteration), float(relative_fitness),
+                              float(relative_rmse), L.ptr(res), ws, wsz, L.stream_ptr()))
+    r = res.cpu().numpy()
+    return [{"transformation": r[i, :16].reshape(4, 4).copy(), "fitness": float(r[i, 16]), "inlier_rmse": float(r[i, 17]),
+             "iterations": int(r[i, 18]), "count": int(r[i, 19])} for i in range(cnt)]
+
+
 # ---- measurement hooks --------------------------------------------------------------------------------
 PROF_KERNELS = ("nn_mfma", "sor_knn", "plane_score", "compact")
 

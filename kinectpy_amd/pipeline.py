@@ -51,11 +51,11 @@ class SensorGroupPipeline:
         tn = ops.estimate_normals(downs[0], 2.0 * p.reg_voxel, p.normals_nn) if p.icp_mode == "p2plane" else None
         Ts = [np.eye(4)]
         stats = []
-        for i in range(1, S):
-            r = ops.icp(downs[i], downs[0], p.icp_max_dist, self.init[i - 1], p.icp_mode, tn, p.icp_max_iteration,
-                        poll_interval=p.poll_interval)
-            Ts.append(r["transformation"])
-            stats.append((r["iterations"], r["fitness"], r["inlier_rmse"]))
+        if S > 1:
+            rs = ops.icp_batch(downs[1:], downs[0], p.icp_max_dist, self.init, p.icp_mode, tn, p.icp_max_iteration)
+            for r in rs:
+                Ts.append(r["transformation"])
+                stats.append((r["iterations"], r["fitness"], r["inlier_rmse"]))
         # -- transform + fuse + filter
         pts = [masked[0][0]] + [ops.transform(masked[i][0], Ts[i]) for i in range(1, S)]
         fused_p = torch.cat(pts, 0)

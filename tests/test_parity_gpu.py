@@ -269,6 +269,22 @@ def test_icp_matches_oracle(ops, oracle, base_cloud, mode):
         assert np.abs(g["transformation"][:3, 3] - T[:3, 3]).max() < 3.0       # recovers the ground truth
 
 
+def test_icp_batch_equals_single_problems(ops, oracle, base_cloud):
+    """several subs onto one master, software-pipelined: same answers as one registration at a time"""
+    src, tgt, T = synth.icp_pair(12000, base_cloud)
+    tn = oracle.estimate_normals(tgt, 70.0, 40)[0].astype(np.float32)
+    srcs = [src, src[:7001], oracle.transform(src, synth.t_star())[:9000]]
+    inits = [np.eye(4), np.eye(4), np.linalg.inv(synth.t_star())]
+    for mode, nrm in (("p2p", None), ("p2plane", tn)):
+        batch = ops.icp_batch(srcs, tgt, 100.0, inits, mode, nrm, 12)
+        for s, i0, b in zip(srcs, inits, batch):
+            one = ops.icp(s, tgt, 100.0, i0, mode, nrm, 12)
+            assert b["iterations"] == one["iterations"] and b["fitness"] == one["fitness"]
+            assert np.array_equal(b["transformation"], one["transformation"])       # same kernels, same order
+            rT, rf, _, rit = oracle.registration_icp(s, tgt, 100.0, i0, mode, nrm, 12)
+            assert rit == b["iterations"] and rf == b["fitness"] and np.abs(rT - b["transformation"]).max() < TOL_T
+
+
 def test_kabsch_pairs(ops, oracle, base_cloud):
     src, tgt, T = synth.icp_pair(5000, base_cloud)
     rng = np.random.default_rng(0)
