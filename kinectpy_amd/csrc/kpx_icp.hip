@@ -22,6 +22,7 @@
 // and accumulates the sums the update needs.  The ICP loop runs on the device; a small kernel solves the
 // 3x3 (Kabsch) or 6x6 (point-to-plane) system, updates T and raises `done`.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "kpx_internal.h"
 #include "kpx_linalg.h"
@@ -37,6 +38,11 @@ constexpr int kCT = 32;                      // 16-column tiles per LDS stage (1
 constexpr int kStageDoubles = kCT * 64;
 constexpr int kSeedStride = 64;              // the seed sweep visits every 64th target tile
 constexpr double kSentinel = 1e300;
+constexpr int kFRT = 4;                      // f32 screening sweep: 16-row tiles per wave
+constexpr int kFRowsPerBlock = kWaves * kFRT * 16; // 256
+constexpr int kFCT = 64;                     // f32 tiles per LDS stage (16 KiB)
+constexpr int kFStageFloats = kFCT * 64;
+constexpr int kCand = 64;                    // candidate slots per source row
 constexpr int kAcc = 44;                     // accumulator slots: count, sum d2, sum s, sum t, sum t s^T, J^T J (21), J^T r (6)
 
 struct IcpState {
@@ -78,36 +84,254 @@ __global__ __launch_bounds__(256) void nn_prep_kernel(const float *__restrict__ 
     }
 }
 
-// ---- upper bound from a known partner (previous iteration): D(i, prev[i]) by the same fma chain ----------
-__global__ __launch_bounds__(256) void nn_bound_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
-                                                       const double *__restrict__ T, const int32_t *__restrict__ done,
-                                                       const int32_t *__restrict__ prev, double *__restrict__ init_val,
-                                                       int32_t *__restrict__ init_idx)
+// ---- per-row operands of one search: transformed source, row seed, bound from a known partner, f32 screening row --
+// One thread per source row, once per search (the sweeps are split over the columns: computing these in their
+// prologues would repeat the fp64 work in every split).
+//   A64[row] = (s_x, s_y, s_z, 1)   K64[row] = K_i            -> fp64 sweep operands
+//   prev != NULL: init_val/init_idx = exact D(i, prev[i]) by the MFMA's fma chain, and its partner
+//   aux  != NULL (needs prev): A32[row] = fl32(s - c, 1), thr32[row] = (C_i, round_up((U_i - 1 - |s-c|^2) + C_i + E_i)),
+//                              C_i = |s-c|^2 + E_i + 1 makes the f32 metric positive (integer compares)
+struct NnAux {
+    double c[3];      // centre used for the f32 operands
+    double rt2;       // >= max_j |t_j - c|^2
+};
+__global__ __launch_bounds__(256) void nn_rowprep_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+                                                         const double *__restrict__ T, const int32_t *__restrict__ done,
+                                                         const int32_t *__restrict__ prev, const NnAux *__restrict__ aux,
+                                                         double *__restrict__ init_val, int32_t *__restrict__ init_idx,
+                                                         double *__restrict__ A64, double *__restrict__ K64,
+                                                         float *__restrict__ A32, float *__restrict__ thr32)
 {
     if (done && *done) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s[3];
     xform_row(T, src + 3 * i, s);
+    const double seed = row_seed(s);
+    reinterpret_cast<double2 *>(A64)[2 * i] = make_double2(s[0], s[1]);
+    reinterpret_cast<double2 *>(A64)[2 * i + 1] = make_double2(s[2], 1.0);
+    K64[i] = seed;
+    if (!prev) return;
     const int32_t j = prev[i];
     const float *tp = tgt + 3 * (int64_t)j;
     const double tx = tp[0], ty = tp[1], tz = tp[2];
     const double t2 = fma(tx, tx, fma(ty, ty, tz * tz));
-    double d = fma(s[0], -2.0 * tx, row_seed(s));
+    double d = fma(s[0], -2.0 * tx, seed);
     d = fma(s[1], -2.0 * ty, d);
     d = fma(s[2], -2.0 * tz, d);
     d = fma(1.0, t2, d);
     init_val[i] = d;
     init_idx[i] = j;
+    if (!aux) return;
+    const double ux = s[0] - aux->c[0], uy = s[1] - aux->c[1], uz = s[2] - aux->c[2];
+    const double q = fma(ux, ux, fma(uy, uy, uz * uz));
+    // E_i bounds |D32 - exact|: operand roundings 2^-24 (6X + Y) + four chain roundings of partial sums <= C + X + Y,
+    // X = 2|s-c||t-c| <= 2 sqrt(q rt2), Y = |t-c|^2 <= rt2, C ~ q + E + 1  (10 % and 1e-6 slack for second-order terms)
+    const double x = 2.0 * sqrt(q * aux->rt2), y = aux->rt2;
+    const double e = 1.1 * 5.9604644775390625e-08 * (10.0 * x + 9.0 * y + 4.0 * (q + 2.0)) * (1.0 + 1e-6) + 1e-6;
+    const float cq = __double2float_ru(q + e + 1.0);                 // row constant: D32 = cq + approx >= 1 > 0
+    reinterpret_cast<float4 *>(A32)[i] = make_float4((float)ux, (float)uy, (float)uz, 1.0f);
+    thr32[2 * i] = cq;
+    thr32[2 * i + 1] = __double2float_ru(((d - 1.0 - q) + (double)cq) + e);
+}
+
+// ---- float32 screening sweep (ICP iterations >= 1) ------------------------------------------------------------
+// With a valid upper bound U_i (the exact D of last iteration's partner under the new transform) the exact
+// argmin only needs the columns whose D can be <= U_i.  Those are found by ONE sweep of the f32 MFMA
+// (v_mfma_f32_16x16x4_f32, ~3x the fp64 MFMA rate) on centred coordinates:
+//     approx_ij = fl32 chain of (s-c) . (-2(t-c)) + |t-c|^2  ~  d_ij^2 - |s_i-c|^2
+// with the rigorous error bound  |approx - exact| <= E_i = 2^-24 (12 |s_i-c| R_t + 5 R_t^2)  (two roundings of
+// every operand, four chain roundings; R_t >= max |t-c|).  Every column with approx_ij <= (U_i - 1 - |s_i-c|^2) + E_i
+// (+10 % and 1e-6 slack) is appended to row i's candidate list; nn_merge_kernel then evaluates the exact fp64
+// metric (the same fma chain as the MFMA path / the oracle) for the candidates and the bound's partner and takes
+// the lexicographic (value, column) minimum -- the result is bit-identical to the fp64 sweep.  Rows whose list
+// overflows are resolved by an exact brute-force scan (nn_overflow_kernel).
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ void nn_aux_kernel(const double *__restrict__ bbox, NnAux *aux)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    double r2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        double c = rint(0.5 * (bbox[a] + bbox[3 + a]));
+        aux->c[a] = c;
+        double e = fmax(fabs(bbox[a] - c), fabs(bbox[3 + a] - c));
+        r2 += e * e;
+    }
+    aux->rt2 = r2 * (1.0 + 1e-12);
+}
+
+// Bf tiles: element (k, j) of tile t at Bf[t*64 + k*16 + j] (float)
+__global__ __launch_bounds__(256) void nn_prep_f32_kernel(const float *__restrict__ tgt, int64_t m, int64_t tiles_pad,
+                                                          const NnAux *__restrict__ aux, float *__restrict__ Bf)
+{
+    const double cx = aux->c[0], cy = aux->c[1], cz = aux->c[2];
+    const int64_t total = tiles_pad * 16;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 3.0e38f;
+        if (j < m) {
+            double ux = (double)tgt[3 * j] - cx, uy = (double)tgt[3 * j + 1] - cy, uz = (double)tgt[3 * j + 2] - cz;
+            b0 = (float)(-2.0 * ux); b1 = (float)(-2.0 * uy); b2 = (float)(-2.0 * uz);
+            b3 = (float)fma(ux, ux, fma(uy, uy, uz * uz));
+        }
+        float *o = Bf + (j >> 4) * 64 + (j & 15);
+        o[0] = b0; o[16] = b1; o[32] = b2; o[48] = b3;
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void nn_screen_kernel(int64_t n, const float *__restrict__ Bf, int32_t tiles_per_split,
+                                                           const int32_t *__restrict__ done, const float *__restrict__ A32,
+                                                           const float *__restrict__ thr32, const int32_t *__restrict__ partner,
+                                                           int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand)
+{
+    if (done && *done) return;
+    __shared__ __align__(16) float lds[2][kFStageFloats];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row_base = (int64_t)blockIdx.x * kFRowsPerBlock + (int64_t)wave * (kFRT * 16);
+    const int64_t t0 = (int64_t)blockIdx.y * tiles_per_split;
+    const int nstages = tiles_per_split / kFCT;
+
+    // A operands: component k = lane>>4 of centred row (lane&15); thresholds of the rows this lane sees in D
+    // (f32 layout: row = 4*(lane>>4) + reg)
+    // the bound's own partner always passes the test and is always evaluated by nn_merge_kernel: it is not
+    // appended (in steady state it is ~99 % of the hits, and an append costs a returning global atomic)
+    float a[kFRT];
+    f4 cq[kFRT];
+    unsigned thr[kFRT][4];
+    int32_t pcol[kFRT][4];
+#pragma unroll
+    for (int rt = 0; rt < kFRT; ++rt) {
+        const int64_t row = row_base + rt * 16 + (lane & 15);
+        a[rt] = row < n ? A32[row * 4 + (lane >> 4)] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t drow = row_base + rt * 16 + 4 * (lane >> 4) + r;
+            const float2 ct = drow < n ? reinterpret_cast<const float2 *>(thr32)[drow] : make_float2(1.0f, 0.0f);
+            cq[rt][r] = ct.x;
+            thr[rt][r] = __float_as_uint(ct.y);          // D32 > 0 and thr >= 0: unsigned order of the patterns
+            pcol[rt][r] = drow < n ? partner[drow] : -1;
+        }
+    }
+
+    const float *gB = Bf + t0 * 64;
+    auto stage_load = [&](int stage, int buf) {
+        const float *g = gB + (int64_t)stage * kFStageFloats;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave * 4 + q;      // 16 pieces of 1 KiB (= 4 tiles) per 16 KiB stage
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + piece * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(&lds[buf][piece * 256]), 16, 0, 0);
+        }
+    };
+    stage_load(0, 0);
+    __syncthreads();
+
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstages) stage_load(st + 1, buf ^ 1);
+        const float *lb = lds[buf] + lane;
+        const int32_t tile0 = (int32_t)t0 + st * kFCT;
+#pragma unroll 1
+        for (int ct = 0; ct < kFCT; ct += 4) {
+            // four column tiles (16 MFMAs) per trip; per D row: one min3 + one min + one compare on the bit patterns
+            float bq[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) bq[h] = lb[(ct + h) * 64];
+            f4 c[4][kFRT];
+#pragma unroll
+            for (int rt = 0; rt < kFRT; ++rt)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) c[h][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[h], cq[rt], 0, 0, 0);
+            bool hit = false;
+            unsigned m4[kFRT][4];
+#pragma unroll
+            for (int rt = 0; rt < kFRT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned u0 = __float_as_uint(c[0][rt][r]), u1 = __float_as_uint(c[1][rt][r]);
+                    const unsigned u2 = __float_as_uint(c[2][rt][r]), u3 = __float_as_uint(c[3][rt][r]);
+                    m4[rt][r] = min(min(min(u0, u1), u2), u3);
+                    hit |= m4[rt][r] <= thr[rt][r];
+                }
+            if (__builtin_amdgcn_ballot_w64(hit) != 0) {          // wave-uniform; a few columns per row per sweep
+                const int32_t col0 = (tile0 + ct) * 16 + (lane & 15);
+#pragma unroll
+                for (int rt = 0; rt < kFRT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (m4[rt][r] <= thr[rt][r]) {            // this D row has a column under its threshold
+                            const int64_t row = row_base + rt * 16 + 4 * (lane >> 4) + r;
+#pragma unroll
+                            for (int h = 0; h < 4; ++h)
+                                if (__float_as_uint(c[h][rt][r]) <= thr[rt][r] && col0 + h * 16 != pcol[rt][r]) {
+                                    const int slot = atomicAdd(&cand_cnt[row], 1);
+                                    if (slot < kCand) cand[row * kCand + slot] = col0 + h * 16;
+                                }
+                        }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// rows whose candidate list overflowed: exact brute-force scan (fp64 fma chain), one block per row at a time
+__global__ __launch_bounds__(256) void nn_overflow_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt, int64_t m,
+                                                          const double *__restrict__ T, const int32_t *__restrict__ done,
+                                                          int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
+                                                          int32_t *__restrict__ overflow_total)
+{
+    if (done && *done) return;
+    __shared__ int list[256];
+    __shared__ int nlist;
+    __shared__ double sv[256];
+    __shared__ int sj[256];
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) nlist = 0;
+        __syncthreads();
+        const int64_t r = base + threadIdx.x;
+        if (r < n && cand_cnt[r] > kCand) list[atomicAdd(&nlist, 1)] = (int)threadIdx.x;
+        __syncthreads();
+        const int cnt = nlist;
+        if (cnt && threadIdx.x == 0) atomicAdd(overflow_total, cnt);
+        for (int e = 0; e < cnt; ++e) {
+            // list order depends on the LDS atomic; each entry is an independent row, so the result does not
+            const int64_t row = base + list[e];
+            double s[3];
+            xform_row(T, src + 3 * row, s);
+            const double seed = row_seed(s);
+            double bv = INFINITY;
+            int bj = INT_MAX;
+            for (int64_t j = threadIdx.x; j < m; j += 256) {
+                const double tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
+                double d = fma(s[0], -2.0 * tx, seed);
+                d = fma(s[1], -2.0 * ty, d);
+                d = fma(s[2], -2.0 * tz, d);
+                d = fma(1.0, fma(tx, tx, fma(ty, ty, tz * tz)), d);
+                if (d < bv) { bv = d; bj = (int)j; }           // ascending j per thread: first minimum kept
+            }
+            sv[threadIdx.x] = bv; sj[threadIdx.x] = bj;
+            __syncthreads();
+            for (int w = 128; w > 0; w >>= 1) {
+                if ((int)threadIdx.x < w) {
+                    double ov = sv[threadIdx.x + w]; int oj = sj[threadIdx.x + w];
+                    if (ov < sv[threadIdx.x] || (ov == sv[threadIdx.x] && oj < sj[threadIdx.x])) { sv[threadIdx.x] = ov; sj[threadIdx.x] = oj; }
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) { cand[row * kCand] = sj[0]; cand_cnt[row] = 1; }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
 }
 
 // ---- the MFMA nearest-neighbour sweep ------------------------------------------------------------------
 // tile_stride: 1 for the full operand, kSeedStride for the seed operand (column = tile * tile_stride * 16 + lane&15)
-__global__ __launch_bounds__(256, 4) void nn_mfma_kernel(const float *__restrict__ src, int64_t n, const double *__restrict__ B,
-                                                         int32_t tiles_per_split, int32_t tile_stride, const double *__restrict__ T,
-                                                         const int32_t *__restrict__ done, const double *__restrict__ init_val,
-                                                         const int32_t *__restrict__ init_idx, double *__restrict__ part_val,
-                                                         int32_t *__restrict__ part_idx)
+__global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double *__restrict__ B, int32_t tiles_per_split,
+                                                         int32_t tile_stride, const int32_t *__restrict__ done,
+                                                         const double *__restrict__ A64, const double *__restrict__ K64,
+                                                         const double *__restrict__ init_val, const int32_t *__restrict__ init_idx,
+                                                         double *__restrict__ part_val, int32_t *__restrict__ part_idx)
 {
     if (done && *done) return;
     __shared__ __align__(16) double lds[2][kStageDoubles];
@@ -118,18 +342,11 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(const float *__restrict
     const int nstages = tiles_per_split / kCT;
 
     // A operands: lane holds component k = lane>>4 of row (lane&15) of each of its row tiles
-    const int kcomp = lane >> 4;
     double a[kRT];
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) {
         const int64_t row = row_base + rt * 16 + (lane & 15);
-        double v = 0.0;
-        if (row < n) {
-            double s[3];
-            xform_row(T, src + 3 * row, s);
-            v = kcomp == 0 ? s[0] : (kcomp == 1 ? s[1] : (kcomp == 2 ? s[2] : 1.0));
-        }
-        a[rt] = v;
+        a[rt] = row < n ? A64[row * 4 + (lane >> 4)] : 0.0;
     }
     // C operands (row seeds K_i), running best and its column: D layout row = (lane>>4) + 4*reg
     d4 seed[kRT];
@@ -143,9 +360,7 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(const float *__restrict
             double kk = 1.0, bv = INFINITY;
             int32_t bj = INT_MAX;
             if (row < n) {
-                double s[3];
-                xform_row(T, src + 3 * row, s);
-                kk = row_seed(s);
+                kk = K64[row];
                 if (init_val) { bv = init_val[row]; bj = init_idx[row]; }
             }
             seed[rt][r] = kk; best[rt][r] = bv; bcol[rt][r] = bj;
@@ -255,7 +470,8 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ done, const double *__restrict__ part_val,
                                                        const int32_t *__restrict__ part_idx, int splits, double max_d2, int mode,
                                                        int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
-                                                       double *__restrict__ val_out, double *__restrict__ part_acc)
+                                                       double *__restrict__ val_out, double *__restrict__ part_acc,
+                                                       const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand)
 {
     if (done && *done) return;
     __shared__ double sh[4][kAcc];
@@ -266,10 +482,30 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(const float *__restrict__
     if (i < n) {
         double bv = part_val[i];
         int32_t bj = part_idx[i];
-        for (int s = 1; s < splits; ++s) {
-            double v = part_val[(int64_t)s * n + i];
-            int32_t j = part_idx[(int64_t)s * n + i];
-            if (v < bv || (v == bv && j < bj)) { bv = v; bj = j; }
+        if (cand_cnt) {
+            // screening path: (part_val, part_idx) hold the bound (exact D of last iteration's partner); the exact
+            // metric of every screened candidate decides, by the same fma chain as the MFMA sweep
+            double s[3];
+            xform_row(T, src + 3 * i, s);
+            const double seed = row_seed(s);
+            int c = cand_cnt[i];
+            c = c < kCand ? c : kCand;
+            for (int e = 0; e < c; ++e) {
+                const int32_t j = cand[i * kCand + e];
+                const float *tp = tgt + 3 * (int64_t)j;
+                const double tx = tp[0], ty = tp[1], tz = tp[2];
+                double d = fma(s[0], -2.0 * tx, seed);
+                d = fma(s[1], -2.0 * ty, d);
+                d = fma(s[2], -2.0 * tz, d);
+                d = fma(1.0, fma(tx, tx, fma(ty, ty, tz * tz)), d);
+                if (d < bv || (d == bv && j < bj)) { bv = d; bj = j; }
+            }
+        } else {
+            for (int s = 1; s < splits; ++s) {
+                double v = part_val[(int64_t)s * n + i];
+                int32_t j = part_idx[(int64_t)s * n + i];
+                if (v < bv || (v == bv && j < bj)) { bv = v; bj = j; }
+            }
         }
         if (idx_out) idx_out[i] = bj;
         if (mode == -2) {
@@ -450,8 +686,9 @@ __global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restric
 
 // ---- host side ----------------------------------------------------------------------------------------------
 struct NnPlan {
-    int64_t tiles_pad, seed_tiles_pad, n_src, n_tgt;
+    int64_t tiles_pad, seed_tiles_pad, n_src, n_tgt, f_tiles_pad;
     int32_t tiles_per_split, splits, row_blocks;
+    int32_t f_tiles_per_split, f_splits, f_row_blocks;     // float32 screening sweep
 };
 static NnPlan nn_plan(int64_t n, int64_t m)
 {
@@ -469,12 +706,26 @@ static NnPlan nn_plan(int64_t n, int64_t m)
     p.tiles_per_split = (int32_t)(stages_per_split * kCT);
     p.tiles_pad = (int64_t)p.splits * p.tiles_per_split;
     p.seed_tiles_pad = cdiv(cdiv(tiles, kSeedStride), kCT) * kCT;
+    {
+        int64_t fstages = cdiv(tiles, kFCT);
+        p.f_row_blocks = (int32_t)cdiv(n > 0 ? n : 1, kFRowsPerBlock);
+        int64_t fwant = cdiv(2048, p.f_row_blocks);
+        if (fwant > fstages) fwant = fstages;
+        if (fwant < 1) fwant = 1;
+        if (fwant > 64) fwant = 64;
+        int64_t per = cdiv(fstages, fwant);
+        p.f_splits = (int32_t)cdiv(fstages, per);
+        p.f_tiles_per_split = (int32_t)(per * kFCT);
+        p.f_tiles_pad = (int64_t)p.f_splits * p.f_tiles_per_split;
+    }
     return p;
 }
 
 struct NnBuffers {
-    double *B, *Bseed, *part_val, *part_acc, *init_val, *d2_cur;
-    int32_t *part_idx, *init_idx, *idx_cur;
+    double *B, *Bseed, *part_val, *part_acc, *init_val, *d2_cur, *tbbox, *A64, *K64;
+    float *Bf, *A32, *thr32;
+    NnAux *aux;
+    int32_t *part_idx, *init_idx, *idx_cur, *cand_cnt, *cand, *overflow;
     IcpState *state;
     double *T0;
 };
@@ -482,6 +733,9 @@ static void nn_carve_target(Arena &a, const NnPlan &p, NnBuffers *b)
 {
     b->B = a.get<double>((size_t)p.tiles_pad * 64);
     b->Bseed = a.get<double>((size_t)p.seed_tiles_pad * 64);
+    b->Bf = a.get<float>((size_t)p.f_tiles_pad * 64);
+    b->aux = a.get<NnAux>(1);
+    b->tbbox = a.get<double>((size_t)kBboxBlocks * 6 + 8);
 }
 static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
 {
@@ -495,6 +749,13 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->d2_cur = a.get<double>(nn);
     b->state = a.get<IcpState>(1);
     b->T0 = a.get<double>(16);
+    b->A64 = a.get<double>(nn * 4);
+    b->K64 = a.get<double>(nn);
+    b->A32 = a.get<float>(nn * 4);
+    b->thr32 = a.get<float>(nn * 2);                     // (row constant, threshold) pairs
+    b->cand_cnt = a.get<int32_t>(nn + 1);               // [n] counters + overflow total
+    b->cand = a.get<int32_t>(nn * kCand);
+    b->overflow = b->cand_cnt ? b->cand_cnt + nn : nullptr;
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
 {
@@ -502,11 +763,26 @@ static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers 
     nn_carve_source(a, n, p, b);
 }
 
+static bool screening_enabled()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("KPX_NN_SCREEN"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
 static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st)
 {
     int64_t work = (p.tiles_pad + p.seed_tiles_pad) * 16;
     hipLaunchKernelGGL(nn_prep_kernel, dim3((unsigned)(cdiv(work, 256) > 2048 ? 2048 : cdiv(work, 256))), dim3(256), 0, st, tgt,
                        p.n_tgt, p.tiles_pad, b.B, p.seed_tiles_pad, b.Bseed);
+    {   // float32 screening operand: centre + radius from the target's bounding box
+        double *bbox = b.tbbox + (size_t)kBboxBlocks * 6;
+        int rc = bbox_f32(tgt, p.n_tgt, bbox, b.tbbox, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nn_aux_kernel, dim3(1), dim3(1), 0, st, bbox, b.aux);
+        int64_t fw = p.f_tiles_pad * 16;
+        hipLaunchKernelGGL(nn_prep_f32_kernel, dim3((unsigned)(cdiv(fw, 256) > 2048 ? 2048 : cdiv(fw, 256))), dim3(256), 0, st, tgt,
+                           p.n_tgt, p.f_tiles_pad, b.aux, b.Bf);
+    }
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
@@ -518,22 +794,38 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
 {
     const int64_t n = p.n_src;
     const dim3 thr(256);
-    if (have_prev) {
-        hipLaunchKernelGGL(nn_bound_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, T, done, b.idx_cur,
-                           b.init_val, b.init_idx);
-    } else {
-        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, 1), thr, 0, st, src, n, b.Bseed, (int32_t)p.seed_tiles_pad,
-                           (int32_t)kSeedStride, T, done, (const double *)nullptr, (const int32_t *)nullptr, b.part_val, b.part_idx);
+    const bool screen = have_prev && screening_enabled();
+    hipLaunchKernelGGL(nn_rowprep_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, T, done,
+                       have_prev ? b.idx_cur : (const int32_t *)nullptr, screen ? b.aux : (const NnAux *)nullptr, b.init_val, b.init_idx,
+                       b.A64, b.K64, b.A32, b.thr32);
+    if (screen) {
+        KPX_HIP(hipMemsetAsync(b.cand_cnt, 0, ((size_t)n + 1) * sizeof(int32_t), st));
+        {
+            ProfScope prof(KPX_PROF_NN_SCREEN, 8.0 * (double)p.n_src * (double)p.n_tgt, st);   // 4 MAC per (source, target) pair
+            hipLaunchKernelGGL(nn_screen_kernel, dim3(p.f_row_blocks, p.f_splits), thr, 0, st, n, b.Bf, p.f_tiles_per_split, done, b.A32,
+                               b.thr32, b.init_idx, b.cand_cnt, b.cand);
+        }
+        hipLaunchKernelGGL(nn_overflow_kernel, dim3((unsigned)(cdiv(n, 256) > 512 ? 512 : cdiv(n, 256))), thr, 0, st, src, n, tgt,
+                           p.n_tgt, T, done, b.cand_cnt, b.cand, b.overflow);
+        hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.init_val, b.init_idx, 1,
+                           max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, b.cand_cnt, b.cand);
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
+    if (!have_prev) {
+        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, 1), thr, 0, st, n, b.Bseed, (int32_t)p.seed_tiles_pad, (int32_t)kSeedStride,
+                           done, b.A64, b.K64, (const double *)nullptr, (const int32_t *)nullptr, b.part_val, b.part_idx);
         hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx, 1,
-                           0.0, -2, b.init_idx, (double *)nullptr, b.init_val, b.part_acc);
+                           0.0, -2, b.init_idx, (double *)nullptr, b.init_val, b.part_acc, (const int32_t *)nullptr, (const int32_t *)nullptr);
     }
     {
         ProfScope prof(KPX_PROF_NN_MFMA, 8.0 * (double)p.n_src * (double)p.n_tgt, st);     // 4 MAC per (source, target) pair
-        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), thr, 0, st, src, n, b.B, p.tiles_per_split, 1, T, done,
+        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
                            b.init_val, b.init_idx, b.part_val, b.part_idx);
     }
     hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
-                       p.splits, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc);
+                       p.splits, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
@@ -650,7 +942,11 @@ KPX_EXPORT size_t kpx_icp_batch_workspace_bytes(int32_t count, const int64_t *h_
     NnBuffers b;
     if (count < 1 || !h_n_src) return 0;
     NnPlan tplan = nn_plan(h_n_src[0], n_tgt);          // the shared operand is padded for the largest split plan
-    for (int i = 1; i < count; ++i) { NnPlan q = nn_plan(h_n_src[i], n_tgt); if (q.tiles_pad > tplan.tiles_pad) tplan = q; }
+    for (int i = 1; i < count; ++i) {
+        NnPlan q = nn_plan(h_n_src[i], n_tgt);
+        if (q.tiles_pad > tplan.tiles_pad) tplan.tiles_pad = q.tiles_pad;
+        if (q.f_tiles_pad > tplan.f_tiles_pad) tplan.f_tiles_pad = q.f_tiles_pad;
+    }
     nn_carve_target(a, tplan, &b);
     for (int i = 0; i < count; ++i) nn_carve_source(a, h_n_src[i], nn_plan(h_n_src[i], n_tgt), &b);
     return a.off;
@@ -674,12 +970,17 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     if (!side) KPX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     Arena a(ws, ws_bytes);
     NnPlan plans[64];
-    NnBuffers bufs[64];
+    NnBuffers bufs[64] = {};
     NnPlan tplan = nn_plan(h_n_src[0], n_tgt);          // the shared operand is padded for the largest split plan
-    for (int i = 0; i < count; ++i) { plans[i] = nn_plan(h_n_src[i], n_tgt); if (plans[i].tiles_pad > tplan.tiles_pad) tplan = plans[i]; }
+    for (int i = 0; i < count; ++i) {
+        plans[i] = nn_plan(h_n_src[i], n_tgt);
+        if (plans[i].tiles_pad > tplan.tiles_pad) tplan.tiles_pad = plans[i].tiles_pad;
+        if (plans[i].f_tiles_pad > tplan.f_tiles_pad) tplan.f_tiles_pad = plans[i].f_tiles_pad;
+    }
     nn_carve_target(a, tplan, &bufs[0]);
     for (int i = 0; i < count; ++i) {
-        bufs[i].B = bufs[0].B; bufs[i].Bseed = bufs[0].Bseed;
+        bufs[i].B = bufs[0].B; bufs[i].Bseed = bufs[0].Bseed; bufs[i].Bf = bufs[0].Bf; bufs[i].aux = bufs[0].aux;
+        bufs[i].tbbox = bufs[0].tbbox;
         nn_carve_source(a, h_n_src[i], plans[i], &bufs[i]);
     }
     KPX_ARENA_CHECK(a);

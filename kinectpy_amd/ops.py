@@ -329,7 +329,7 @@ def icp_batch(srcs, tgt, max_dist, inits, mode="p2p", tgt_normals=None, max_iter
 
 
 # ---- measurement hooks --------------------------------------------------------------------------------
-PROF_KERNELS = ("nn_mfma", "sor_knn", "plane_score", "compact")
+PROF_KERNELS = ("nn_mfma", "sor_knn", "plane_score", "compact", "nn_screen")
 
 
 def prof_begin(capacity=65536):
@@ -338,8 +338,8 @@ def prof_begin(capacity=65536):
 
 def prof_end():
     """-> {kernel: (total_ms, launches, work)}; work = flops (nn_mfma) or algorithmic bytes"""
-    ms = np.zeros(4)
-    cnt = np.zeros(4, dtype=np.int64)
-    work = np.zeros(4)
+    ms = np.zeros(len(PROF_KERNELS))
+    cnt = np.zeros(len(PROF_KERNELS), dtype=np.int64)
+    work = np.zeros(len(PROF_KERNELS))
     L.check(L.load().kpx_prof_end(L.hptr(ms), cnt.ctypes.data_as(C.c_void_p), L.hptr(work)))
     return {k: (float(ms[i]), int(cnt[i]), float(work[i])) for i, k in enumerate(PROF_KERNELS)}

@@ -5,7 +5,7 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-template <int V> __global__ __launch_bounds__(256) void k(const float *in, float *out, int iters, int *cand)
+template <int V> __global__ __launch_bounds__(256, 4) void k(const float *in, float *out, int iters, int *cand)
 {
     const int lane = threadIdx.x & 63;
     float a0 = in[lane], a1 = in[64 + lane], a2 = in[128 + lane], a3 = in[192 + lane];
