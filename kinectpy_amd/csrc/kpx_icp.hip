@@ -100,11 +100,14 @@ __global__ __launch_bounds__(256) void nn_rowprep_kernel(const float *__restrict
                                                          const int32_t *__restrict__ prev, const NnAux *__restrict__ aux,
                                                          double *__restrict__ init_val, int32_t *__restrict__ init_idx,
                                                          double *__restrict__ A64, double *__restrict__ K64,
-                                                         float *__restrict__ A32, float *__restrict__ thr32)
+                                                         float *__restrict__ A32, float *__restrict__ thr32,
+                                                         int32_t *__restrict__ cand_cnt)
 {
     if (done && *done) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) cand_cnt[n] = 0;          // number of rows whose candidate list overflowed
     if (i >= n) return;
+    cand_cnt[i] = 0;
     double s[3];
     xform_row(T, src + 3 * i, s);
     const double seed = row_seed(s);
@@ -182,7 +185,8 @@ __global__ __launch_bounds__(256) void nn_prep_f32_kernel(const float *__restric
 __global__ __launch_bounds__(256, 3) void nn_screen_kernel(int64_t n, const float *__restrict__ Bf, int32_t tiles_per_split,
                                                            const int32_t *__restrict__ done, const float *__restrict__ A32,
                                                            const float *__restrict__ thr32, const int32_t *__restrict__ partner,
-                                                           int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand)
+                                                           int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
+                                                           int32_t *__restrict__ over_rows)
 {
     if (done && *done) return;
     __shared__ __align__(16) float lds[2][kFStageFloats];
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(256, 3) void nn_screen_kernel(int64_t n, const floa
                                 if (__float_as_uint(c[h][rt][r]) <= thr[rt][r] && col0 + h * 16 != pcol[rt][r]) {
                                     const int slot = atomicAdd(&cand_cnt[row], 1);
                                     if (slot < kCand) cand[row * kCand + slot] = col0 + h * 16;
+                                    else if (slot == kCand) over_rows[atomicAdd(&cand_cnt[n], 1)] = (int32_t)row;   // first overflow of this row
                                 }
                         }
             }
@@ -274,53 +279,42 @@ __global__ __launch_bounds__(256, 3) void nn_screen_kernel(int64_t n, const floa
     }
 }
 
-// rows whose candidate list overflowed: exact brute-force scan (fp64 fma chain), one block per row at a time
+// rows whose candidate list overflowed (listed by the screening sweep): exact brute-force scan (fp64 fma chain),
+// one block per row at a time.  With nothing listed the kernel returns at once.
 __global__ __launch_bounds__(256) void nn_overflow_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt, int64_t m,
                                                           const double *__restrict__ T, const int32_t *__restrict__ done,
                                                           int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
-                                                          int32_t *__restrict__ overflow_total)
+                                                          const int32_t *__restrict__ over_rows)
 {
     if (done && *done) return;
-    __shared__ int list[256];
-    __shared__ int nlist;
+    const int total = cand_cnt[n];
     __shared__ double sv[256];
     __shared__ int sj[256];
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
-        if (threadIdx.x == 0) nlist = 0;
+    for (int e = blockIdx.x; e < total; e += gridDim.x) {
+        const int64_t row = over_rows[e];
+        double s[3];
+        xform_row(T, src + 3 * row, s);
+        const double seed = row_seed(s);
+        double bv = INFINITY;
+        int bj = INT_MAX;
+        for (int64_t j = threadIdx.x; j < m; j += 256) {
+            const double tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
+            double d = fma(s[0], -2.0 * tx, seed);
+            d = fma(s[1], -2.0 * ty, d);
+            d = fma(s[2], -2.0 * tz, d);
+            d = fma(1.0, fma(tx, tx, fma(ty, ty, tz * tz)), d);
+            if (d < bv) { bv = d; bj = (int)j; }           // ascending j per thread: first minimum kept
+        }
+        sv[threadIdx.x] = bv; sj[threadIdx.x] = bj;
         __syncthreads();
-        const int64_t r = base + threadIdx.x;
-        if (r < n && cand_cnt[r] > kCand) list[atomicAdd(&nlist, 1)] = (int)threadIdx.x;
-        __syncthreads();
-        const int cnt = nlist;
-        if (cnt && threadIdx.x == 0) atomicAdd(overflow_total, cnt);
-        for (int e = 0; e < cnt; ++e) {
-            // list order depends on the LDS atomic; each entry is an independent row, so the result does not
-            const int64_t row = base + list[e];
-            double s[3];
-            xform_row(T, src + 3 * row, s);
-            const double seed = row_seed(s);
-            double bv = INFINITY;
-            int bj = INT_MAX;
-            for (int64_t j = threadIdx.x; j < m; j += 256) {
-                const double tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
-                double d = fma(s[0], -2.0 * tx, seed);
-                d = fma(s[1], -2.0 * ty, d);
-                d = fma(s[2], -2.0 * tz, d);
-                d = fma(1.0, fma(tx, tx, fma(ty, ty, tz * tz)), d);
-                if (d < bv) { bv = d; bj = (int)j; }           // ascending j per thread: first minimum kept
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) {
+                double ov = sv[threadIdx.x + w]; int oj = sj[threadIdx.x + w];
+                if (ov < sv[threadIdx.x] || (ov == sv[threadIdx.x] && oj < sj[threadIdx.x])) { sv[threadIdx.x] = ov; sj[threadIdx.x] = oj; }
             }
-            sv[threadIdx.x] = bv; sj[threadIdx.x] = bj;
-            __syncthreads();
-            for (int w = 128; w > 0; w >>= 1) {
-                if ((int)threadIdx.x < w) {
-                    double ov = sv[threadIdx.x + w]; int oj = sj[threadIdx.x + w];
-                    if (ov < sv[threadIdx.x] || (ov == sv[threadIdx.x] && oj < sj[threadIdx.x])) { sv[threadIdx.x] = ov; sj[threadIdx.x] = oj; }
-                }
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) { cand[row * kCand] = sj[0]; cand_cnt[row] = 1; }
             __syncthreads();
         }
+        if (threadIdx.x == 0) { cand[row * kCand] = sj[0]; cand_cnt[row] = 1; }
         __syncthreads();
     }
 }
@@ -753,9 +747,9 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->K64 = a.get<double>(nn);
     b->A32 = a.get<float>(nn * 4);
     b->thr32 = a.get<float>(nn * 2);                     // (row constant, threshold) pairs
-    b->cand_cnt = a.get<int32_t>(nn + 1);               // [n] counters + overflow total
+    b->cand_cnt = a.get<int32_t>(nn + 1);               // [n] counters + number of overflowed rows
     b->cand = a.get<int32_t>(nn * kCand);
-    b->overflow = b->cand_cnt ? b->cand_cnt + nn : nullptr;
+    b->overflow = a.get<int32_t>(nn);                   // list of overflowed rows
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
 {
@@ -797,15 +791,14 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
     const bool screen = have_prev && screening_enabled();
     hipLaunchKernelGGL(nn_rowprep_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, T, done,
                        have_prev ? b.idx_cur : (const int32_t *)nullptr, screen ? b.aux : (const NnAux *)nullptr, b.init_val, b.init_idx,
-                       b.A64, b.K64, b.A32, b.thr32);
+                       b.A64, b.K64, b.A32, b.thr32, b.cand_cnt);
     if (screen) {
-        KPX_HIP(hipMemsetAsync(b.cand_cnt, 0, ((size_t)n + 1) * sizeof(int32_t), st));
         {
             ProfScope prof(KPX_PROF_NN_SCREEN, 8.0 * (double)p.n_src * (double)p.n_tgt, st);   // 4 MAC per (source, target) pair
             hipLaunchKernelGGL(nn_screen_kernel, dim3(p.f_row_blocks, p.f_splits), thr, 0, st, n, b.Bf, p.f_tiles_per_split, done, b.A32,
-                               b.thr32, b.init_idx, b.cand_cnt, b.cand);
+                               b.thr32, b.init_idx, b.cand_cnt, b.cand, b.overflow);
         }
-        hipLaunchKernelGGL(nn_overflow_kernel, dim3((unsigned)(cdiv(n, 256) > 512 ? 512 : cdiv(n, 256))), thr, 0, st, src, n, tgt,
+        hipLaunchKernelGGL(nn_overflow_kernel, dim3(1024), thr, 0, st, src, n, tgt,
                            p.n_tgt, T, done, b.cand_cnt, b.cand, b.overflow);
         hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.init_val, b.init_idx, 1,
                            max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, b.cand_cnt, b.cand);
