@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void nn_prep_f32_kernel(const float *__restric
     }
 }
 
-__global__ __launch_bounds__(256, 3) void nn_screen_kernel(int64_t n, const float *__restrict__ Bf, int32_t tiles_per_split,
+template <int TRIP, int MINW>
+__global__ __launch_bounds__(256, MINW) void nn_screen_kernel(int64_t n, const float *__restrict__ Bf, int32_t tiles_per_split,
                                                            const int32_t *__restrict__ done, const float *__restrict__ A32,
                                                            const float *__restrict__ thr32, const int32_t *__restrict__ partner,
                                                            int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
@@ -202,7 +203,6 @@ __global__ __launch_bounds__(256, 3) void nn_screen_kernel(int64_t n, const floa
     float a[kFRT];
     f4 cq[kFRT];
     unsigned thr[kFRT][4];
-    int32_t pcol[kFRT][4];
 #pragma unroll
     for (int rt = 0; rt < kFRT; ++rt) {
         const int64_t row = row_base + rt * 16 + (lane & 15);
@@ -213,7 +213,6 @@ __global__ __launch_bounds__(256, 3) void nn_screen_kernel(int64_t n, const floa
             const float2 ct = drow < n ? reinterpret_cast<const float2 *>(thr32)[drow] : make_float2(1.0f, 0.0f);
             cq[rt][r] = ct.x;
             thr[rt][r] = __float_as_uint(ct.y);          // D32 > 0 and thr >= 0: unsigned order of the patterns
-            pcol[rt][r] = drow < n ? partner[drow] : -1;
         }
     }
 
@@ -236,43 +235,42 @@ __global__ __launch_bounds__(256, 3) void nn_screen_kernel(int64_t n, const floa
         const float *lb = lds[buf] + lane;
         const int32_t tile0 = (int32_t)t0 + st * kFCT;
 #pragma unroll 1
-        for (int ct = 0; ct < kFCT; ct += 4) {
-            // four column tiles (16 MFMAs) per trip; per D row: one min3 + one min + one compare on the bit patterns
-            float bq[4];
+        for (int ct = 0; ct < kFCT; ct += TRIP) {
+            // TRIP column tiles (TRIP x 4 MFMAs) per trip; per D row the minimum of the TRIP bit patterns
+            // (v_min3_u32 / v_min_u32) and one unsigned compare against the row's threshold
+            float bq[TRIP];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) bq[h] = lb[(ct + h) * 64];
-            f4 c[4][kFRT];
+            for (int h = 0; h < TRIP; ++h) bq[h] = lb[(ct + h) * 64];
+            f4 c[TRIP][kFRT];
 #pragma unroll
             for (int rt = 0; rt < kFRT; ++rt)
 #pragma unroll
-                for (int h = 0; h < 4; ++h) c[h][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[h], cq[rt], 0, 0, 0);
+                for (int h = 0; h < TRIP; ++h) c[h][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[h], cq[rt], 0, 0, 0);
             bool hit = false;
-            unsigned m4[kFRT][4];
 #pragma unroll
             for (int rt = 0; rt < kFRT; ++rt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const unsigned u0 = __float_as_uint(c[0][rt][r]), u1 = __float_as_uint(c[1][rt][r]);
-                    const unsigned u2 = __float_as_uint(c[2][rt][r]), u3 = __float_as_uint(c[3][rt][r]);
-                    m4[rt][r] = min(min(min(u0, u1), u2), u3);
-                    hit |= m4[rt][r] <= thr[rt][r];
+                    unsigned m = __float_as_uint(c[0][rt][r]);
+#pragma unroll
+                    for (int h = 1; h < TRIP; ++h) m = min(m, __float_as_uint(c[h][rt][r]));
+                    hit |= m <= thr[rt][r];
                 }
             if (__builtin_amdgcn_ballot_w64(hit) != 0) {          // wave-uniform; a few columns per row per sweep
                 const int32_t col0 = (tile0 + ct) * 16 + (lane & 15);
 #pragma unroll
                 for (int rt = 0; rt < kFRT; ++rt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (m4[rt][r] <= thr[rt][r]) {            // this D row has a column under its threshold
-                            const int64_t row = row_base + rt * 16 + 4 * (lane >> 4) + r;
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = row_base + rt * 16 + 4 * (lane >> 4) + r;
 #pragma unroll
-                            for (int h = 0; h < 4; ++h)
-                                if (__float_as_uint(c[h][rt][r]) <= thr[rt][r] && col0 + h * 16 != pcol[rt][r]) {
-                                    const int slot = atomicAdd(&cand_cnt[row], 1);
-                                    if (slot < kCand) cand[row * kCand + slot] = col0 + h * 16;
-                                    else if (slot == kCand) over_rows[atomicAdd(&cand_cnt[n], 1)] = (int32_t)row;   // first overflow of this row
-                                }
-                        }
+                        for (int h = 0; h < TRIP; ++h)
+                            if (__float_as_uint(c[h][rt][r]) <= thr[rt][r] && col0 + h * 16 != partner[row]) {
+                                const int slot = atomicAdd(&cand_cnt[row], 1);
+                                if (slot < kCand) cand[row * kCand + slot] = col0 + h * 16;
+                                else if (slot == kCand) over_rows[atomicAdd(&cand_cnt[n], 1)] = (int32_t)row;   // first overflow of this row
+                            }
+                    }
             }
         }
         __syncthreads();
@@ -459,7 +457,8 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
 // ---- merge splits, direct distance, accumulation ---------------------------------------------------------
 // mode: -2 = write (value, column) as the bound of the next sweep, -1 = correspondences only,
 //        0 = point-to-point sums, 1 = + point-to-plane normal equations
-__global__ __launch_bounds__(256) void nn_merge_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+constexpr int kMergeThreads = 64;
+__global__ __launch_bounds__(kMergeThreads) void nn_merge_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ T,
                                                        const int32_t *__restrict__ done, const double *__restrict__ part_val,
                                                        const int32_t *__restrict__ part_idx, int splits, double max_d2, int mode,
@@ -468,7 +467,7 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand)
 {
     if (done && *done) return;
-    __shared__ double sh[4][kAcc];
+    __shared__ double sh[kAcc][kMergeThreads + 1];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[kAcc];
 #pragma unroll
@@ -537,18 +536,19 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(const float *__restrict__
         }
     }
     if (mode < 0) return;
-    // fixed-order block sums: wave tree per slot, then the four waves in order (one barrier in total)
+    // fixed-order block sums through LDS: slot q of lane l at sh[q][l] (row stride 65 doubles: conflict-free
+    // column walks), lane q then adds its row in lane order -- no cross-lane shuffles (a 64-lane fp64 shuffle
+    // tree for 44 slots costs ~500 ds_bpermutes per wave)
+    const int nacc = mode == 1 ? kAcc : 17;
 #pragma unroll
-    for (int q = 0; q < kAcc; ++q) {
-        if (q < 17 || mode == 1) {
-            double v = wave_sum(acc[q]);
-            if (lane_id() == 0) sh[wave_id()][q] = v;
-        }
-    }
+    for (int q = 0; q < kAcc; ++q)
+        if (q < 17 || mode == 1) sh[q][threadIdx.x] = acc[q];
     __syncthreads();
-    if (threadIdx.x < kAcc && (threadIdx.x < 17 || mode == 1))
-        part_acc[(int64_t)blockIdx.x * kAcc + threadIdx.x] =
-            ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+    if ((int)threadIdx.x < nacc) {
+        double v = 0.0;
+        for (int l = 0; l < kMergeThreads; ++l) v += sh[threadIdx.x][l];
+        part_acc[(int64_t)blockIdx.x * kAcc + threadIdx.x] = v;
+    }
 }
 
 // ---- update step ------------------------------------------------------------------------------------------
@@ -593,29 +593,42 @@ __device__ void update_p2plane(const double *acc, double U[16])
     U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
 }
 
-// 256 threads: thread (slot q = t & 63, slice s = t >> 6) sums its slice of the per-block partials, the four
-// slices are added in order (fixed summation tree), thread 0 does the algebra.
-// k = index of the correspondence search just finished (0 = the initial one).
-__global__ __launch_bounds__(256) void icp_solve_kernel(const double *__restrict__ part_acc, int nblocks, int64_t n, int mode, int k,
-                                                        int max_iter, double rel_fit, double rel_rmse, IcpState *st,
-                                                        double *__restrict__ result)
+// 1024 threads: thread (slot q = t & 63, slice = t >> 6) sums its slice of the per-block partials with four
+// interleaved accumulators, the sixteen slices are then added in order (a fixed summation tree: bitwise
+// reproducible), thread 0 does the algebra.  k = index of the correspondence search just finished.
+constexpr int kSolveThreads = 1024;
+__global__ __launch_bounds__(kSolveThreads) void icp_solve_kernel(const double *__restrict__ part_acc, int nblocks, int64_t n, int mode, int k,
+                                                                  int max_iter, double rel_fit, double rel_rmse, IcpState *st,
+                                                                  double *__restrict__ result)
 {
     if (st->done) return;
-    __shared__ double part[4][64];
+    __shared__ double part[kSolveThreads / 64][64];
     __shared__ double acc[kAcc];
     const int nacc = mode == 1 ? kAcc : 17;
     const int q = threadIdx.x & 63, slice = threadIdx.x >> 6;
     {
-        double s = 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         if (q < nacc) {
-            const int per = (nblocks + 3) / 4;
+            const int per = (nblocks + kSolveThreads / 64 - 1) / (kSolveThreads / 64);
             const int b0 = slice * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-            for (int b = b0; b < b1; ++b) s += part_acc[(int64_t)b * kAcc + q];
+            int b = b0;
+            for (; b + 3 < b1; b += 4) {
+                s0 += part_acc[(int64_t)b * kAcc + q];
+                s1 += part_acc[(int64_t)(b + 1) * kAcc + q];
+                s2 += part_acc[(int64_t)(b + 2) * kAcc + q];
+                s3 += part_acc[(int64_t)(b + 3) * kAcc + q];
+            }
+            for (; b < b1; ++b) s0 += part_acc[(int64_t)b * kAcc + q];
         }
-        part[slice][q] = s;
+        part[slice][q] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
-    if (threadIdx.x < kAcc) acc[threadIdx.x] = threadIdx.x < nacc ? ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x] : 0.0;
+    if (threadIdx.x < kAcc) {
+        double v = 0.0;
+        if ((int)threadIdx.x < nacc)
+            for (int sl = 0; sl < kSolveThreads / 64; ++sl) v += part[sl][threadIdx.x];
+        acc[threadIdx.x] = v;
+    }
     __syncthreads();
     if (threadIdx.x) return;
     double cnt = acc[0];
@@ -736,7 +749,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     const size_t nn = (size_t)(n > 0 ? n : 1);
     b->part_val = a.get<double>((size_t)p.splits * nn);
     b->part_idx = a.get<int32_t>((size_t)p.splits * nn);
-    b->part_acc = a.get<double>((size_t)cdiv((int64_t)nn, 256) * kAcc);
+    b->part_acc = a.get<double>((size_t)cdiv((int64_t)nn, kMergeThreads) * kAcc);
     b->init_val = a.get<double>(nn);
     b->init_idx = a.get<int32_t>(nn);
     b->idx_cur = a.get<int32_t>(nn);
@@ -795,12 +808,12 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
     if (screen) {
         {
             ProfScope prof(KPX_PROF_NN_SCREEN, 8.0 * (double)p.n_src * (double)p.n_tgt, st);   // 4 MAC per (source, target) pair
-            hipLaunchKernelGGL(nn_screen_kernel, dim3(p.f_row_blocks, p.f_splits), thr, 0, st, n, b.Bf, p.f_tiles_per_split, done, b.A32,
-                               b.thr32, b.init_idx, b.cand_cnt, b.cand, b.overflow);
+            hipLaunchKernelGGL((nn_screen_kernel<4, 3>), dim3(p.f_row_blocks, p.f_splits), thr, 0, st, n, b.Bf, p.f_tiles_per_split, done,
+                               b.A32, b.thr32, b.init_idx, b.cand_cnt, b.cand, b.overflow);
         }
         hipLaunchKernelGGL(nn_overflow_kernel, dim3(1024), thr, 0, st, src, n, tgt,
                            p.n_tgt, T, done, b.cand_cnt, b.cand, b.overflow);
-        hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.init_val, b.init_idx, 1,
+        hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.init_val, b.init_idx, 1,
                            max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, b.cand_cnt, b.cand);
         KPX_LAUNCH_CHECK();
         return KPX_OK;
@@ -808,7 +821,7 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
     if (!have_prev) {
         hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, 1), thr, 0, st, n, b.Bseed, (int32_t)p.seed_tiles_pad, (int32_t)kSeedStride,
                            done, b.A64, b.K64, (const double *)nullptr, (const int32_t *)nullptr, b.part_val, b.part_idx);
-        hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx, 1,
+        hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx, 1,
                            0.0, -2, b.init_idx, (double *)nullptr, b.init_val, b.part_acc, (const int32_t *)nullptr, (const int32_t *)nullptr);
     }
     {
@@ -816,7 +829,7 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
         hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
                            b.init_val, b.init_idx, b.part_val, b.part_idx);
     }
-    hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
+    hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
                        p.splits, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, (const int32_t *)nullptr,
                        (const int32_t *)nullptr);
     KPX_LAUNCH_CHECK();
@@ -908,7 +921,7 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
     for (int k = 0; k <= max_iteration; ++k) {
         rc = nn_search_launch(src, tgt, tgt_normals, p, b, b.state->T, &b.state->done, k > 0, md2, mode, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, st, b.part_acc, (int)cdiv(n_src, 256), n_src, mode, k,
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, b.part_acc, (int)cdiv(n_src, kMergeThreads), n_src, mode, k,
                            max_iteration, relative_fitness, relative_rmse, b.state, d_result);
         if (poll_interval > 0 && (k + 1) % poll_interval == 0 && k < max_iteration) {
             int32_t h_done = 0;
@@ -987,7 +1000,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         int r = nn_search_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], bufs[i].state->T, &bufs[i].state->done, k > 0, md2,
                                  mode, st);
         if (r) return r;
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, st, bufs[i].part_acc, (int)cdiv(h_n_src[i], 256), h_n_src[i], mode, k,
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, bufs[i].part_acc, (int)cdiv(h_n_src[i], kMergeThreads), h_n_src[i], mode, k,
                            max_iteration, relative_fitness, relative_rmse, bufs[i].state, d_results + 20 * i);
         KPX_HIP(hipEventRecord(ev[i], st));
         return KPX_OK;
