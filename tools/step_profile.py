@@ -1,0 +1,24 @@
+"""dev-only: wall time of each phase of one pipeline step (with syncs)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from kinectpy_amd import ops
+from kinectpy_amd.pipeline import PipelineParams
+xy, depth_h, rgb_h, inits, truth, _ = bench.make_group(0, 1, 4, 1)
+depth = torch.as_tensor(depth_h[0]).cuda(); rgb = torch.as_tensor(rgb_h[0]).cuda(); xyd = torch.as_tensor(xy).cuda().reshape(-1)
+p = PipelineParams(); S = 4
+def T(name, fn, reps=5):
+    fn(); torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps): out = fn()
+    torch.cuda.synchronize(); print(f"{name:40s} {(time.perf_counter()-t)/reps*1e3:8.3f} ms"); return out
+full = T("depth_to_cloud full x4", lambda: ops.depth_to_cloud(depth, xyd, None, S, False, False))
+masked = T("depth_to_cloud masked x4", lambda: ops.depth_to_cloud(depth, xyd, rgb, S, True, True))
+downs = T("voxel 35 x4", lambda: [ops.voxel_downsample(full[i][0], 35.0)[0] for i in range(S)])
+tn = T("normals", lambda: ops.estimate_normals(downs[0], 70.0, 40))
+rs = T("icp_batch x3", lambda: ops.icp_batch(downs[1:], downs[0], 100.0, inits, "p2plane", tn, 30), reps=3)
+Ts = [np.eye(4)] + [r["transformation"] for r in rs]
+pts = T("transform x3 + cat", lambda: (torch.cat([masked[0][0]] + [ops.transform(masked[i][0], Ts[i]) for i in range(1, S)], 0), torch.cat([m[1] for m in masked], 0)))
+vp = T("voxel 10 fused", lambda: ops.voxel_downsample(pts[0], 10.0, pts[1]))
+keep = T("sor k=20", lambda: ops.sor(vp[0], 20, 2.0))
+out = T("select", lambda: ops.select_by_index([vp[0], vp[1]], keep[0]))
