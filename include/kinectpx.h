@@ -176,6 +176,29 @@ int kpx_icp(const float *src, int64_t n_src, const float *tgt, const float *tgt_
             double relative_rmse, int32_t poll_interval, double *d_result, int32_t *idx, double *d2, void *ws,
             size_t ws_bytes, void *stream);
 
+/* ---- global registration (rows a11-a13) ------------------------------------------------- */
+
+/* compute_fpfh_feature(pcd, KDTreeSearchParamHybrid(radius, max_nn)) (preprocessing/registration.py:15-20).
+ * fpfh: f64 [n][33] (Open3D's Feature.data is the transpose, (33, n)).  Needs normals.  max_nn <= 128. */
+size_t kpx_fpfh_workspace_bytes(int64_t n, int32_t max_nn);
+int kpx_fpfh(const float *pts, const float *normals, int64_t n, double radius, int32_t max_nn, double *fpfh, void *ws,
+             size_t ws_bytes, void *stream);
+
+/* 1-nearest neighbour of every row of fa among the rows of fb in the 33-D feature space (the matching stage of
+ * registration_ransac_based_on_feature_matching, registration.py:50-57); ties to the lowest index. */
+int kpx_feature_nn(const double *fa, int64_t na, const double *fb, int64_t nb, int32_t *idx, void *stream);
+
+/* RegistrationRANSACBasedOnCorrespondence: ransac_n = 3 correspondences per hypothesis (Philox-seeded, with
+ * replacement), Umeyama without scale, CorrespondenceCheckerBasedOnEdgeLength(edge_similarity) and
+ * ...BasedOnDistance(max_dist), validation by the full nearest-neighbour correspondence count within max_dist,
+ * RANSACConvergenceCriteria(max_iteration, confidence).  Synchronous (the exit test needs each batch's result).
+ * corres: i32 [n_corres][2] (source, target) on the device.
+ * h_result (host) f64 [20]: T (16) | fitness | inlier_rmse | iterations run | validations. */
+size_t kpx_ransac_workspace_bytes(int64_t n_src, int64_t n_tgt);
+int kpx_ransac_corres(const float *src, int64_t n_src, const float *tgt, int64_t n_tgt, const int32_t *corres, int64_t n_corres,
+                      double max_dist, int32_t ransac_n, double edge_similarity, int32_t max_iteration, double confidence,
+                      uint64_t seed, double *h_result, void *ws, size_t ws_bytes, void *stream);
+
 /* Several registrations onto ONE shared target (preprocessing/data.py:144-161 registers every sub device onto
  * the master cloud).  The target operand is prepared once; the problems' iterations are queued round-robin on
  * `stream` and each problem's convergence flag is polled through a side stream that waits only for that

@@ -1,0 +1,504 @@
+// kpx_fpfh.hip -- global registration (reference rows a11-a13):
+//   compute_fpfh_feature(KDTreeSearchParamHybrid)                        preprocessing/registration.py:15-20
+//   registration_ransac_based_on_feature_matching(..., mutual_filter,    preprocessing/registration.py:50-57
+//       PointToPoint(False), 3, [EdgeLength(0.95), Distance(thr)], RANSACConvergenceCriteria(250000, 0.999))
+// Kernels: hybrid neighbour lists (exact grid search, ascending (d2, idx)), SPFH histograms, FPFH weighting,
+// 33-D feature nearest neighbour (LDS-tiled fp64, the oracle's accumulation order), batched RANSAC hypotheses
+// (Philox sampling, 3-point Umeyama, edge-length + distance checkers), validation by an exact radius-limited
+// nearest-neighbour count on the target grid, inlier ratio of the correspondence set.  The sequential
+// better-than / est_k logic of Open3D is replayed on the host in iteration order.
+#include <vector>
+
+#include "kpx_gridknn.h"
+#include "kpx_linalg.h"
+
+namespace kpx {
+
+// ---- neighbour lists ------------------------------------------------------------------------------------------
+__global__ void nbr_list_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
+                                const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t n, int k, double r2,
+                                int32_t *__restrict__ nbr, double *__restrict__ d2, int32_t *__restrict__ cnt)
+{
+    extern __shared__ __align__(16) double lds[];
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const GridParams g = *gp;
+    int32_t *ilds = reinterpret_cast<int32_t *>(lds + (size_t)k * blockDim.x);
+    HeapDI heap{ lds + threadIdx.x, ilds + threadIdx.x, (int)blockDim.x, k, 0 };
+    grid_knn_scan(g, cell_start, spts, sidx, (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2], r2, heap);
+    const int64_t me = sidx[s];
+    const int m = heap.sz;
+    cnt[me] = m;
+    // heap-sort extraction: the maximum goes to the last free slot -> ascending (d2, idx)
+    for (int last = m - 1; last >= 0; --last) {
+        const double dm = heap.h[0]; const int32_t im = heap.ix[0];
+        const double dv = heap.h[last * heap.stride]; const int32_t iv = heap.ix[last * heap.stride];
+        int c = 0;
+        for (;;) {
+            int l = 2 * c + 1, r = l + 1;
+            if (l >= last) break;
+            int b = l; double hb = heap.h[l * heap.stride]; int32_t ib = heap.ix[l * heap.stride];
+            if (r < last) { double hr = heap.h[r * heap.stride]; int32_t ir = heap.ix[r * heap.stride]; if (HeapDI::less(hb, ib, hr, ir)) { b = r; hb = hr; ib = ir; } }
+            if (HeapDI::less(dv, iv, hb, ib)) { heap.h[c * heap.stride] = hb; heap.ix[c * heap.stride] = ib; c = b; } else break;
+        }
+        if (last > 0) { heap.h[c * heap.stride] = dv; heap.ix[c * heap.stride] = iv; }
+        nbr[me * k + last] = im;
+        d2[me * k + last] = dm;
+    }
+    for (int t = m; t < k; ++t) { nbr[me * k + t] = -1; d2[me * k + t] = 0.0; }
+}
+
+// ---- SPFH / FPFH ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bin11(double x)
+{
+    int h = (int)floor(x);
+    return h < 0 ? 0 : (h >= 11 ? 10 : h);
+}
+__device__ __forceinline__ void pair_features(const double p1[3], const double n1[3], const double p2[3], const double n2[3], double f[4])
+{
+    double dp[3] = { p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2] };
+    f[0] = f[1] = f[2] = 0.0;
+    f[3] = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
+    if (f[3] == 0.0) return;
+    double a[3] = { n1[0], n1[1], n1[2] }, b[3] = { n2[0], n2[1], n2[2] };
+    const double angle1 = (a[0] * dp[0] + a[1] * dp[1] + a[2] * dp[2]) / f[3];
+    const double angle2 = (b[0] * dp[0] + b[1] * dp[1] + b[2] * dp[2]) / f[3];
+    if (fabs(angle1) < fabs(angle2)) {            // acos|a1| > acos|a2|
+        for (int k = 0; k < 3; ++k) { a[k] = n2[k]; b[k] = n1[k]; dp[k] = -dp[k]; }
+        f[2] = -angle2;
+    } else f[2] = angle1;
+    double v[3] = { dp[1] * a[2] - dp[2] * a[1], dp[2] * a[0] - dp[0] * a[2], dp[0] * a[1] - dp[1] * a[0] };
+    const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (vn == 0.0) { f[0] = f[1] = f[2] = f[3] = 0.0; return; }
+    v[0] /= vn; v[1] /= vn; v[2] /= vn;
+    const double w[3] = { a[1] * v[2] - a[2] * v[1], a[2] * v[0] - a[0] * v[2], a[0] * v[1] - a[1] * v[0] };
+    f[1] = v[0] * b[0] + v[1] * b[1] + v[2] * b[2];
+    f[0] = atan2(w[0] * b[0] + w[1] * b[1] + w[2] * b[2], a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+}
+
+constexpr int kFeatThreads = 128;
+__global__ __launch_bounds__(kFeatThreads) void spfh_kernel(const float *__restrict__ pts, const float *__restrict__ nrm, int64_t n,
+                                                            const int32_t *__restrict__ nbr, const int32_t *__restrict__ cnt, int k,
+                                                            double *__restrict__ spfh)
+{
+    __shared__ double hist[33][kFeatThreads];
+    const int64_t i = (int64_t)blockIdx.x * kFeatThreads + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 33; ++j) hist[j][threadIdx.x] = 0.0;
+    if (i >= n) return;
+    const int m = cnt[i];
+    if (m > 1) {
+        const double p1[3] = { pts[3 * i], pts[3 * i + 1], pts[3 * i + 2] }, n1[3] = { nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2] };
+        const double inc = 100.0 / (double)(m - 1);
+        for (int t = 1; t < m; ++t) {                  // slot 0 is the point itself
+            const int64_t j = nbr[i * k + t];
+            const double p2[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] }, n2[3] = { nrm[3 * j], nrm[3 * j + 1], nrm[3 * j + 2] };
+            double f[4];
+            pair_features(p1, n1, p2, n2, f);
+            hist[bin11(11.0 * (f[0] + M_PI) / (2.0 * M_PI))][threadIdx.x] += inc;
+            hist[11 + bin11(11.0 * (f[1] + 1.0) * 0.5)][threadIdx.x] += inc;
+            hist[22 + bin11(11.0 * (f[2] + 1.0) * 0.5)][threadIdx.x] += inc;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 33; ++j) spfh[i * 33 + j] = hist[j][threadIdx.x];
+}
+
+__global__ __launch_bounds__(kFeatThreads) void fpfh_kernel(int64_t n, const int32_t *__restrict__ nbr, const double *__restrict__ d2,
+                                                            const int32_t *__restrict__ cnt, int k, const double *__restrict__ spfh,
+                                                            double *__restrict__ fpfh)
+{
+    const int64_t i = (int64_t)blockIdx.x * kFeatThreads + threadIdx.x;
+    if (i >= n) return;
+    double acc[33];
+#pragma unroll
+    for (int j = 0; j < 33; ++j) acc[j] = 0.0;
+    double sum[3] = { 0.0, 0.0, 0.0 };
+    const int m = cnt[i];
+    if (m > 1) {
+        for (int t = 1; t < m; ++t) {
+            const double dist = d2[i * k + t];
+            if (dist == 0.0) continue;
+            const double *sp = spfh + 33 * (int64_t)nbr[i * k + t];
+#pragma unroll
+            for (int j = 0; j < 33; ++j) { const double val = sp[j] / dist; sum[j / 11] += val; acc[j] += val; }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if (sum[j] != 0.0) sum[j] = 100.0 / sum[j];
+#pragma unroll
+        for (int j = 0; j < 33; ++j) acc[j] = acc[j] * sum[j / 11] + spfh[i * 33 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 33; ++j) fpfh[i * 33 + j] = acc[j];
+}
+
+// ---- 33-D feature nearest neighbour -----------------------------------------------------------------------------
+// thread = query row held in registers; targets staged through LDS, read as broadcasts.  d = fma(e,e,d), k = 0..32,
+// strict "<" over ascending target index (ties -> lowest index): identical to the oracle.
+constexpr int kFnnThreads = 128, kFnnTile = 64;
+__global__ __launch_bounds__(kFnnThreads) void feature_nn_kernel(const double *__restrict__ fa, int64_t na, const double *__restrict__ fb,
+                                                                 int64_t nb, int32_t *__restrict__ idx)
+{
+    __shared__ double tile[kFnnTile][33];
+    const int64_t i = (int64_t)blockIdx.x * kFnnThreads + threadIdx.x;
+    double q[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) q[k] = i < na ? fa[i * 33 + k] : 0.0;
+    double best = INFINITY;
+    int32_t bj = 0;
+    for (int64_t j0 = 0; j0 < nb; j0 += kFnnTile) {
+        const int cntj = nb - j0 < kFnnTile ? (int)(nb - j0) : kFnnTile;
+        __syncthreads();
+        for (int t = threadIdx.x; t < cntj * 33; t += kFnnThreads) (&tile[0][0])[t] = fb[j0 * 33 + t];
+        __syncthreads();
+        for (int j = 0; j < cntj; ++j) {
+            double d = 0.0;
+#pragma unroll
+            for (int k = 0; k < 33; ++k) { const double e = q[k] - tile[j][k]; d = fma(e, e, d); }
+            if (d < best) { best = d; bj = (int32_t)(j0 + j); }
+        }
+    }
+    if (i < na) idx[i] = bj;
+}
+
+// ---- RANSAC hypotheses -----------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// one thread per iteration `itr0 + t`: sample 3 correspondences (with replacement), edge-length check, Umeyama,
+// distance check.  pass[t] = 1 and T[t] (16 doubles) when the hypothesis survives.
+__global__ __launch_bounds__(256) void ransac_hyp_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
+                                                         const int32_t *__restrict__ corres, int64_t nc, int32_t itr0, int32_t count,
+                                                         uint32_t seed_lo, uint32_t seed_hi, double edge_sim, double max_dist,
+                                                         uint8_t *__restrict__ pass, double *__restrict__ Ts)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    uint32_t out[4];
+    philox4x32_10(0u, (uint32_t)(itr0 + t), 1u, 0u, seed_lo, seed_hi, out);
+    double sp[3][3], tp[3][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int64_t pick = (int64_t)(((uint64_t)out[q] * (uint64_t)nc) >> 32);
+        const float *s = src + 3 * (int64_t)corres[2 * pick], *g = tgt + 3 * (int64_t)corres[2 * pick + 1];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { sp[q][a] = s[a]; tp[q][a] = g[a]; }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j) {
+            double ds = 0.0, dt = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { double e = sp[i][a] - sp[j][a]; ds += e * e; e = tp[i][a] - tp[j][a]; dt += e * e; }
+            ds = sqrt(ds); dt = sqrt(dt);
+            ok = ok && !(ds < dt * edge_sim || dt < ds * edge_sim);
+        }
+    pass[t] = 0;
+    if (!ok) return;
+    double ms[3] = { 0, 0, 0 }, mt[3] = { 0, 0, 0 }, S[9], R[9];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ms[a] += sp[q][a]; mt[a] += tp[q][a]; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ms[a] /= 3.0; mt[a] /= 3.0; }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) S[a] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) S[3 * a + b] += (tp[q][a] - mt[a]) * (sp[q][b] - ms[b]);
+    kabsch_rotation(S, R);
+    double T[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) T[4 * a + b] = R[3 * a + b];
+        T[4 * a + 3] = mt[a] - (R[3 * a] * ms[0] + R[3 * a + 1] * ms[1] + R[3 * a + 2] * ms[2]);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double e2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double o = fma(T[4 * a], sp[q][0], fma(T[4 * a + 1], sp[q][1], fma(T[4 * a + 2], sp[q][2], T[4 * a + 3])));
+            e2 += (o - tp[q][a]) * (o - tp[q][a]);
+        }
+        ok = ok && !(sqrt(e2) > max_dist);
+    }
+    if (!ok) return;
+    pass[t] = 1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Ts[(int64_t)t * 16 + k] = T[k];
+}
+struct PassPred {
+    const uint8_t *pass;
+    __device__ bool operator()(int64_t i, int) const { return pass[i] != 0; }
+};
+struct PassEmit {
+    int32_t *list;
+    __device__ void operator()(int64_t i, int, int32_t dst) const { list[dst] = (int32_t)i; }
+};
+
+// single-slot "heap": nearest point with d2 < r2max
+struct Nearest1 {
+    double best; int32_t bi;
+    __device__ bool full() const { return bi >= 0; }
+    __device__ double worst() const { return best; }
+    __device__ void push(double d, int j) { if (d < best || (d == best && (j < bi || bi < 0))) { best = d; bi = j; } }
+};
+
+// validation of surviving hypotheses: for hypothesis h = list[blockIdx.y], every source point transformed by T_h
+// looks for its nearest target point within max_dist on the target grid; per-block (count, sum d2) partials.
+__global__ __launch_bounds__(256) void ransac_validate_kernel(const float *__restrict__ src, int64_t n, const GridParams *__restrict__ gp,
+                                                              const uint32_t *__restrict__ cell_start, const float *__restrict__ tpts,
+                                                              const int32_t *__restrict__ list, const double *__restrict__ Ts, double r2,
+                                                              int64_t *__restrict__ part_cnt, double *__restrict__ part_err)
+{
+    __shared__ double shd[4];
+    __shared__ long long shc[4];
+    const int h = list[blockIdx.y];
+    const double *T = Ts + (int64_t)h * 16;
+    const GridParams g = *gp;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long c = 0;
+    double e = 0.0;
+    if (i < n) {
+        const double x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+        double s[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] = fma(T[4 * k], x, fma(T[4 * k + 1], y, fma(T[4 * k + 2], z, T[4 * k + 3])));
+        // points outside the grid by more than the radius cannot match
+        bool far = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double lo = g.org[a], hi = g.org[a] + (double)g.dim[a] * g.h;
+            const double o = s[a] < lo ? lo - s[a] : (s[a] > hi ? s[a] - hi : 0.0);
+            far = far || o * o >= r2;
+        }
+        if (!far) {
+            Nearest1 nn{ r2, -1 };
+            grid_knn_scan(g, cell_start, tpts, (const int32_t *)nullptr, s[0], s[1], s[2], r2, nn);
+            if (nn.best < r2) { c = 1; e = nn.best; }
+        }
+    }
+    e = block_sum(e, shd);
+    c = block_sum(c, shc);
+    if (threadIdx.x == 0) {
+        part_cnt[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = c;
+        part_err[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = e;
+    }
+}
+// inlier ratio of the correspondence set under T_h (EvaluateInlierCorrespondenceRatio) + reduction of the partials
+__global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
+                                                           const int32_t *__restrict__ corres, int64_t nc, const int32_t *__restrict__ list,
+                                                           const double *__restrict__ Ts, double max_dist, const int64_t *__restrict__ part_cnt,
+                                                           const double *__restrict__ part_err, int nblocks, double *__restrict__ score)
+{
+    __shared__ long long shc[4];
+    const int h = list[blockIdx.x];
+    const double *T = Ts + (int64_t)h * 16;
+    long long inl = 0;
+    for (int64_t c = threadIdx.x; c < nc; c += blockDim.x) {
+        const float *s = src + 3 * (int64_t)corres[2 * c], *g = tgt + 3 * (int64_t)corres[2 * c + 1];
+        double e2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double o = fma(T[4 * a], (double)s[0], fma(T[4 * a + 1], (double)s[1], fma(T[4 * a + 2], (double)s[2], T[4 * a + 3])));
+            e2 += (o - (double)g[a]) * (o - (double)g[a]);
+        }
+        inl += sqrt(e2) < max_dist;
+    }
+    inl = block_sum(inl, shc);
+    if (threadIdx.x == 0) {
+        long long cnt = 0; double err = 0.0;
+        for (int b = 0; b < nblocks; ++b) { cnt += part_cnt[(int64_t)blockIdx.x * nblocks + b]; err += part_err[(int64_t)blockIdx.x * nblocks + b]; }
+        score[4 * blockIdx.x] = (double)cnt; score[4 * blockIdx.x + 1] = err; score[4 * blockIdx.x + 2] = (double)inl;
+        score[4 * blockIdx.x + 3] = (double)h;
+    }
+}
+
+static int knn_lists(const float *pts, int64_t n, double radius, int k, Arena &a, Grid *g, int32_t **nbr, double **d2, int32_t **cnt, hipStream_t st)
+{
+    int rc = grid_build(pts, n, 24.0, a, g, st);
+    if (rc) return rc;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    *nbr = a.get<int32_t>(nn * k);
+    *d2 = a.get<double>(nn * k);
+    *cnt = a.get<int32_t>(nn);
+    if (a.dry) return KPX_OK;
+    KPX_ARENA_CHECK(a);
+    const int threads = k <= 48 ? 128 : 64;
+    const size_t lds = (size_t)k * threads * (sizeof(double) + sizeof(int32_t));
+    static bool attr_set = false;
+    if (!attr_set) {
+        KPX_HIP(hipFuncSetAttribute((const void *)nbr_list_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nbr_list_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g->params, g->cell_start, g->sorted_pts,
+                       g->sorted_idx, n, k, radius * radius, *nbr, *d2, *cnt);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+static int fpfh_impl(const float *pts, const float *nrm, int64_t n, double radius, int max_nn, double *fpfh, Arena &a, hipStream_t st)
+{
+    Grid g;
+    int32_t *nbr, *cnt; double *d2;
+    int kk = (int64_t)max_nn < n ? max_nn : (int)(n > 0 ? n : 1);
+    int rc = knn_lists(pts, n, radius, kk, a, &g, &nbr, &d2, &cnt, st);
+    if (rc) return rc;
+    double *spfh = a.get<double>((size_t)(n > 0 ? n : 1) * 33);
+    if (a.dry) return KPX_OK;
+    KPX_ARENA_CHECK(a);
+    hipLaunchKernelGGL(spfh_kernel, dim3((unsigned)cdiv(n, kFeatThreads)), dim3(kFeatThreads), 0, st, pts, nrm, n, nbr, cnt, kk, spfh);
+    hipLaunchKernelGGL(fpfh_kernel, dim3((unsigned)cdiv(n, kFeatThreads)), dim3(kFeatThreads), 0, st, n, nbr, d2, cnt, kk, spfh, fpfh);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+constexpr int kRansacBatch = 8192;
+struct RansacBuffers {
+    Grid g;
+    uint8_t *pass;
+    double *Ts, *score, *part_err;
+    int64_t *part_cnt;
+    int32_t *list, *counts, *n_pass;
+    int vblocks;
+};
+static int ransac_carve(const float *tgt, int64_t n_src, int64_t n_tgt, int max_validate, Arena &a, RansacBuffers *b, hipStream_t st)
+{
+    int rc = grid_build(tgt, n_tgt, 8.0, a, &b->g, st);
+    if (rc) return rc;
+    b->vblocks = (int)cdiv(n_src > 0 ? n_src : 1, 256);
+    b->pass = a.get<uint8_t>(kRansacBatch);
+    b->Ts = a.get<double>((size_t)kRansacBatch * 16);
+    b->list = a.get<int32_t>(kRansacBatch);
+    b->counts = a.get<int32_t>((size_t)compact_tiles(kRansacBatch));
+    b->n_pass = a.get<int32_t>(1);
+    b->part_cnt = a.get<int64_t>((size_t)max_validate * b->vblocks);
+    b->part_err = a.get<double>((size_t)max_validate * b->vblocks);
+    b->score = a.get<double>((size_t)max_validate * 4);
+    return KPX_OK;
+}
+constexpr int kMaxValidate = 512;      // validations per launch (surviving hypotheses are processed in chunks)
+
+}  // namespace kpx
+
+using namespace kpx;
+
+KPX_EXPORT size_t kpx_fpfh_workspace_bytes(int64_t n, int32_t max_nn)
+{
+    Arena a(nullptr, 0);
+    fpfh_impl(nullptr, nullptr, n, 1.0, max_nn < 1 ? 1 : max_nn, nullptr, a, nullptr);
+    return a.off;
+}
+KPX_EXPORT int kpx_fpfh(const float *pts, const float *normals, int64_t n, double radius, int32_t max_nn, double *fpfh, void *ws,
+                        size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(radius > 0.0 && max_nn >= 1, "compute_fpfh_feature: radius and max_nn must be positive");
+    KPX_REQUIRE(max_nn <= KPX_NORMALS_MAX_NN, "compute_fpfh_feature: max_nn > %d is not supported", KPX_NORMALS_MAX_NN);
+    KPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) / 128, "kpx_fpfh: bad size");
+    if (n == 0) return KPX_OK;
+    KPX_REQUIRE(pts && fpfh && ws, "kpx_fpfh: null pointer");
+    KPX_REQUIRE(normals, "Failed because input point cloud has no normal.");      // [O3D]
+    Arena a(ws, ws_bytes);
+    return fpfh_impl(pts, normals, n, radius, max_nn, fpfh, a, (hipStream_t)stream);
+}
+
+KPX_EXPORT int kpx_feature_nn(const double *fa, int64_t na, const double *fb, int64_t nb, int32_t *idx, void *stream)
+{
+    KPX_REQUIRE(na >= 0 && nb >= 1, "kpx_feature_nn: empty feature set");
+    if (na == 0) return KPX_OK;
+    KPX_REQUIRE(fa && fb && idx, "kpx_feature_nn: null pointer");
+    hipLaunchKernelGGL(feature_nn_kernel, dim3((unsigned)cdiv(na, kFnnThreads)), dim3(kFnnThreads), 0, (hipStream_t)stream, fa, na, fb, nb, idx);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+KPX_EXPORT size_t kpx_ransac_workspace_bytes(int64_t n_src, int64_t n_tgt)
+{
+    Arena a(nullptr, 0);
+    RansacBuffers b;
+    ransac_carve(nullptr, n_src, n_tgt, kMaxValidate, a, &b, nullptr);
+    return a.off;
+}
+// h_result: T (16) | fitness | inlier_rmse | iterations run | validations
+KPX_EXPORT int kpx_ransac_corres(const float *src, int64_t n_src, const float *tgt, int64_t n_tgt, const int32_t *corres, int64_t n_corres,
+                                 double max_dist, int32_t ransac_n, double edge_similarity, int32_t max_iteration, double confidence,
+                                 uint64_t seed, double *h_result, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(h_result, "kpx_ransac_corres: null result");
+    for (int k = 0; k < 16; ++k) h_result[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    h_result[16] = h_result[17] = h_result[18] = h_result[19] = 0.0;
+    KPX_REQUIRE(ransac_n == 3, "kpx_ransac_corres: ransac_n must be 3 (preprocessing/registration.py:53)");
+    if (n_corres < ransac_n || !(max_dist > 0.0)) return KPX_OK;                  // [O3D] returns an empty RegistrationResult
+    KPX_REQUIRE(n_src >= 1 && n_tgt >= 1 && src && tgt && corres && ws, "kpx_ransac_corres: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    RansacBuffers b;
+    int rc = ransac_carve(tgt, n_src, n_tgt, kMaxValidate, a, &b, st);
+    if (rc) return rc;
+    KPX_ARENA_CHECK(a);
+    const double r2 = max_dist * max_dist;
+    double best_fit = 0.0, best_rmse = 0.0;
+    int est_k = max_iteration, validations = 0, itr_done = 0;
+    std::vector<int32_t> h_list(kRansacBatch);
+    std::vector<double> h_score((size_t)kMaxValidate * 4), h_T(16);
+    for (int itr0 = 0; itr0 < max_iteration && itr0 < est_k; itr0 += kRansacBatch) {
+        const int count = max_iteration - itr0 < kRansacBatch ? max_iteration - itr0 : kRansacBatch;
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)cdiv(count, 256)), dim3(256), 0, st, src, tgt, corres, n_corres, itr0, count,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), edge_similarity, max_dist, b.pass, b.Ts);
+        rc = compact(PassPred{ b.pass }, PassEmit{ b.list }, count, 1, b.counts, b.n_pass, st);
+        if (rc) return rc;
+        int32_t n_pass = 0;
+        KPX_HIP(hipMemcpyAsync(&n_pass, b.n_pass, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KPX_HIP(hipStreamSynchronize(st));
+        if (n_pass) KPX_HIP(hipMemcpy(h_list.data(), b.list, (size_t)n_pass * sizeof(int32_t), hipMemcpyDeviceToHost));
+        bool stop = false;
+        for (int c0 = 0; c0 < n_pass && !stop; c0 += kMaxValidate) {
+            const int nv = n_pass - c0 < kMaxValidate ? n_pass - c0 : kMaxValidate;
+            if (itr0 + h_list[c0] >= est_k) break;                       // everything left is beyond the exit iteration
+            hipLaunchKernelGGL(ransac_validate_kernel, dim3(b.vblocks, nv), dim3(256), 0, st, src, n_src, b.g.params, b.g.cell_start,
+                               b.g.sorted_pts, b.list + c0, b.Ts, r2, b.part_cnt, b.part_err);
+            hipLaunchKernelGGL(ransac_score_kernel, dim3(nv), dim3(256), 0, st, src, tgt, corres, n_corres, b.list + c0, b.Ts, max_dist,
+                               b.part_cnt, b.part_err, b.vblocks, b.score);
+            KPX_HIP(hipMemcpyAsync(h_score.data(), b.score, (size_t)nv * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+            KPX_HIP(hipStreamSynchronize(st));
+            for (int v = 0; v < nv; ++v) {                               // Open3D's loop body, in iteration order
+                const int itr = itr0 + (int)h_score[4 * v + 3];
+                if (itr >= est_k) { stop = true; break; }
+                ++validations;
+                const double cnt = h_score[4 * v], err = h_score[4 * v + 1];
+                const double fit = cnt > 0 ? cnt / (double)n_src : 0.0, rmse = cnt > 0 ? sqrt(err / cnt) : 0.0;
+                if (fit > best_fit || (fit == best_fit && rmse < best_rmse)) {
+                    best_fit = fit; best_rmse = rmse;
+                    KPX_HIP(hipMemcpy(h_result, b.Ts + (int64_t)h_score[4 * v + 3] * 16, 16 * sizeof(double), hipMemcpyDeviceToHost));
+                    const double ratio = h_score[4 * v + 2] / (double)n_corres;
+                    const double ek = log(1.0 - confidence) / log(1.0 - pow(ratio, (double)ransac_n));
+                    if (ek < (double)est_k) est_k = (int)ceil(ek);
+                }
+            }
+        }
+        itr_done = itr0 + count < est_k ? itr0 + count : est_k;
+        if (stop) break;
+    }
+    h_result[16] = best_fit; h_result[17] = best_rmse; h_result[18] = (double)itr_done; h_result[19] = (double)validations;
+    return KPX_OK;
+}

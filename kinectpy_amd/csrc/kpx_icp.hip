@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned h0 = hi32(best[0][r]), h1 = hi32(best[1][r]);
-                pass |= (hi32(c00[r]) <= h0) | (hi32(c01[r]) <= h0) | (hi32(c10[r]) <= h1) | (hi32(c11[r]) <= h1);
+                pass |= (bool)((int)(hi32(c00[r]) <= h0) | (int)(hi32(c01[r]) <= h0) | (int)(hi32(c10[r]) <= h1) | (int)(hi32(c11[r]) <= h1));
             }
             if (__builtin_amdgcn_ballot_w64(pass) != 0) {   // wave-uniform, rare once the bound is tight
                 const int32_t col0 = (tile0 + ct) * tile_stride * 16 + (lane & 15);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const unsigned h0 = hi32(best[0][r]), h1 = hi32(best[1][r]);
-                    anyeq |= (hi32(c00[r]) == h0) | (hi32(c01[r]) == h0) | (hi32(c10[r]) == h1) | (hi32(c11[r]) == h1);
+                    anyeq |= (bool)((int)(hi32(c00[r]) == h0) | (int)(hi32(c01[r]) == h0) | (int)(hi32(c10[r]) == h1) | (int)(hi32(c11[r]) == h1));
                 }
                 if (__builtin_amdgcn_ballot_w64(anyeq) == 0) {
                     // every high word differs from its bound: the high words alone decide "<" (no fp64 op)
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
                     // near-ties (equal high words, e.g. the bound's own column): exact lexicographic (value, column)
 #define KPX_NN_EXACT(ACC, RT, COL)                                                                  \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
-                        const bool t = (ACC[r] < best[RT][r]) | ((ACC[r] == best[RT][r]) & ((COL) < bcol[RT][r])); \
+                        const bool t = (int)(ACC[r] < best[RT][r]) | ((int)(ACC[r] == best[RT][r]) & (int)((COL) < bcol[RT][r])); \
                         best[RT][r] = t ? ACC[r] : best[RT][r];                                    \
                         bcol[RT][r] = t ? (COL) : bcol[RT][r];                                     \
                     }

@@ -65,6 +65,70 @@ def registration_icp(source, target, max_correspondence_distance, init=None, est
     return RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], corr)
 
 
+class Feature:
+    """o3d.pipelines.registration.Feature: `.data` is (33, N) float64 like Open3D's; the device copy is (N, 33)."""
+
+    def __init__(self, dev):
+        self._dev = dev
+
+    @property
+    def data(self):
+        return self._dev.cpu().numpy().T.copy()
+
+    def dimension(self):
+        return 33
+
+    def num(self):
+        return int(self._dev.shape[0])
+
+
+class CorrespondenceCheckerBasedOnEdgeLength:
+    def __init__(self, similarity_threshold=0.9):
+        self.similarity_threshold = float(similarity_threshold)
+
+
+class CorrespondenceCheckerBasedOnDistance:
+    def __init__(self, distance_threshold):
+        self.distance_threshold = float(distance_threshold)
+
+
+class RANSACConvergenceCriteria:
+    def __init__(self, max_iteration=100000, confidence=0.999):
+        self.max_iteration, self.confidence = int(max_iteration), float(confidence)
+
+
+def compute_fpfh_feature(input, search_param):
+    """preprocessing/registration.py:15-20"""
+    if not input.has_normals():
+        raise RuntimeError("Failed because input point cloud has no normal.")
+    return Feature(ops.fpfh(input._pts, input._nrm, search_param.radius, min(search_param.max_nn, 128)))
+
+
+def registration_ransac_based_on_feature_matching(source, target, source_feature, target_feature, mutual_filter,
+                                                  max_correspondence_distance, estimation_method=None, ransac_n=3,
+                                                  checkers=(), criteria=None, seed=None):
+    """preprocessing/registration.py:50-57.  Open3D's RANSAC is unseeded and runs its iterations in an OpenMP
+    loop; ours draws from Philox with `seed` (None -> fresh random seed) and replays the iterations in order."""
+    crit = criteria if criteria is not None else RANSACConvergenceCriteria()
+    est = estimation_method if estimation_method is not None else TransformationEstimationPointToPoint()
+    if est.mode != "p2p":
+        raise NotImplementedError("feature-matching RANSAC is used with TransformationEstimationPointToPoint(False) by KinectPy")
+    edge, dist_thr = 0.0, float(max_correspondence_distance)
+    for c in checkers:
+        if isinstance(c, CorrespondenceCheckerBasedOnEdgeLength):
+            edge = c.similarity_threshold
+        elif isinstance(c, CorrespondenceCheckerBasedOnDistance):
+            dist_thr = c.distance_threshold
+    if dist_thr != float(max_correspondence_distance):
+        raise NotImplementedError("distance checker threshold must equal max_correspondence_distance (as in KinectPy)")
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+    corres = ops.feature_correspondences(source_feature._dev, target_feature._dev, bool(mutual_filter), int(ransac_n))
+    r = ops.ransac_corres(source._pts, target._pts, corres, float(max_correspondence_distance), int(ransac_n), edge,
+                          crit.max_iteration, crit.confidence, seed)
+    return RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], corres)
+
+
 def _off_path(name):
     def f(*a, **k):
         raise NotImplementedError(f"{name} is outside the round-1 hot path of kinectpy_amd (SURVEY.md 8f); "
@@ -82,8 +146,12 @@ pipelines = types.SimpleNamespace(registration=types.SimpleNamespace(
     RegistrationResult=RegistrationResult,
     TransformationEstimationPointToPoint=TransformationEstimationPointToPoint,
     TransformationEstimationPointToPlane=TransformationEstimationPointToPlane,
-    compute_fpfh_feature=_off_path("compute_fpfh_feature"),
-    registration_ransac_based_on_feature_matching=_off_path("registration_ransac_based_on_feature_matching"),
+    compute_fpfh_feature=compute_fpfh_feature,
+    registration_ransac_based_on_feature_matching=registration_ransac_based_on_feature_matching,
+    Feature=Feature,
+    CorrespondenceCheckerBasedOnEdgeLength=CorrespondenceCheckerBasedOnEdgeLength,
+    CorrespondenceCheckerBasedOnDistance=CorrespondenceCheckerBasedOnDistance,
+    RANSACConvergenceCriteria=RANSACConvergenceCriteria,
     registration_colored_icp=_off_path("registration_colored_icp"),
 ))
 visualization = types.SimpleNamespace(VisualizerWithEditing=_off_path("VisualizerWithEditing"),

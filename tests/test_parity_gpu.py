@@ -328,7 +328,7 @@ def test_default_filter_outliers_on_mm_data(oracle):
 
 def test_point_to_plane_registration_api(oracle):
     from kinectpy_amd.geometry import PointCloud
-    from kinectpy_amd.preprocessing.registration import execute_point_to_plane_registration, execute_global_registration
+    from kinectpy_amd.preprocessing.registration import execute_point_to_plane_registration
     E0, E1 = synth.camera_pose(0, 8), synth.camera_pose(1, 8)
     xy = synth.xy_table()
     clouds = []
@@ -354,8 +354,67 @@ def test_point_to_plane_registration_api(oracle):
     assert np.abs(T - oT).max() < 1e-6
     assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < 15 and np.abs(T[:3, :3] - T_true[:3, :3]).max() < 5e-3
     assert (np.abs((mn * mn_gpu.astype(np.float64)).sum(1)) > 0.999).mean() > 0.95
-    with pytest.raises(NotImplementedError):
-        execute_global_registration(master, sub)
+
+
+# ----------------------------------------------------------------- global registration (rows a11-a13)
+@pytest.fixture(scope="module")
+def two_views(oracle):
+    """two cluttered views 22.5 degrees apart, voxel 50 (keeps the oracle's brute-force feature matching short)"""
+    xy = synth.xy_table()
+    ex = synth.clutter()
+    out = []
+    for i, seed in ((0, 100), (1, 101)):
+        E = synth.camera_pose(i, 16)
+        dep = synth.render_depth(E, seed=seed, xy=xy, extra=ex)
+        p, _, _ = oracle.rgbd_compact(oracle.unproject_u16(dep, xy))
+        out.append((E, oracle.voxel_downsample(p, 50.0)[0]))
+    return out
+
+
+def test_fpfh_matches_oracle(ops, oracle, two_views):
+    for _, d in two_views:
+        nrm = npy(ops.estimate_normals(d, 100.0, 40))              # the oracle gets the same float32 normals
+        got = npy(ops.fpfh(d, nrm, 250.0, 40))
+        want, _ = oracle.fpfh(d, nrm, 250.0, 40)
+        assert got.shape == want.shape == (len(d), 33)
+        # histogram sums: 3 x 100 from SPFH (+ 3 x 100 weighted) for every point with neighbours
+        assert np.allclose(got.sum(1)[want.sum(1) > 0], 600.0, atol=1e-6)
+        bad = np.abs(got - want).max(1) > 1e-6                      # a libm atan2 ulp can move one pair across a bin edge
+        assert bad.mean() < 1e-3
+        assert np.allclose(got[~bad], want[~bad], rtol=1e-9, atol=1e-9)
+
+
+def test_feature_matching_and_ransac_match_oracle(ops, oracle, two_views):
+    (E0, tgt), (E1, src) = two_views
+    feats = []
+    for d in (src, tgt):
+        nrm = npy(ops.estimate_normals(d, 100.0, 40))
+        feats.append(oracle.fpfh(d, nrm, 250.0, 40)[0])            # identical features on both sides
+    gi = npy(ops.feature_nn(feats[0], feats[1]))
+    assert np.array_equal(gi, oracle.feature_nn(feats[0], feats[1]))          # bit-exact 33-D nearest neighbour
+    corr = ops.feature_correspondences(feats[0], feats[1], True, 3)
+    assert np.array_equal(corr, oracle.feature_correspondences(feats[0], feats[1], True, 3))
+    for seed, iters in ((1, 60000), (2, 20000)):
+        g = ops.ransac_corres(src, tgt, corr, 75.0, 3, 0.95, iters, 0.999, seed)
+        oT, ost = oracle.ransac_corres(src, tgt, corr, 75.0, 3, 0.95, iters, 0.999, seed)
+        assert g["iterations"] == ost["iterations"] and g["validations"] == ost["validations"]
+        assert g["fitness"] == ost["fitness"] and abs(g["inlier_rmse"] - ost["rmse"]) < 1e-9
+        assert np.abs(g["transformation"] - oT).max() < 1e-6
+
+
+def test_execute_global_registration_recovers_pose(oracle, two_views):
+    from kinectpy_amd.geometry import PointCloud
+    from kinectpy_amd.preprocessing.registration import execute_global_registration, execute_point_to_plane_registration
+    (E0, tgt), (E1, src) = two_views
+    T_true = np.linalg.inv(E0) @ E1
+    master, sub = PointCloud(tgt), PointCloud(src)
+    T0 = execute_global_registration(master, sub, voxel_size=50, ransac_n_trials=3, seed=5)
+    assert T0 is not None
+    ang = np.degrees(np.arccos(np.clip((np.trace(T0[:3, :3].T @ T_true[:3, :3]) - 1) / 2, -1, 1)))
+    assert ang < 6.0 and np.abs(T0[:3, 3] - T_true[:3, 3]).max() < 250.0          # coarse: good enough to start ICP
+    T1 = execute_point_to_plane_registration(master, sub, T0, voxel_size=50)       # the reference's next step (data.py:156-157)
+    ang = np.degrees(np.arccos(np.clip((np.trace(T1[:3, :3].T @ T_true[:3, :3]) - 1) / 2, -1, 1)))
+    assert ang < 0.5 and np.abs(T1[:3, 3] - T_true[:3, 3]).max() < 15.0
 
 
 def test_data_processor_frame(oracle):
