@@ -22,6 +22,8 @@
 // and accumulates the sums the update needs.  The ICP loop runs on the device; a small kernel solves the
 // 3x3 (Kabsch) or 6x6 (point-to-plane) system, updates T and raises `done`.
 #include <limits.h>
+#include <stddef.h>
+#include <time.h>
 #include <stdlib.h>
 
 #include "kpx_internal.h"
@@ -728,6 +730,21 @@ static NnPlan nn_plan(int64_t n, int64_t m)
     return p;
 }
 
+// Which sweep serves iteration k: the float32 screening sweep pays off when the cloud barely moved since the
+// last search (short candidate lists); after a large update (first iterations) the bound is loose, lists
+// overflow and the exact fp64 sweep is cheaper.  The host sees (fitness, rmse) at every poll and uses their
+// relative change as the motion proxy.
+struct ScreenPolicy {
+    double fit = -1.0, rmse = -1.0;
+    bool calm = false;
+    void observe(double f, double r)
+    {
+        calm = fit >= 0.0 && fabs(f - fit) <= 0.02 && fabs(r - rmse) <= 0.05 * (rmse > 1e-12 ? rmse : 1e-12);
+        fit = f; rmse = r;
+    }
+    bool allow(int k) const { static const bool force = getenv("KPX_ICP_FORCE_SCREEN") != nullptr; return force ? k >= 1 : (k >= 2 && calm); }
+};
+
 struct NnBuffers {
     double *B, *Bseed, *part_val, *part_acc, *init_val, *d2_cur, *tbbox, *A64, *K64;
     float *Bf, *A32, *thr32;
@@ -797,11 +814,11 @@ static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStr
 // One correspondence search.  have_prev: b.idx_cur holds the partners of the previous search (bound from them),
 // otherwise a seed sweep over every 64th target tile provides the bound.
 static int nn_search_launch(const float *src, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b,
-                            const double *T, const int32_t *done, bool have_prev, double max_d2, int mode, hipStream_t st)
+                            const double *T, const int32_t *done, bool have_prev, bool allow_screen, double max_d2, int mode, hipStream_t st)
 {
     const int64_t n = p.n_src;
     const dim3 thr(256);
-    const bool screen = have_prev && screening_enabled();
+    const bool screen = have_prev && allow_screen && screening_enabled();
     hipLaunchKernelGGL(nn_rowprep_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, T, done,
                        have_prev ? b.idx_cur : (const int32_t *)nullptr, screen ? b.aux : (const NnAux *)nullptr, b.init_val, b.init_idx,
                        b.A64, b.K64, b.A32, b.thr32, b.cand_cnt);
@@ -862,7 +879,7 @@ KPX_EXPORT int kpx_nn_search(const float *src, int64_t n_src, const float *tgt, 
     KPX_ARENA_CHECK(a);
     int rc = nn_prep(tgt, p, b, st);
     if (rc) return rc;
-    rc = nn_search_launch(src, tgt, nullptr, p, b, d_T, nullptr, false, 0.0, -1, st);
+    rc = nn_search_launch(src, tgt, nullptr, p, b, d_T, nullptr, false, false, 0.0, -1, st);
     if (rc) return rc;
     KPX_HIP(hipMemcpyAsync(idx, b.idx_cur, (size_t)n_src * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     KPX_HIP(hipMemcpyAsync(d2, b.d2_cur, (size_t)n_src * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -918,16 +935,30 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
     int rc = nn_prep(tgt, p, b, st);
     if (rc) return rc;
     const double md2 = max_dist * max_dist;
+    ScreenPolicy policy;
+    static const bool trace = getenv("KPX_ICP_TRACE") != nullptr;   // development aid: per-iteration sweep choice on stderr
     for (int k = 0; k <= max_iteration; ++k) {
-        rc = nn_search_launch(src, tgt, tgt_normals, p, b, b.state->T, &b.state->done, k > 0, md2, mode, st);
+        rc = nn_search_launch(src, tgt, tgt_normals, p, b, b.state->T, &b.state->done, k > 0,
+                              poll_interval == 1 ? policy.allow(k) : k >= 2, md2, mode, st);
         if (rc) return rc;
         hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, b.part_acc, (int)cdiv(n_src, kMergeThreads), n_src, mode, k,
                            max_iteration, relative_fitness, relative_rmse, b.state, d_result);
         if (poll_interval > 0 && (k + 1) % poll_interval == 0 && k < max_iteration) {
-            int32_t h_done = 0;
-            KPX_HIP(hipMemcpyAsync(&h_done, &b.state->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            IcpState h_state;
+            KPX_HIP(hipMemcpyAsync(&h_state.fitness, &b.state->fitness, sizeof(IcpState) - offsetof(IcpState, fitness), hipMemcpyDeviceToHost, st));
             KPX_HIP(hipStreamSynchronize(st));
-            if (h_done) break;
+            if (trace) {
+                int32_t total = 0;
+                KPX_HIP(hipMemcpy(&total, b.cand_cnt + n_src, sizeof(int32_t), hipMemcpyDeviceToHost));
+                static double t_prev = 0.0;
+                timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+                const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+                fprintf(stderr, "[kpx_icp] k=%d screen=%d fitness=%.6f rmse=%.6f overflow_rows=%d dt=%.3f ms\n", k, (int)(k > 0 && policy.allow(k)),
+                        h_state.fitness, h_state.rmse, (k > 0 && policy.allow(k)) ? total : 0, now - t_prev);
+                t_prev = now;
+            }
+            if (h_state.done) break;
+            policy.observe(h_state.fitness, h_state.rmse);
         }
     }
     if (idx) KPX_HIP(hipMemcpyAsync(idx, b.idx_cur, (size_t)n_src * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -996,9 +1027,10 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     for (int i = 0; i < count; ++i) KPX_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     const double md2 = max_dist * max_dist;
     int iter[64], queue[64], qn = 0;
+    ScreenPolicy policy[64];
     auto launch = [&](int i, int k) -> int {
-        int r = nn_search_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], bufs[i].state->T, &bufs[i].state->done, k > 0, md2,
-                                 mode, st);
+        int r = nn_search_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], bufs[i].state->T, &bufs[i].state->done, k > 0,
+                                 policy[i].allow(k), md2, mode, st);
         if (r) return r;
         hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, bufs[i].part_acc, (int)cdiv(h_n_src[i], kMergeThreads), h_n_src[i], mode, k,
                            max_iteration, relative_fitness, relative_rmse, bufs[i].state, d_results + 20 * i);
@@ -1016,12 +1048,14 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     while (!rc && head < qn) {
         const int i = queue[head % 64];
         ++head;
-        int32_t h_done = 0;
+        IcpState h_state;
         rc = hipStreamWaitEvent(side, ev[i], 0) == hipSuccess ? KPX_OK : fail(KPX_ERR_HIP, "hipStreamWaitEvent failed");
         if (rc) break;
-        if (hipMemcpyAsync(&h_done, &bufs[i].state->done, sizeof(int32_t), hipMemcpyDeviceToHost, side) != hipSuccess ||
+        if (hipMemcpyAsync(&h_state.fitness, &bufs[i].state->fitness, sizeof(IcpState) - offsetof(IcpState, fitness), hipMemcpyDeviceToHost,
+                           side) != hipSuccess ||
             hipStreamSynchronize(side) != hipSuccess) { rc = fail(KPX_ERR_HIP, "convergence poll failed"); break; }
-        if (h_done || iter[i] >= max_iteration) continue;
+        if (h_state.done || iter[i] >= max_iteration) continue;
+        policy[i].observe(h_state.fitness, h_state.rmse);
         ++iter[i];
         rc = launch(i, iter[i]);
         queue[qn % 64] = i;

@@ -111,6 +111,25 @@ def main():
     ms, nrm = timed(lambda: ops.estimate_normals(vp[:100000].contiguous(), 70.0, 40), reps=3, warm=1)
     report("estimate_normals r=70 nn=40 on 100k (a11)", ms, 24 * 100000, n=100000)
 
+    # ---- global registration (rows a11-a13) on two cluttered views, voxel 35
+    from oracle import oracle as O          # only to build the test views on the host
+    xy2, ex = synth.xy_table(), synth.clutter()
+    views = []
+    for i, seed in ((0, 100), (1, 101)):
+        dep = synth.render_depth(synth.camera_pose(i, 16), seed=seed, xy=xy2, extra=ex)
+        pcl = ops.depth_to_cloud(dep, xy2, None, 1, False, False)[0][0]
+        views.append(ops.voxel_downsample(pcl, 35.0)[0])
+    nrm = [ops.estimate_normals(v, 70.0, 40) for v in views]
+    ms, f0 = timed(lambda: ops.fpfh(views[0], nrm[0], 175.0, 40), reps=3, warm=1)
+    report("compute_fpfh_feature r=175 nn=40 (a11)", ms, n=int(views[0].shape[0]))
+    f1 = ops.fpfh(views[1], nrm[1], 175.0, 40)
+    ms, _ = timed(lambda: ops.feature_nn(f1, f0), reps=3, warm=1)
+    report("feature_nn 33-D (a13 matching)", ms, flops=3.0 * 33 * f1.shape[0] * f0.shape[0], na=int(f1.shape[0]), nb=int(f0.shape[0]))
+    corr = ops.feature_correspondences(f1, f0, True, 3)
+    ms, r = timed(lambda: ops.ransac_corres(views[1], views[0], corr, 52.5, 3, 0.95, 250000, 0.999, 1), reps=2, warm=1)
+    report("ransac feature matching 250k it (a13)", ms, corres=int(len(corr)), iterations=r["iterations"], validations=r["validations"],
+           fitness=round(r["fitness"], 4))
+
     # ---- registration (config 2)
     src, tgt, _ = synth.icp_pair(100_000)
     s, t = torch.as_tensor(src).to(dev), torch.as_tensor(tgt).to(dev)
