@@ -220,7 +220,8 @@ int kpx_icp_batch(int32_t count, const float *const *h_src, const int64_t *h_n_s
 #define KPX_PROF_PLANE_SCORE 2
 #define KPX_PROF_COMPACT 3
 #define KPX_PROF_NN_SCREEN 4
-#define KPX_PROF_KERNELS 5
+#define KPX_PROF_NN_LOCAL 5
+#define KPX_PROF_KERNELS 6
 int kpx_prof_begin(int32_t capacity);
 int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work);
 

@@ -502,9 +502,12 @@ __global__ __launch_bounds__(kMergeThreads) void nn_merge_kernel(const float *__
                 if (v < bv || (v == bv && j < bj)) { bv = v; bj = j; }
             }
         }
-        if (idx_out) idx_out[i] = bj;
+        const bool none = bj < 0 || bj == INT_MAX;        // culled sweep inside a registration: nothing within max_dist
+        if (idx_out) idx_out[i] = none ? -1 : bj;
         if (mode == -2) {
             val_out[i] = bv;
+        } else if (none) {
+            if (d2_out) d2_out[i] = INFINITY;
         } else {
             double s[3];
             xform_row(T, src + 3 * i, s);
@@ -693,9 +696,23 @@ __global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restric
     for (int q = 0; q < 16; ++q) T[q] = U[q];
 }
 
+}  // namespace kpx
+#include "kpx_nnlocal.h"
+namespace kpx {
+
 // ---- host side ----------------------------------------------------------------------------------------------
+// KPX_NN_ENGINE=dense selects the all-pairs sweeps (fp64 + f32 screening) instead of the culled sweep: the two
+// engines return identical results; the dense one is kept as the cross-check and for A/B measurements.
+static bool local_engine()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("KPX_NN_ENGINE"); on = (e && e[0] == 'd') ? 0 : 1; }
+    return on != 0;
+}
+
 struct NnPlan {
     int64_t tiles_pad, seed_tiles_pad, n_src, n_tgt, f_tiles_pad;
+    int32_t l_groups;                                       // culled sweep: groups of 256 sorted target columns
     int32_t tiles_per_split, splits, row_blocks;
     int32_t f_tiles_per_split, f_splits, f_row_blocks;     // float32 screening sweep
 };
@@ -703,6 +720,7 @@ static NnPlan nn_plan(int64_t n, int64_t m)
 {
     NnPlan p;
     p.n_src = n; p.n_tgt = m;
+    p.l_groups = (int32_t)cdiv(m > 0 ? m : 1, 16 * kLGroupTiles);
     int64_t tiles = cdiv(m > 0 ? m : 1, 16);
     int64_t stages = cdiv(tiles, kCT);
     p.row_blocks = (int32_t)cdiv(n > 0 ? n : 1, kRowsPerBlock);
@@ -752,9 +770,21 @@ struct NnBuffers {
     int32_t *part_idx, *init_idx, *idx_cur, *cand_cnt, *cand, *overflow;
     IcpState *state;
     double *T0;
+    // culled sweep
+    double *Bs;
+    int32_t *orig_t, *row_of;
+    float *tile_box, *group_box;
+    unsigned long long *visits;
+    SortScratch sort_t, sort_s;
 };
 static void nn_carve_target(Arena &a, const NnPlan &p, NnBuffers *b)
 {
+    b->Bs = a.get<double>((size_t)p.l_groups * kLGroupTiles * 64);
+    b->orig_t = a.get<int32_t>((size_t)p.l_groups * kLGroupTiles * 16);
+    b->tile_box = a.get<float>((size_t)p.l_groups * kLGroupTiles * 6);
+    b->group_box = a.get<float>((size_t)p.l_groups * 6);
+    b->visits = a.get<unsigned long long>(1);
+    sort_carve(a, p.n_tgt, &b->sort_t);
     b->B = a.get<double>((size_t)p.tiles_pad * 64);
     b->Bseed = a.get<double>((size_t)p.seed_tiles_pad * 64);
     b->Bf = a.get<float>((size_t)p.f_tiles_pad * 64);
@@ -780,6 +810,8 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->cand_cnt = a.get<int32_t>(nn + 1);               // [n] counters + number of overflowed rows
     b->cand = a.get<int32_t>(nn * kCand);
     b->overflow = a.get<int32_t>(nn);                   // list of overflowed rows
+    b->row_of = a.get<int32_t>(nn);
+    sort_carve(a, n, &b->sort_s);
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
 {
@@ -793,8 +825,22 @@ static bool screening_enabled()
     if (on < 0) { const char *e = getenv("KPX_NN_SCREEN"); on = (e && e[0] == '0') ? 0 : 1; }
     return on != 0;
 }
+static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b, hipStream_t st)
+{
+    if (!local_engine()) return KPX_OK;
+    return morton_order(src, p.n_src, b.sort_s, b.row_of, st);
+}
 static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st)
 {
+    if (local_engine()) {
+        int rc = morton_order(tgt, p.n_tgt, b.sort_t, b.orig_t, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nn_local_prep_kernel, dim3((unsigned)p.l_groups), dim3(256), 0, st, tgt, p.n_tgt, b.Bs, b.orig_t, b.tile_box,
+                           b.group_box);
+        KPX_HIP(hipMemsetAsync(b.visits, 0, sizeof(unsigned long long), st));
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
     int64_t work = (p.tiles_pad + p.seed_tiles_pad) * 16;
     hipLaunchKernelGGL(nn_prep_kernel, dim3((unsigned)(cdiv(work, 256) > 2048 ? 2048 : cdiv(work, 256))), dim3(256), 0, st, tgt,
                        p.n_tgt, p.tiles_pad, b.B, p.seed_tiles_pad, b.Bseed);
@@ -818,6 +864,22 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
 {
     const int64_t n = p.n_src;
     const dim3 thr(256);
+    if (local_engine()) {
+        hipLaunchKernelGGL(nn_local_rowprep_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, T, done, b.row_of,
+                           have_prev ? b.idx_cur : (const int32_t *)nullptr, mode >= 0 ? max_d2 : 0.0, b.sort_t.bbox, b.init_val, b.init_idx,
+                           b.A64, b.K64);
+        {
+            ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
+            hipLaunchKernelGGL(nn_local_kernel, dim3((unsigned)cdiv(n, kLRows)), dim3(64), 0, st, n, b.Bs, b.orig_t, b.tile_box, b.group_box,
+                               p.l_groups, b.sort_t.bbox, done, b.A64, b.K64, b.init_val, b.init_idx, b.row_of, b.part_val, b.part_idx,
+                               b.visits);
+        }
+        hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done,
+                           b.part_val, b.part_idx, 1, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr);
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
     const bool screen = have_prev && allow_screen && screening_enabled();
     hipLaunchKernelGGL(nn_rowprep_kernel, dim3((unsigned)cdiv(n, 256)), thr, 0, st, src, n, tgt, T, done,
                        have_prev ? b.idx_cur : (const int32_t *)nullptr, screen ? b.aux : (const NnAux *)nullptr, b.init_val, b.init_idx,
@@ -879,6 +941,8 @@ KPX_EXPORT int kpx_nn_search(const float *src, int64_t n_src, const float *tgt, 
     KPX_ARENA_CHECK(a);
     int rc = nn_prep(tgt, p, b, st);
     if (rc) return rc;
+    rc = nn_prep_source(src, p, b, st);
+    if (rc) return rc;
     rc = nn_search_launch(src, tgt, nullptr, p, b, d_T, nullptr, false, false, 0.0, -1, st);
     if (rc) return rc;
     KPX_HIP(hipMemcpyAsync(idx, b.idx_cur, (size_t)n_src * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -933,6 +997,8 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
     KPX_HIP(hipMemcpyAsync(b.T0, h_init, 16 * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, b.state, b.T0);
     int rc = nn_prep(tgt, p, b, st);
+    if (rc) return rc;
+    rc = nn_prep_source(src, p, b, st);
     if (rc) return rc;
     const double md2 = max_dist * max_dist;
     ScreenPolicy policy;
@@ -1018,6 +1084,8 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     for (int i = 0; i < count; ++i) {
         bufs[i].B = bufs[0].B; bufs[i].Bseed = bufs[0].Bseed; bufs[i].Bf = bufs[0].Bf; bufs[i].aux = bufs[0].aux;
         bufs[i].tbbox = bufs[0].tbbox;
+        bufs[i].Bs = bufs[0].Bs; bufs[i].orig_t = bufs[0].orig_t; bufs[i].tile_box = bufs[0].tile_box; bufs[i].group_box = bufs[0].group_box;
+        bufs[i].visits = bufs[0].visits; bufs[i].sort_t = bufs[0].sort_t;
         nn_carve_source(a, h_n_src[i], plans[i], &bufs[i]);
     }
     KPX_ARENA_CHECK(a);
@@ -1040,6 +1108,8 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     for (int i = 0; i < count && !rc; ++i) {
         KPX_HIP(hipMemcpyAsync(bufs[i].T0, h_init + 16 * i, 16 * sizeof(double), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, bufs[i].state, bufs[i].T0);
+        rc = nn_prep_source(h_src[i], plans[i], bufs[i], st);
+        if (rc) break;
         iter[i] = 0;
         rc = launch(i, 0);
         queue[qn++] = i;

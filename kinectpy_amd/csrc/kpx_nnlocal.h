@@ -1,0 +1,377 @@
+// kpx_nnlocal.h -- the exact nearest-neighbour sweep with spatial tile culling (included by kpx_icp.hip only).
+//
+// Same arithmetic as the dense sweep (contract AC2: v_mfma_f64_16x16x4_f64 = the k-ordered fma chain seeded with
+// K_i; argmin, ties to the lowest ORIGINAL target index), but only the 16-column tiles that can hold a column
+// with D <= the row bound are multiplied:
+//   * the target is sorted once along a 30-bit Morton curve (cubic cells over its bounding box); 16 consecutive
+//     sorted points form a column tile, 16 tiles a group; every tile and every group carries its exact float
+//     bounding box.  orig[col] maps a sorted column back to the caller's index.
+//   * the source rows are sorted the same way once per registration (a rigid transform keeps them compact); a wave
+//     owns 16 consecutive sorted rows.  Its box (from the transformed rows) and its radius R^2 = max_i bound_i - 1
+//     select the groups, then the tiles, with gap^2(row box, tile box) <= R^2 (+ a margin 2^-38 (K + |t|^2) that
+//     covers the rounding of the expanded metric; the skipped columns are STRICTLY farther than every row's bound, so
+//     neither the minimum nor a tie can hide there).  Surviving tiles go to a list in LDS and are multiplied four per
+//     trip behind the same 32-bit high-word prefilter as the dense sweep.
+//   * bounds: the previous partner (ICP iterations >= 1), clamped to max_correspondence_distance^2 inside a
+//     registration (rows with nothing inside report "no partner": they are not correspondences by definition,
+//     pipelines/registration/Registration.cpp semantics [O3D]); without either, the far-corner distance to the
+//     nearest group box is a valid radius for all 16 rows.
+// The result is bit-identical to the dense sweep and to the oracle wherever a partner exists within the bound.
+#pragma once
+#include <hipcub/hipcub.hpp>
+
+namespace kpx {
+
+constexpr int kLGroupTiles = 16;                 // tiles per group (256 sorted columns)
+constexpr int kLRows = 16;                       // source rows per wave
+constexpr int kLList = 512;                      // tile list capacity (LDS, per wave)
+constexpr float kBoxBig = 3.0e38f;
+
+// butterfly reductions: the result is valid in EVERY lane (kpx_common.h's wave_min / wave_max leave it in lane 0)
+__device__ __forceinline__ double wave_all_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_all_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t morton_spread10(uint32_t v)
+{
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void morton_key_kernel(const float *__restrict__ pts, int64_t n, const double *__restrict__ bbox,
+                                                         uint32_t *__restrict__ keys, int32_t *__restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double ext = fmax(bbox[3] - bbox[0], fmax(bbox[4] - bbox[1], bbox[5] - bbox[2]));
+    const double scale = ext > 0.0 ? 1023.0 / ext : 0.0;
+    uint32_t q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double v = ((double)pts[3 * i + a] - bbox[a]) * scale;
+        q[a] = v >= 0.0 ? (uint32_t)(v < 1023.0 ? v : 1023.0) : 0u;          // NaN -> cell 0
+    }
+    keys[i] = morton_spread10(q[0]) | (morton_spread10(q[1]) << 1) | (morton_spread10(q[2]) << 2);
+    vals[i] = (int32_t)i;
+}
+
+// Sorted fp64 B operand (element (k, j) of tile t at Bs[t*64 + k*16 + j]), original index of every sorted column
+// (INT_MAX in the padding), tile and group boxes (lo xyz, hi xyz as floats; empty = (+big, -big)).  One block = one group.
+__global__ __launch_bounds__(256) void nn_local_prep_kernel(const float *__restrict__ tgt, int64_t m, double *__restrict__ Bs,
+                                                            int32_t *__restrict__ orig, float *__restrict__ tile_box,
+                                                            float *__restrict__ group_box)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = kSentinel;
+    float lo[3] = { kBoxBig, kBoxBig, kBoxBig }, hi[3] = { -kBoxBig, -kBoxBig, -kBoxBig };
+    if (j < m) {
+        const int64_t o = orig[j];                  // written by the sort
+        const float fx = tgt[3 * o], fy = tgt[3 * o + 1], fz = tgt[3 * o + 2];
+        const double tx = fx, ty = fy, tz = fz;
+        b0 = -2.0 * tx; b1 = -2.0 * ty; b2 = -2.0 * tz;
+        b3 = fma(tx, tx, fma(ty, ty, tz * tz));
+        lo[0] = hi[0] = fx; lo[1] = hi[1] = fy; lo[2] = hi[2] = fz;
+    } else {
+        orig[j] = INT_MAX;
+    }
+    double *o = Bs + (j >> 4) * 64 + (j & 15);
+    o[0] = b0; o[16] = b1; o[32] = b2; o[48] = b3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int msk = 1; msk < 16; msk <<= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], msk, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], msk, 64));
+        }
+    __shared__ float sb[16][6];
+    if ((threadIdx.x & 15) == 0) {
+        float *tb = tile_box + (j >> 4) * 6;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { tb[a] = lo[a]; tb[3 + a] = hi[a]; sb[threadIdx.x >> 4][a] = lo[a]; sb[threadIdx.x >> 4][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sb[0][threadIdx.x];
+        for (int t = 1; t < 16; ++t) v = threadIdx.x < 3 ? fminf(v, sb[t][threadIdx.x]) : fmaxf(v, sb[t][threadIdx.x]);
+        group_box[(int64_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// Per-row operands in sorted row order.  prev (indexed by ORIGINAL row) = partners of the last search or NULL;
+// max_d2 > 0 clamps the bound to the correspondence distance.
+__global__ __launch_bounds__(256) void nn_local_rowprep_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+                                                               const double *__restrict__ T, const int32_t *__restrict__ done,
+                                                               const int32_t *__restrict__ row_of, const int32_t *__restrict__ prev,
+                                                               double max_d2, const double *__restrict__ tbbox,
+                                                               double *__restrict__ init_val, int32_t *__restrict__ init_idx,
+                                                               double *__restrict__ A64, double *__restrict__ K64)
+{
+    if (done && *done) return;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t i = row_of[r];
+    double s[3];
+    xform_row(T, src + 3 * i, s);
+    const double seed = row_seed(s);
+    reinterpret_cast<double2 *>(A64)[2 * r] = make_double2(s[0], s[1]);
+    reinterpret_cast<double2 *>(A64)[2 * r + 1] = make_double2(s[2], 1.0);
+    K64[r] = seed;
+    double bv = INFINITY;
+    int32_t bj = INT_MAX;
+    if (prev) {
+        const int32_t j = prev[i];
+        if (j >= 0 && j != INT_MAX) {
+            const float *tp = tgt + 3 * (int64_t)j;
+            const double tx = tp[0], ty = tp[1], tz = tp[2];
+            const double t2 = fma(tx, tx, fma(ty, ty, tz * tz));
+            double d = fma(s[0], -2.0 * tx, seed);
+            d = fma(s[1], -2.0 * ty, d);
+            d = fma(s[2], -2.0 * tz, d);
+            bv = fma(1.0, t2, d);
+            bj = j;
+        }
+    }
+    if (max_d2 > 0.0) {
+        double t2max = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t2max += fmax(tbbox[a] * tbbox[a], tbbox[3 + a] * tbbox[3 + a]);
+        const double clamp = (max_d2 + 1.0) * (1.0 + 9.31322574615478515625e-10) + ldexp(seed + t2max + 1.0, -38);
+        if (!(bv <= clamp)) { bv = clamp; bj = INT_MAX; }
+    }
+    init_val[r] = bv;
+    init_idx[r] = bj;
+}
+
+__device__ __forceinline__ double box_gap2(const double slo[3], const double shi[3], const float *__restrict__ bx)
+{
+    double g2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double g = fmax(0.0, fmax((double)bx[a] - shi[a], slo[a] - (double)bx[3 + a]));
+        g2 = fma(g, g, g2);
+    }
+    return g2;
+}
+__device__ __forceinline__ double box_far2(const double slo[3], const double shi[3], const float *__restrict__ bx)
+{
+    double f2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double f = fmax(fabs((double)bx[3 + a] - slo[a]), fabs(shi[a] - (double)bx[a]));
+        f2 = fma(f, f, f2);
+    }
+    return f2;
+}
+
+// One wave (= one block) per 16 sorted rows.  out_val / out_idx are indexed by ORIGINAL row.
+__global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
+                                                      const float *__restrict__ tile_box, const float *__restrict__ group_box,
+                                                      int32_t n_groups, const double *__restrict__ tbbox, const int32_t *__restrict__ done,
+                                                      const double *__restrict__ A64, const double *__restrict__ K64,
+                                                      const double *__restrict__ init_val, const int32_t *__restrict__ init_idx,
+                                                      const int32_t *__restrict__ row_of, double *__restrict__ out_val,
+                                                      int32_t *__restrict__ out_idx, unsigned long long *__restrict__ tile_visits)
+{
+    if (done && *done) return;
+    __shared__ int32_t list[kLList];
+    const int lane = threadIdx.x;
+    const int64_t row_base = (int64_t)blockIdx.x * kLRows;
+    const int64_t last = n - 1;
+
+    // A operand: component k = lane>>4 of row lane&15 (rows past the end repeat the last row: same box, never written)
+    const int64_t arow = row_base + (lane & 15) < last ? row_base + (lane & 15) : last;
+    const double a = A64[arow * 4 + (lane >> 4)];
+    double slo[3], shi[3];
+    {
+        double mn = a, mx = a;
+#pragma unroll
+        for (int msk = 1; msk < 16; msk <<= 1) {
+            mn = fmin(mn, __shfl_xor(mn, msk, 64));
+            mx = fmax(mx, __shfl_xor(mx, msk, 64));
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { slo[k] = __shfl(mn, 16 * k, 64); shi[k] = __shfl(mx, 16 * k, 64); }
+    }
+    // C operand (row seeds), running best and its ORIGINAL column: D layout row = (lane>>4) + 4*reg
+    d4 seed;
+    double best[4];
+    int32_t bcol[4];
+    double kmax = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row_base + (lane >> 4) + 4 * r < last ? row_base + (lane >> 4) + 4 * r : last;
+        seed[r] = K64[row];
+        best[r] = init_val[row];
+        bcol[r] = init_idx[row];
+        kmax = fmax(kmax, seed[r]);
+    }
+    kmax = wave_all_max(kmax);
+    double t2max = 0.0;
+#pragma unroll
+    for (int a3 = 0; a3 < 3; ++a3) t2max += fmax(tbbox[a3] * tbbox[a3], tbbox[3 + a3] * tbbox[3 + a3]);
+    const double eps = ldexp(kmax + t2max + 1.0, -38);
+    auto radius2 = [&]() {
+        const double mx = wave_all_max(fmax(fmax(best[0], best[1]), fmax(best[2], best[3])));
+        return (mx - 1.0) * (1.0 + 9.31322574615478515625e-10) + eps;          // +inf stays +inf
+    };
+    double R2 = radius2();
+    if (!(R2 < 1e290)) {
+        // no finite bound for some row: every group holds a real point, so the far-corner distance to the nearest
+        // group box bounds the nearest-neighbour distance of all 16 rows
+        double u = INFINITY;
+        for (int g0 = 0; g0 < n_groups; g0 += 64) {
+            const int g = g0 + lane;
+            if (g < n_groups) u = fmin(u, box_far2(slo, shi, group_box + (int64_t)g * 6));
+        }
+        u = wave_all_min(u);
+        R2 = fmin(R2, u * (1.0 + 9.31322574615478515625e-10) + eps);
+    }
+
+    const double bpad = (lane >> 4) == 3 ? kSentinel : 0.0;
+    int nlist = 0;
+    unsigned long long visited = 0;
+
+    auto process = [&]() {
+        __syncthreads();                                   // single wave: orders the LDS list writes before the reads
+        bool updated = false;
+        double b[4];
+        int32_t t[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            t[h] = h < nlist ? list[h] : -1;
+            b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
+        }
+        for (int q = 0; q < nlist; q += 4) {
+            const d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[0], seed, 0, 0, 0);
+            const d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[1], seed, 0, 0, 0);
+            const d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[2], seed, 0, 0, 0);
+            const d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[3], seed, 0, 0, 0);
+            int32_t tc[4] = { t[0], t[1], t[2], t[3] };
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {                  // operands of the next trip
+                t[h] = q + 4 + h < nlist ? list[q + 4 + h] : -1;
+                b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
+            }
+            bool pass = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned hb = hi32(best[r]);
+                pass |= (bool)((int)(hi32(c0[r]) <= hb) | (int)(hi32(c1[r]) <= hb) | (int)(hi32(c2[r]) <= hb) | (int)(hi32(c3[r]) <= hb));
+            }
+            if (__builtin_amdgcn_ballot_w64(pass) != 0) {
+                updated = true;
+                int32_t oc[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) oc[h] = tc[h] >= 0 ? orig[(int64_t)tc[h] * 16 + (lane & 15)] : INT_MAX;
+#define KPX_NNL_EXACT(ACC, COL)                                                                     \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
+                    const bool tk = (int)(ACC[r] < best[r]) | ((int)(ACC[r] == best[r]) & (int)((COL) < bcol[r])); \
+                    best[r] = tk ? ACC[r] : best[r];                                               \
+                    bcol[r] = tk ? (COL) : bcol[r];                                                \
+                }
+                KPX_NNL_EXACT(c0, oc[0]) KPX_NNL_EXACT(c1, oc[1]) KPX_NNL_EXACT(c2, oc[2]) KPX_NNL_EXACT(c3, oc[3])
+#undef KPX_NNL_EXACT
+            }
+        }
+        visited += (unsigned long long)nlist;
+        nlist = 0;
+        if (updated) R2 = fmin(R2, radius2());
+        __syncthreads();
+    };
+
+    for (int g0 = 0; g0 < n_groups; g0 += 64) {
+        const int g = g0 + lane;
+        const bool gp = g < n_groups && box_gap2(slo, shi, group_box + (int64_t)g * 6) <= R2;
+        unsigned long long gmask = __builtin_amdgcn_ballot_w64(gp);
+        while (gmask) {
+            // up to four surviving groups per step: lane>>4 picks the group, lane&15 the tile inside it
+            int gsel = -1;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if (gmask) {
+                    const int bit = __builtin_ctzll(gmask);
+                    gmask &= gmask - 1;
+                    if ((lane >> 4) == h) gsel = g0 + bit;
+                }
+            }
+            bool tp = false;
+            int32_t tile = 0;
+            if (gsel >= 0) {
+                tile = gsel * kLGroupTiles + (lane & 15);
+                tp = box_gap2(slo, shi, tile_box + (int64_t)tile * 6) <= R2;
+            }
+            const unsigned long long tmask = __builtin_amdgcn_ballot_w64(tp);
+            if (tp) list[nlist + __builtin_popcountll(tmask & ((1ull << lane) - 1ull))] = tile;
+            nlist += __builtin_popcountll(tmask);
+            if (nlist > kLList - 64) process();
+        }
+    }
+    if (nlist) process();
+
+    // reduce over the 16 lanes that hold the same rows (lexicographic (value, original column) minimum)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double v = best[r];
+        int32_t c = bcol[r];
+#pragma unroll
+        for (int msk = 1; msk < 16; msk <<= 1) {
+            const double ov = __shfl_xor(v, msk, 64);
+            const int32_t oc = __shfl_xor(c, msk, 64);
+            const bool take = ov < v || (ov == v && oc < c);
+            v = take ? ov : v;
+            c = take ? oc : c;
+        }
+        const int64_t row = row_base + (lane >> 4) + 4 * r;
+        if ((lane & 15) == 0 && row < n) {
+            const int64_t i = row_of[row];
+            out_val[i] = v;
+            out_idx[i] = c;
+        }
+    }
+    if (tile_visits && lane == 0) atomicAdd(tile_visits, visited);
+}
+
+// Morton order of a cloud: d_perm[r] = original index of the r-th point along the curve.
+struct SortScratch {
+    uint32_t *keys_in, *keys_out;
+    int32_t *vals_in;
+    void *tmp;
+    size_t tmp_bytes;
+    double *bbox_part, *bbox;
+};
+static void sort_carve(Arena &a, int64_t n, SortScratch *s)
+{
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    s->keys_in = a.get<uint32_t>(nn);
+    s->keys_out = a.get<uint32_t>(nn);
+    s->vals_in = a.get<int32_t>(nn);
+    s->tmp_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->tmp_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_in, (int)nn, 0, 30,
+                                             (hipStream_t) nullptr);
+    s->tmp = a.get<char>(s->tmp_bytes);
+    s->bbox_part = a.get<double>((size_t)kBboxBlocks * 6);
+    s->bbox = a.get<double>(8);
+}
+static int morton_order(const float *pts, int64_t n, const SortScratch &s, int32_t *d_perm, hipStream_t st)
+{
+    int rc = bbox_f32(pts, n, s.bbox, s.bbox_part, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, pts, n, s.bbox, s.keys_in, s.vals_in);
+    size_t bytes = s.tmp_bytes;
+    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.tmp, bytes, s.keys_in, s.keys_out, s.vals_in, d_perm, (int)n, 0, 30, st));
+    return KPX_OK;
+}
+
+}  // namespace kpx

@@ -376,7 +376,7 @@ def icp_batch(srcs, tgt, max_dist, inits, mode="p2p", tgt_normals=None, max_iter
 
 
 # ---- measurement hooks --------------------------------------------------------------------------------
-PROF_KERNELS = ("nn_mfma", "sor_knn", "plane_score", "compact", "nn_screen")
+PROF_KERNELS = ("nn_mfma", "sor_knn", "plane_score", "compact", "nn_screen", "nn_local")
 
 
 def prof_begin(capacity=65536):
