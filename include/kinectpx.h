@@ -214,7 +214,8 @@ int kpx_icp_batch(int32_t count, const float *const *h_src, const int64_t *h_n_s
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it
  * (capacity = max launches recorded); every launch of a tagged kernel is bracketed by an event pair;
  * kpx_prof_end synchronises, sums per kernel id and disarms.  h_ms / h_launches / h_work: arrays of
- * KPX_PROF_KERNELS entries (work = flops for the two MFMA kernels, algorithmic bytes for the others). */
+ * KPX_PROF_KERNELS entries (work = flops for the MFMA kernels -- for NN_LOCAL the flops of the tiles actually
+ * multiplied, counted on the device -- and algorithmic bytes for the others). */
 #define KPX_PROF_NN_MFMA 0
 #define KPX_PROF_SOR_KNN 1
 #define KPX_PROF_PLANE_SCORE 2

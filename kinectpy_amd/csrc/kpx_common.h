@@ -53,6 +53,7 @@ struct Arena {
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- HIP-event profiler (armed by kpx_prof_begin; a no-op otherwise) ----------------------------
+bool prof_armed();
 struct ProfScope {
     int slot;
     hipStream_t st;

@@ -3,7 +3,7 @@
 // utils/io.py:15-43, preprocessing/data.py:165-178.  All HBM-streaming kernels.
 #include <stdarg.h>
 
-#include "kpx_common.h"
+#include "kpx_internal.h"
 
 namespace kpx {
 
@@ -26,6 +26,7 @@ static struct {
     double *work = nullptr;
 } g_prof;
 
+bool prof_armed() { return g_prof.on; }
 ProfScope::ProfScope(int kernel_id, double w, hipStream_t stream) : slot(-1), st(stream)
 {
     if (!g_prof.on || g_prof.used >= g_prof.cap) return;
@@ -266,6 +267,7 @@ KPX_EXPORT int kpx_prof_begin(int32_t capacity)
     }
     g_prof.used = 0;
     g_prof.on = true;
+    (void)nn_local_take_visits();
     return KPX_OK;
 }
 KPX_EXPORT int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work)
@@ -281,6 +283,7 @@ KPX_EXPORT int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work)
         h_ms[k] += ms; h_launches[k] += 1; h_work[k] += g_prof.work[i];
     }
     g_prof.used = 0;
+    h_work[KPX_PROF_NN_LOCAL] = 2048.0 * nn_local_take_visits();     // flops actually issued: 16 x 16 x 4 MAC per tile
     return KPX_OK;
 }
 KPX_EXPORT int kpx_version(void) { return KPX_VERSION; }

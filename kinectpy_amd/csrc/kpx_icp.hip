@@ -703,6 +703,26 @@ namespace kpx {
 // ---- host side ----------------------------------------------------------------------------------------------
 // KPX_NN_ENGINE=dense selects the all-pairs sweeps (fp64 + f32 screening) instead of the culled sweep: the two
 // engines return identical results; the dense one is kept as the cross-check and for A/B measurements.
+// tiles multiplied by nn_local_kernel while the profiler is armed (one atomic per wave, spread over kVisitSlots
+// addresses: same-address atomics from thousands of waves serialise in L2); read by kpx_prof_end
+__device__ unsigned long long g_nn_visits[kVisitSlots];
+static unsigned long long *nn_visits_ptr()
+{
+    static unsigned long long *p = nullptr;
+    if (!p && hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_nn_visits)) != hipSuccess) p = nullptr;
+    return p;
+}
+double nn_local_take_visits()
+{
+    static unsigned long long v[kVisitSlots], zero[kVisitSlots];
+    unsigned long long *p = nn_visits_ptr();
+    if (!p || hipMemcpy(v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0.0;
+    (void)hipMemcpy(p, zero, sizeof(zero), hipMemcpyHostToDevice);
+    double sum = 0.0;
+    for (int i = 0; i < kVisitSlots; ++i) sum += (double)v[i];
+    return sum;
+}
+
 static bool local_engine()
 {
     static int on = -1;
@@ -774,7 +794,6 @@ struct NnBuffers {
     double *Bs;
     int32_t *orig_t, *row_of;
     float *tile_box, *group_box;
-    unsigned long long *visits;
     SortScratch sort_t, sort_s;
 };
 static void nn_carve_target(Arena &a, const NnPlan &p, NnBuffers *b)
@@ -783,7 +802,6 @@ static void nn_carve_target(Arena &a, const NnPlan &p, NnBuffers *b)
     b->orig_t = a.get<int32_t>((size_t)p.l_groups * kLGroupTiles * 16);
     b->tile_box = a.get<float>((size_t)p.l_groups * kLGroupTiles * 6);
     b->group_box = a.get<float>((size_t)p.l_groups * 6);
-    b->visits = a.get<unsigned long long>(1);
     sort_carve(a, p.n_tgt, &b->sort_t);
     b->B = a.get<double>((size_t)p.tiles_pad * 64);
     b->Bseed = a.get<double>((size_t)p.seed_tiles_pad * 64);
@@ -837,7 +855,6 @@ static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStr
         if (rc) return rc;
         hipLaunchKernelGGL(nn_local_prep_kernel, dim3((unsigned)p.l_groups), dim3(256), 0, st, tgt, p.n_tgt, b.Bs, b.orig_t, b.tile_box,
                            b.group_box);
-        KPX_HIP(hipMemsetAsync(b.visits, 0, sizeof(unsigned long long), st));
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
@@ -872,7 +889,7 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
             ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
             hipLaunchKernelGGL(nn_local_kernel, dim3((unsigned)cdiv(n, kLRows)), dim3(64), 0, st, n, b.Bs, b.orig_t, b.tile_box, b.group_box,
                                p.l_groups, b.sort_t.bbox, done, b.A64, b.K64, b.init_val, b.init_idx, b.row_of, b.part_val, b.part_idx,
-                               b.visits);
+                               prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr);
         }
         hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done,
                            b.part_val, b.part_idx, 1, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc,
@@ -1085,7 +1102,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         bufs[i].B = bufs[0].B; bufs[i].Bseed = bufs[0].Bseed; bufs[i].Bf = bufs[0].Bf; bufs[i].aux = bufs[0].aux;
         bufs[i].tbbox = bufs[0].tbbox;
         bufs[i].Bs = bufs[0].Bs; bufs[i].orig_t = bufs[0].orig_t; bufs[i].tile_box = bufs[0].tile_box; bufs[i].group_box = bufs[0].group_box;
-        bufs[i].visits = bufs[0].visits; bufs[i].sort_t = bufs[0].sort_t;
+        bufs[i].sort_t = bufs[0].sort_t;
         nn_carve_source(a, h_n_src[i], plans[i], &bufs[i]);
     }
     KPX_ARENA_CHECK(a);

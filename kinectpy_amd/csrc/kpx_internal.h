@@ -29,4 +29,8 @@ struct Grid {
 // target_per_cell: desired mean occupancy of non-empty cells.
 int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Grid *g, hipStream_t st);
 
+// Column tiles (16 rows x 16 columns, 2048 flops each) the culled nearest-neighbour sweep has multiplied since the
+// last call; resets the device counter (kpx_icp.hip).
+double nn_local_take_visits();
+
 }  // namespace kpx

@@ -26,6 +26,7 @@ constexpr int kLGroupTiles = 16;                 // tiles per group (256 sorted 
 constexpr int kLRows = 16;                       // source rows per wave
 constexpr int kLList = 512;                      // tile list capacity (LDS, per wave)
 constexpr float kBoxBig = 3.0e38f;
+constexpr int kVisitSlots = 1024;                // profiling counter slots
 
 // butterfly reductions: the result is valid in EVERY lane (kpx_common.h's wave_min / wave_max leave it in lane 0)
 __device__ __forceinline__ double wave_all_max(double v)
@@ -164,18 +165,33 @@ __device__ __forceinline__ double box_gap2(const double slo[3], const double shi
     }
     return g2;
 }
-__device__ __forceinline__ double box_far2(const double slo[3], const double shi[3], const float *__restrict__ bx)
+// squared distance from a point to a box (0 inside) and to the box's farthest corner
+__device__ __forceinline__ double pt_gap2(double x, double y, double z, const double lo[3], const double hi[3])
 {
-    double f2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double f = fmax(fabs((double)bx[3 + a] - slo[a]), fabs(shi[a] - (double)bx[a]));
-        f2 = fma(f, f, f2);
-    }
-    return f2;
+    const double gx = fmax(0.0, fmax(lo[0] - x, x - hi[0]));
+    const double gy = fmax(0.0, fmax(lo[1] - y, y - hi[1]));
+    const double gz = fmax(0.0, fmax(lo[2] - z, z - hi[2]));
+    return fma(gz, gz, fma(gy, gy, gx * gx));
 }
+__device__ __forceinline__ double pt_far2(double x, double y, double z, const double lo[3], const double hi[3])
+{
+    const double fx = fmax(fabs(hi[0] - x), fabs(x - lo[0]));
+    const double fy = fmax(fabs(hi[1] - y), fabs(y - lo[1]));
+    const double fz = fmax(fabs(hi[2] - z), fabs(z - lo[2]));
+    return fma(fz, fz, fma(fy, fy, fx * fx));
+}
+__device__ __forceinline__ void load_box(const float *__restrict__ bx, double lo[3], double hi[3])
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = (double)bx[a]; hi[a] = (double)bx[3 + a]; }
+}
+// OR of the four 16-lane fields of a ballot
+__device__ __forceinline__ unsigned fold16(unsigned long long m) { return (unsigned)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xFFFFull); }
 
 // One wave (= one block) per 16 sorted rows.  out_val / out_idx are indexed by ORIGINAL row.
+// Lane (q = lane>>4, j = lane&15) owns rows q, q+4, q+8, q+12 of the wave (the MFMA D layout) and, in the culling
+// tests, box j of the 16 groups / tiles under test: a box survives when ANY of the 16 rows has
+// gap^2(row point, box) <= that row's own bound.  (A cheap wave-box test rejects most groups 64 at a time first.)
 __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
                                                       const float *__restrict__ tile_box, const float *__restrict__ group_box,
                                                       int32_t n_groups, const double *__restrict__ tbbox, const int32_t *__restrict__ done,
@@ -186,13 +202,14 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
 {
     if (done && *done) return;
     __shared__ int32_t list[kLList];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
     const int64_t row_base = (int64_t)blockIdx.x * kLRows;
     const int64_t last = n - 1;
+    constexpr double kRel = 1.0 + 9.31322574615478515625e-10;      // 1 + 2^-30
 
-    // A operand: component k = lane>>4 of row lane&15 (rows past the end repeat the last row: same box, never written)
-    const int64_t arow = row_base + (lane & 15) < last ? row_base + (lane & 15) : last;
-    const double a = A64[arow * 4 + (lane >> 4)];
+    // A operand: component k = q of row j (rows past the end repeat the last row: same points, never written)
+    const int64_t arow = row_base + j < last ? row_base + j : last;
+    const double a = A64[arow * 4 + q];
     double slo[3], shi[3];
     {
         double mn = a, mx = a;
@@ -204,14 +221,16 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
 #pragma unroll
         for (int k = 0; k < 3; ++k) { slo[k] = __shfl(mn, 16 * k, 64); shi[k] = __shfl(mx, 16 * k, 64); }
     }
-    // C operand (row seeds), running best and its ORIGINAL column: D layout row = (lane>>4) + 4*reg
+    // rows of this lane in the D layout: seeds (C operand), coordinates, running best and its ORIGINAL column
     d4 seed;
-    double best[4];
+    double best[4], px[4], py[4], pz[4], rb[4];
     int32_t bcol[4];
     double kmax = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int64_t row = row_base + (lane >> 4) + 4 * r < last ? row_base + (lane >> 4) + 4 * r : last;
+        const int64_t row = row_base + q + 4 * r < last ? row_base + q + 4 * r : last;
+        const double2 xy = reinterpret_cast<const double2 *>(A64)[2 * row];
+        px[r] = xy.x; py[r] = xy.y; pz[r] = A64[4 * row + 2];
         seed[r] = K64[row];
         best[r] = init_val[row];
         bcol[r] = init_idx[row];
@@ -222,24 +241,33 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
 #pragma unroll
     for (int a3 = 0; a3 < 3; ++a3) t2max += fmax(tbbox[a3] * tbbox[a3], tbbox[3 + a3] * tbbox[3 + a3]);
     const double eps = ldexp(kmax + t2max + 1.0, -38);
-    auto radius2 = [&]() {
-        const double mx = wave_all_max(fmax(fmax(best[0], best[1]), fmax(best[2], best[3])));
-        return (mx - 1.0) * (1.0 + 9.31322574615478515625e-10) + eps;          // +inf stays +inf
-    };
-    double R2 = radius2();
+    // rb[r]: the row's bound on d^2 (same value in the 16 lanes of a quad); R2: the largest of them
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rb[r] = (best[r] - 1.0) * kRel + eps;             // +inf stays +inf
+    double R2 = wave_all_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     if (!(R2 < 1e290)) {
-        // no finite bound for some row: every group holds a real point, so the far-corner distance to the nearest
-        // group box bounds the nearest-neighbour distance of all 16 rows
-        double u = INFINITY;
-        for (int g0 = 0; g0 < n_groups; g0 += 64) {
-            const int g = g0 + lane;
-            if (g < n_groups) u = fmin(u, box_far2(slo, shi, group_box + (int64_t)g * 6));
+        // some row has no finite bound: every group holds a real point, so the distance to the farthest corner of
+        // the nearest group box bounds that row's nearest-neighbour distance
+        double u[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
+        for (int g0 = 0; g0 < n_groups; g0 += 16) {
+            const int g = g0 + j;
+            if (g < n_groups) {
+                double lo[3], hi[3];
+                load_box(group_box + (int64_t)g * 6, lo, hi);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[r] = fmin(u[r], pt_far2(px[r], py[r], pz[r], lo, hi));
+            }
         }
-        u = wave_all_min(u);
-        R2 = fmin(R2, u * (1.0 + 9.31322574615478515625e-10) + eps);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int msk = 1; msk < 16; msk <<= 1) u[r] = fmin(u[r], __shfl_xor(u[r], msk, 64));
+            rb[r] = fmin(rb[r], u[r] * kRel + eps);
+        }
+        R2 = wave_all_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     }
 
-    const double bpad = (lane >> 4) == 3 ? kSentinel : 0.0;
+    const double bpad = q == 3 ? kSentinel : 0.0;
     int nlist = 0;
     unsigned long long visited = 0;
 
@@ -253,15 +281,15 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
             t[h] = h < nlist ? list[h] : -1;
             b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
         }
-        for (int q = 0; q < nlist; q += 4) {
+        for (int e = 0; e < nlist; e += 4) {
             const d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[0], seed, 0, 0, 0);
             const d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[1], seed, 0, 0, 0);
             const d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[2], seed, 0, 0, 0);
             const d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[3], seed, 0, 0, 0);
-            int32_t tc[4] = { t[0], t[1], t[2], t[3] };
+            const int32_t tc[4] = { t[0], t[1], t[2], t[3] };
 #pragma unroll
             for (int h = 0; h < 4; ++h) {                  // operands of the next trip
-                t[h] = q + 4 + h < nlist ? list[q + 4 + h] : -1;
+                t[h] = e + 4 + h < nlist ? list[e + 4 + h] : -1;
                 b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
             }
             bool pass = false;
@@ -274,7 +302,7 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
                 updated = true;
                 int32_t oc[4];
 #pragma unroll
-                for (int h = 0; h < 4; ++h) oc[h] = tc[h] >= 0 ? orig[(int64_t)tc[h] * 16 + (lane & 15)] : INT_MAX;
+                for (int h = 0; h < 4; ++h) oc[h] = tc[h] >= 0 ? orig[(int64_t)tc[h] * 16 + j] : INT_MAX;
 #define KPX_NNL_EXACT(ACC, COL)                                                                     \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
                     const bool tk = (int)(ACC[r] < best[r]) | ((int)(ACC[r] == best[r]) & (int)((COL) < bcol[r])); \
@@ -287,35 +315,49 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
         }
         visited += (unsigned long long)nlist;
         nlist = 0;
-        if (updated) R2 = fmin(R2, radius2());
+        if (updated) {
+            // tighten the row bounds with the best value any of the row's 16 lanes holds
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = best[r];
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) v = fmin(v, __shfl_xor(v, msk, 64));
+                rb[r] = fmin(rb[r], (v - 1.0) * kRel + eps);
+            }
+            R2 = wave_all_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
+        }
         __syncthreads();
+    };
+    auto any_row_within = [&](const float *__restrict__ bx) {
+        double lo[3], hi[3];
+        load_box(bx, lo, hi);
+        bool t = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t |= pt_gap2(px[r], py[r], pz[r], lo, hi) <= rb[r];
+        return t;
     };
 
     for (int g0 = 0; g0 < n_groups; g0 += 64) {
         const int g = g0 + lane;
         const bool gp = g < n_groups && box_gap2(slo, shi, group_box + (int64_t)g * 6) <= R2;
-        unsigned long long gmask = __builtin_amdgcn_ballot_w64(gp);
-        while (gmask) {
-            // up to four surviving groups per step: lane>>4 picks the group, lane&15 the tile inside it
-            int gsel = -1;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                if (gmask) {
-                    const int bit = __builtin_ctzll(gmask);
-                    gmask &= gmask - 1;
-                    if ((lane >> 4) == h) gsel = g0 + bit;
-                }
+        const unsigned long long gmask = __builtin_amdgcn_ballot_w64(gp);
+        if (!gmask) continue;
+        for (int c = 0; c < 4; ++c) {
+            const unsigned chunk = (unsigned)(gmask >> (16 * c)) & 0xFFFFu;
+            if (!chunk) continue;
+            // per-row test of the 16 groups of this chunk (lane: rows of quad q against group j)
+            const int gj = g0 + 16 * c + j;
+            const bool gt = ((chunk >> j) & 1u) && any_row_within(group_box + (int64_t)gj * 6);
+            unsigned gm16 = fold16(__builtin_amdgcn_ballot_w64(gt));
+            while (gm16) {
+                const int grp = g0 + 16 * c + __builtin_ctz(gm16);
+                gm16 &= gm16 - 1;
+                const int32_t tile = grp * kLGroupTiles + j;
+                const unsigned tm16 = fold16(__builtin_amdgcn_ballot_w64(any_row_within(tile_box + (int64_t)tile * 6)));
+                if (q == 0 && ((tm16 >> j) & 1u)) list[nlist + __builtin_popcount(tm16 & ((1u << j) - 1u))] = tile;
+                nlist += __builtin_popcount(tm16);
+                if (nlist > kLList - 16) process();
             }
-            bool tp = false;
-            int32_t tile = 0;
-            if (gsel >= 0) {
-                tile = gsel * kLGroupTiles + (lane & 15);
-                tp = box_gap2(slo, shi, tile_box + (int64_t)tile * 6) <= R2;
-            }
-            const unsigned long long tmask = __builtin_amdgcn_ballot_w64(tp);
-            if (tp) list[nlist + __builtin_popcountll(tmask & ((1ull << lane) - 1ull))] = tile;
-            nlist += __builtin_popcountll(tmask);
-            if (nlist > kLList - 64) process();
         }
     }
     if (nlist) process();
@@ -333,14 +375,14 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
             v = take ? ov : v;
             c = take ? oc : c;
         }
-        const int64_t row = row_base + (lane >> 4) + 4 * r;
-        if ((lane & 15) == 0 && row < n) {
+        const int64_t row = row_base + q + 4 * r;
+        if (j == 0 && row < n) {
             const int64_t i = row_of[row];
             out_val[i] = v;
             out_idx[i] = c;
         }
     }
-    if (tile_visits && lane == 0) atomicAdd(tile_visits, visited);
+    if (tile_visits && lane == 0) atomicAdd(tile_visits + (blockIdx.x & (kVisitSlots - 1)), visited);
 }
 
 // Morton order of a cloud: d_perm[r] = original index of the r-th point along the curve.

@@ -131,26 +131,32 @@ def main():
            fitness=round(r["fitness"], 4))
 
     # ---- registration (config 2)
+    def sweep(prof):
+        """the sweep kernel that ran (culled by default, dense with KPX_NN_ENGINE=dense): avg ms, TFLOP/s issued"""
+        for name in ("nn_local", "nn_mfma", "nn_screen"):
+            ms_k, cnt, work = prof[name]
+            if cnt:
+                return {"sweep_kernel": name, "sweep_kernel_ms": round(ms_k / cnt, 4), "sweep_launches": cnt,
+                        "sweep_TFLOPs_issued": round(work / ms_k / 1e9, 2), "sweep_flops_per_launch": int(work / cnt)}
+        return {}
+
     src, tgt, _ = synth.icp_pair(100_000)
     s, t = torch.as_tensor(src).to(dev), torch.as_tensor(tgt).to(dev)
+    dense = 8.0 * len(src) * len(tgt)
     ops.prof_begin(256)
     ms, _ = timed(lambda: ops.nn_search(s, t, np.eye(4)), reps=5, warm=1)
-    pk = ops.prof_end()["nn_mfma"]
-    report("nn_search 100k x 100k, cold (seed bound)", ms, flops=8.0 * len(src) * len(tgt), sweep_kernel_ms=round(pk[0] / pk[1], 3),
-           sweep_TFLOPs=round(pk[2] / pk[0] / 1e9, 2))
+    report("nn_search 100k x 100k, cold", ms, dense_equivalent_flops=int(dense), **sweep(ops.prof_end()))
     ops.prof_begin(256)
     ms, r = timed(lambda: ops.icp(s, t, 100.0, None, "p2p", None, 30), reps=2, warm=1)
-    pk = ops.prof_end()["nn_mfma"]
-    report("registration_icp p2p 100k x 100k, 30 it (a16, config 2)", ms, flops=8.0 * len(src) * len(tgt) * (r["iterations"] + 1),
-           iterations=r["iterations"], fitness=round(r["fitness"], 5), sweep_kernel_ms=round(pk[0] / pk[1], 3),
-           sweep_TFLOPs=round(pk[2] / pk[0] / 1e9, 2))
+    report("registration_icp p2p 100k x 100k, 30 it (a16, config 2)", ms, iterations=r["iterations"], fitness=round(r["fitness"], 5),
+           ms_per_iteration=round(ms / (r["iterations"] + 1), 4), dense_equivalent_flops=int(dense * (r["iterations"] + 1)),
+           **sweep(ops.prof_end()))
     tn = ops.estimate_normals(t, 70.0, 40)
     ops.prof_begin(256)
     ms, r = timed(lambda: ops.icp(s, t, 100.0, None, "p2plane", tn, 30), reps=2, warm=1)
-    pk = ops.prof_end()["nn_mfma"]
-    report("registration_icp p2plane 100k x 100k (a14)", ms, flops=8.0 * len(src) * len(tgt) * (r["iterations"] + 1),
-           iterations=r["iterations"], fitness=round(r["fitness"], 5), sweep_kernel_ms=round(pk[0] / pk[1], 3),
-           sweep_TFLOPs=round(pk[2] / pk[0] / 1e9, 2))
+    report("registration_icp p2plane 100k x 100k (a14)", ms, iterations=r["iterations"], fitness=round(r["fitness"], 5),
+           ms_per_iteration=round(ms / (r["iterations"] + 1), 4), dense_equivalent_flops=int(dense * (r["iterations"] + 1)),
+           **sweep(ops.prof_end()))
 
 
 if __name__ == "__main__":
