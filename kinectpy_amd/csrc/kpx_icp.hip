@@ -598,6 +598,29 @@ __device__ void update_p2plane(const double *acc, double U[16])
     U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
 }
 
+// fitness / rmse / convergence test / update of T from the accumulated sums (one thread).  k = index of the
+// correspondence search the sums come from.
+__device__ void icp_finish(const double *acc, int64_t n, int mode, int k, int max_iter, double rel_fit, double rel_rmse, IcpState *st,
+                           double *__restrict__ result)
+{
+    double cnt = acc[0];
+    double fit = (n > 0 && cnt > 0) ? cnt / (double)n : 0.0;
+    double rmse = cnt > 0 ? sqrt(acc[1] / cnt) : 0.0;
+    bool done = false;
+    if (k >= 1 && fabs(st->fitness - fit) < rel_fit && fabs(st->rmse - rmse) < rel_rmse) done = true;
+    st->fitness = fit; st->rmse = rmse; st->count = cnt; st->iter = k;
+    if (k >= max_iter) done = true;
+    if (!done) {
+        double U[16], Tn[16];
+        if (mode == 1) update_p2plane(acc, U); else update_p2p(acc, U);
+        mat4_mul(U, st->T, Tn);
+        for (int c = 0; c < 16; ++c) st->T[c] = Tn[c];
+    }
+    if (done) st->done = 1;
+    for (int c = 0; c < 16; ++c) result[c] = st->T[c];
+    result[16] = fit; result[17] = rmse; result[18] = (double)k; result[19] = cnt;
+}
+
 // 1024 threads: thread (slot q = t & 63, slice = t >> 6) sums its slice of the per-block partials with four
 // interleaved accumulators, the sixteen slices are then added in order (a fixed summation tree: bitwise
 // reproducible), thread 0 does the algebra.  k = index of the correspondence search just finished.
@@ -636,22 +659,7 @@ __global__ __launch_bounds__(kSolveThreads) void icp_solve_kernel(const double *
     }
     __syncthreads();
     if (threadIdx.x) return;
-    double cnt = acc[0];
-    double fit = (n > 0 && cnt > 0) ? cnt / (double)n : 0.0;
-    double rmse = cnt > 0 ? sqrt(acc[1] / cnt) : 0.0;
-    bool done = false;
-    if (k >= 1 && fabs(st->fitness - fit) < rel_fit && fabs(st->rmse - rmse) < rel_rmse) done = true;
-    st->fitness = fit; st->rmse = rmse; st->count = cnt; st->iter = k;
-    if (k >= max_iter) done = true;
-    if (!done) {
-        double U[16], Tn[16];
-        if (mode == 1) update_p2plane(acc, U); else update_p2p(acc, U);
-        mat4_mul(U, st->T, Tn);
-        for (int c = 0; c < 16; ++c) st->T[c] = Tn[c];
-    }
-    if (done) st->done = 1;
-    for (int c = 0; c < 16; ++c) result[c] = st->T[c];
-    result[16] = fit; result[17] = rmse; result[18] = (double)k; result[19] = cnt;
+    icp_finish(acc, n, mode, k, max_iter, rel_fit, rel_rmse, st, result);
 }
 
 __global__ void icp_init_kernel(IcpState *st, const double *__restrict__ T0)
@@ -700,9 +708,135 @@ __global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restric
 #include "kpx_nnlocal.h"
 namespace kpx {
 
-// ---- host side ----------------------------------------------------------------------------------------------
-// KPX_NN_ENGINE=dense selects the all-pairs sweeps (fp64 + f32 screening) instead of the culled sweep: the two
-// engines return identical results; the dense one is kept as the cross-check and for A/B measurements.
+// ---- one ICP iteration in one kernel (culled engine) -----------------------------------------------------------
+// Block = 4 waves x 16 sorted rows.  Prologue: lanes 0..15 of a wave transform their row, seed it and bound it
+// with last iteration's partner (clamped to the correspondence distance); the wave sweeps (sweep_wave); lanes 0..15
+// then form the chosen pair's direct distance (AC3) and the row's contribution to the update sums, which are added
+// in a fixed order per block; icp_solve_kernel adds the per-block partials and performs the update step.  (A
+// "last block finishes the job" variant was measured 10x slower: the device-scope fences it needs write back and
+// invalidate the XCD's L2 once per block.)
+constexpr int kIWaves = 4;
+constexpr int kIRows = kIWaves * kLRows;
+__global__ __launch_bounds__(256) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+                                                       const float *__restrict__ tn, const double *__restrict__ Bs,
+                                                       const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
+                                                       const float *__restrict__ group_box, int32_t n_groups,
+                                                       const double *__restrict__ tbbox, const int32_t *__restrict__ row_of,
+                                                       int32_t *__restrict__ idx_cur, double *__restrict__ d2_cur, double max_d2, int mode,
+                                                       int k, const IcpState *__restrict__ st, double *__restrict__ part_acc,
+                                                       unsigned long long *__restrict__ tile_visits)
+{
+    if (st->done) return;
+    __shared__ int32_t lists[kIWaves][kLList];
+    __shared__ double rowd[kIWaves][16][5];          // s_x, s_y, s_z, K, bound / result value
+    __shared__ int32_t rowi[kIWaves][16][2];         // partner (bound / result), original row
+    __shared__ double sh[kAcc][kIRows + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const int64_t row_base = ((int64_t)blockIdx.x * kIWaves + wave) * kLRows;
+    const int64_t last = n - 1;
+    const int nacc = mode == 1 ? kAcc : 17;
+
+    if (lane < 16) {
+        const int64_t r = row_base + lane < last ? row_base + lane : last;
+        const int64_t i = row_of[r];
+        double s[3];
+        xform_row(st->T, src + 3 * i, s);
+        const double seed = row_seed(s);
+        double bv = INFINITY;
+        int32_t bj = INT_MAX;
+        if (k > 0) {
+            const int32_t p = idx_cur[i];
+            if (p >= 0) {
+                const float *tp = tgt + 3 * (int64_t)p;
+                const double tx = tp[0], ty = tp[1], tz = tp[2];
+                const double t2 = fma(tx, tx, fma(ty, ty, tz * tz));
+                double d = fma(s[0], -2.0 * tx, seed);
+                d = fma(s[1], -2.0 * ty, d);
+                d = fma(s[2], -2.0 * tz, d);
+                bv = fma(1.0, t2, d);
+                bj = p;
+            }
+        }
+        double t2max = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t2max += fmax(tbbox[a] * tbbox[a], tbbox[3 + a] * tbbox[3 + a]);
+        const double clamp = (max_d2 + 1.0) * (1.0 + 9.31322574615478515625e-10) + ldexp(seed + t2max + 1.0, -38);
+        if (!(bv <= clamp)) { bv = clamp; bj = INT_MAX; }
+        rowd[wave][lane][0] = s[0]; rowd[wave][lane][1] = s[1]; rowd[wave][lane][2] = s[2];
+        rowd[wave][lane][3] = seed; rowd[wave][lane][4] = bv;
+        rowi[wave][lane][0] = bj; rowi[wave][lane][1] = (int32_t)i;
+    }
+    wave_lds_fence();
+    WaveRows w;
+    w.a = q < 3 ? rowd[wave][j][q] : 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = q + 4 * r;
+        w.px[r] = rowd[wave][rr][0]; w.py[r] = rowd[wave][rr][1]; w.pz[r] = rowd[wave][rr][2];
+        w.seed[r] = rowd[wave][rr][3];
+        w.best[r] = rowd[wave][rr][4];
+        w.bcol[r] = rowi[wave][rr][0];
+    }
+    const unsigned visited = sweep_wave(w, Bs, orig, tile_box, group_box, n_groups, tbbox, lists[wave]);
+    if (tile_visits && lane == 0) atomicAdd(tile_visits + ((blockIdx.x * kIWaves + wave) & (kVisitSlots - 1)), (unsigned long long)visited);
+    wave_lds_fence();
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowi[wave][q + 4 * r][0] = w.bcol[r];
+    }
+    wave_lds_fence();
+
+    // the chosen pairs: direct distance, contribution to the sums (one row per lane 0..15)
+    if (lane < 16) {
+        const int col = wave * 16 + lane;
+        for (int a = 0; a < nacc; ++a) sh[a][col] = 0.0;
+        if (row_base + lane <= last) {
+            const int32_t bj = rowi[wave][lane][0];
+            const int64_t i = rowi[wave][lane][1];
+            const bool none = bj < 0 || bj == INT_MAX;
+            idx_cur[i] = none ? -1 : bj;
+            if (none) {
+                d2_cur[i] = INFINITY;
+            } else {
+                const double s[3] = { rowd[wave][lane][0], rowd[wave][lane][1], rowd[wave][lane][2] };
+                const float *tp = tgt + 3 * (int64_t)bj;
+                const double t[3] = { (double)tp[0], (double)tp[1], (double)tp[2] };
+                const double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
+                const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                d2_cur[i] = d2;
+                if (d2 < max_d2) {
+                    sh[0][col] = 1.0; sh[1][col] = d2;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { sh[2 + c][col] = s[c]; sh[5 + c][col] = t[c]; }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) sh[8 + 3 * a + c][col] = t[a] * s[c];
+                    if (mode == 1) {
+                        const float *np_ = tn + 3 * (int64_t)bj;
+                        const double nx = np_[0], ny = np_[1], nz = np_[2];
+                        const double res = (s[0] - t[0]) * nx + (s[1] - t[1]) * ny + (s[2] - t[2]) * nz;
+                        const double J[6] = { s[1] * nz - s[2] * ny, s[2] * nx - s[0] * nz, s[0] * ny - s[1] * nx, nx, ny, nz };
+                        int slot = 17;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int c = a; c < 6; ++c) sh[slot++][col] = J[a] * J[c];
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) sh[38 + a][col] = J[a] * res;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nacc) {
+        double v = 0.0;
+        for (int l = 0; l < kIRows; ++l) v += sh[threadIdx.x][l];
+        part_acc[(int64_t)blockIdx.x * kAcc + threadIdx.x] = v;
+    }
+}
+
 // tiles multiplied by nn_local_kernel while the profiler is armed (one atomic per wave, spread over kVisitSlots
 // addresses: same-address atomics from thousands of waves serialise in L2); read by kpx_prof_end
 __device__ unsigned long long g_nn_visits[kVisitSlots];
@@ -847,6 +981,19 @@ static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b,
 {
     if (!local_engine()) return KPX_OK;
     return morton_order(src, p.n_src, b.sort_s, b.row_of, st);
+}
+// one ICP iteration (search k + update) of the culled engine: two launches
+static void icp_iter_launch(const float *src, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b, double max_d2, int mode,
+                            int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st)
+{
+    {
+        ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
+        hipLaunchKernelGGL(icp_iter_kernel, dim3((unsigned)cdiv(p.n_src, kIRows)), dim3(256), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t,
+                           b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.idx_cur, b.d2_cur, max_d2, mode, k, b.state,
+                           b.part_acc, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr);
+    }
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, b.part_acc, (int)cdiv(p.n_src, kIRows), p.n_src, mode, k, max_iter,
+                       rel_fit, rel_rmse, b.state, d_result);
 }
 static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st)
 {
@@ -1018,30 +1165,33 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
     rc = nn_prep_source(src, p, b, st);
     if (rc) return rc;
     const double md2 = max_dist * max_dist;
-    ScreenPolicy policy;
-    static const bool trace = getenv("KPX_ICP_TRACE") != nullptr;   // development aid: per-iteration sweep choice on stderr
-    for (int k = 0; k <= max_iteration; ++k) {
-        rc = nn_search_launch(src, tgt, tgt_normals, p, b, b.state->T, &b.state->done, k > 0,
-                              poll_interval == 1 ? policy.allow(k) : k >= 2, md2, mode, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, b.part_acc, (int)cdiv(n_src, kMergeThreads), n_src, mode, k,
-                           max_iteration, relative_fitness, relative_rmse, b.state, d_result);
-        if (poll_interval > 0 && (k + 1) % poll_interval == 0 && k < max_iteration) {
-            IcpState h_state;
-            KPX_HIP(hipMemcpyAsync(&h_state.fitness, &b.state->fitness, sizeof(IcpState) - offsetof(IcpState, fitness), hipMemcpyDeviceToHost, st));
-            KPX_HIP(hipStreamSynchronize(st));
-            if (trace) {
-                int32_t total = 0;
-                KPX_HIP(hipMemcpy(&total, b.cand_cnt + n_src, sizeof(int32_t), hipMemcpyDeviceToHost));
-                static double t_prev = 0.0;
-                timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
-                const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-                fprintf(stderr, "[kpx_icp] k=%d screen=%d fitness=%.6f rmse=%.6f overflow_rows=%d dt=%.3f ms\n", k, (int)(k > 0 && policy.allow(k)),
-                        h_state.fitness, h_state.rmse, (k > 0 && policy.allow(k)) ? total : 0, now - t_prev);
-                t_prev = now;
+    if (local_engine()) {
+        // one launch per iteration; kernels queued behind a raised `done` return at once, so the flag is only read back
+        // every poll_interval iterations (0 = never)
+        for (int k = 0; k <= max_iteration; ++k) {
+            icp_iter_launch(src, tgt, tgt_normals, p, b, md2, mode, k, max_iteration, relative_fitness, relative_rmse, d_result, st);
+            if (poll_interval > 0 && (k + 1) % poll_interval == 0 && k < max_iteration) {
+                int32_t h_done = 0;
+                KPX_HIP(hipMemcpyAsync(&h_done, &b.state->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                KPX_HIP(hipStreamSynchronize(st));
+                if (h_done) break;
             }
-            if (h_state.done) break;
-            policy.observe(h_state.fitness, h_state.rmse);
+        }
+    } else {
+        ScreenPolicy policy;
+        for (int k = 0; k <= max_iteration; ++k) {
+            rc = nn_search_launch(src, tgt, tgt_normals, p, b, b.state->T, &b.state->done, k > 0,
+                                  poll_interval == 1 ? policy.allow(k) : k >= 2, md2, mode, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, b.part_acc, (int)cdiv(n_src, kMergeThreads), n_src, mode, k,
+                               max_iteration, relative_fitness, relative_rmse, b.state, d_result);
+            if (poll_interval > 0 && (k + 1) % poll_interval == 0 && k < max_iteration) {
+                IcpState h_state;
+                KPX_HIP(hipMemcpyAsync(&h_state.fitness, &b.state->fitness, sizeof(IcpState) - offsetof(IcpState, fitness), hipMemcpyDeviceToHost, st));
+                KPX_HIP(hipStreamSynchronize(st));
+                if (h_state.done) break;
+                policy.observe(h_state.fitness, h_state.rmse);
+            }
         }
     }
     if (idx) KPX_HIP(hipMemcpyAsync(idx, b.idx_cur, (size_t)n_src * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -1113,7 +1263,17 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     const double md2 = max_dist * max_dist;
     int iter[64], queue[64], qn = 0;
     ScreenPolicy policy[64];
+    // culled engine: kChunk iterations per problem between two reads of its flag (an iteration is one short kernel;
+    // kernels behind a raised flag return at once)
+    const int chunk = local_engine() ? 4 : 1;
     auto launch = [&](int i, int k) -> int {
+        if (local_engine()) {
+            for (int c = 0; c < chunk && k + c <= max_iteration; ++c)
+                icp_iter_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], md2, mode, k + c, max_iteration, relative_fitness,
+                                relative_rmse, d_results + 20 * i, st);
+            KPX_HIP(hipEventRecord(ev[i], st));
+            return KPX_OK;
+        }
         int r = nn_search_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], bufs[i].state->T, &bufs[i].state->done, k > 0,
                                  policy[i].allow(k), md2, mode, st);
         if (r) return r;
@@ -1141,6 +1301,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         if (hipMemcpyAsync(&h_state.fitness, &bufs[i].state->fitness, sizeof(IcpState) - offsetof(IcpState, fitness), hipMemcpyDeviceToHost,
                            side) != hipSuccess ||
             hipStreamSynchronize(side) != hipSuccess) { rc = fail(KPX_ERR_HIP, "convergence poll failed"); break; }
+        iter[i] += chunk - 1;                       // last iteration index already queued
         if (h_state.done || iter[i] >= max_iteration) continue;
         policy[i].observe(h_state.fitness, h_state.rmse);
         ++iter[i];

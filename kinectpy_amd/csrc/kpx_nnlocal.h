@@ -188,31 +188,35 @@ __device__ __forceinline__ void load_box(const float *__restrict__ bx, double lo
 // OR of the four 16-lane fields of a ballot
 __device__ __forceinline__ unsigned fold16(unsigned long long m) { return (unsigned)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xFFFFull); }
 
-// One wave (= one block) per 16 sorted rows.  out_val / out_idx are indexed by ORIGINAL row.
-// Lane (q = lane>>4, j = lane&15) owns rows q, q+4, q+8, q+12 of the wave (the MFMA D layout) and, in the culling
-// tests, box j of the 16 groups / tiles under test: a box survives when ANY of the 16 rows has
-// gap^2(row point, box) <= that row's own bound.  (A cheap wave-box test rejects most groups 64 at a time first.)
-__global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
-                                                      const float *__restrict__ tile_box, const float *__restrict__ group_box,
-                                                      int32_t n_groups, const double *__restrict__ tbbox, const int32_t *__restrict__ done,
-                                                      const double *__restrict__ A64, const double *__restrict__ K64,
-                                                      const double *__restrict__ init_val, const int32_t *__restrict__ init_idx,
-                                                      const int32_t *__restrict__ row_of, double *__restrict__ out_val,
-                                                      int32_t *__restrict__ out_idx, unsigned long long *__restrict__ tile_visits)
+// wave-level ordering of LDS traffic (the DS unit executes one wave's instructions in order; this only stops the
+// compiler from moving accesses across the point)
+__device__ __forceinline__ void wave_lds_fence()
 {
-    if (done && *done) return;
-    __shared__ int32_t list[kLList];
-    const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
-    const int64_t row_base = (int64_t)blockIdx.x * kLRows;
-    const int64_t last = n - 1;
-    constexpr double kRel = 1.0 + 9.31322574615478515625e-10;      // 1 + 2^-30
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-    // A operand: component k = q of row j (rows past the end repeat the last row: same points, never written)
-    const int64_t arow = row_base + j < last ? row_base + j : last;
-    const double a = A64[arow * 4 + q];
+// Per-lane state of one wave's 16 rows.  Lane (q = lane>>4, j = lane&15) owns rows q, q+4, q+8, q+12 (the MFMA D
+// layout) and, in the culling tests, box j of the 16 groups / tiles under test.
+struct WaveRows {
+    double a;                  // A operand: component q of row j
+    d4 seed;                   // C operand: K of the lane's rows
+    double px[4], py[4], pz[4];
+    double best[4];            // running minimum (per lane: over the columns j of the tiles seen)
+    int32_t bcol[4];           // its ORIGINAL target index
+};
+
+// The culled sweep of one wave: on return best/bcol hold, in every lane, the row minimum (lexicographic (value,
+// original column)).  list: kLList ints of LDS owned by this wave.  Returns the number of tiles multiplied.
+__device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
+                                               const float *__restrict__ tile_box, const float *__restrict__ group_box,
+                                               int32_t n_groups, const double *__restrict__ tbbox, int32_t *list)
+{
+    const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    constexpr double kRel = 1.0 + 9.31322574615478515625e-10;      // 1 + 2^-30
     double slo[3], shi[3];
     {
-        double mn = a, mx = a;
+        double mn = w.a, mx = w.a;
 #pragma unroll
         for (int msk = 1; msk < 16; msk <<= 1) {
             mn = fmin(mn, __shfl_xor(mn, msk, 64));
@@ -221,29 +225,15 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
 #pragma unroll
         for (int k = 0; k < 3; ++k) { slo[k] = __shfl(mn, 16 * k, 64); shi[k] = __shfl(mx, 16 * k, 64); }
     }
-    // rows of this lane in the D layout: seeds (C operand), coordinates, running best and its ORIGINAL column
-    d4 seed;
-    double best[4], px[4], py[4], pz[4], rb[4];
-    int32_t bcol[4];
-    double kmax = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t row = row_base + q + 4 * r < last ? row_base + q + 4 * r : last;
-        const double2 xy = reinterpret_cast<const double2 *>(A64)[2 * row];
-        px[r] = xy.x; py[r] = xy.y; pz[r] = A64[4 * row + 2];
-        seed[r] = K64[row];
-        best[r] = init_val[row];
-        bcol[r] = init_idx[row];
-        kmax = fmax(kmax, seed[r]);
-    }
-    kmax = wave_all_max(kmax);
+    double kmax = wave_all_max(fmax(fmax(w.seed[0], w.seed[1]), fmax(w.seed[2], w.seed[3])));
     double t2max = 0.0;
 #pragma unroll
     for (int a3 = 0; a3 < 3; ++a3) t2max += fmax(tbbox[a3] * tbbox[a3], tbbox[3 + a3] * tbbox[3 + a3]);
     const double eps = ldexp(kmax + t2max + 1.0, -38);
     // rb[r]: the row's bound on d^2 (same value in the 16 lanes of a quad); R2: the largest of them
+    double rb[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rb[r] = (best[r] - 1.0) * kRel + eps;             // +inf stays +inf
+    for (int r = 0; r < 4; ++r) rb[r] = (w.best[r] - 1.0) * kRel + eps;             // +inf stays +inf
     double R2 = wave_all_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     if (!(R2 < 1e290)) {
         // some row has no finite bound: every group holds a real point, so the distance to the farthest corner of
@@ -255,7 +245,7 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
                 double lo[3], hi[3];
                 load_box(group_box + (int64_t)g * 6, lo, hi);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) u[r] = fmin(u[r], pt_far2(px[r], py[r], pz[r], lo, hi));
+                for (int r = 0; r < 4; ++r) u[r] = fmin(u[r], pt_far2(w.px[r], w.py[r], w.pz[r], lo, hi));
             }
         }
 #pragma unroll
@@ -269,10 +259,10 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
 
     const double bpad = q == 3 ? kSentinel : 0.0;
     int nlist = 0;
-    unsigned long long visited = 0;
+    unsigned visited = 0;
 
     auto process = [&]() {
-        __syncthreads();                                   // single wave: orders the LDS list writes before the reads
+        wave_lds_fence();                                  // the list writes before the reads
         bool updated = false;
         double b[4];
         int32_t t[4];
@@ -282,10 +272,10 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
             b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
         }
         for (int e = 0; e < nlist; e += 4) {
-            const d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[0], seed, 0, 0, 0);
-            const d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[1], seed, 0, 0, 0);
-            const d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[2], seed, 0, 0, 0);
-            const d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[3], seed, 0, 0, 0);
+            const d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[0], w.seed, 0, 0, 0);
+            const d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[1], w.seed, 0, 0, 0);
+            const d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[2], w.seed, 0, 0, 0);
+            const d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[3], w.seed, 0, 0, 0);
             const int32_t tc[4] = { t[0], t[1], t[2], t[3] };
 #pragma unroll
             for (int h = 0; h < 4; ++h) {                  // operands of the next trip
@@ -295,7 +285,7 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
             bool pass = false;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned hb = hi32(best[r]);
+                const unsigned hb = hi32(w.best[r]);
                 pass |= (bool)((int)(hi32(c0[r]) <= hb) | (int)(hi32(c1[r]) <= hb) | (int)(hi32(c2[r]) <= hb) | (int)(hi32(c3[r]) <= hb));
             }
             if (__builtin_amdgcn_ballot_w64(pass) != 0) {
@@ -305,35 +295,35 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
                 for (int h = 0; h < 4; ++h) oc[h] = tc[h] >= 0 ? orig[(int64_t)tc[h] * 16 + j] : INT_MAX;
 #define KPX_NNL_EXACT(ACC, COL)                                                                     \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
-                    const bool tk = (int)(ACC[r] < best[r]) | ((int)(ACC[r] == best[r]) & (int)((COL) < bcol[r])); \
-                    best[r] = tk ? ACC[r] : best[r];                                               \
-                    bcol[r] = tk ? (COL) : bcol[r];                                                \
+                    const bool tk = (int)(ACC[r] < w.best[r]) | ((int)(ACC[r] == w.best[r]) & (int)((COL) < w.bcol[r])); \
+                    w.best[r] = tk ? ACC[r] : w.best[r];                                           \
+                    w.bcol[r] = tk ? (COL) : w.bcol[r];                                            \
                 }
                 KPX_NNL_EXACT(c0, oc[0]) KPX_NNL_EXACT(c1, oc[1]) KPX_NNL_EXACT(c2, oc[2]) KPX_NNL_EXACT(c3, oc[3])
 #undef KPX_NNL_EXACT
             }
         }
-        visited += (unsigned long long)nlist;
+        visited += (unsigned)nlist;
         nlist = 0;
         if (updated) {
             // tighten the row bounds with the best value any of the row's 16 lanes holds
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double v = best[r];
+                double v = w.best[r];
 #pragma unroll
                 for (int msk = 1; msk < 16; msk <<= 1) v = fmin(v, __shfl_xor(v, msk, 64));
                 rb[r] = fmin(rb[r], (v - 1.0) * kRel + eps);
             }
             R2 = wave_all_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
         }
-        __syncthreads();
+        wave_lds_fence();
     };
     auto any_row_within = [&](const float *__restrict__ bx) {
         double lo[3], hi[3];
         load_box(bx, lo, hi);
         bool t = false;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t |= pt_gap2(px[r], py[r], pz[r], lo, hi) <= rb[r];
+        for (int r = 0; r < 4; ++r) t |= pt_gap2(w.px[r], w.py[r], w.pz[r], lo, hi) <= rb[r];
         return t;
     };
 
@@ -365,8 +355,8 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
     // reduce over the 16 lanes that hold the same rows (lexicographic (value, original column) minimum)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        double v = best[r];
-        int32_t c = bcol[r];
+        double v = w.best[r];
+        int32_t c = w.bcol[r];
 #pragma unroll
         for (int msk = 1; msk < 16; msk <<= 1) {
             const double ov = __shfl_xor(v, msk, 64);
@@ -375,14 +365,50 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
             v = take ? ov : v;
             c = take ? oc : c;
         }
+        w.best[r] = v;
+        w.bcol[r] = c;
+    }
+    return visited;
+}
+
+// One wave (= one block) per 16 sorted rows.  out_val / out_idx are indexed by ORIGINAL row.
+__global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
+                                                      const float *__restrict__ tile_box, const float *__restrict__ group_box,
+                                                      int32_t n_groups, const double *__restrict__ tbbox, const int32_t *__restrict__ done,
+                                                      const double *__restrict__ A64, const double *__restrict__ K64,
+                                                      const double *__restrict__ init_val, const int32_t *__restrict__ init_idx,
+                                                      const int32_t *__restrict__ row_of, double *__restrict__ out_val,
+                                                      int32_t *__restrict__ out_idx, unsigned long long *__restrict__ tile_visits)
+{
+    if (done && *done) return;
+    __shared__ int32_t list[kLList];
+    const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    const int64_t row_base = (int64_t)blockIdx.x * kLRows;
+    const int64_t last = n - 1;
+    WaveRows w;
+    // rows past the end repeat the last row: same points, never written
+    const int64_t arow = row_base + j < last ? row_base + j : last;
+    w.a = A64[arow * 4 + q];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row_base + q + 4 * r < last ? row_base + q + 4 * r : last;
+        const double2 xy = reinterpret_cast<const double2 *>(A64)[2 * row];
+        w.px[r] = xy.x; w.py[r] = xy.y; w.pz[r] = A64[4 * row + 2];
+        w.seed[r] = K64[row];
+        w.best[r] = init_val[row];
+        w.bcol[r] = init_idx[row];
+    }
+    const unsigned visited = sweep_wave(w, Bs, orig, tile_box, group_box, n_groups, tbbox, list);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
         const int64_t row = row_base + q + 4 * r;
         if (j == 0 && row < n) {
             const int64_t i = row_of[row];
-            out_val[i] = v;
-            out_idx[i] = c;
+            out_val[i] = w.best[r];
+            out_idx[i] = w.bcol[r];
         }
     }
-    if (tile_visits && lane == 0) atomicAdd(tile_visits + (blockIdx.x & (kVisitSlots - 1)), visited);
+    if (tile_visits && lane == 0) atomicAdd(tile_visits + (blockIdx.x & (kVisitSlots - 1)), (unsigned long long)visited);
 }
 
 // Morton order of a cloud: d_perm[r] = original index of the r-th point along the curve.

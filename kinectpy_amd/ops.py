@@ -275,7 +275,7 @@ def kabsch(src, tgt, corr):
 
 
 def icp(src, tgt, max_dist, init=None, mode="p2p", tgt_normals=None, max_iteration=30, relative_fitness=1e-6,
-        relative_rmse=1e-6, want_corr=False, poll_interval=1):
+        relative_rmse=1e-6, want_corr=False, poll_interval=4):
     """registration_icp.  Returns dict(transformation, fitness, inlier_rmse, iterations, count[, idx, d2])."""
     lib = L.load()
     src = _dev(src, torch.float32).reshape(-1, 3)
