@@ -12,8 +12,10 @@ point-to-plane ICP, threshold 100, <= 30 iterations; a11-a14)  ->  transform, fu
 (weak scaling: per-GPU work is fixed) and the frame ends with the fuse exchange over RCCL
 (transforms + filtered clouds, kinectpy_amd/parallel.py).
 
-One JSON line is printed by rank 0.  `roofline` is the dominant kernel (the fp64-MFMA nearest-neighbour
-sweep of ICP) timed with HIP events on its own stream inside the timed region (kpx_prof_*);
+One JSON line is printed by rank 0.  `roofline` is the dominant kernel (the ICP iteration kernel: row prep +
+culled fp64-MFMA nearest-neighbour sweep + pair sums; KPX_NN_ENGINE=dense selects the all-pairs sweeps instead)
+timed with HIP events on its own stream inside the timed region (kpx_prof_*); its `achieved` counts the flops of
+the 16x16x4 tiles the kernel really multiplied (counted on the device), not the all-pairs product it avoids;
 `cpu_baseline` is the CPU oracle (oracle/, OpenMP over the host cores) running the same step.
 """
 import argparse
@@ -142,19 +144,28 @@ def main():
         return
     ms_step = dt / args.steps * 1e3
     value = world * spg * N_PX * args.steps / dt / 1e6
-    # dominant kernel = whichever correspondence sweep took more device time: the float32 screening sweep
-    # (ICP iterations >= 1) or the fp64 sweep (first iteration of every registration)
-    kname = max(("nn_screen", "nn_mfma"), key=lambda k: prof[k][0])
+    # dominant kernel = the correspondence sweep that took most device time: the fused ICP iteration kernel of the
+    # culled engine, or (KPX_NN_ENGINE=dense) the float32 screening sweep / the fp64 all-pairs sweep
+    kname = max(("nn_local", "nn_screen", "nn_mfma"), key=lambda k: prof[k][0])
     ms, launches, flops = prof[kname]
-    peak = {"nn_screen": FP32_MFMA_PEAK_TFLOPS, "nn_mfma": FP64_MFMA_PEAK_TFLOPS}[kname]
+    peak = FP32_MFMA_PEAK_TFLOPS if kname == "nn_screen" else FP64_MFMA_PEAK_TFLOPS
+    kernel = {"nn_local": "icp_iter_kernel", "nn_screen": "nn_screen_kernel", "nn_mfma": "nn_mfma_kernel"}[kname]
     roof = None
     if launches:
         achieved = flops / (ms * 1e-3) / 1e12
-        roof = {"kernel": kname + "_kernel", "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
+        roof = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                 "launches": launches, "avg_launch_us": round(ms / launches * 1e3, 2),
                 "flop_per_launch": round(flops / launches), "share_of_step": round(ms / (dt * 1e3), 3),
                 "mfma_dtype": "f32" if kname == "nn_screen" else "f64"}
+        if kname == "nn_local":
+            nd = pipe.last.get("n_down") if isinstance(pipe.last, dict) else None
+            if nd and len(nd) > 1:
+                dense = 8.0 * float(np.mean(nd[1:])) * float(nd[0])
+                roof["all_pairs_flop_per_launch"] = round(dense)
+                roof["culled_to"] = round(flops / launches / dense, 5)
+            roof["note"] = ("latency-bound: spatial culling leaves ~0.3 % of the all-pairs tiles; see DESIGN.md 4 for the "
+                            "dense engine's MFMA utilisation (KPX_NN_ENGINE=dense)")
     other = {k: {"launches": v[1], "avg_us": round(v[0] / max(v[1], 1) * 1e3, 2)} for k, v in prof.items() if k != kname}
 
     cpu = None
