@@ -86,6 +86,14 @@ template <class T> __device__ __forceinline__ T wave_max(T v)
     return v;
 }
 
+// wave-level ordering of LDS traffic (the DS unit executes one wave's instructions in order; this only stops the
+// compiler from moving accesses across the point)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Block-wide sum in a FIXED order (wave-tree, then waves in order): bitwise reproducible run to run.
 // All threads must call; result valid in thread 0.  `sh` holds >= blockDim/64 elements of T.
 template <class T> __device__ __forceinline__ T block_sum(T v, T *sh)

@@ -82,6 +82,7 @@ __device__ __forceinline__ void grid_knn_scan(const GridParams &g, const uint32_
     for (int a = 0; a < 3; ++a) c[a] = cell_coord(q[a], g.org[a], g.h, g.dim[a]);
     int maxr = g.dim[0] > g.dim[1] ? g.dim[0] : g.dim[1];
     if (g.dim[2] > maxr) maxr = g.dim[2];
+    double gate = heap.full() ? heap.worst() : INFINITY;     // register copy of the heap's worst value
     for (int r = 0; r <= maxr; ++r) {
         if (r > 0) {
             double dcov = INFINITY;
@@ -116,11 +117,26 @@ __device__ __forceinline__ void grid_knn_scan(const GridParams &g, const uint32_
                         else { if (z1 >= g.dim[2] || r == 0) continue; zs = ze = z1; }
                     }
                     uint32_t s0 = cell_start[col + zs], s1 = cell_start[col + ze + 1];
-                    for (uint32_t s = s0; s < s1; ++s) {
-                        double dx = qx - (double)spts[3 * s], dy = qy - (double)spts[3 * s + 1], dz = qz - (double)spts[3 * s + 2];
-                        double d = fma(dz, dz, fma(dy, dy, dx * dx));
-                        if (r2max >= 0.0 && !(d < r2max)) continue;
-                        heap.push(d, sidx ? sidx[s] : 0);
+                    // candidates in batches of 8: all coordinate loads of a batch are issued before the first push
+                    // (a push is LDS traffic and branches; interleaved with the loads it exposes one memory latency
+                    // per candidate)
+                    for (uint32_t sb = s0; sb < s1; sb += 8) {
+                        float cx[8], cy[8], cz[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const uint32_t s = sb + e < s1 ? sb + e : s1 - 1;
+                            cx[e] = spts[3 * s]; cy[e] = spts[3 * s + 1]; cz[e] = spts[3 * s + 2];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (sb + e >= s1) break;
+                            const double dx = qx - (double)cx[e], dy = qy - (double)cy[e], dz = qz - (double)cz[e];
+                            const double d = fma(dz, dz, fma(dy, dy, dx * dx));
+                            if (r2max >= 0.0 && !(d < r2max)) continue;
+                            if (d > gate) continue;                 // cannot enter a full heap (ties are decided by push)
+                            heap.push(d, sidx ? sidx[sb + e] : 0);
+                            gate = heap.full() ? heap.worst() : INFINITY;
+                        }
                     }
                 }
             }

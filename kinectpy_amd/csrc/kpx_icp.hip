@@ -621,9 +621,10 @@ __device__ void icp_finish(const double *acc, int64_t n, int mode, int k, int ma
     result[16] = fit; result[17] = rmse; result[18] = (double)k; result[19] = cnt;
 }
 
-// 1024 threads: thread (slot q = t & 63, slice = t >> 6) sums its slice of the per-block partials with four
-// interleaved accumulators, the sixteen slices are then added in order (a fixed summation tree: bitwise
-// reproducible), thread 0 does the algebra.  k = index of the correspondence search just finished.
+// 1024 threads: thread (slot q = t & 63, slice = t >> 6) sums its slice of the per-block partials with eight
+// interleaved accumulators (lanes of a wave read consecutive slots of one partial row: coalesced; a row-per-thread
+// variant was 3x slower, the single CU's address path saturates), the sixteen slices are then added in order (a
+// fixed summation tree: bitwise reproducible), thread 0 does the algebra.  k = index of the search just finished.
 constexpr int kSolveThreads = 1024;
 __global__ __launch_bounds__(kSolveThreads) void icp_solve_kernel(const double *__restrict__ part_acc, int nblocks, int64_t n, int mode, int k,
                                                                   int max_iter, double rel_fit, double rel_rmse, IcpState *st,
@@ -635,20 +636,20 @@ __global__ __launch_bounds__(kSolveThreads) void icp_solve_kernel(const double *
     const int nacc = mode == 1 ? kAcc : 17;
     const int q = threadIdx.x & 63, slice = threadIdx.x >> 6;
     {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        double u[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
         if (q < nacc) {
             const int per = (nblocks + kSolveThreads / 64 - 1) / (kSolveThreads / 64);
             const int b0 = slice * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
             int b = b0;
-            for (; b + 3 < b1; b += 4) {
-                s0 += part_acc[(int64_t)b * kAcc + q];
-                s1 += part_acc[(int64_t)(b + 1) * kAcc + q];
-                s2 += part_acc[(int64_t)(b + 2) * kAcc + q];
-                s3 += part_acc[(int64_t)(b + 3) * kAcc + q];
+            for (; b + 7 < b1; b += 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[e] += part_acc[(int64_t)(b + e) * kAcc + q];
             }
-            for (; b < b1; ++b) s0 += part_acc[(int64_t)b * kAcc + q];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (b + e < b1) u[e] += part_acc[(int64_t)(b + e) * kAcc + q];
         }
-        part[slice][q] = (s0 + s1) + (s2 + s3);
+        part[slice][q] = ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
     }
     __syncthreads();
     if (threadIdx.x < kAcc) {

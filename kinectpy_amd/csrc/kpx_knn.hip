@@ -148,23 +148,190 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
 }
 
 // ---- a8 SOR ------------------------------------------------------------------------------------------
-// Exact ring walk, one thread per query (queries in cell order: neighbouring threads walk neighbouring cells).
-// (A wave-per-cell variant with LDS-staged shared candidates plus a cooperative kernel for isolated points was
-// measured and lost to this kernel once the cell size follows the measured occupancy: 4.3 vs 3.4 ms at 259k, k=20.)
-__global__ void sor_knn_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
-                               const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t n, int k,
-                               double *__restrict__ avg)
+// One WAVE per query.  The lanes gather the squared distances (AC3, fp64) of every point of the (2r+1)^3 cell block
+// around the query into LDS, shell by shell; as soon as the block holds k candidates the k-th smallest is found by
+// bisection on the IEEE bit patterns (d^2 >= 0: the patterns order like the values; one ballot + popcount per 64
+// candidates and step) and the walk ends when that value lies inside the distance the block covers -- the same
+// termination rule as the ring walk of kpx_gridknn.h.  The mean needs no identities: sum of sqrt over the selected
+// set, ties at the k-th value counted k - (#smaller) times.  Queries whose candidates exceed the LDS buffer are
+// listed and finished by the thread-per-query ring walk below.
+__device__ __forceinline__ unsigned long long wave_all_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_all_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+// squared distance the block [c-r, c+r] covers around q (infinity once it holds the whole grid)
+__device__ __forceinline__ double block_cover2(const GridParams &g, const double q[3], const int c[3], int r)
+{
+    double dcov = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double lo = g.org[a] + (double)(c[a] - r) * g.h;
+        const double hi = g.org[a] + (double)(c[a] + r + 1) * g.h;
+        const double dl = (c[a] - r <= 0) ? INFINITY : q[a] - lo;
+        const double dh = (c[a] + r + 1 >= g.dim[a]) ? INFINITY : hi - q[a];
+        dcov = fmin(dcov, fmin(dl, dh));
+    }
+    if (dcov == INFINITY) return INFINITY;
+    if (dcov < 0.0) dcov = 0.0;
+    return dcov * dcov * (1.0 - 1e-12);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
+                                                              const float *__restrict__ spts, const int32_t *__restrict__ sidx,
+                                                              int64_t n, int k, int cap, double *__restrict__ avg,
+                                                              const int32_t *__restrict__ in_list, const int32_t *__restrict__ in_count,
+                                                              int32_t *__restrict__ fb_list, int32_t *__restrict__ fb_count)
 {
     extern __shared__ __align__(16) double lds[];
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
+    __shared__ uint32_t run_s0[WAVES][64];
+    __shared__ int32_t run_off[WAVES][65];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *vals = lds + (size_t)wave * cap;
     const GridParams g = *gp;
-    HeapD heap{ lds + threadIdx.x, (int)blockDim.x, k, 0 };
-    grid_knn_scan(g, cell_start, spts, (const int32_t *)nullptr, (double)spts[3 * s], (double)spts[3 * s + 1],
-                  (double)spts[3 * s + 2], -1.0, heap);
-    double sum = 0.0;
-    for (int e = 0; e < heap.sz; ++e) sum += sqrt(heap.h[e * heap.stride]);
-    avg[sidx[s]] = heap.sz > 0 ? sum / (double)heap.sz : -1.0;
+    int maxr = g.dim[0] > g.dim[1] ? g.dim[0] : g.dim[1];
+    if (g.dim[2] > maxr) maxr = g.dim[2];
+    const int64_t nq = in_list ? (int64_t)*in_count : n;         // in_list: the queries an earlier pass could not hold
+    for (int64_t e = (int64_t)blockIdx.x * WAVES + wave; e < nq; e += (int64_t)gridDim.x * WAVES) {
+        const int64_t s = in_list ? (int64_t)in_list[e] : e;
+        const double q[3] = { (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2] };
+        int c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c[a] = cell_coord(q[a], g.org[a], g.h, g.dim[a]);
+
+        // Gathers d^2 of every point of the block [c-r, c+r] into vals; returns the count, -1 if it exceeds the buffer.
+        // Every (x, y) column of the block is one contiguous run of the cell-sorted points: 64 columns at a time, lane c
+        // looks up run c, a wave scan places the runs, then the lanes fetch the candidates of the chunk together.
+        auto gather_block = [&](int r) -> int {
+            const int xa = c[0] - r < 0 ? 0 : c[0] - r, xb = c[0] + r >= g.dim[0] ? g.dim[0] - 1 : c[0] + r;
+            const int ya = c[1] - r < 0 ? 0 : c[1] - r, yb = c[1] + r >= g.dim[1] ? g.dim[1] - 1 : c[1] + r;
+            const int za = c[2] - r < 0 ? 0 : c[2] - r, zb = c[2] + r >= g.dim[2] ? g.dim[2] - 1 : c[2] + r;
+            const int ny = yb - ya + 1, ncols = (xb - xa + 1) * ny;
+            int m = 0;
+            for (int c0 = 0; c0 < ncols; c0 += 64) {
+                const int nruns = ncols - c0 < 64 ? ncols - c0 : 64;
+                uint32_t s0 = 0;
+                int len = 0;
+                if (lane < nruns) {
+                    const int x = xa + (c0 + lane) / ny, y = ya + (c0 + lane) % ny;
+                    const int64_t col = ((int64_t)x * g.dim[1] + y) * g.dim[2];
+                    s0 = cell_start[col + za];
+                    len = (int)(cell_start[col + zb + 1] - s0);
+                }
+                const int incl = wave_incl_scan(len);
+                const int mc = __shfl(incl, 63, 64);
+                if (mc == 0) continue;
+                if (m + mc > cap) return -1;
+                run_s0[wave][lane] = s0;
+                run_off[wave][lane] = incl - len;
+                wave_lds_fence();
+                for (int t = lane; t < mc; t += 64) {
+                    int lo = 0, hi = nruns - 1;                                    // last run with off <= t
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (run_off[wave][mid] <= t) lo = mid; else hi = mid - 1;
+                    }
+                    const float *pp = spts + 3 * (int64_t)(run_s0[wave][lo] + (uint32_t)(t - run_off[wave][lo]));
+                    const double dx = q[0] - (double)pp[0], dy = q[1] - (double)pp[1], dz = q[2] - (double)pp[2];
+                    vals[m + t] = fma(dz, dz, fma(dy, dy, dx * dx));
+                }
+                wave_lds_fence();
+                m += mc;
+            }
+            return m;
+        };
+
+        bool have = false, over = false;
+        double total = 0.0;
+        int used = 0, r = 1;
+        while (!have && !over) {
+            const int m = gather_block(r);
+            if (m < 0) { over = true; break; }
+            const double cov2 = block_cover2(g, q, c, r);
+            if (m < k && cov2 != INFINITY) {                    // too few candidates: grow by the density seen so far
+                const double f = cbrt((double)(k + 1) / (double)(m > 0 ? m : 1));
+                int rn = (int)((double)r * (f < 4.0 ? f : 4.0)) + 1;
+                r = rn > r ? rn : r + 1;
+                if (r > maxr) r = maxr;
+                continue;
+            }
+            const int kk = m < k ? m : k;                       // m < k only when the block is the whole grid
+            // k-th smallest by bisection between the smallest and the largest pattern
+            unsigned long long lo = ~0ull, hi = 0ull;
+            for (int t = lane; t < m; t += 64) {
+                const unsigned long long p = (unsigned long long)__double_as_longlong(vals[t]);
+                lo = p < lo ? p : lo; hi = p > hi ? p : hi;
+            }
+            lo = wave_all_min_u64(lo); hi = wave_all_max_u64(hi);
+            while (lo < hi) {
+                const unsigned long long mid = lo + ((hi - lo) >> 1);
+                int cnt = 0;
+                for (int t0 = 0; t0 < m; t0 += 64) {
+                    const int t = t0 + lane;
+                    const bool le = t < m && (unsigned long long)__double_as_longlong(vals[t]) <= mid;
+                    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
+                }
+                if (cnt == kk) { lo = hi = mid; break; }       // the set is determined
+                if (cnt > kk) hi = mid; else lo = mid + 1;
+            }
+            // sum of sqrt over the selected set, its largest member, its size
+            double sum = 0.0, top = 0.0;
+            int cnt = 0;
+            for (int t0 = 0; t0 < m; t0 += 64) {
+                const int t = t0 + lane;
+                const bool le = t < m && (unsigned long long)__double_as_longlong(vals[t]) <= lo;
+                if (le) { sum += sqrt(vals[t]); top = fmax(top, vals[t]); }
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); top = fmax(top, __shfl_xor(top, o, 64)); }
+            if (cov2 == INFINITY || top < cov2) {
+                total = sum - (double)(cnt - kk) * sqrt(top);   // ties at the k-th value beyond the k-th slot
+                used = kk;
+                have = true;
+            } else {
+                // the k-th candidate lies outside the covered distance: it bounds the true k-th distance, so the block
+                // that covers it settles the query
+                int rn = (int)(sqrt(top) / g.h) + 1;
+                r = rn > r ? rn : r + 1;
+                if (r > maxr) r = maxr;
+            }
+            wave_lds_fence();
+        }
+        if (over) {
+            if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = (int32_t)s;
+            continue;
+        }
+        if (lane == 0) avg[sidx[s]] = used > 0 ? total / (double)used : -1.0;
+    }
+}
+
+// Exact ring walk, one thread per query (queries in cell order: neighbouring threads walk neighbouring cells).
+// list != NULL: only the queries list[0 .. *list_count) (the wave kernel's overflow list).
+__global__ void sor_knn_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
+                               const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t n, int k,
+                               double *__restrict__ avg, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count)
+{
+    extern __shared__ __align__(16) double lds[];
+    const GridParams g = *gp;
+    const int64_t total = list ? (int64_t)*list_count : n;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = list ? (int64_t)list[t] : t;
+        HeapD heap{ lds + threadIdx.x, (int)blockDim.x, k, 0 };
+        grid_knn_scan(g, cell_start, spts, (const int32_t *)nullptr, (double)spts[3 * s], (double)spts[3 * s + 1],
+                      (double)spts[3 * s + 2], -1.0, heap);
+        double sum = 0.0;
+        for (int e = 0; e < heap.sz; ++e) sum += sqrt(heap.h[e * heap.stride]);
+        avg[sidx[s]] = heap.sz > 0 ? sum / (double)heap.sz : -1.0;
+    }
 }
 
 // mean / std exactly as [O3D]: mean = sum(avg>0)/n ; std = sqrt(sum_{avg>0}(avg-mean)^2/(n-1))
@@ -210,26 +377,51 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
 {
     Grid g;
     int kk = (int64_t)k < n ? k : (int)(n > 0 ? n : 1);
-    // cell occupancy (as seen by a point) of ~48: measured optimum of the ring walk for k = 20 ... 200
-    int rc = grid_build(pts, n, 48.0, a, &g, st);
+    // cell occupancy (as seen by a point) ~0.4 k: the 27-cell block then holds ~10 k candidates and usually covers the
+    // k-th neighbour
+    // (k > 40: the thread-per-query ring walk with its measured optimum of ~48 is still the faster kernel)
+    const bool wave_path = kk <= 40;
+    double occ = wave_path ? 0.4 * (double)kk : 48.0;
+    occ = occ < 6.0 ? 6.0 : occ;
+    int rc = grid_build(pts, n, occ, a, &g, st);
     if (rc) return rc;
     double *avg = a.get<double>((size_t)(n > 0 ? n : 1));
     double *part = a.get<double>(1024);
     int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    int32_t *fb_list = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
+    int32_t *fb_list2 = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     if (d_avg) avg = d_avg;
+    int32_t *fb_count = fb_list + (n > 0 ? n : 1), *fb_count2 = fb_list2 + (n > 0 ? n : 1);
     const int threads = sor_block_threads(kk);
     const size_t lds = (size_t)kk * threads * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         KPX_HIP(hipFuncSetAttribute((const void *)sor_knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KPX_HIP(hipFuncSetAttribute((const void *)sor_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        KPX_HIP(hipFuncSetAttribute((const void *)sor_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
+    KPX_HIP(hipMemsetAsync(fb_count, 0, sizeof(int32_t), st));
+    KPX_HIP(hipMemsetAsync(fb_count2, 0, sizeof(int32_t), st));
     {
         ProfScope prof(KPX_PROF_SOR_KNN, 12.0 * (double)n + 8.0 * (double)n, st);     // read points, write mean distances
-        hipLaunchKernelGGL(sor_knn_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g.params, g.cell_start,
-                           g.sorted_pts, g.sorted_idx, n, kk, avg);
+        const int32_t *none = nullptr;
+        if (wave_path) {
+            // pass 1: every query, 1024-candidate buffer (many waves per CU)
+            hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256), (size_t)4 * 1024 * 8, st,
+                               g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk, 1024, avg, none, none, fb_list, fb_count);
+            // pass 2: the queries whose block did not fit (isolated points next to a dense sheet), 8192-candidate buffer
+            hipLaunchKernelGGL(sor_wave_kernel<1>, dim3(2048), dim3(64), (size_t)8192 * 8, st, g.params, g.cell_start, g.sorted_pts,
+                               g.sorted_idx, n, kk, 8192, avg, fb_list, fb_count, fb_list2, fb_count2);
+            // pass 3: whatever is left: thread-per-query ring walk with a k-heap
+            hipLaunchKernelGGL(sor_knn_kernel, dim3(256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk,
+                               avg, fb_list2, fb_count2);
+        } else {
+            hipLaunchKernelGGL(sor_knn_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts,
+                               g.sorted_idx, n, kk, avg, none, none);
+        }
     }
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
     for (int pass = 0; pass < 2; ++pass) {
