@@ -148,8 +148,9 @@ int kpx_segment_plane(const float *pts, int64_t n, double distance_threshold, in
 
 /* One correspondence search of registration_icp (manual_pointcloud_registration.py:96-98,
  * preprocessing/registration.py:78-84): for every source point transformed by d_T (device f64 [16]),
- * the nearest target point -- an fp64 MFMA distance GEMM (K=4 augmented form) with a fused running
- * argmin.  idx i32 [n], d2 f64 [n] (direct squared distance of the chosen pair). */
+ * the nearest target point (exact; ties to the lowest target index) -- fp64 MFMA distance tiles in the K=4
+ * augmented form with a fused running argmin, multiplied only where the tile's bounding box can hold a nearer
+ * point (Morton-sorted operands).  idx i32 [n], d2 f64 [n] (direct squared distance of the chosen pair). */
 size_t kpx_nn_workspace_bytes(int64_t n_src, int64_t n_tgt);
 int kpx_nn_search(const float *src, int64_t n_src, const float *tgt, int64_t n_tgt, const double *d_T,
                   int32_t *idx, double *d2, void *ws, size_t ws_bytes, void *stream);
@@ -164,10 +165,12 @@ int kpx_kabsch(const float *src, const float *tgt, const int32_t *corr, int64_t 
 /* registration_icp(source, target, max_dist, init, estimation, criteria) -- the whole loop runs on
  * the device without host synchronisation.  mode 0 = point-to-point (Kabsch, a16), 1 = point-to-plane
  * (needs tgt_normals, a14).  h_init: f64 [16] host.  d_result f64 [20]: T (16), fitness, inlier_rmse,
- * iterations done, correspondence count.  idx/d2 (optional) receive the last correspondence set.
+ * iterations done, correspondence count.  idx/d2 (optional) receive the last correspondence set: the
+ * nearest target of every source point, or idx = -1 / d2 = +inf where no target lies within max_dist
+ * (such points are not correspondences).
  * poll_interval == 0: every iteration is enqueued up front and later launches return at once after
  * convergence (fully asynchronous).  poll_interval = p > 0: the host reads the device `done` flag every
- * p iterations (one 4-byte copy + stream sync) and stops enqueuing -- no empty launches. */
+ * p iterations (one 4-byte copy + stream sync) and stops enqueuing. */
 #define KPX_ICP_POINT_TO_POINT 0
 #define KPX_ICP_POINT_TO_PLANE 1
 size_t kpx_icp_workspace_bytes(int64_t n_src, int64_t n_tgt);
