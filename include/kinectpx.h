@@ -213,6 +213,14 @@ int kpx_icp_batch(int32_t count, const float *const *h_src, const int64_t *h_n_s
                   int32_t max_iteration, double relative_fitness, double relative_rmse, double *d_results, void *ws,
                   size_t ws_bytes, void *stream);
 
+/* The correspondence searches above have two interchangeable implementations with identical results: the culled
+ * sweep (default) and the all-pairs sweeps it replaced (fp64 MFMA + float32 screening), kept as an independent
+ * cross-check and for A/B measurements.  kpx_nn_engine(e) selects one for the following calls and returns the
+ * engine that was active (e < 0: query only).  Initial value: environment KPX_NN_ENGINE=dense|culled. */
+#define KPX_NN_ENGINE_CULLED 0
+#define KPX_NN_ENGINE_DENSE 1
+int kpx_nn_engine(int32_t engine);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it
  * (capacity = max launches recorded); every launch of a tagged kernel is bracketed by an event pair;

@@ -858,11 +858,11 @@ double nn_local_take_visits()
     return sum;
 }
 
+static int g_nn_engine = -1;          // KPX_NN_ENGINE_*; -1 = not chosen yet (environment decides at first use)
 static bool local_engine()
 {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("KPX_NN_ENGINE"); on = (e && e[0] == 'd') ? 0 : 1; }
-    return on != 0;
+    if (g_nn_engine < 0) { const char *e = getenv("KPX_NN_ENGINE"); g_nn_engine = (e && e[0] == 'd') ? KPX_NN_ENGINE_DENSE : KPX_NN_ENGINE_CULLED; }
+    return g_nn_engine == KPX_NN_ENGINE_CULLED;
 }
 
 struct NnPlan {
@@ -915,7 +915,7 @@ struct ScreenPolicy {
         calm = fit >= 0.0 && fabs(f - fit) <= 0.02 && fabs(r - rmse) <= 0.05 * (rmse > 1e-12 ? rmse : 1e-12);
         fit = f; rmse = r;
     }
-    bool allow(int k) const { static const bool force = getenv("KPX_ICP_FORCE_SCREEN") != nullptr; return force ? k >= 1 : (k >= 2 && calm); }
+    bool allow(int k) const { return k >= 2 && calm; }
 };
 
 struct NnBuffers {
@@ -1083,6 +1083,15 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
 }  // namespace kpx
 
 using namespace kpx;
+
+KPX_EXPORT int kpx_nn_engine(int32_t engine)
+{
+    const int cur = local_engine() ? KPX_NN_ENGINE_CULLED : KPX_NN_ENGINE_DENSE;
+    if (engine < 0) return cur;
+    KPX_REQUIRE(engine == KPX_NN_ENGINE_CULLED || engine == KPX_NN_ENGINE_DENSE, "kpx_nn_engine: unknown engine %d", engine);
+    g_nn_engine = engine;
+    return cur;
+}
 
 KPX_EXPORT size_t kpx_nn_workspace_bytes(int64_t n_src, int64_t n_tgt)
 {

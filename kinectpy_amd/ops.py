@@ -376,6 +376,18 @@ def icp_batch(srcs, tgt, max_dist, inits, mode="p2p", tgt_normals=None, max_iter
 
 
 # ---- measurement hooks --------------------------------------------------------------------------------
+NN_ENGINES = ("culled", "dense")
+
+
+def nn_engine(name=None):
+    """Select the correspondence-search implementation ("culled" default, "dense" all-pairs cross-check); returns the
+    name of the engine that was active.  Results are identical; see include/kinectpx.h."""
+    prev = L.load().kpx_nn_engine(-1 if name is None else NN_ENGINES.index(name))
+    if prev < 0:
+        L.check(prev)
+    return NN_ENGINES[prev]
+
+
 PROF_KERNELS = ("nn_mfma", "sor_knn", "plane_score", "compact", "nn_screen", "nn_local")
 
 

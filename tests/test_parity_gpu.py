@@ -230,8 +230,16 @@ def test_segment_plane_inliers_bit_exact(ops, oracle, n, rn, iters, prob, seed):
 
 
 # ------------------------------------------------------------------------------------------- registration
-@pytest.mark.parametrize("n,m", [(20000, 20000), (1000, 777), (333, 5000), (5, 1), (64, 17), (4097, 16)])
-def test_nn_bit_exact(ops, oracle, base_cloud, n, m):
+@pytest.fixture(params=["culled", "dense"])
+def engine(request, ops):
+    """both correspondence-search implementations: the culled sweep (default) and the all-pairs sweeps"""
+    prev = ops.nn_engine(request.param)
+    yield request.param
+    ops.nn_engine(prev)
+
+
+@pytest.mark.parametrize("n,m", [(20000, 20000), (1000, 777), (333, 5000), (5, 1), (64, 17), (4097, 16), (17, 4097)])
+def test_nn_bit_exact(ops, oracle, base_cloud, engine, n, m):
     src, tgt, T = synth.icp_pair(max(n, m), base_cloud)
     src, tgt = src[:n], tgt[:m]
     for M in (np.eye(4), np.linalg.inv(T)):
@@ -240,7 +248,7 @@ def test_nn_bit_exact(ops, oracle, base_cloud, n, m):
         assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd)
 
 
-def test_nn_ties_go_to_the_lowest_index(ops, oracle):
+def test_nn_ties_go_to_the_lowest_index(ops, oracle, engine):
     """integer-grid data (raw Kinect XYZ is int16): exact ties, exact arithmetic in both forms"""
     rng = np.random.default_rng(4)
     tgt = rng.integers(-50, 50, size=(3000, 3)).astype(np.float32)
@@ -251,8 +259,46 @@ def test_nn_ties_go_to_the_lowest_index(ops, oracle):
     assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd) and (ri < 1500).all()
 
 
+def test_nn_ties_between_distinct_points(ops, oracle, engine):
+    """sources half way between lattice targets: equidistant DISTINCT targets that the Morton order puts into
+    different column tiles; the lowest caller index must win"""
+    g = np.arange(-12, 12, dtype=np.float32)
+    tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) * 4.0
+    tgt = tgt[np.random.default_rng(2).permutation(len(tgt))]
+    src = tgt[::3] + np.array([2.0, 0.0, 0.0], np.float32)          # exactly between two lattice points
+    src = np.concatenate([src, tgt[1::5] + np.array([2.0, 2.0, 2.0], np.float32)])       # centre of a cell: 8 ties
+    gi, gd = ops.nn_search(src, tgt, np.eye(4))
+    ri, rd, _ = oracle.nn(src, np.eye(4), tgt)
+    assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd)
+
+
+def test_nn_far_apart_and_clustered(ops, oracle, base_cloud, engine):
+    """rows without any finite bound (clouds 20 m apart), dense clumps plus isolated points, collinear targets"""
+    rng = np.random.default_rng(11)
+    src, tgt, _ = synth.icp_pair(6000, base_cloud)
+    far = (src + np.array([20000.0, -3000.0, 500.0])).astype(np.float32)
+    clumps = np.concatenate([rng.normal(c, 2.0, size=(800, 3)) for c in ((0, 0, 0), (5000, 0, 0), (0, 7000, 100))]
+                            + [rng.uniform(-9000, 9000, size=(50, 3))]).astype(np.float32)
+    line = np.stack([np.linspace(-4000, 4000, 3000), np.zeros(3000), np.full(3000, 2000.0)], -1).astype(np.float32)
+    for s_, t_ in ((far, tgt), (src, clumps), (clumps, tgt), (src[:500], line), (line, src)):
+        gi, gd = ops.nn_search(s_, t_, np.eye(4))
+        ri, rd, _ = oracle.nn(s_, np.eye(4), t_)
+        assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd)
+
+
+def test_icp_without_any_correspondence(ops, oracle, base_cloud, engine):
+    """nothing within max_correspondence_distance: fitness 0, the transform stays the initial one"""
+    src, tgt, _ = synth.icp_pair(3000, base_cloud)
+    far = (src + np.array([20000.0, 0.0, 0.0])).astype(np.float32)
+    g = ops.icp(far, tgt, 100.0, None, "p2p", None, 5, want_corr=True)
+    rT, rf, rr, rit = oracle.registration_icp(far, tgt, 100.0, None, "p2p", None, 5)
+    assert g["fitness"] == rf == 0.0 and g["iterations"] == rit
+    assert np.array_equal(g["transformation"], rT)
+    assert (npy(g["d2"]) >= 100.0 ** 2).all()
+
+
 @pytest.mark.parametrize("mode", ["p2p", "p2plane"])
-def test_icp_matches_oracle(ops, oracle, base_cloud, mode):
+def test_icp_matches_oracle(ops, oracle, base_cloud, engine, mode):
     src, tgt, T = synth.icp_pair(20000, base_cloud)
     tn = oracle.estimate_normals(tgt, 70.0, 40)[0].astype(np.float32) if mode == "p2plane" else None
     g = ops.icp(src, tgt, 100.0, None, mode, tn, want_corr=True)
@@ -269,7 +315,27 @@ def test_icp_matches_oracle(ops, oracle, base_cloud, mode):
         assert np.abs(g["transformation"][:3, 3] - T[:3, 3]).max() < 3.0       # recovers the ground truth
 
 
-def test_icp_batch_equals_single_problems(ops, oracle, base_cloud):
+def test_icp_engines_agree(ops, base_cloud):
+    """culled and all-pairs engines: same iterations, fitness and correspondences (within max_dist); transforms agree
+    to the tolerance of the reordered sums"""
+    src, tgt, _ = synth.icp_pair(15000, base_cloud)
+    out = {}
+    for name in ("culled", "dense"):
+        prev = ops.nn_engine(name)
+        try:
+            out[name] = ops.icp(src, tgt, 100.0, None, "p2p", None, 10, want_corr=True)
+        finally:
+            ops.nn_engine(prev)
+    a, b = out["culled"], out["dense"]
+    assert a["iterations"] == b["iterations"] and a["fitness"] == b["fitness"]
+    assert np.abs(a["transformation"] - b["transformation"]).max() < TOL_T
+    near = npy(b["d2"]) < 100.0 ** 2
+    assert np.array_equal(npy(a["idx"])[near], npy(b["idx"])[near])
+    assert np.allclose(npy(a["d2"])[near], npy(b["d2"])[near], rtol=1e-9, atol=1e-9)
+    assert (npy(a["idx"])[~near] == -1).all() or (npy(a["d2"])[~near] >= 100.0 ** 2).all()
+
+
+def test_icp_batch_equals_single_problems(ops, oracle, base_cloud, engine):
     """several subs onto one master, software-pipelined: same answers as one registration at a time"""
     src, tgt, T = synth.icp_pair(12000, base_cloud)
     tn = oracle.estimate_normals(tgt, 70.0, 40)[0].astype(np.float32)
