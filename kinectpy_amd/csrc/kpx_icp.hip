@@ -713,9 +713,12 @@ namespace kpx {
 // Block = 4 waves x 16 sorted rows.  Prologue: lanes 0..15 of a wave transform their row, seed it and bound it
 // with last iteration's partner (clamped to the correspondence distance); the wave sweeps (sweep_wave); lanes 0..15
 // then form the chosen pair's direct distance (AC3) and the row's contribution to the update sums, which are added
-// in a fixed order per block; icp_solve_kernel adds the per-block partials and performs the update step.  (A
-// "last block finishes the job" variant was measured 10x slower: the device-scope fences it needs write back and
-// invalidate the XCD's L2 once per block.)
+// in a fixed order per block; icp_solve_kernel adds the per-block partials and performs the update step.
+// ("Last block finishes the job" inside this launch was measured twice and lost both times: with plain stores +
+// __threadfence() the release writes back / invalidates the XCD's L2 once per block (10x slower); with write-through
+// device-scope stores, a drained vmcnt and a relaxed ticket it still adds ~13 us at 485 blocks -- the same-address
+// ticket atomics serialise at ~12 ns each and the last block reads 170 KB through sc1 loads -- against ~11 us for
+// the boundary + the 1024-thread solve kernel.)
 constexpr int kIWaves = 4;
 constexpr int kIRows = kIWaves * kLRows;
 __global__ __launch_bounds__(256) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
