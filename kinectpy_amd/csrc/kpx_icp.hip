@@ -1213,12 +1213,12 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
     return KPX_OK;
 }
 
-// ---- several registrations onto one shared target, software-pipelined on ONE stream ------------------------------
+// ---- several registrations onto one shared target -----------------------------------------------------------------
 // (preprocessing/data.py:144-161 registers every sub device onto the same master cloud.)  The target operand is
-// prepared once.  Iterations of the problems are queued round-robin on the caller's stream; a problem's convergence
-// flag is read back through a side stream that only waits for that problem's last kernel, and its next iteration is
-// queued while the other problems' sweeps are still running -- the GPU never waits for the host round trip, and
-// kernels never overlap (per-launch timings stay those of a solo kernel).
+// prepared once on the caller's stream; the problems then run side by side on internal lanes (their kernels are
+// short and latency-bound: one problem alone leaves most of the chip idle), each with two chunks of iterations in
+// flight and its state copied to pinned memory after every chunk, so neither the lanes nor the host wait for a round
+// trip.  The caller's stream continues after all lanes have finished.
 KPX_EXPORT size_t kpx_icp_batch_workspace_bytes(int32_t count, const int64_t *h_n_src, int64_t n_tgt)
 {
     Arena a(nullptr, 0);
@@ -1249,8 +1249,20 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     for (int i = 0; i < count; ++i)
         KPX_REQUIRE(h_src[i] && h_n_src[i] >= 1 && h_n_src[i] < ((int64_t)1 << 31), "kpx_icp_batch: bad source cloud %d", i);
     hipStream_t st = (hipStream_t)stream;
-    static hipStream_t side = nullptr;                  // library-internal, created once
-    if (!side) KPX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    // library-internal lanes, created once: the problems of a batch are independent chains of short, latency-bound
+    // kernels, so they run on kBatchLanes streams side by side (forked from / joined to the caller's stream by events)
+    constexpr int kBatchLanes = 4;
+    static hipStream_t lanes[kBatchLanes] = {};
+    static hipEvent_t ev_fork = nullptr, ev_join[kBatchLanes] = {};
+    static IcpState *h_states = nullptr;                // pinned: two poll slots per problem
+    if (!h_states) {
+        for (int l = 0; l < kBatchLanes; ++l) {
+            KPX_HIP(hipStreamCreateWithFlags(&lanes[l], hipStreamNonBlocking));
+            KPX_HIP(hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming));
+        }
+        KPX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        KPX_HIP(hipHostMalloc((void **)&h_states, 64 * 2 * sizeof(IcpState), hipHostMallocDefault));
+    }
     Arena a(ws, ws_bytes);
     NnPlan plans[64];
     NnBuffers bufs[64] = {};
@@ -1271,58 +1283,70 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     KPX_ARENA_CHECK(a);
     int rc = nn_prep(tgt, tplan, bufs[0], st);
     if (rc) return rc;
-    hipEvent_t ev[64];
-    for (int i = 0; i < count; ++i) KPX_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    hipEvent_t ev[64][2];
+    for (int i = 0; i < count; ++i)
+        for (int e = 0; e < 2; ++e) KPX_HIP(hipEventCreateWithFlags(&ev[i][e], hipEventDisableTiming));
     const double md2 = max_dist * max_dist;
-    int iter[64], queue[64], qn = 0;
     ScreenPolicy policy[64];
-    // culled engine: kChunk iterations per problem between two reads of its flag (an iteration is one short kernel;
-    // kernels behind a raised flag return at once)
-    const int chunk = local_engine() ? 4 : 1;
-    auto launch = [&](int i, int k) -> int {
-        if (local_engine()) {
-            for (int c = 0; c < chunk && k + c <= max_iteration; ++c)
-                icp_iter_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], md2, mode, k + c, max_iteration, relative_fitness,
-                                relative_rmse, d_results + 20 * i, st);
-            KPX_HIP(hipEventRecord(ev[i], st));
-            return KPX_OK;
+    // A chunk = `chunk` iterations of one problem followed by a copy of its state to a pinned slot and an event.  The
+    // culled engine keeps two chunks per problem in flight (an iteration is two short kernels; kernels behind a raised
+    // flag return at once), so a lane never waits for the host's round trip; the all-pairs engine polls every iteration
+    // (its sweep choice follows the polled state).
+    const int chunk = local_engine() ? 4 : 1, in_flight = local_engine() ? 2 : 1;
+    int next_k[64], enq[64], polled[64];
+    auto enqueue_chunk = [&](int i) -> int {
+        hipStream_t ls = lanes[i % kBatchLanes];
+        for (int c = 0; c < chunk && next_k[i] <= max_iteration; ++c, ++next_k[i]) {
+            const int k = next_k[i];
+            if (local_engine()) {
+                icp_iter_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], md2, mode, k, max_iteration, relative_fitness, relative_rmse,
+                                d_results + 20 * i, ls);
+            } else {
+                int r = nn_search_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], bufs[i].state->T, &bufs[i].state->done, k > 0,
+                                         policy[i].allow(k), md2, mode, ls);
+                if (r) return r;
+                hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, ls, bufs[i].part_acc, (int)cdiv(h_n_src[i], kMergeThreads),
+                                   h_n_src[i], mode, k, max_iteration, relative_fitness, relative_rmse, bufs[i].state, d_results + 20 * i);
+            }
         }
-        int r = nn_search_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], bufs[i].state->T, &bufs[i].state->done, k > 0,
-                                 policy[i].allow(k), md2, mode, st);
-        if (r) return r;
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, bufs[i].part_acc, (int)cdiv(h_n_src[i], kMergeThreads), h_n_src[i], mode, k,
-                           max_iteration, relative_fitness, relative_rmse, bufs[i].state, d_results + 20 * i);
-        KPX_HIP(hipEventRecord(ev[i], st));
+        const int slot = enq[i] & 1;
+        KPX_HIP(hipMemcpyAsync(&h_states[2 * i + slot], bufs[i].state, sizeof(IcpState), hipMemcpyDeviceToHost, ls));
+        KPX_HIP(hipEventRecord(ev[i][slot], ls));
+        ++enq[i];
         return KPX_OK;
     };
+    KPX_HIP(hipEventRecord(ev_fork, st));
+    const int used_lanes = count < kBatchLanes ? count : kBatchLanes;
+    for (int l = 0; l < used_lanes; ++l) KPX_HIP(hipStreamWaitEvent(lanes[l], ev_fork, 0));
     for (int i = 0; i < count && !rc; ++i) {
-        KPX_HIP(hipMemcpyAsync(bufs[i].T0, h_init + 16 * i, 16 * sizeof(double), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, bufs[i].state, bufs[i].T0);
-        rc = nn_prep_source(h_src[i], plans[i], bufs[i], st);
-        if (rc) break;
-        iter[i] = 0;
-        rc = launch(i, 0);
-        queue[qn++] = i;
+        hipStream_t ls = lanes[i % kBatchLanes];
+        KPX_HIP(hipMemcpyAsync(bufs[i].T0, h_init + 16 * i, 16 * sizeof(double), hipMemcpyHostToDevice, ls));
+        hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, ls, bufs[i].state, bufs[i].T0);
+        rc = nn_prep_source(h_src[i], plans[i], bufs[i], ls);
+        next_k[i] = 0; enq[i] = 0; polled[i] = 0;
+        for (int c = 0; c < in_flight && !rc && next_k[i] <= max_iteration; ++c) rc = enqueue_chunk(i);
     }
-    int head = 0;
-    while (!rc && head < qn) {
-        const int i = queue[head % 64];
-        ++head;
-        IcpState h_state;
-        rc = hipStreamWaitEvent(side, ev[i], 0) == hipSuccess ? KPX_OK : fail(KPX_ERR_HIP, "hipStreamWaitEvent failed");
-        if (rc) break;
-        if (hipMemcpyAsync(&h_state.fitness, &bufs[i].state->fitness, sizeof(IcpState) - offsetof(IcpState, fitness), hipMemcpyDeviceToHost,
-                           side) != hipSuccess ||
-            hipStreamSynchronize(side) != hipSuccess) { rc = fail(KPX_ERR_HIP, "convergence poll failed"); break; }
-        iter[i] += chunk - 1;                       // last iteration index already queued
-        if (h_state.done || iter[i] >= max_iteration) continue;
-        policy[i].observe(h_state.fitness, h_state.rmse);
-        ++iter[i];
-        rc = launch(i, iter[i]);
-        queue[qn % 64] = i;
-        ++qn;
+    for (bool busy = true; busy && !rc;) {
+        busy = false;
+        for (int i = 0; i < count && !rc; ++i) {
+            if (polled[i] >= enq[i]) continue;
+            busy = true;
+            const int slot = polled[i] & 1;
+            if (hipEventSynchronize(ev[i][slot]) != hipSuccess) { rc = fail(KPX_ERR_HIP, "convergence poll failed"); break; }
+            const IcpState hs = h_states[2 * i + slot];
+            ++polled[i];
+            if (hs.done || next_k[i] > max_iteration) continue;
+            policy[i].observe(hs.fitness, hs.rmse);
+            rc = enqueue_chunk(i);
+        }
     }
-    for (int i = 0; i < count; ++i) (void)hipEventDestroy(ev[i]);
+    for (int l = 0; l < used_lanes; ++l) {
+        if (hipEventRecord(ev_join[l], lanes[l]) != hipSuccess || hipStreamWaitEvent(st, ev_join[l], 0) != hipSuccess)
+            rc = rc ? rc : fail(KPX_ERR_HIP, "kpx_icp_batch: joining the lanes failed");
+    }
+    if (rc) for (int l = 0; l < used_lanes; ++l) (void)hipStreamSynchronize(lanes[l]);     // leave nothing in flight on an error
+    for (int i = 0; i < count; ++i)
+        for (int e = 0; e < 2; ++e) (void)hipEventDestroy(ev[i][e]);
     if (rc) return rc;
     KPX_LAUNCH_CHECK();
     return KPX_OK;
