@@ -119,6 +119,15 @@ int kpx_voxel_downsample(const float *pts, const float *col, const float *nrm, i
                          float *opts, float *ocol, float *onrm, int32_t *d_count, void *ws, size_t ws_bytes,
                          void *stream);
 
+/* The same for `count` independent clouds (the per-device clouds of one frame set, preprocessing/data.py:129-143 /
+ * registration.py:24-29 down-sample every device's cloud): the clouds are processed side by side on internal
+ * lanes; `stream` continues after all of them.  h_*: host arrays of device pointers (h_col / h_ocol may be NULL),
+ * d_counts: i32 [count] on the device. */
+size_t kpx_voxel_batch_workspace_bytes(int32_t count, const int64_t *h_n);
+int kpx_voxel_downsample_batch(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n,
+                               double voxel, float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws,
+                               size_t ws_bytes, void *stream);
+
 /* a8: PointCloud.remove_statistical_outlier(nb_neighbors, std_ratio) (filtering.py:24,
  * floor_removal.py:73, utils/processing.py:309).  keep_idx ascending, d_count = kept,
  * d_stats f64 [3] = (mean, std, threshold), d_avg f64 [n] (optional) = per-point mean kNN distance.

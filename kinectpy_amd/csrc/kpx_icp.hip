@@ -1249,20 +1249,15 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     for (int i = 0; i < count; ++i)
         KPX_REQUIRE(h_src[i] && h_n_src[i] >= 1 && h_n_src[i] < ((int64_t)1 << 31), "kpx_icp_batch: bad source cloud %d", i);
     hipStream_t st = (hipStream_t)stream;
-    // library-internal lanes, created once: the problems of a batch are independent chains of short, latency-bound
-    // kernels, so they run on kBatchLanes streams side by side (forked from / joined to the caller's stream by events)
-    constexpr int kBatchLanes = 4;
-    static hipStream_t lanes[kBatchLanes] = {};
-    static hipEvent_t ev_fork = nullptr, ev_join[kBatchLanes] = {};
+    // the problems of a batch are independent chains of short, latency-bound kernels: they run side by side on the
+    // library's internal lanes (kpx_internal.h), forked from / joined to the caller's stream by events
+    LaneSet *ln = nullptr;
+    int lrc = lanes_get(&ln);
+    if (lrc) return lrc;
+    hipStream_t *lanes = ln->s;
+    constexpr int kBatchLanes = kLaneCount;
     static IcpState *h_states = nullptr;                // pinned: two poll slots per problem
-    if (!h_states) {
-        for (int l = 0; l < kBatchLanes; ++l) {
-            KPX_HIP(hipStreamCreateWithFlags(&lanes[l], hipStreamNonBlocking));
-            KPX_HIP(hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming));
-        }
-        KPX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        KPX_HIP(hipHostMalloc((void **)&h_states, 64 * 2 * sizeof(IcpState), hipHostMallocDefault));
-    }
+    if (!h_states) KPX_HIP(hipHostMalloc((void **)&h_states, 64 * 2 * sizeof(IcpState), hipHostMallocDefault));
     Arena a(ws, ws_bytes);
     NnPlan plans[64];
     NnBuffers bufs[64] = {};
@@ -1315,9 +1310,8 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         ++enq[i];
         return KPX_OK;
     };
-    KPX_HIP(hipEventRecord(ev_fork, st));
     const int used_lanes = count < kBatchLanes ? count : kBatchLanes;
-    for (int l = 0; l < used_lanes; ++l) KPX_HIP(hipStreamWaitEvent(lanes[l], ev_fork, 0));
+    rc = lanes_fork(ln, st, used_lanes);
     for (int i = 0; i < count && !rc; ++i) {
         hipStream_t ls = lanes[i % kBatchLanes];
         KPX_HIP(hipMemcpyAsync(bufs[i].T0, h_init + 16 * i, 16 * sizeof(double), hipMemcpyHostToDevice, ls));
@@ -1340,9 +1334,9 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
             rc = enqueue_chunk(i);
         }
     }
-    for (int l = 0; l < used_lanes; ++l) {
-        if (hipEventRecord(ev_join[l], lanes[l]) != hipSuccess || hipStreamWaitEvent(st, ev_join[l], 0) != hipSuccess)
-            rc = rc ? rc : fail(KPX_ERR_HIP, "kpx_icp_batch: joining the lanes failed");
+    {
+        const int jrc = lanes_join(ln, st, used_lanes);
+        rc = rc ? rc : jrc;
     }
     if (rc) for (int l = 0; l < used_lanes; ++l) (void)hipStreamSynchronize(lanes[l]);     // leave nothing in flight on an error
     for (int i = 0; i < count; ++i)

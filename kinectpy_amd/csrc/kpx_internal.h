@@ -29,6 +29,19 @@ struct Grid {
 // target_per_cell: desired mean occupancy of non-empty cells.
 int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Grid *g, hipStream_t st);
 
+// ---- library-internal lanes ------------------------------------------------------------------------
+// Batched entry points run their independent problems (chains of short, latency-bound kernels) side by side on
+// kLaneCount internal streams: lanes_fork makes the lanes wait for everything queued on the caller's stream,
+// lanes_join makes the caller's stream wait for everything queued on the lanes.  Created at first use.
+constexpr int kLaneCount = 4;
+struct LaneSet {
+    hipStream_t s[kLaneCount];
+    hipEvent_t fork, join[kLaneCount];
+};
+int lanes_get(LaneSet **out);
+int lanes_fork(LaneSet *l, hipStream_t caller, int used);
+int lanes_join(LaneSet *l, hipStream_t caller, int used);
+
 // Column tiles (16 rows x 16 columns, 2048 flops each) the culled nearest-neighbour sweep has multiplied since the
 // last call; resets the device counter (kpx_icp.hip).
 double nn_local_take_visits();

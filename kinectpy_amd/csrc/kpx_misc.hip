@@ -92,6 +92,36 @@ __global__ __launch_bounds__(64) void bbox_final_kernel(const double *__restrict
         bbox[threadIdx.x] = v;
     }
 }
+int lanes_get(LaneSet **out)
+{
+    static LaneSet set;
+    static bool ready = false;
+    if (!ready) {
+        for (int l = 0; l < kLaneCount; ++l) {
+            KPX_HIP(hipStreamCreateWithFlags(&set.s[l], hipStreamNonBlocking));
+            KPX_HIP(hipEventCreateWithFlags(&set.join[l], hipEventDisableTiming));
+        }
+        KPX_HIP(hipEventCreateWithFlags(&set.fork, hipEventDisableTiming));
+        ready = true;
+    }
+    *out = &set;
+    return KPX_OK;
+}
+int lanes_fork(LaneSet *l, hipStream_t caller, int used)
+{
+    KPX_HIP(hipEventRecord(l->fork, caller));
+    for (int i = 0; i < used && i < kLaneCount; ++i) KPX_HIP(hipStreamWaitEvent(l->s[i], l->fork, 0));
+    return KPX_OK;
+}
+int lanes_join(LaneSet *l, hipStream_t caller, int used)
+{
+    for (int i = 0; i < used && i < kLaneCount; ++i) {
+        KPX_HIP(hipEventRecord(l->join[i], l->s[i]));
+        KPX_HIP(hipStreamWaitEvent(caller, l->join[i], 0));
+    }
+    return KPX_OK;
+}
+
 int bbox_f32(const float *pts, int64_t n, double *d_bbox6, double *ws_partials, hipStream_t st)
 {
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > kBboxBlocks ? kBboxBlocks : cdiv(n, 256 * 8)));

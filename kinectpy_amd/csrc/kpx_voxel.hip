@@ -127,3 +127,37 @@ KPX_EXPORT int kpx_voxel_downsample(const float *pts, const float *col, const fl
     Arena a(ws, ws_bytes);
     return voxel_impl(pts, col, nrm, n, voxel, opts, ocol, onrm, d_count, a, st);
 }
+
+KPX_EXPORT size_t kpx_voxel_batch_workspace_bytes(int32_t count, const int64_t *h_n)
+{
+    if (count < 1 || !h_n) return 0;
+    Arena a(nullptr, 0);
+    for (int i = 0; i < count; ++i) voxel_impl(nullptr, nullptr, nullptr, h_n[i], 1.0, nullptr, nullptr, nullptr, nullptr, a, nullptr);
+    return a.off;
+}
+KPX_EXPORT int kpx_voxel_downsample_batch(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n,
+                                          double voxel, float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws,
+                                          size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(voxel > 0.0, "voxel_size <= 0");
+    KPX_REQUIRE(count >= 1 && count <= 64 && h_pts && h_n && h_opts && d_counts && ws, "kpx_voxel_downsample_batch: bad arguments");
+    for (int i = 0; i < count; ++i)
+        KPX_REQUIRE(h_n[i] >= 0 && h_n[i] < ((int64_t)1 << 31) && (h_n[i] == 0 || (h_pts[i] && h_opts[i])),
+                    "kpx_voxel_downsample_batch: bad cloud %d", i);
+    hipStream_t st = (hipStream_t)stream;
+    LaneSet *ln = nullptr;
+    int rc = lanes_get(&ln);
+    if (rc) return rc;
+    const int used = count < kLaneCount ? count : kLaneCount;
+    rc = lanes_fork(ln, st, used);
+    if (rc) return rc;
+    Arena a(ws, ws_bytes);
+    for (int i = 0; i < count && !rc; ++i) {
+        hipStream_t ls = ln->s[i % kLaneCount];
+        if (h_n[i] == 0) { rc = hipMemsetAsync(d_counts + i, 0, sizeof(int32_t), ls) == hipSuccess ? KPX_OK : fail(KPX_ERR_HIP, "memset failed"); continue; }
+        rc = voxel_impl(h_pts[i], h_col ? h_col[i] : nullptr, nullptr, h_n[i], voxel, h_opts[i], (h_col && h_ocol) ? h_ocol[i] : nullptr, nullptr,
+                        d_counts + i, a, ls);
+    }
+    const int jrc = lanes_join(ln, st, used);
+    return rc ? rc : jrc;
+}

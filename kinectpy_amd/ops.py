@@ -203,6 +203,28 @@ def voxel_downsample(pts, voxel, col=None, nrm=None):
     return op[:m], (oc[:m] if oc is not None else None), (on[:m] if on is not None else None)
 
 
+def voxel_downsample_batch(clouds, voxel, cols=None):
+    """voxel_down_sample of several independent clouds in one call (processed side by side on the library's internal
+    lanes, one read-back for all counts).  Returns a list of (points, colours | None)."""
+    lib = L.load()
+    clouds = [_dev(p, torch.float32).reshape(-1, 3) for p in clouds]
+    cnt = len(clouds)
+    if cnt == 0:
+        return []
+    dev = clouds[0].device
+    cols = [_dev(c, torch.float32).reshape(-1, 3) for c in cols] if cols is not None else None
+    outs = [torch.empty((max(p.shape[0], 1), 3), dtype=torch.float32, device=dev) for p in clouds]
+    ocols = [torch.empty_like(o) for o in outs] if cols is not None else None
+    n_arr = np.array([p.shape[0] for p in clouds], dtype=np.int64)
+    arr = lambda ts: C.cast((C.c_void_p * cnt)(*[t.data_ptr() for t in ts]), C.c_void_p) if ts is not None else None
+    counts = torch.zeros(cnt, dtype=torch.int32, device=dev)
+    ws, wsz = L.workspace(lib.kpx_voxel_batch_workspace_bytes(cnt, n_arr.ctypes.data_as(C.c_void_p)))
+    L.check(lib.kpx_voxel_downsample_batch(cnt, arr(clouds), arr(cols), n_arr.ctypes.data_as(C.c_void_p), float(voxel), arr(outs),
+                                           arr(ocols), L.ptr(counts), ws, wsz, L.stream_ptr()))
+    ms = _count(counts)
+    return [(outs[i][: ms[i]], ocols[i][: ms[i]] if ocols is not None else None) for i in range(cnt)]
+
+
 def sor(pts, nb_neighbors, std_ratio, want_avg=False):
     """a8.  Returns keep_idx i32 (K), stats f64 (3) [mean, std, thr] (device), avg f64 (N)|None."""
     lib = L.load()

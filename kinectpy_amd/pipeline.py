@@ -47,7 +47,7 @@ class SensorGroupPipeline:
         full = ops.depth_to_cloud(depth, self.xy, None, S, False, False)                 # registration input
         masked = ops.depth_to_cloud(depth, self.xy, rgb, S, True, True, gate=p.gate)     # person clouds
         # -- registration: every sub onto the master, exactly execute_point_to_plane_registration
-        downs = [ops.voxel_downsample(full[i][0], p.reg_voxel)[0] for i in range(S)]
+        downs = [d[0] for d in ops.voxel_downsample_batch([full[i][0] for i in range(S)], p.reg_voxel)]
         tn = ops.estimate_normals(downs[0], 2.0 * p.reg_voxel, p.normals_nn) if p.icp_mode == "p2plane" else None
         Ts = [np.eye(4)]
         stats = []

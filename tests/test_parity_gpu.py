@@ -158,6 +158,24 @@ def test_voxel_bit_exact(ops, oracle, base_cloud, voxel):
     assert np.array_equal(npy(gp), rp) and np.array_equal(npy(gc), rc) and np.array_equal(npy(gn), rn)
 
 
+def test_voxel_batch_equals_single_calls(ops, oracle, base_cloud):
+    """several clouds side by side (ragged sizes, one empty, seven > number of lanes): bit-identical to one call each"""
+    rng = np.random.default_rng(5)
+    clouds = [base_cloud, base_cloud[:5001] + 7.0, np.zeros((0, 3), np.float32), base_cloud[::3].copy(), base_cloud[:17],
+              (base_cloud[:30000] * 0.5).astype(np.float32), base_cloud[1000:1001]]
+    cols = [rng.random(c.shape).astype(np.float32) for c in clouds]
+    got = ops.voxel_downsample_batch(clouds, 35.0, cols)
+    assert len(got) == len(clouds)
+    for c, col, (gp, gc) in zip(clouds, cols, got):
+        if len(c) == 0:
+            assert gp.shape[0] == 0
+            continue
+        rp, rc, _ = oracle.voxel_downsample(c, 35.0, col)
+        assert np.array_equal(npy(gp), rp) and np.array_equal(npy(gc), rc)
+    nocol = ops.voxel_downsample_batch(clouds[:2], 10.0)
+    assert nocol[0][1] is None and np.array_equal(npy(nocol[0][0]), oracle.voxel_downsample(clouds[0], 10.0)[0])
+
+
 def test_voxel_edge_cases(ops, oracle):
     from kinectpy_amd._lib import KinectPxError
     one = np.array([[1.0, 2.0, 3.0]], np.float32)
