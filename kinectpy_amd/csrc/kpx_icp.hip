@@ -721,7 +721,7 @@ namespace kpx {
 // the boundary + the 1024-thread solve kernel.)
 constexpr int kIWaves = 4;
 constexpr int kIRows = kIWaves * kLRows;
-__global__ __launch_bounds__(256) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
