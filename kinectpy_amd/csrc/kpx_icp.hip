@@ -1256,7 +1256,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     if (lrc) return lrc;
     hipStream_t *lanes = ln->s;
     constexpr int kBatchLanes = kLaneCount;
-    static IcpState *h_states = nullptr;                // pinned: two poll slots per problem
+    static thread_local IcpState *h_states = nullptr;   // pinned: two poll slots per problem (per calling thread)
     if (!h_states) KPX_HIP(hipHostMalloc((void **)&h_states, 64 * 2 * sizeof(IcpState), hipHostMallocDefault));
     Arena a(ws, ws_bytes);
     NnPlan plans[64];

@@ -207,16 +207,20 @@ __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *
 #pragma unroll
         for (int a = 0; a < 3; ++a) c[a] = cell_coord(q[a], g.org[a], g.h, g.dim[a]);
 
-        // Gathers d^2 of every point of the block [c-r, c+r] into vals; returns the count, -1 if it exceeds the buffer.
-        // Every (x, y) column of the block is one contiguous run of the cell-sorted points: 64 columns at a time, lane c
-        // looks up run c, a wave scan places the runs, then the lanes fetch the candidates of the chunk together.
-        auto gather_block = [&](int r) -> int {
+        // Gathers into vals the d^2 <= tau of the points of the block [c-r, c+r]; returns the count.  When the buffer
+        // fills, gathering stops and `truncated` is set (the cap candidates held are still real points: their k-th
+        // smallest bounds the true k-th distance).  Every (x, y) column of the block is one contiguous run of the
+        // cell-sorted points: 64 columns at a time, lane c looks up run c, a wave scan places the runs, then the lanes
+        // fetch the candidates of the chunk together and append the ones that pass (ballot + popcount).
+        bool truncated = false;
+        auto gather_block = [&](int r, double tau) -> int {
             const int xa = c[0] - r < 0 ? 0 : c[0] - r, xb = c[0] + r >= g.dim[0] ? g.dim[0] - 1 : c[0] + r;
             const int ya = c[1] - r < 0 ? 0 : c[1] - r, yb = c[1] + r >= g.dim[1] ? g.dim[1] - 1 : c[1] + r;
             const int za = c[2] - r < 0 ? 0 : c[2] - r, zb = c[2] + r >= g.dim[2] ? g.dim[2] - 1 : c[2] + r;
             const int ny = yb - ya + 1, ncols = (xb - xa + 1) * ny;
             int m = 0;
-            for (int c0 = 0; c0 < ncols; c0 += 64) {
+            truncated = false;
+            for (int c0 = 0; c0 < ncols && !truncated; c0 += 64) {
                 const int nruns = ncols - c0 < 64 ? ncols - c0 : 64;
                 uint32_t s0 = 0;
                 int len = 0;
@@ -229,34 +233,43 @@ __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *
                 const int incl = wave_incl_scan(len);
                 const int mc = __shfl(incl, 63, 64);
                 if (mc == 0) continue;
-                if (m + mc > cap) return -1;
                 run_s0[wave][lane] = s0;
                 run_off[wave][lane] = incl - len;
                 wave_lds_fence();
-                for (int t = lane; t < mc; t += 64) {
-                    int lo = 0, hi = nruns - 1;                                    // last run with off <= t
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (run_off[wave][mid] <= t) lo = mid; else hi = mid - 1;
+                for (int t0 = 0; t0 < mc; t0 += 64) {
+                    const int t = t0 + lane;
+                    double d = INFINITY;
+                    if (t < mc) {
+                        int lo = 0, hi = nruns - 1;                                // last run with off <= t
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (run_off[wave][mid] <= t) lo = mid; else hi = mid - 1;
+                        }
+                        const float *pp = spts + 3 * (int64_t)(run_s0[wave][lo] + (uint32_t)(t - run_off[wave][lo]));
+                        const double dx = q[0] - (double)pp[0], dy = q[1] - (double)pp[1], dz = q[2] - (double)pp[2];
+                        d = fma(dz, dz, fma(dy, dy, dx * dx));
                     }
-                    const float *pp = spts + 3 * (int64_t)(run_s0[wave][lo] + (uint32_t)(t - run_off[wave][lo]));
-                    const double dx = q[0] - (double)pp[0], dy = q[1] - (double)pp[1], dz = q[2] - (double)pp[2];
-                    vals[m + t] = fma(dz, dz, fma(dy, dy, dx * dx));
+                    const bool keep = t < mc && d <= tau;
+                    const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+                    const int pos = m + __builtin_popcountll(km & ((1ull << lane) - 1ull));
+                    if (keep && pos < cap) vals[pos] = d;
+                    m += __builtin_popcountll(km);
+                    if (m >= cap) { m = cap; truncated = true; break; }
                 }
                 wave_lds_fence();
-                m += mc;
             }
             return m;
         };
 
         bool have = false, over = false;
-        double total = 0.0;
+        double total = 0.0, tau = INFINITY;
         int used = 0, r = 1;
-        while (!have && !over) {
-            const int m = gather_block(r);
-            if (m < 0) { over = true; break; }
+        for (int round = 0; !have && !over; ++round) {
+            if (round > 24) { over = true; break; }            // safety net: hand the query to the next pass
+            const int m = gather_block(r, tau);
+            wave_lds_fence();
             const double cov2 = block_cover2(g, q, c, r);
-            if (m < k && cov2 != INFINITY) {                    // too few candidates: grow by the density seen so far
+            if (!truncated && m < k && cov2 != INFINITY) {     // too few candidates: grow by the density seen so far
                 const double f = cbrt((double)(k + 1) / (double)(m > 0 ? m : 1));
                 int rn = (int)((double)r * (f < 4.0 ? f : 4.0)) + 1;
                 r = rn > r ? rn : r + 1;
@@ -293,16 +306,18 @@ __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); top = fmax(top, __shfl_xor(top, o, 64)); }
-            if (cov2 == INFINITY || top < cov2) {
+            if (!truncated && (cov2 == INFINITY || top < cov2)) {
                 total = sum - (double)(cnt - kk) * sqrt(top);   // ties at the k-th value beyond the k-th slot
                 used = kk;
                 have = true;
             } else {
-                // the k-th candidate lies outside the covered distance: it bounds the true k-th distance, so the block
-                // that covers it settles the query
+                // the k-th candidate found so far bounds the true k-th distance: gather again, only what lies within
+                // it, from the block that covers it -- that settles the query unless even the ball overflows the buffer
+                if (truncated && top >= tau) { over = true; break; }
+                tau = top;
                 int rn = (int)(sqrt(top) / g.h) + 1;
-                r = rn > r ? rn : r + 1;
-                if (r > maxr) r = maxr;
+                if (rn > maxr) rn = maxr;
+                r = rn;
             }
             wave_lds_fence();
         }
@@ -379,10 +394,8 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     int kk = (int64_t)k < n ? k : (int)(n > 0 ? n : 1);
     // cell occupancy (as seen by a point) ~0.4 k: the 27-cell block then holds ~10 k candidates and usually covers the
     // k-th neighbour
-    // (k > 40: the thread-per-query ring walk with its measured optimum of ~48 is still the faster kernel)
-    const bool wave_path = kk <= 40;
-    double occ = wave_path ? 0.4 * (double)kk : 48.0;
-    occ = occ < 6.0 ? 6.0 : occ;
+    double occ = 0.4 * (double)kk;
+    occ = occ < 6.0 ? 6.0 : (occ > 96.0 ? 96.0 : occ);
     int rc = grid_build(pts, n, occ, a, &g, st);
     if (rc) return rc;
     double *avg = a.get<double>((size_t)(n > 0 ? n : 1));
@@ -408,20 +421,15 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     {
         ProfScope prof(KPX_PROF_SOR_KNN, 12.0 * (double)n + 8.0 * (double)n, st);     // read points, write mean distances
         const int32_t *none = nullptr;
-        if (wave_path) {
-            // pass 1: every query, 1024-candidate buffer (many waves per CU)
-            hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256), (size_t)4 * 1024 * 8, st,
-                               g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk, 1024, avg, none, none, fb_list, fb_count);
-            // pass 2: the queries whose block did not fit (isolated points next to a dense sheet), 8192-candidate buffer
-            hipLaunchKernelGGL(sor_wave_kernel<1>, dim3(2048), dim3(64), (size_t)8192 * 8, st, g.params, g.cell_start, g.sorted_pts,
-                               g.sorted_idx, n, kk, 8192, avg, fb_list, fb_count, fb_list2, fb_count2);
-            // pass 3: whatever is left: thread-per-query ring walk with a k-heap
-            hipLaunchKernelGGL(sor_knn_kernel, dim3(256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk,
-                               avg, fb_list2, fb_count2);
-        } else {
-            hipLaunchKernelGGL(sor_knn_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts,
-                               g.sorted_idx, n, kk, avg, none, none);
-        }
+        // pass 1: every query, 1024-candidate buffer (k <= KPX_SOR_MAX_K = 288 < 1024; many waves per CU)
+        hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256), (size_t)4 * 1024 * 8, st,
+                           g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk, 1024, avg, none, none, fb_list, fb_count);
+        // pass 2: the queries whose block did not fit (isolated points next to a dense sheet), 8192-candidate buffer
+        hipLaunchKernelGGL(sor_wave_kernel<1>, dim3(2048), dim3(64), (size_t)8192 * 8, st, g.params, g.cell_start, g.sorted_pts,
+                           g.sorted_idx, n, kk, 8192, avg, fb_list, fb_count, fb_list2, fb_count2);
+        // pass 3: whatever is left: thread-per-query ring walk with a k-heap
+        hipLaunchKernelGGL(sor_knn_kernel, dim3(256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk,
+                           avg, fb_list2, fb_count2);
     }
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
     for (int pass = 0; pass < 2; ++pass) {

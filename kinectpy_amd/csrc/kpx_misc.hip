@@ -94,15 +94,21 @@ __global__ __launch_bounds__(64) void bbox_final_kernel(const double *__restrict
 }
 int lanes_get(LaneSet **out)
 {
-    static LaneSet set;
-    static bool ready = false;
-    if (!ready) {
+    // one set per device (streams belong to the device that was current when they were created)
+    constexpr int kMaxDevices = 16;
+    static LaneSet sets[kMaxDevices];
+    static bool ready[kMaxDevices] = {};
+    int dev = 0;
+    KPX_HIP(hipGetDevice(&dev));
+    KPX_REQUIRE(dev >= 0 && dev < kMaxDevices, "lanes_get: device ordinal %d out of range", dev);
+    LaneSet &set = sets[dev];
+    if (!ready[dev]) {
         for (int l = 0; l < kLaneCount; ++l) {
             KPX_HIP(hipStreamCreateWithFlags(&set.s[l], hipStreamNonBlocking));
             KPX_HIP(hipEventCreateWithFlags(&set.join[l], hipEventDisableTiming));
         }
         KPX_HIP(hipEventCreateWithFlags(&set.fork, hipEventDisableTiming));
-        ready = true;
+        ready[dev] = true;
     }
     *out = &set;
     return KPX_OK;
