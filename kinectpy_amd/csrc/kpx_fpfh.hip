@@ -14,6 +14,8 @@
 
 namespace kpx {
 
+constexpr double kSentinelF = 1e300;
+
 // ---- neighbour lists ------------------------------------------------------------------------------------------
 __global__ void nbr_list_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
                                 const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t n, int k, double r2,
@@ -133,32 +135,91 @@ __global__ __launch_bounds__(kFeatThreads) void fpfh_kernel(int64_t n, const int
 }
 
 // ---- 33-D feature nearest neighbour -----------------------------------------------------------------------------
-// thread = query row held in registers; targets staged through LDS, read as broadcasts.  d = fma(e,e,d), k = 0..32,
-// strict "<" over ascending target index (ties -> lowest index): identical to the oracle.
-constexpr int kFnnThreads = 128, kFnnTile = 64;
-__global__ __launch_bounds__(kFnnThreads) void feature_nn_kernel(const double *__restrict__ fa, int64_t na, const double *__restrict__ fb,
-                                                                 int64_t nb, int32_t *__restrict__ idx)
+// The matching stage is a dense all-pairs problem (no spatial structure to cull in 33-D): fp64 MFMA distance tiles in
+// the augmented form, K = 36:
+//     A[i] = (a_0 .. a_32, 1, 0, 0)        B[j] = (-2 b_0 .. -2 b_32, |b_j|^2, 0, 0)        C[i] = |a_i|^2
+//     D_ij = fma chain over k = 0 .. 35 of A_ik B_kj seeded with C_i     (nine v_mfma_f64_16x16x4_f64 per tile;
+//     |x|^2 = fma chain x_k x_k from 0)  -> argmin_j, ties to the lowest j.  The oracle restates the same chain.
+// Block = 4 waves x 16 query rows; 64 target columns per stage go through LDS (row-major, stride 37 doubles:
+// conflict-free for the 16 columns a lane group reads), their norms are formed once per stage.
+typedef double fnn_d4 __attribute__((ext_vector_type(4)));
+constexpr int kFnnCols = 64, kFnnStride = 37;
+__global__ __launch_bounds__(256) void feature_nn_kernel(const double *__restrict__ fa, int64_t na, const double *__restrict__ fb,
+                                                         int64_t nb, int32_t *__restrict__ idx)
 {
-    __shared__ double tile[kFnnTile][33];
-    const int64_t i = (int64_t)blockIdx.x * kFnnThreads + threadIdx.x;
-    double q[33];
+    __shared__ double sb[kFnnCols][kFnnStride];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    // A operand: component k = q + 4 s of row j
+    double a[9];
 #pragma unroll
-    for (int k = 0; k < 33; ++k) q[k] = i < na ? fa[i * 33 + k] : 0.0;
-    double best = INFINITY;
-    int32_t bj = 0;
-    for (int64_t j0 = 0; j0 < nb; j0 += kFnnTile) {
-        const int cntj = nb - j0 < kFnnTile ? (int)(nb - j0) : kFnnTile;
-        __syncthreads();
-        for (int t = threadIdx.x; t < cntj * 33; t += kFnnThreads) (&tile[0][0])[t] = fb[j0 * 33 + t];
-        __syncthreads();
-        for (int j = 0; j < cntj; ++j) {
-            double d = 0.0;
+    for (int s = 0; s < 9; ++s) {
+        const int k = q + 4 * s;
+        const int64_t row = row_base + j;
+        a[s] = k < 33 ? (row < na ? fa[row * 33 + k] : 0.0) : (k == 33 ? 1.0 : 0.0);
+    }
+    // C operand: |a|^2 of the rows this lane sees in D (row = q + 4 r)
+    fnn_d4 seed;
 #pragma unroll
-            for (int k = 0; k < 33; ++k) { const double e = q[k] - tile[j][k]; d = fma(e, e, d); }
-            if (d < best) { best = d; bj = (int32_t)(j0 + j); }
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row_base + q + 4 * r;
+        double n2 = 0.0;
+        if (row < na)
+            for (int k = 0; k < 33; ++k) { const double v = fa[row * 33 + k]; n2 = fma(v, v, n2); }
+        seed[r] = n2;
+    }
+    double best[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
+    int32_t bcol[4] = { INT_MAX, INT_MAX, INT_MAX, INT_MAX };
+    for (int64_t j0 = 0; j0 < nb; j0 += kFnnCols) {
+        const int cnt = nb - j0 < kFnnCols ? (int)(nb - j0) : kFnnCols;
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * 33; e += 256) sb[e / 33][e % 33] = fb[j0 * 33 + e];
+        __syncthreads();
+        if ((int)threadIdx.x < kFnnCols) {
+            double n2 = kSentinelF;                            // columns past the end can never win
+            if ((int)threadIdx.x < cnt) {
+                n2 = 0.0;
+                for (int k = 0; k < 33; ++k) { const double v = sb[threadIdx.x][k]; n2 = fma(v, v, n2); }
+            } else {
+                for (int k = 0; k < 33; ++k) sb[threadIdx.x][k] = 0.0;
+            }
+            sb[threadIdx.x][33] = n2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < kFnnCols / 16; ++ct) {
+            fnn_d4 acc = seed;
+            const double *col = sb[ct * 16 + j];
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const int k = q + 4 * s;
+                const double b = k < 33 ? -2.0 * col[k] : (k == 33 ? col[33] : 0.0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
+            }
+            const int32_t c = (int32_t)(j0 + ct * 16 + j);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool t = acc[r] < best[r];               // ascending columns per lane: first minimum kept
+                best[r] = t ? acc[r] : best[r];
+                bcol[r] = t ? c : bcol[r];
+            }
         }
     }
-    if (i < na) idx[i] = bj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double v = best[r];
+        int32_t c = bcol[r];
+#pragma unroll
+        for (int msk = 1; msk < 16; msk <<= 1) {
+            const double ov = __shfl_xor(v, msk, 64);
+            const int32_t oc = __shfl_xor(c, msk, 64);
+            const bool take = ov < v || (ov == v && oc < c);
+            v = take ? ov : v;
+            c = take ? oc : c;
+        }
+        const int64_t row = row_base + q + 4 * r;
+        if (j == 0 && row < na) idx[row] = c;
+    }
 }
 
 // ---- RANSAC hypotheses -----------------------------------------------------------------------------------------
@@ -427,7 +488,7 @@ KPX_EXPORT int kpx_feature_nn(const double *fa, int64_t na, const double *fb, in
     KPX_REQUIRE(na >= 0 && nb >= 1, "kpx_feature_nn: empty feature set");
     if (na == 0) return KPX_OK;
     KPX_REQUIRE(fa && fb && idx, "kpx_feature_nn: null pointer");
-    hipLaunchKernelGGL(feature_nn_kernel, dim3((unsigned)cdiv(na, kFnnThreads)), dim3(kFnnThreads), 0, (hipStream_t)stream, fa, na, fb, nb, idx);
+    hipLaunchKernelGGL(feature_nn_kernel, dim3((unsigned)cdiv(na, 64)), dim3(256), 0, (hipStream_t)stream, fa, na, fb, nb, idx);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

@@ -825,16 +825,28 @@ KPO_API void kpo_fpfh(const float *pts, const float *nrm, int64_t n, const int32
 /* space, squared distance sum_k (a_k - b_k)^2 accumulated k = 0..32 with fma, ties -> lowest index.   */
 KPO_API void kpo_feature_nn(const double *fa, int64_t na, const double *fb, int64_t nb, int32_t *idx)
 {
+    /* metric of the matching stage (the product's MFMA chain, K = 36 augmented form): D = |a|^2, then */
+    /* D = fma(a_k, -2 b_k, D) for k = 0..32, then D = fma(1, |b|^2, D); |x|^2 = fma chain x_k x_k from 0 */
+    double *nb2 = (double *)malloc((size_t)(nb > 0 ? nb : 1) * sizeof(double));
+    for (int64_t j = 0; j < nb; ++j) {
+        double n2 = 0.0;
+        for (int k = 0; k < 33; ++k) n2 = fma(fb[33 * j + k], fb[33 * j + k], n2);
+        nb2[j] = n2;
+    }
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < na; ++i) {
-        double best = DBL_MAX; int64_t bj = 0;
+        double na2 = 0.0;
+        for (int k = 0; k < 33; ++k) na2 = fma(fa[33 * i + k], fa[33 * i + k], na2);
+        double best = INFINITY; int64_t bj = 0;
         for (int64_t j = 0; j < nb; ++j) {
-            double d = 0.0;
-            for (int k = 0; k < 33; ++k) { double e = fa[33 * i + k] - fb[33 * j + k]; d = fma(e, e, d); }
+            double d = na2;
+            for (int k = 0; k < 33; ++k) d = fma(fa[33 * i + k], -2.0 * fb[33 * j + k], d);
+            d = fma(1.0, nb2[j], d);
             if (d < best) { best = d; bj = j; }
         }
         idx[i] = (int32_t)bj;
     }
+    free(nb2);
 }
 
 /* Umeyama without scale on 3+ pairs by Horn's quaternion method (independent of the product's Jacobi/ */

@@ -124,7 +124,8 @@ def main():
     report("compute_fpfh_feature r=175 nn=40 (a11)", ms, n=int(views[0].shape[0]))
     f1 = ops.fpfh(views[1], nrm[1], 175.0, 40)
     ms, _ = timed(lambda: ops.feature_nn(f1, f0), reps=3, warm=1)
-    report("feature_nn 33-D (a13 matching)", ms, flops=3.0 * 33 * f1.shape[0] * f0.shape[0], na=int(f1.shape[0]), nb=int(f0.shape[0]))
+    report("feature_nn 33-D (a13 matching; fp64 MFMA, K = 36 augmented form)", ms, flops=2.0 * 36 * f1.shape[0] * f0.shape[0], na=int(f1.shape[0]),
+           nb=int(f0.shape[0]))
     corr = ops.feature_correspondences(f1, f0, True, 3)
     ms, r = timed(lambda: ops.ransac_corres(views[1], views[0], corr, 52.5, 3, 0.95, 250000, 0.999, 1), reps=2, warm=1)
     report("ransac feature matching 250k it (a13)", ms, corres=int(len(corr)), iterations=r["iterations"], validations=r["validations"],
