@@ -147,14 +147,16 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     return KPX_OK;
 }
 
-// ---- a8 SOR ------------------------------------------------------------------------------------------
-// One WAVE per query.  The lanes gather the squared distances (AC3, fp64) of every point of the (2r+1)^3 cell block
-// around the query into LDS, shell by shell; as soon as the block holds k candidates the k-th smallest is found by
-// bisection on the IEEE bit patterns (d^2 >= 0: the patterns order like the values; one ballot + popcount per 64
-// candidates and step) and the walk ends when that value lies inside the distance the block covers -- the same
-// termination rule as the ring walk of kpx_gridknn.h.  The mean needs no identities: sum of sqrt over the selected
-// set, ties at the k-th value counted k - (#smaller) times.  Queries whose candidates exceed the LDS buffer are
-// listed and finished by the thread-per-query ring walk below.
+// ---- wave-per-query neighbour selection (SOR, normals) -------------------------------------------------------
+// The lanes gather the squared distances (AC3, fp64) of the points of the (2r+1)^3 cell block around the query into
+// LDS (every (x, y) column of the block is one contiguous run of the cell-sorted points: 64 columns at a time, lane c
+// looks up run c, a wave scan places the runs, all candidates of the chunk are fetched together and the ones that pass
+// d^2 <= tau, d^2 < r2max are appended by ballot + popcount).  The k-th smallest is found by bisection on the IEEE
+// bit patterns (d^2 >= 0: the patterns order like the values; one ballot + popcount per 64 candidates and step) and
+// the search ends when that value lies inside the distance the block covers -- the termination rule of the ring walk
+// of kpx_gridknn.h.  Otherwise the k-th candidate found so far bounds the true k-th distance: the candidates are
+// gathered again, only those within it, from the block that covers it.  When the buffer fills, gathering stops; the
+// cap candidates held are still real points, so their k-th smallest is a valid bound too.
 __device__ __forceinline__ unsigned long long wave_all_min_u64(unsigned long long v)
 {
 #pragma unroll
@@ -184,6 +186,149 @@ __device__ __forceinline__ double block_cover2(const GridParams &g, const double
     return dcov * dcov * (1.0 - 1e-12);
 }
 
+struct WaveKnnScratch {        // LDS owned by one wave
+    double *vals;              // cap candidate distances
+    uint32_t *pos;             // cap sorted positions of the candidates (POS only)
+    uint32_t *run_s0;          // 64
+    int32_t *run_off;          // 64
+    int cap;
+};
+struct WaveKnnResult {
+    int m;                     // candidates in vals / pos
+    int kk;                    // neighbours selected: min(k, points within r2max)
+    int cnt;                   // candidates with pattern <= thr (>= kk: ties at the k-th value)
+    unsigned long long thr;    // bit pattern: the selected set is {d^2 pattern <= thr}
+    double top;                // largest selected d^2
+};
+// Returns false when the query does not fit the buffer (the caller hands it to the next pass).
+template <bool POS>
+__device__ __forceinline__ bool wave_knn_select(const GridParams &g, const uint32_t *__restrict__ cell_start, const float *__restrict__ spts,
+                                                const double q[3], int k, double r2max, const WaveKnnScratch &sc, WaveKnnResult &out)
+{
+    const int lane = threadIdx.x & 63;
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = cell_coord(q[a], g.org[a], g.h, g.dim[a]);
+    int maxr = g.dim[0] > g.dim[1] ? g.dim[0] : g.dim[1];
+    if (g.dim[2] > maxr) maxr = g.dim[2];
+    bool truncated = false;
+    auto gather_block = [&](int r, double tau) -> int {
+        const int xa = c[0] - r < 0 ? 0 : c[0] - r, xb = c[0] + r >= g.dim[0] ? g.dim[0] - 1 : c[0] + r;
+        const int ya = c[1] - r < 0 ? 0 : c[1] - r, yb = c[1] + r >= g.dim[1] ? g.dim[1] - 1 : c[1] + r;
+        const int za = c[2] - r < 0 ? 0 : c[2] - r, zb = c[2] + r >= g.dim[2] ? g.dim[2] - 1 : c[2] + r;
+        const int ny = yb - ya + 1, ncols = (xb - xa + 1) * ny;
+        int m = 0;
+        truncated = false;
+        for (int c0 = 0; c0 < ncols && !truncated; c0 += 64) {
+            const int nruns = ncols - c0 < 64 ? ncols - c0 : 64;
+            uint32_t s0 = 0;
+            int len = 0;
+            if (lane < nruns) {
+                const int x = xa + (c0 + lane) / ny, y = ya + (c0 + lane) % ny;
+                const int64_t col = ((int64_t)x * g.dim[1] + y) * g.dim[2];
+                s0 = cell_start[col + za];
+                len = (int)(cell_start[col + zb + 1] - s0);
+            }
+            const int incl = wave_incl_scan(len);
+            const int mc = __shfl(incl, 63, 64);
+            if (mc == 0) continue;
+            sc.run_s0[lane] = s0;
+            sc.run_off[lane] = incl - len;
+            wave_lds_fence();
+            for (int t0 = 0; t0 < mc; t0 += 64) {
+                const int t = t0 + lane;
+                double d = INFINITY;
+                uint32_t sp = 0;
+                if (t < mc) {
+                    int lo = 0, hi = nruns - 1;                                    // last run with off <= t
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (sc.run_off[mid] <= t) lo = mid; else hi = mid - 1;
+                    }
+                    sp = sc.run_s0[lo] + (uint32_t)(t - sc.run_off[lo]);
+                    const float *pp = spts + 3 * (int64_t)sp;
+                    const double dx = q[0] - (double)pp[0], dy = q[1] - (double)pp[1], dz = q[2] - (double)pp[2];
+                    d = fma(dz, dz, fma(dy, dy, dx * dx));
+                }
+                const bool keep = t < mc && d <= tau && d < r2max;
+                const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+                const int pos = m + __builtin_popcountll(km & ((1ull << lane) - 1ull));
+                if (keep && pos < sc.cap) {
+                    sc.vals[pos] = d;
+                    if (POS) sc.pos[pos] = sp;
+                }
+                m += __builtin_popcountll(km);
+                if (m >= sc.cap) { m = sc.cap; truncated = true; break; }
+            }
+            wave_lds_fence();
+        }
+        return m;
+    };
+
+    double tau = INFINITY;
+    int r = 1;
+    for (int round = 0; round <= 24; ++round) {                // safety net: past it the query goes to the next pass
+        const int m = gather_block(r, tau);
+        wave_lds_fence();
+        const double cov2 = block_cover2(g, q, c, r);
+        const bool whole = cov2 == INFINITY || cov2 >= r2max;   // the block holds everything that may be selected
+        if (!truncated && m < k && !whole) {                    // too few candidates: grow by the density seen so far
+            const double f = cbrt((double)(k + 1) / (double)(m > 0 ? m : 1));
+            int rn = (int)((double)r * (f < 4.0 ? f : 4.0)) + 1;
+            r = rn > r ? rn : r + 1;
+            if (r > maxr) r = maxr;
+            continue;
+        }
+        const int kk = m < k ? m : k;
+        // k-th smallest by bisection between the smallest and the largest pattern
+        unsigned long long lo = ~0ull, hi = 0ull;
+        for (int t = lane; t < m; t += 64) {
+            const unsigned long long p = (unsigned long long)__double_as_longlong(sc.vals[t]);
+            lo = p < lo ? p : lo; hi = p > hi ? p : hi;
+        }
+        lo = wave_all_min_u64(lo); hi = wave_all_max_u64(hi);
+        if (m <= k) lo = hi;                                    // everything gathered is selected: no search needed
+        if (m == 0) { lo = hi = 0ull; }
+        while (lo < hi) {
+            const unsigned long long mid = lo + ((hi - lo) >> 1);
+            int cnt = 0;
+            for (int t0 = 0; t0 < m; t0 += 64) {
+                const int t = t0 + lane;
+                const bool le = t < m && (unsigned long long)__double_as_longlong(sc.vals[t]) <= mid;
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
+            }
+            if (cnt == kk) { lo = hi = mid; break; }           // the set is determined
+            if (cnt > kk) hi = mid; else lo = mid + 1;
+        }
+        double top = 0.0;
+        int cnt = 0;
+        for (int t0 = 0; t0 < m; t0 += 64) {
+            const int t = t0 + lane;
+            const bool le = t < m && (unsigned long long)__double_as_longlong(sc.vals[t]) <= lo;
+            if (le) top = fmax(top, sc.vals[t]);
+            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) top = fmax(top, __shfl_xor(top, o, 64));
+        if (!truncated && (whole || top < cov2)) {
+            out.m = m; out.kk = kk; out.cnt = cnt; out.thr = lo; out.top = top;
+            return true;
+        }
+        // the k-th candidate found so far bounds the true k-th distance: gather again, only what lies within it, from
+        // the block that covers it -- that settles the query unless even the ball overflows the buffer
+        if (truncated && top >= tau) return false;
+        tau = top;
+        int rn = (int)(sqrt(top) / g.h) + 1;
+        if (rn > maxr) rn = maxr;
+        r = rn;
+        wave_lds_fence();
+    }
+    return false;
+}
+
+// ---- a8 SOR ------------------------------------------------------------------------------------------
+// One WAVE per query; the mean needs no identities: sum of sqrt over the selected set, ties at the k-th value counted
+// k - (#smaller) times.  Queries whose candidates exceed the LDS buffer are listed for the next pass.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
                                                               const float *__restrict__ spts, const int32_t *__restrict__ sidx,
@@ -193,139 +338,29 @@ __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *
 {
     extern __shared__ __align__(16) double lds[];
     __shared__ uint32_t run_s0[WAVES][64];
-    __shared__ int32_t run_off[WAVES][65];
+    __shared__ int32_t run_off[WAVES][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *vals = lds + (size_t)wave * cap;
+    const WaveKnnScratch sc{ lds + (size_t)wave * cap, nullptr, run_s0[wave], run_off[wave], cap };
     const GridParams g = *gp;
-    int maxr = g.dim[0] > g.dim[1] ? g.dim[0] : g.dim[1];
-    if (g.dim[2] > maxr) maxr = g.dim[2];
     const int64_t nq = in_list ? (int64_t)*in_count : n;         // in_list: the queries an earlier pass could not hold
     for (int64_t e = (int64_t)blockIdx.x * WAVES + wave; e < nq; e += (int64_t)gridDim.x * WAVES) {
         const int64_t s = in_list ? (int64_t)in_list[e] : e;
         const double q[3] = { (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2] };
-        int c[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) c[a] = cell_coord(q[a], g.org[a], g.h, g.dim[a]);
-
-        // Gathers into vals the d^2 <= tau of the points of the block [c-r, c+r]; returns the count.  When the buffer
-        // fills, gathering stops and `truncated` is set (the cap candidates held are still real points: their k-th
-        // smallest bounds the true k-th distance).  Every (x, y) column of the block is one contiguous run of the
-        // cell-sorted points: 64 columns at a time, lane c looks up run c, a wave scan places the runs, then the lanes
-        // fetch the candidates of the chunk together and append the ones that pass (ballot + popcount).
-        bool truncated = false;
-        auto gather_block = [&](int r, double tau) -> int {
-            const int xa = c[0] - r < 0 ? 0 : c[0] - r, xb = c[0] + r >= g.dim[0] ? g.dim[0] - 1 : c[0] + r;
-            const int ya = c[1] - r < 0 ? 0 : c[1] - r, yb = c[1] + r >= g.dim[1] ? g.dim[1] - 1 : c[1] + r;
-            const int za = c[2] - r < 0 ? 0 : c[2] - r, zb = c[2] + r >= g.dim[2] ? g.dim[2] - 1 : c[2] + r;
-            const int ny = yb - ya + 1, ncols = (xb - xa + 1) * ny;
-            int m = 0;
-            truncated = false;
-            for (int c0 = 0; c0 < ncols && !truncated; c0 += 64) {
-                const int nruns = ncols - c0 < 64 ? ncols - c0 : 64;
-                uint32_t s0 = 0;
-                int len = 0;
-                if (lane < nruns) {
-                    const int x = xa + (c0 + lane) / ny, y = ya + (c0 + lane) % ny;
-                    const int64_t col = ((int64_t)x * g.dim[1] + y) * g.dim[2];
-                    s0 = cell_start[col + za];
-                    len = (int)(cell_start[col + zb + 1] - s0);
-                }
-                const int incl = wave_incl_scan(len);
-                const int mc = __shfl(incl, 63, 64);
-                if (mc == 0) continue;
-                run_s0[wave][lane] = s0;
-                run_off[wave][lane] = incl - len;
-                wave_lds_fence();
-                for (int t0 = 0; t0 < mc; t0 += 64) {
-                    const int t = t0 + lane;
-                    double d = INFINITY;
-                    if (t < mc) {
-                        int lo = 0, hi = nruns - 1;                                // last run with off <= t
-                        while (lo < hi) {
-                            const int mid = (lo + hi + 1) >> 1;
-                            if (run_off[wave][mid] <= t) lo = mid; else hi = mid - 1;
-                        }
-                        const float *pp = spts + 3 * (int64_t)(run_s0[wave][lo] + (uint32_t)(t - run_off[wave][lo]));
-                        const double dx = q[0] - (double)pp[0], dy = q[1] - (double)pp[1], dz = q[2] - (double)pp[2];
-                        d = fma(dz, dz, fma(dy, dy, dx * dx));
-                    }
-                    const bool keep = t < mc && d <= tau;
-                    const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
-                    const int pos = m + __builtin_popcountll(km & ((1ull << lane) - 1ull));
-                    if (keep && pos < cap) vals[pos] = d;
-                    m += __builtin_popcountll(km);
-                    if (m >= cap) { m = cap; truncated = true; break; }
-                }
-                wave_lds_fence();
-            }
-            return m;
-        };
-
-        bool have = false, over = false;
-        double total = 0.0, tau = INFINITY;
-        int used = 0, r = 1;
-        for (int round = 0; !have && !over; ++round) {
-            if (round > 24) { over = true; break; }            // safety net: hand the query to the next pass
-            const int m = gather_block(r, tau);
-            wave_lds_fence();
-            const double cov2 = block_cover2(g, q, c, r);
-            if (!truncated && m < k && cov2 != INFINITY) {     // too few candidates: grow by the density seen so far
-                const double f = cbrt((double)(k + 1) / (double)(m > 0 ? m : 1));
-                int rn = (int)((double)r * (f < 4.0 ? f : 4.0)) + 1;
-                r = rn > r ? rn : r + 1;
-                if (r > maxr) r = maxr;
-                continue;
-            }
-            const int kk = m < k ? m : k;                       // m < k only when the block is the whole grid
-            // k-th smallest by bisection between the smallest and the largest pattern
-            unsigned long long lo = ~0ull, hi = 0ull;
-            for (int t = lane; t < m; t += 64) {
-                const unsigned long long p = (unsigned long long)__double_as_longlong(vals[t]);
-                lo = p < lo ? p : lo; hi = p > hi ? p : hi;
-            }
-            lo = wave_all_min_u64(lo); hi = wave_all_max_u64(hi);
-            while (lo < hi) {
-                const unsigned long long mid = lo + ((hi - lo) >> 1);
-                int cnt = 0;
-                for (int t0 = 0; t0 < m; t0 += 64) {
-                    const int t = t0 + lane;
-                    const bool le = t < m && (unsigned long long)__double_as_longlong(vals[t]) <= mid;
-                    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
-                }
-                if (cnt == kk) { lo = hi = mid; break; }       // the set is determined
-                if (cnt > kk) hi = mid; else lo = mid + 1;
-            }
-            // sum of sqrt over the selected set, its largest member, its size
-            double sum = 0.0, top = 0.0;
-            int cnt = 0;
-            for (int t0 = 0; t0 < m; t0 += 64) {
-                const int t = t0 + lane;
-                const bool le = t < m && (unsigned long long)__double_as_longlong(vals[t]) <= lo;
-                if (le) { sum += sqrt(vals[t]); top = fmax(top, vals[t]); }
-                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); top = fmax(top, __shfl_xor(top, o, 64)); }
-            if (!truncated && (cov2 == INFINITY || top < cov2)) {
-                total = sum - (double)(cnt - kk) * sqrt(top);   // ties at the k-th value beyond the k-th slot
-                used = kk;
-                have = true;
-            } else {
-                // the k-th candidate found so far bounds the true k-th distance: gather again, only what lies within
-                // it, from the block that covers it -- that settles the query unless even the ball overflows the buffer
-                if (truncated && top >= tau) { over = true; break; }
-                tau = top;
-                int rn = (int)(sqrt(top) / g.h) + 1;
-                if (rn > maxr) rn = maxr;
-                r = rn;
-            }
-            wave_lds_fence();
-        }
-        if (over) {
+        WaveKnnResult res;
+        if (!wave_knn_select<false>(g, cell_start, spts, q, k, INFINITY, sc, res)) {
             if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = (int32_t)s;
             continue;
         }
-        if (lane == 0) avg[sidx[s]] = used > 0 ? total / (double)used : -1.0;
+        double sum = 0.0;
+        for (int t = lane; t < res.m; t += 64) {
+            const double d = sc.vals[t];
+            if ((unsigned long long)__double_as_longlong(d) <= res.thr) sum += sqrt(d);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const double total = sum - (double)(res.cnt - res.kk) * sqrt(res.top);      // ties beyond the k-th slot
+        if (lane == 0) avg[sidx[s]] = res.kk > 0 ? total / (double)res.kk : -1.0;
+        wave_lds_fence();
     }
 }
 
@@ -443,36 +478,141 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
 // ---- estimate_normals ---------------------------------------------------------------------------------
 __global__ void normals_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
                                const float *__restrict__ spts, const int32_t *__restrict__ sidx, const float *__restrict__ pts,
-                               int64_t n, int k, double r2, float *__restrict__ normals)
+                               int64_t n, int k, double r2, float *__restrict__ normals, const int32_t *__restrict__ list,
+                               const int32_t *__restrict__ list_count)
 {
     extern __shared__ __align__(16) double lds[];
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
+    const int64_t total = list ? (int64_t)*list_count : n;
     const GridParams g = *gp;
     int32_t *ilds = reinterpret_cast<int32_t *>(lds + (size_t)k * blockDim.x);
-    HeapDI heap{ lds + threadIdx.x, ilds + threadIdx.x, (int)blockDim.x, k, 0 };
-    grid_knn_scan(g, cell_start, spts, sidx, (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2], r2, heap);
-    const int64_t me = sidx[s];
-    double nx = 0.0, ny = 0.0, nz = 1.0;
-    if (heap.sz >= 3) {
-        double c[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        for (int e = 0; e < heap.sz; ++e) {
-            int64_t j = heap.ix[e * heap.stride];
-            double x = pts[3 * j], y = pts[3 * j + 1], z = pts[3 * j + 2];
-            c[0] += x; c[1] += y; c[2] += z;
-            c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
-        }
-        const double m = (double)heap.sz;
+    // one query per thread; list != NULL: only the queries list[0 .. *list_count) (the wave kernel's leftovers)
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = list ? (int64_t)list[t] : t;
+        HeapDI heap{ lds + threadIdx.x, ilds + threadIdx.x, (int)blockDim.x, k, 0 };
+        grid_knn_scan(g, cell_start, spts, sidx, (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2], r2, heap);
+        const int64_t me = sidx[s];
+        double nx = 0.0, ny = 0.0, nz = 1.0;
+        if (heap.sz >= 3) {
+            double c[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (int e = 0; e < heap.sz; ++e) {
+                int64_t j = heap.ix[e * heap.stride];
+                double x = pts[3 * j], y = pts[3 * j + 1], z = pts[3 * j + 2];
+                c[0] += x; c[1] += y; c[2] += z;
+                c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
+            }
+            const double m = (double)heap.sz;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) c[q] /= m;
+            for (int q = 0; q < 9; ++q) c[q] /= m;
+            double cov[6] = { c[3] - c[0] * c[0], c[4] - c[0] * c[1], c[5] - c[0] * c[2],
+                              c[6] - c[1] * c[1], c[7] - c[1] * c[2], c[8] - c[2] * c[2] };
+            double w[3], V[9];
+            sym3_eigen(cov, w, V);
+            nx = V[0]; ny = V[3]; nz = V[6];                       // eigenvector of the smallest eigenvalue
+            double nn = sqrt(nx * nx + ny * ny + nz * nz);
+            if (nn > 0.0) { nx /= nn; ny /= nn; nz /= nn; } else { nx = 0.0; ny = 0.0; nz = 1.0; }
+        }
+        normals[3 * me] = (float)nx; normals[3 * me + 1] = (float)ny; normals[3 * me + 2] = (float)nz;
+    }
+}
+
+// One wave per query: wave_knn_select with identities, then the covariance of the selected neighbours.  Ties at the
+// k-th distance are resolved like the (d^2, index) heap of normals_kernel: the lowest original indices stay.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void normals_wave_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
+                                                                  const float *__restrict__ spts, const int32_t *__restrict__ sidx,
+                                                                  int64_t n, int k, int cap, double r2, double *__restrict__ covbuf,
+                                                                  int32_t *__restrict__ fb_list, int32_t *__restrict__ fb_count)
+{
+    extern __shared__ __align__(16) double lds[];
+    __shared__ uint32_t run_s0[WAVES][64];
+    __shared__ int32_t run_off[WAVES][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t *posbase = reinterpret_cast<uint32_t *>(lds + (size_t)WAVES * cap);
+    const WaveKnnScratch sc{ lds + (size_t)wave * cap, posbase + (size_t)wave * cap, run_s0[wave], run_off[wave], cap };
+    const GridParams g = *gp;
+    for (int64_t s = (int64_t)blockIdx.x * WAVES + wave; s < n; s += (int64_t)gridDim.x * WAVES) {
+        const double q[3] = { (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2] };
+        WaveKnnResult res;
+        if (!wave_knn_select<true>(g, cell_start, spts, q, k, r2, sc, res)) {
+            if (lane == 0) { fb_list[atomicAdd(fb_count, 1)] = (int32_t)s; covbuf[10 * s + 9] = -1.0; }
+            continue;
+        }
+        const unsigned long long topp = (unsigned long long)__double_as_longlong(res.top);
+        int32_t idx_thr = INT_MAX;
+        if (res.cnt > res.kk) {
+            // more candidates at the k-th distance than slots: keep the `need` lowest original indices among them
+            int ntied = 0;
+            for (int t0 = 0; t0 < res.m; t0 += 64) {
+                const int t = t0 + lane;
+                const bool tie = t < res.m && (unsigned long long)__double_as_longlong(sc.vals[t]) == topp;
+                ntied += __builtin_popcountll(__builtin_amdgcn_ballot_w64(tie));
+            }
+            const int need = res.kk - (res.cnt - ntied);
+            int32_t last = -1;
+            for (int round = 0; round < need; ++round) {
+                int32_t cand = INT_MAX;
+                for (int t = lane; t < res.m; t += 64)
+                    if ((unsigned long long)__double_as_longlong(sc.vals[t]) == topp) {
+                        const int32_t oi = sidx[sc.pos[t]];
+                        if (oi > last && oi < cand) cand = oi;
+                    }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const int32_t t2 = __shfl_xor(cand, o, 64); cand = t2 < cand ? t2 : cand; }
+                last = cand;
+            }
+            idx_thr = last;
+        }
+        double c[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int t = lane; t < res.m; t += 64) {
+            const unsigned long long p = (unsigned long long)__double_as_longlong(sc.vals[t]);
+            bool sel = p < topp || (p == topp && res.cnt == res.kk);
+            if (!sel && p == topp) sel = sidx[sc.pos[t]] <= idx_thr;
+            if (p > res.thr) sel = false;
+            if (sel) {
+                const float *pp = spts + 3 * (int64_t)sc.pos[t];
+                const double x = pp[0], y = pp[1], z = pp[2];
+                c[0] += x; c[1] += y; c[2] += z;
+                c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
+            }
+        }
+#pragma unroll
+        for (int a9 = 0; a9 < 9; ++a9)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c[a9] += __shfl_xor(c[a9], o, 64);
+        // the 3x3 eigen-problem is serial work: it runs one thread per query in normals_eigen_kernel
+        if (lane == 0) {
+            double *o = covbuf + 10 * s;
+#pragma unroll
+            for (int a9 = 0; a9 < 9; ++a9) o[a9] = c[a9];
+            o[9] = (double)res.kk;
+        }
+        wave_lds_fence();
+    }
+}
+// sums -> covariance -> eigenvector of the smallest eigenvalue; one thread per (cell-sorted) query.  count < 0: the
+// query was handed to the heap walk, which writes its normal itself.
+__global__ __launch_bounds__(256) void normals_eigen_kernel(const double *__restrict__ covbuf, const int32_t *__restrict__ sidx, int64_t n,
+                                                            float *__restrict__ normals)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const double *in = covbuf + 10 * s;
+    const double m = in[9];
+    if (m < 0.0) return;
+    double nx = 0.0, ny = 0.0, nz = 1.0;
+    if (m >= 3.0) {
+        double c[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) c[q] = in[q] / m;
         double cov[6] = { c[3] - c[0] * c[0], c[4] - c[0] * c[1], c[5] - c[0] * c[2],
                           c[6] - c[1] * c[1], c[7] - c[1] * c[2], c[8] - c[2] * c[2] };
         double w[3], V[9];
         sym3_eigen(cov, w, V);
-        nx = V[0]; ny = V[3]; nz = V[6];                       // eigenvector of the smallest eigenvalue
-        double nn = sqrt(nx * nx + ny * ny + nz * nz);
+        nx = V[0]; ny = V[3]; nz = V[6];
+        const double nn = sqrt(nx * nx + ny * ny + nz * nz);
         if (nn > 0.0) { nx /= nn; ny /= nn; nz /= nn; } else { nx = 0.0; ny = 0.0; nz = 1.0; }
     }
+    const int64_t me = sidx[s];
     normals[3 * me] = (float)nx; normals[3 * me + 1] = (float)ny; normals[3 * me + 2] = (float)nz;
 }
 
@@ -482,17 +622,28 @@ static int normals_impl(const float *pts, int64_t n, double radius, int max_nn, 
     int kk = (int64_t)max_nn < n ? max_nn : (int)(n > 0 ? n : 1);
     int rc = grid_build(pts, n, 8.0, a, &g, st);
     if (rc) return rc;
+    int32_t *fb_list = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
+    double *covbuf = a.get<double>((size_t)(n > 0 ? n : 1) * 10);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
+    int32_t *fb_count = fb_list + (n > 0 ? n : 1);
     const int threads = kk <= 48 ? 128 : 64;
     const size_t lds = (size_t)kk * threads * (sizeof(double) + sizeof(int32_t));
     static bool attr_set = false;
     if (!attr_set) {
         KPX_HIP(hipFuncSetAttribute((const void *)normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KPX_HIP(hipFuncSetAttribute((const void *)normals_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(normals_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g.params, g.cell_start,
-                       g.sorted_pts, g.sorted_idx, pts, n, kk, radius * radius, normals);
+    KPX_HIP(hipMemsetAsync(fb_count, 0, sizeof(int32_t), st));
+    // pass 1: one wave per query, 1024-candidate buffer; pass 2: the few queries that did not fit, thread-per-query heap walk
+    const int cap = 1024;
+    hipLaunchKernelGGL(normals_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256),
+                       (size_t)4 * cap * (sizeof(double) + sizeof(uint32_t)), st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk,
+                       cap, radius * radius, covbuf, fb_list, fb_count);
+    hipLaunchKernelGGL(normals_eigen_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, covbuf, g.sorted_idx, n, normals);
+    hipLaunchKernelGGL(normals_kernel, dim3(256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, pts, n, kk,
+                       radius * radius, normals, fb_list, fb_count);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
