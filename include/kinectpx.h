@@ -244,6 +244,9 @@ int kpx_nn_engine(int32_t engine);
 #define KPX_PROF_NN_LOCAL 5
 #define KPX_PROF_KERNELS 6
 int kpx_prof_begin(int32_t capacity);
+/* Time only every stride-th launch of each kernel id (default 1).  An event pair costs ~2 us of stream time; around
+ * every launch of a 16 us kernel that is measurable in the end-to-end number (bench.py uses 8). */
+int kpx_prof_stride(int32_t stride);
 int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work);
 
 #ifdef __cplusplus

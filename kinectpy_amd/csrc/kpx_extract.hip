@@ -20,6 +20,8 @@ int fail(int code, const char *fmt, ...)
 // ---- profiler -------------------------------------------------------------------------------------
 static struct {
     bool on = false;
+    int stride = 1;                          // time every stride-th launch of a kernel id
+    long long total[KPX_PROF_KERNELS] = {};  // launches seen while armed, timed or not
     int cap = 0, used = 0;
     hipEvent_t *e0 = nullptr, *e1 = nullptr;
     int *kid = nullptr;
@@ -29,7 +31,8 @@ static struct {
 bool prof_armed() { return g_prof.on; }
 ProfScope::ProfScope(int kernel_id, double w, hipStream_t stream) : slot(-1), st(stream)
 {
-    if (!g_prof.on || g_prof.used >= g_prof.cap) return;
+    if (!g_prof.on) return;
+    if ((g_prof.total[kernel_id]++ % g_prof.stride) != 0 || g_prof.used >= g_prof.cap) return;
     slot = g_prof.used++;
     g_prof.kid[slot] = kernel_id;
     g_prof.work[slot] = w;
@@ -266,8 +269,15 @@ KPX_EXPORT int kpx_prof_begin(int32_t capacity)
         g_prof.cap = capacity;
     }
     g_prof.used = 0;
+    for (int k = 0; k < KPX_PROF_KERNELS; ++k) g_prof.total[k] = 0;
     g_prof.on = true;
     (void)nn_local_take_visits();
+    return KPX_OK;
+}
+KPX_EXPORT int kpx_prof_stride(int32_t stride)
+{
+    KPX_REQUIRE(stride >= 1, "kpx_prof_stride: stride must be >= 1");
+    g_prof.stride = stride;
     return KPX_OK;
 }
 KPX_EXPORT int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work)
@@ -283,7 +293,9 @@ KPX_EXPORT int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work)
         h_ms[k] += ms; h_launches[k] += 1; h_work[k] += g_prof.work[i];
     }
     g_prof.used = 0;
-    h_work[KPX_PROF_NN_LOCAL] = 2048.0 * nn_local_take_visits();     // flops actually issued: 16 x 16 x 4 MAC per tile
+    // flops actually issued (16 x 16 x 4 MAC per tile), scaled to the timed share of the launches
+    h_work[KPX_PROF_NN_LOCAL] = 2048.0 * nn_local_take_visits() * (g_prof.total[KPX_PROF_NN_LOCAL] > 0
+                                    ? (double)h_launches[KPX_PROF_NN_LOCAL] / (double)g_prof.total[KPX_PROF_NN_LOCAL] : 0.0);
     return KPX_OK;
 }
 KPX_EXPORT int kpx_version(void) { return KPX_VERSION; }

@@ -413,6 +413,11 @@ def nn_engine(name=None):
 PROF_KERNELS = ("nn_mfma", "sor_knn", "plane_score", "compact", "nn_screen", "nn_local")
 
 
+def prof_stride(stride):
+    """time only every stride-th launch of each tagged kernel"""
+    L.check(L.load().kpx_prof_stride(int(stride)))
+
+
 def prof_begin(capacity=65536):
     L.check(L.load().kpx_prof_begin(int(capacity)))
 
