@@ -84,12 +84,24 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
         part[(int64_t)blockIdx.x * 6 + threadIdx.x] = (double)v;
     }
 }
-__global__ __launch_bounds__(64) void bbox_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ bbox)
+__global__ __launch_bounds__(256) void bbox_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ bbox)
 {
+    // min / max are exact and order-independent: thread t folds the partial rows t, t+256, ..., then waves, then LDS
+    __shared__ double sh[6][4];
+    double v[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    for (int b = threadIdx.x; b < nb; b += 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { v[a] = fmin(v[a], part[(int64_t)b * 6 + a]); v[3 + a] = fmax(v[3 + a], part[(int64_t)b * 6 + 3 + a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { v[a] = wave_min(v[a]); v[3 + a] = wave_max(v[3 + a]); }
+    if (lane_id() == 0)
+        for (int a = 0; a < 6; ++a) sh[a][wave_id()] = v[a];
+    __syncthreads();
     if (threadIdx.x < 6) {
-        double v = part[threadIdx.x];
-        for (int b = 1; b < nb; ++b) { double t = part[(int64_t)b * 6 + threadIdx.x]; v = threadIdx.x < 3 ? fmin(v, t) : fmax(v, t); }
-        bbox[threadIdx.x] = v;
+        double r = sh[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) r = threadIdx.x < 3 ? fmin(r, sh[threadIdx.x][w]) : fmax(r, sh[threadIdx.x][w]);
+        bbox[threadIdx.x] = r;
     }
 }
 int lanes_get(LaneSet **out)
@@ -132,7 +144,7 @@ int bbox_f32(const float *pts, int64_t n, double *d_bbox6, double *ws_partials, 
 {
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > kBboxBlocks ? kBboxBlocks : cdiv(n, 256 * 8)));
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, st, pts, n, ws_partials);
-    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, ws_partials, nb, d_bbox6);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, st, ws_partials, nb, d_bbox6);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
