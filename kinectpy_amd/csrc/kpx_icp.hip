@@ -705,6 +705,59 @@ __global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restric
     for (int q = 0; q < 16; ++q) T[q] = U[q];
 }
 
+
+// ---- exact accumulation of the update sums (culled engine) --------------------------------------------------------
+// Every block turns its 44 fp64 partial sums into 128-bit fixed point (64 integer + 64 fractional bits: exact for
+// |v| >= 2^-12, truncated at 2^-64 below; |v| < 2^63) and adds them with two 64-bit integer atomics (carry propagated
+// by whoever wraps the low word).  Integer addition is associative: the total does not depend on the order of the
+// blocks, so the registration stays bitwise reproducible with ONE pair of words per sum instead of one partial row
+// per block -- the solve kernel reads 8 x 44 pairs instead of N/64 x 44 doubles.  kAccCopies copies (block & 7)
+// keep the same-address atomic traffic low.
+constexpr int kAccCopies = 8;
+__device__ __forceinline__ void fixed_add(unsigned long long *acc2, double v)
+{
+    const bool neg = v < 0.0;
+    const double m = fabs(v);
+    const double ip = floor(m);
+    unsigned long long hi = (unsigned long long)ip;
+    unsigned long long lo = (unsigned long long)((m - ip) * 18446744073709551616.0);     // frac * 2^64, exact
+    if (neg) {                                              // two's complement of the 128-bit magnitude
+        lo = ~lo + 1ull;
+        hi = ~hi + (lo == 0ull ? 1ull : 0ull);
+    }
+    if (hi == 0ull && lo == 0ull) return;
+    const unsigned long long old = atomicAdd(acc2, lo);
+    const unsigned long long carry = (old + lo) < old ? 1ull : 0ull;
+    if (hi + carry != 0ull) atomicAdd(acc2 + 1, hi + carry);
+}
+__device__ __forceinline__ double fixed_total(const unsigned long long *acc, int slot)
+{
+    unsigned long long lo = 0ull, hi = 0ull;
+#pragma unroll
+    for (int c = 0; c < kAccCopies; ++c) {
+        const unsigned long long l = acc[((int64_t)c * kAcc + slot) * 2], h = acc[((int64_t)c * kAcc + slot) * 2 + 1];
+        lo += l;
+        hi += h + (lo < l ? 1ull : 0ull);
+    }
+    const bool neg = (long long)hi < 0;
+    if (neg) { lo = ~lo + 1ull; hi = ~hi + (lo == 0ull ? 1ull : 0ull); }
+    const double v = (double)hi + (double)lo * 5.421010862427522170037e-20;              // 2^-64
+    return neg ? -v : v;
+}
+// sums -> update step; clears the accumulators for the next iteration (single block: no race)
+__global__ __launch_bounds__(256) void icp_solve_fixed_kernel(unsigned long long *acc, int64_t n, int mode, int k, int max_iter, double rel_fit,
+                                                              double rel_rmse, IcpState *st, double *__restrict__ result)
+{
+    if (st->done) return;
+    __shared__ double sums[kAcc];
+    const int nacc = mode == 1 ? kAcc : 17;
+    if (threadIdx.x < kAcc) sums[threadIdx.x] = (int)threadIdx.x < nacc ? fixed_total(acc, threadIdx.x) : 0.0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < kAccCopies * kAcc * 2; e += 256) acc[e] = 0ull;
+    if (threadIdx.x) return;
+    icp_finish(sums, n, mode, k, max_iter, rel_fit, rel_rmse, st, result);
+}
+
 }  // namespace kpx
 #include "kpx_nnlocal.h"
 namespace kpx {
@@ -713,7 +766,8 @@ namespace kpx {
 // Block = 4 waves x 16 sorted rows.  Prologue: lanes 0..15 of a wave transform their row, seed it and bound it
 // with last iteration's partner (clamped to the correspondence distance); the wave sweeps (sweep_wave); lanes 0..15
 // then form the chosen pair's direct distance (AC3) and the row's contribution to the update sums, which are added
-// in a fixed order per block; icp_solve_kernel adds the per-block partials and performs the update step.
+// in a fixed order per block and added to the exact fixed-point accumulators; icp_solve_fixed_kernel performs the
+// update step.
 // ("Last block finishes the job" inside this launch was measured twice and lost both times: with plain stores +
 // __threadfence() the release writes back / invalidates the XCD's L2 once per block (10x slower); with write-through
 // device-scope stores, a drained vmcnt and a relaxed ticket it still adds ~13 us at 485 blocks -- the same-address
@@ -727,7 +781,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                        const float *__restrict__ group_box, int32_t n_groups,
                                                        const double *__restrict__ tbbox, const int32_t *__restrict__ row_of,
                                                        int32_t *__restrict__ idx_cur, double *__restrict__ d2_cur, double max_d2, int mode,
-                                                       int k, const IcpState *__restrict__ st, double *__restrict__ part_acc,
+                                                       int k, const IcpState *__restrict__ st, unsigned long long *acc,
                                                        unsigned long long *__restrict__ tile_visits)
 {
     if (st->done) return;
@@ -837,7 +891,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if ((int)threadIdx.x < nacc) {
         double v = 0.0;
         for (int l = 0; l < kIRows; ++l) v += sh[threadIdx.x][l];
-        part_acc[(int64_t)blockIdx.x * kAcc + threadIdx.x] = v;
+        fixed_add(acc + (((int64_t)(blockIdx.x & (kAccCopies - 1)) * kAcc + threadIdx.x) * 2), v);
     }
 }
 
@@ -931,6 +985,7 @@ struct NnBuffers {
     // culled sweep
     double *Bs;
     int32_t *orig_t, *row_of;
+    unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
     float *tile_box, *group_box;
     SortScratch sort_t, sort_s;
 };
@@ -967,6 +1022,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->cand = a.get<int32_t>(nn * kCand);
     b->overflow = a.get<int32_t>(nn);                   // list of overflowed rows
     b->row_of = a.get<int32_t>(nn);
+    b->acc_fixed = a.get<unsigned long long>((size_t)kAccCopies * kAcc * 2);
     sort_carve(a, n, &b->sort_s);
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
@@ -984,6 +1040,7 @@ static bool screening_enabled()
 static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b, hipStream_t st)
 {
     if (!local_engine()) return KPX_OK;
+    KPX_HIP(hipMemsetAsync(b.acc_fixed, 0, (size_t)kAccCopies * kAcc * 2 * sizeof(unsigned long long), st));
     return morton_order(src, p.n_src, b.sort_s, b.row_of, st);
 }
 // one ICP iteration (search k + update) of the culled engine: two launches
@@ -994,10 +1051,10 @@ static void icp_iter_launch(const float *src, const float *tgt, const float *tn,
         ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
         hipLaunchKernelGGL(icp_iter_kernel, dim3((unsigned)cdiv(p.n_src, kIRows)), dim3(256), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t,
                            b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.idx_cur, b.d2_cur, max_d2, mode, k, b.state,
-                           b.part_acc, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr);
+                           b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr);
     }
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, b.part_acc, (int)cdiv(p.n_src, kIRows), p.n_src, mode, k, max_iter,
-                       rel_fit, rel_rmse, b.state, d_result);
+    hipLaunchKernelGGL(icp_solve_fixed_kernel, dim3(1), dim3(256), 0, st, b.acc_fixed, p.n_src, mode, k, max_iter, rel_fit, rel_rmse, b.state,
+                       d_result);
 }
 static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st)
 {
