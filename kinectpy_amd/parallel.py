@@ -1,9 +1,9 @@
 """Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" for the
 CPU rehearsal in tests).  The path shards by sensor (preprocessing/data.py:96-122 loops the devices with no
 cross-talk); the only exchange is the fuse (data.py:44-58): the rigid transforms (128 B each) and the
-filtered clouds.  Messages are small and latency-bound on xGMI, so each frame uses exactly two
-collectives: an all-gather of a fixed-size header (count + transforms) and an all-gather of the padded
-cloud buffers (direct peer writes; no ring reduction of payload).
+filtered clouds.  Messages are small and latency-bound on xGMI, so each frame uses exactly ONE collective: an
+all-gather of the padded cloud buffer with the fixed-size header (count + transforms, float64 bit patterns)
+appended as extra rows (direct peer writes; no ring reduction of payload).
 """
 import os
 from typing import List, Tuple
@@ -61,20 +61,46 @@ def allgather_header(header: torch.Tensor) -> torch.Tensor:
     return torch.stack(_all_gather(header))
 
 
+def _all_gather_flat(t: torch.Tensor) -> torch.Tensor:
+    """(...)-> (world, ...) with one all_gather_into_tensor (host-staged under gloo when the tensor is on a GPU)"""
+    w = world_size()
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype)
+        try:
+            dist.all_gather_into_tensor(out, t.cpu().contiguous())
+        except (RuntimeError, NotImplementedError):
+            out = torch.stack(_all_gather(t.cpu()))
+        return out.to(t.device)
+    out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(out, t.contiguous())
+    except (RuntimeError, NotImplementedError):
+        out = torch.stack(_all_gather(t))
+    return out
+
+
 def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor):
     """padded: (cap, C) float32 buffer whose first `count` rows are valid (same cap on every rank);
     transforms: (k, 4, 4) float64 of this rank's sensors (same k on every rank).
-    Returns (cloud (sum counts, C), all transforms (world*k, 4, 4), counts list)."""
+    Returns (cloud (sum counts, C), all transforms (world*k, 4, 4), counts list).
+    One collective: the header (count, transforms) travels as float64 bit patterns in extra rows of the buffer."""
     k = transforms.shape[0]
-    hdr = torch.cat([torch.tensor([float(count)], dtype=torch.float64, device=padded.device),
-                     transforms.reshape(-1).to(padded.device)])
-    hdrs = allgather_header(hdr)
-    counts = [int(c) for c in hdrs[:, 0].tolist()]
-    all_T = hdrs[:, 1:].reshape(-1, 4, 4)
+    hdr = torch.cat([torch.tensor([float(count)], dtype=torch.float64), transforms.reshape(-1).to("cpu", torch.float64)])
     if world_size() == 1:
-        return padded[:count], all_T, counts
-    bufs = _all_gather(padded)
-    cloud = torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+        return padded[:count], hdr[1:].reshape(-1, 4, 4).to(padded.device), [int(count)]
+    cap, C = padded.shape
+    words = hdr.numel() * 2                                     # float32 words carrying the float64 header
+    hrows = (words + C - 1) // C
+    msg = torch.empty((cap + hrows, C), dtype=torch.float32, device=padded.device)
+    msg[:cap] = padded
+    tail = torch.zeros(hrows * C, dtype=torch.float32)
+    tail[:words] = hdr.view(torch.float32)
+    msg[cap:] = tail.reshape(hrows, C).to(padded.device, non_blocking=True)
+    allm = _all_gather_flat(msg)                                # (world, cap + hrows, C)
+    hdrs = allm[:, cap:].reshape(world_size(), -1)[:, :words].contiguous().cpu().view(torch.float64)   # one read-back
+    counts = [int(c) for c in hdrs[:, 0].tolist()]
+    all_T = hdrs[:, 1:].reshape(-1, 4, 4).to(padded.device)
+    cloud = torch.cat([allm[r, :c] for r, c in enumerate(counts)], 0)
     assert all_T.shape[0] == k * world_size()
     return cloud, all_T, counts
 
