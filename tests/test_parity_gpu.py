@@ -266,6 +266,14 @@ def test_nn_bit_exact(ops, oracle, base_cloud, engine, n, m):
         assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd)
 
 
+def test_nn_bit_exact_one_million(ops, oracle):
+    """BASELINE-scale clouds through the culled search (10^12 pairs, ~1 ms): still the oracle's argmin, bit for bit"""
+    src, tgt, T = synth.icp_pair(1_000_000)
+    gi, gd = ops.nn_search(src, tgt, np.linalg.inv(T))
+    ri, rd, _ = oracle.nn(src, np.linalg.inv(T), tgt, grid=True)
+    assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd)
+
+
 def test_nn_ties_go_to_the_lowest_index(ops, oracle, engine):
     """integer-grid data (raw Kinect XYZ is int16): exact ties, exact arithmetic in both forms"""
     rng = np.random.default_rng(4)
