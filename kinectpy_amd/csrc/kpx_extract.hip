@@ -357,6 +357,99 @@ KPX_EXPORT int kpx_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t 
     return compact(pred, emit, n, frames, counts, d_count, (hipStream_t)stream);
 }
 
+// ---- vectorised fused depth -> cloud (n_px % 8 == 0, 16-byte aligned frames) ---------------------------------------
+// Same predicate and arithmetic as DepthPred / DepthEmit.  A thread owns 8 consecutive pixels: one 16-byte load of
+// depth, four of the xy table, three 8-byte loads of rgb.  The scatter pass stages the block's kept points in LDS and
+// writes them with consecutive lanes on consecutive dwords (the block's output range is contiguous).
+struct Px8 {
+    int16_t x[8], y[8], z[8];
+    unsigned keep;                      // bit k: pixel k survives
+    uint8_t c[24];
+};
+__device__ __forceinline__ void load_px8(const uint16_t *__restrict__ depth, const float *__restrict__ xy, const uint8_t *__restrict__ rgb,
+                                         const double *__restrict__ median, int64_t n, int f, int64_t base, int flags, double gate, Px8 &p)
+{
+    union { uint4 v; uint16_t s[8]; } d;
+    d.v = *reinterpret_cast<const uint4 *>(depth + (int64_t)f * n + base);
+    union { float4 v[4]; float s[16]; } t;
+    const float4 *tp = reinterpret_cast<const float4 *>(xy + 2 * base);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t.v[q] = tp[q];
+    const bool mask = (flags & KPX_COMPACT_COLOR_MASK) && rgb;
+    if (rgb) {
+        union { uint2 v[3]; uint8_t b[24]; } c;
+        const uint2 *cp = reinterpret_cast<const uint2 *>(rgb + ((int64_t)f * n + base) * 3);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c.v[q] = cp[q];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) p.c[q] = c.b[q];
+    }
+    const double lim = (flags & KPX_COMPACT_DEPTH_GATE) ? median[f] + gate : 0.0;
+    p.keep = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unproject1(d.s[k], t.s[2 * k], t.s[2 * k + 1], p.x[k], p.y[k], p.z[k]);
+        bool keep = (p.x[k] != 0) & (p.y[k] != 0) & (p.z[k] != 0);
+        if (mask) keep = keep & (p.c[3 * k] != 0) & (p.c[3 * k + 1] != 0) & (p.c[3 * k + 2] != 0);
+        if (flags & KPX_COMPACT_DEPTH_GATE) keep = keep & ((double)p.z[k] <= lim);
+        p.keep |= keep ? 1u << k : 0u;
+    }
+}
+__global__ __launch_bounds__(kCompactThreads) void depth_count_vec_kernel(const uint16_t *__restrict__ depth, const float *__restrict__ xy,
+                                                                          const uint8_t *__restrict__ rgb, const double *__restrict__ median,
+                                                                          int64_t n, int flags, double gate, int32_t *__restrict__ block_counts)
+{
+    __shared__ int sh[kCompactThreads / 64];
+    const int f = blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
+    int c = 0;
+    if (base < n) {
+        Px8 p;
+        load_px8(depth, xy, rgb, median, n, f, base, flags, gate, p);
+        c = __builtin_popcount(p.keep);
+    }
+    c = block_sum(c, sh);
+    if (threadIdx.x == 0) block_counts[(int64_t)f * gridDim.x + blockIdx.x] = c;
+}
+template <bool COL, bool IDX>
+__global__ __launch_bounds__(kCompactThreads) void depth_scatter_vec_kernel(const uint16_t *__restrict__ depth, const float *__restrict__ xy,
+                                                                            const uint8_t *__restrict__ rgb, const double *__restrict__ median,
+                                                                            int64_t n, int flags, double gate, const int32_t *__restrict__ block_offsets,
+                                                                            float *__restrict__ pts, float *__restrict__ col, int32_t *__restrict__ idx)
+{
+    __shared__ int sh[kCompactThreads / 64 + 1];
+    __shared__ float sp[kCompactTile * 3];
+    __shared__ float sc[COL ? kCompactTile * 3 : 1];
+    __shared__ int32_t si[IDX ? kCompactTile : 1];
+    const int f = blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
+    Px8 p;
+    p.keep = 0;
+    if (base < n) load_px8(depth, xy, rgb, median, n, f, base, flags, gate, p);
+    int tot;
+    int pos = block_excl_scan(__builtin_popcount(p.keep), sh, &tot);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (p.keep & (1u << k)) {
+            sp[3 * pos] = (float)p.x[k]; sp[3 * pos + 1] = (float)p.y[k]; sp[3 * pos + 2] = (float)p.z[k];
+            if (COL) {
+                sc[3 * pos] = (float)((double)p.c[3 * k] / 255.0);
+                sc[3 * pos + 1] = (float)((double)p.c[3 * k + 1] / 255.0);
+                sc[3 * pos + 2] = (float)((double)p.c[3 * k + 2] / 255.0);
+            }
+            if (IDX) si[pos] = (int32_t)(base + k);
+            ++pos;
+        }
+    __syncthreads();
+    const int64_t o = (int64_t)f * n + block_offsets[(int64_t)f * gridDim.x + blockIdx.x];
+    for (int e = threadIdx.x; e < tot * 3; e += kCompactThreads) {
+        pts[o * 3 + e] = sp[e];
+        if (COL) col[o * 3 + e] = sc[e];
+    }
+    if (IDX)
+        for (int e = threadIdx.x; e < tot; e += kCompactThreads) idx[o + e] = si[e];
+}
+
 static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uint8_t *rgb, int64_t n, int32_t frames,
                                int32_t flags, double gate, float *pts, float *col, int32_t *idx, int32_t *d_count,
                                Arena &a, hipStream_t st)
@@ -372,7 +465,22 @@ static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uin
     DepthEmit emit{ depth, xy, rgb, n, pts, col, idx };
     // algorithmic input bytes (u16 depth + rgb); outputs depend on the kept count and are added by the caller
     ProfScope prof(KPX_PROF_COMPACT, (double)frames * (double)n * (2.0 + (rgb ? 3.0 : 0.0)), st);
-    return compact(pred, emit, n, frames, counts, d_count, st);
+    const bool vec = (n % 8 == 0) && (((uintptr_t)depth | (uintptr_t)xy) % 16 == 0) && ((uintptr_t)rgb % 8 == 0);
+    if (!vec) return compact(pred, emit, n, frames, counts, d_count, st);
+    const int32_t tiles = (int32_t)compact_tiles(n);
+    const dim3 grid(tiles, frames), thr(kCompactThreads);
+    hipLaunchKernelGGL(depth_count_vec_kernel, grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(256), 0, st, counts, tiles, d_count);
+    const bool wc = col && rgb;
+#define KPX_D2C(COL, IDX)                                                                                           \
+    hipLaunchKernelGGL((depth_scatter_vec_kernel<COL, IDX>), grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts, pts, col, idx)
+    if (wc && idx) KPX_D2C(true, true);
+    else if (wc) KPX_D2C(true, false);
+    else if (idx) KPX_D2C(false, true);
+    else KPX_D2C(false, false);
+#undef KPX_D2C
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
 }
 KPX_EXPORT size_t kpx_depth_to_cloud_workspace_bytes(int64_t n_px, int32_t frames)
 {
