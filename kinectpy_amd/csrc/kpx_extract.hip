@@ -106,31 +106,52 @@ struct MedianSel {
     int64_t rank_a, rank_b;     // ranks inside those bins
 };
 
+// Depth values crowd into a handful of bins and neighbouring pixels share them: 64 lanes adding to one LDS word
+// serialise.  Sixteen copies of every bin (lane & 15), laid out copy-minor so that equal bins of different copies fall
+// into different banks, cut the serialisation 16-fold; the copies are folded before the global add.
+constexpr int kHistCopies = 16;
 __global__ __launch_bounds__(256) void median_hist_kernel(const int16_t *__restrict__ v, int64_t n, int64_t stride,
                                                           int64_t frame_stride, const MedianSel *__restrict__ sel,
                                                           uint32_t *__restrict__ hist /* [frames][2][256] */, int pass)
 {
-    __shared__ uint32_t h[2][256];
+    __shared__ uint32_t h[2][256][kHistCopies];
     const int frame = blockIdx.y;
-    h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
+    const int cp = threadIdx.x & (kHistCopies - 1);
+    for (int e = threadIdx.x; e < 2 * 256 * kHistCopies; e += 256) (&h[0][0][0])[e] = 0;
     __syncthreads();
     const int16_t *p = v + (int64_t)frame * frame_stride;
     int ba = 0, bb = 0;
     if (pass == 1) { ba = sel[frame].bin_a; bb = sel[frame].bin_b; }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t key = ((uint32_t)(uint16_t)p[i * stride]) ^ 0x8000u;
+    auto take = [&](uint32_t raw) {
+        const uint32_t key = (raw & 0xFFFFu) ^ 0x8000u;
         if (pass == 0) {
-            atomicAdd(&h[0][key >> 8], 1u);
+            atomicAdd(&h[0][key >> 8][cp], 1u);
         } else {
-            int top = (int)(key >> 8);
-            if (top == ba) atomicAdd(&h[0][key & 255u], 1u);
-            if (top == bb) atomicAdd(&h[1][key & 255u], 1u);
+            const int top = (int)(key >> 8);
+            if (top == ba) atomicAdd(&h[0][key & 255u][cp], 1u);
+            if (top == bb) atomicAdd(&h[1][key & 255u][cp], 1u);
         }
+    };
+    const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0);
+    if (vec) {
+        const int64_t groups = n >> 3;
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+            union { uint4 q; uint16_t s[8]; } d;
+            d.q = reinterpret_cast<const uint4 *>(p)[g];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) take(d.s[k]);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            take((uint32_t)(uint16_t)p[i * stride]);
     }
     __syncthreads();
     uint32_t *g = hist + (int64_t)frame * 512;
-    if (h[0][threadIdx.x]) atomicAdd(&g[threadIdx.x], h[0][threadIdx.x]);
-    if (pass == 1 && h[1][threadIdx.x]) atomicAdd(&g[256 + threadIdx.x], h[1][threadIdx.x]);
+    uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+    for (int c = 0; c < kHistCopies; ++c) { s0 += h[0][threadIdx.x][c]; s1 += h[1][threadIdx.x][c]; }
+    if (s0) atomicAdd(&g[threadIdx.x], s0);
+    if (pass == 1 && s1) atomicAdd(&g[256 + threadIdx.x], s1);
 }
 
 // one block (256 threads) per frame; finds the bin holding a rank by a serial walk (256 bins)
@@ -341,22 +362,6 @@ KPX_EXPORT size_t kpx_compact_workspace_bytes(int64_t n, int32_t frames)
     a.get<int32_t>((size_t)(frames < 1 ? 1 : frames) * compact_tiles(n));
     return a.off;
 }
-KPX_EXPORT int kpx_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t n, int32_t frames, int32_t flags,
-                                const double *d_median, double gate, float *pts, float *col, int32_t *idx,
-                                int32_t *d_count, void *ws, size_t ws_bytes, void *stream)
-{
-    KPX_REQUIRE(n >= 0 && frames > 0, "kpx_rgbd_compact: bad size");
-    KPX_REQUIRE(xyz && pts && d_count && ws, "kpx_rgbd_compact: null pointer");
-    KPX_REQUIRE(!(flags & KPX_COMPACT_DEPTH_GATE) || d_median, "kpx_rgbd_compact: depth gate needs d_median");
-    KPX_REQUIRE(n < ((int64_t)1 << 31), "kpx_rgbd_compact: frame too large");
-    Arena a(ws, ws_bytes);
-    int32_t *counts = a.get<int32_t>((size_t)frames * compact_tiles(n));
-    KPX_ARENA_CHECK(a);
-    XyzPred pred{ xyz, rgb, d_median, n, flags, gate };
-    XyzEmit emit{ xyz, rgb, n, pts, col, idx };
-    return compact(pred, emit, n, frames, counts, d_count, (hipStream_t)stream);
-}
-
 // ---- vectorised fused depth -> cloud (n_px % 8 == 0, 16-byte aligned frames) ---------------------------------------
 // Same predicate and arithmetic as DepthPred / DepthEmit.  A thread owns 8 consecutive pixels: one 16-byte load of
 // depth, four of the xy table, three 8-byte loads of rgb.  The scatter pass stages the block's kept points in LDS and
@@ -366,15 +371,23 @@ struct Px8 {
     unsigned keep;                      // bit k: pixel k survives
     uint8_t c[24];
 };
+// xy == NULL: `depth` is an int16 XYZ image (3 values per pixel, the .dat contract) instead of u16 depth + table
 __device__ __forceinline__ void load_px8(const uint16_t *__restrict__ depth, const float *__restrict__ xy, const uint8_t *__restrict__ rgb,
                                          const double *__restrict__ median, int64_t n, int f, int64_t base, int flags, double gate, Px8 &p)
 {
     union { uint4 v; uint16_t s[8]; } d;
-    d.v = *reinterpret_cast<const uint4 *>(depth + (int64_t)f * n + base);
     union { float4 v[4]; float s[16]; } t;
-    const float4 *tp = reinterpret_cast<const float4 *>(xy + 2 * base);
+    union { uint4 v[3]; int16_t s[24]; } im;
+    if (xy) {
+        d.v = *reinterpret_cast<const uint4 *>(depth + (int64_t)f * n + base);
+        const float4 *tp = reinterpret_cast<const float4 *>(xy + 2 * base);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t.v[q] = tp[q];
+        for (int q = 0; q < 4; ++q) t.v[q] = tp[q];
+    } else {
+        const uint4 *ip = reinterpret_cast<const uint4 *>(reinterpret_cast<const int16_t *>(depth) + ((int64_t)f * n + base) * 3);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) im.v[q] = ip[q];
+    }
     const bool mask = (flags & KPX_COMPACT_COLOR_MASK) && rgb;
     if (rgb) {
         union { uint2 v[3]; uint8_t b[24]; } c;
@@ -388,7 +401,8 @@ __device__ __forceinline__ void load_px8(const uint16_t *__restrict__ depth, con
     p.keep = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        unproject1(d.s[k], t.s[2 * k], t.s[2 * k + 1], p.x[k], p.y[k], p.z[k]);
+        if (xy) unproject1(d.s[k], t.s[2 * k], t.s[2 * k + 1], p.x[k], p.y[k], p.z[k]);
+        else { p.x[k] = im.s[3 * k]; p.y[k] = im.s[3 * k + 1]; p.z[k] = im.s[3 * k + 2]; }
         bool keep = (p.x[k] != 0) & (p.y[k] != 0) & (p.z[k] != 0);
         if (mask) keep = keep & (p.c[3 * k] != 0) & (p.c[3 * k + 1] != 0) & (p.c[3 * k + 2] != 0);
         if (flags & KPX_COMPACT_DEPTH_GATE) keep = keep & ((double)p.z[k] <= lim);
@@ -450,6 +464,26 @@ __global__ __launch_bounds__(kCompactThreads) void depth_scatter_vec_kernel(cons
         for (int e = threadIdx.x; e < tot; e += kCompactThreads) idx[o + e] = si[e];
 }
 
+// count -> scan -> scatter with the 8-pixel kernels (xy == NULL: int16 XYZ image input)
+static int px8_compact(const uint16_t *depth, const float *xy, const uint8_t *rgb, const double *med, int64_t n, int32_t frames, int32_t flags,
+                       double gate, int32_t *counts, float *pts, float *col, int32_t *idx, int32_t *d_count, hipStream_t st)
+{
+    const int32_t tiles = (int32_t)compact_tiles(n);
+    const dim3 grid(tiles, frames), thr(kCompactThreads);
+    hipLaunchKernelGGL(depth_count_vec_kernel, grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(256), 0, st, counts, tiles, d_count);
+    const bool wc = col && rgb;
+#define KPX_D2C(COL, IDX)                                                                                           \
+    hipLaunchKernelGGL((depth_scatter_vec_kernel<COL, IDX>), grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts, pts, col, idx)
+    if (wc && idx) KPX_D2C(true, true);
+    else if (wc) KPX_D2C(true, false);
+    else if (idx) KPX_D2C(false, true);
+    else KPX_D2C(false, false);
+#undef KPX_D2C
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
 static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uint8_t *rgb, int64_t n, int32_t frames,
                                int32_t flags, double gate, float *pts, float *col, int32_t *idx, int32_t *d_count,
                                Arena &a, hipStream_t st)
@@ -467,21 +501,28 @@ static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uin
     ProfScope prof(KPX_PROF_COMPACT, (double)frames * (double)n * (2.0 + (rgb ? 3.0 : 0.0)), st);
     const bool vec = (n % 8 == 0) && (((uintptr_t)depth | (uintptr_t)xy) % 16 == 0) && ((uintptr_t)rgb % 8 == 0);
     if (!vec) return compact(pred, emit, n, frames, counts, d_count, st);
-    const int32_t tiles = (int32_t)compact_tiles(n);
-    const dim3 grid(tiles, frames), thr(kCompactThreads);
-    hipLaunchKernelGGL(depth_count_vec_kernel, grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(256), 0, st, counts, tiles, d_count);
-    const bool wc = col && rgb;
-#define KPX_D2C(COL, IDX)                                                                                           \
-    hipLaunchKernelGGL((depth_scatter_vec_kernel<COL, IDX>), grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts, pts, col, idx)
-    if (wc && idx) KPX_D2C(true, true);
-    else if (wc) KPX_D2C(true, false);
-    else if (idx) KPX_D2C(false, true);
-    else KPX_D2C(false, false);
-#undef KPX_D2C
-    KPX_LAUNCH_CHECK();
-    return KPX_OK;
+    return px8_compact(depth, xy, rgb, med, n, frames, flags, gate, counts, pts, col, idx, d_count, st);
 }
+KPX_EXPORT int kpx_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t n, int32_t frames, int32_t flags,
+                                const double *d_median, double gate, float *pts, float *col, int32_t *idx,
+                                int32_t *d_count, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n >= 0 && frames > 0, "kpx_rgbd_compact: bad size");
+    KPX_REQUIRE(xyz && pts && d_count && ws, "kpx_rgbd_compact: null pointer");
+    KPX_REQUIRE(!(flags & KPX_COMPACT_DEPTH_GATE) || d_median, "kpx_rgbd_compact: depth gate needs d_median");
+    KPX_REQUIRE(n < ((int64_t)1 << 31), "kpx_rgbd_compact: frame too large");
+    Arena a(ws, ws_bytes);
+    int32_t *counts = a.get<int32_t>((size_t)frames * compact_tiles(n));
+    KPX_ARENA_CHECK(a);
+    XyzPred pred{ xyz, rgb, d_median, n, flags, gate };
+    XyzEmit emit{ xyz, rgb, n, pts, col, idx };
+    if (n == 0) return compact(pred, emit, n, frames, counts, d_count, (hipStream_t)stream);
+    const bool vec = (n % 8 == 0) && ((uintptr_t)xyz % 16 == 0) && ((uintptr_t)rgb % 8 == 0);
+    if (!vec) return compact(pred, emit, n, frames, counts, d_count, (hipStream_t)stream);
+    return px8_compact(reinterpret_cast<const uint16_t *>(xyz), nullptr, rgb, d_median, n, frames, flags, gate, counts, pts, col, idx, d_count,
+                       (hipStream_t)stream);
+}
+
 KPX_EXPORT size_t kpx_depth_to_cloud_workspace_bytes(int64_t n_px, int32_t frames)
 {
     Arena a(nullptr, 0);
