@@ -5,6 +5,7 @@ there is no CPU fallback.  PyTorch-ROCm tensors are used only as the device-memo
 (allocation, streams); every computation is a call into the C ABI.
 """
 import ctypes as C
+import threading
 import os
 
 import torch
@@ -127,8 +128,14 @@ class Workspace:
         return C.c_void_p(self.buf.data_ptr()), C.c_size_t(self.buf.numel())
 
 
-_ws = Workspace()
+_ws = {}
 
 
 def workspace(nbytes):
-    return _ws.get(nbytes)
+    """scratch of the calling thread's current stream (ops of one stream run in order and may share it; another stream or
+    host thread gets its own)"""
+    key = (threading.get_ident(), torch.cuda.current_stream().cuda_stream)
+    ws = _ws.get(key)
+    if ws is None:
+        ws = _ws[key] = Workspace()
+    return ws.get(nbytes)

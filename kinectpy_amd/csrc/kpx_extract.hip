@@ -3,6 +3,8 @@
 // utils/io.py:15-43, preprocessing/data.py:165-178.  All HBM-streaming kernels.
 #include <stdarg.h>
 
+#include <mutex>
+
 #include "kpx_internal.h"
 
 namespace kpx {
@@ -29,9 +31,11 @@ static struct {
 } g_prof;
 
 bool prof_armed() { return g_prof.on; }
+static std::mutex g_prof_mutex;         // launches may come from several host threads
 ProfScope::ProfScope(int kernel_id, double w, hipStream_t stream) : slot(-1), st(stream)
 {
     if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     if ((g_prof.total[kernel_id]++ % g_prof.stride) != 0 || g_prof.used >= g_prof.cap) return;
     slot = g_prof.used++;
     g_prof.kid[slot] = kernel_id;

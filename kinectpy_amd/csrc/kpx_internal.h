@@ -32,8 +32,8 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
 // ---- library-internal lanes ------------------------------------------------------------------------
 // Batched entry points run their independent problems (chains of short, latency-bound kernels) side by side on
 // kLaneCount internal streams: lanes_fork makes the lanes wait for everything queued on the caller's stream,
-// lanes_join makes the caller's stream wait for everything queued on the lanes.  One set per device, created at
-// first use; fork and join are event-ordered, so concurrent callers only share the lanes' throughput.
+// lanes_join makes the caller's stream wait for everything queued on the lanes.  One set per host thread and device,
+// created at first use.
 constexpr int kLaneCount = 4;
 struct LaneSet {
     hipStream_t s[kLaneCount];

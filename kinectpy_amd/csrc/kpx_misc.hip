@@ -106,10 +106,11 @@ __global__ __launch_bounds__(256) void bbox_final_kernel(const double *__restric
 }
 int lanes_get(LaneSet **out)
 {
-    // one set per device (streams belong to the device that was current when they were created)
+    // one set per host thread and device: the fork / join events belong to one call at a time, and streams belong to
+    // the device that was current when they were created
     constexpr int kMaxDevices = 16;
-    static LaneSet sets[kMaxDevices];
-    static bool ready[kMaxDevices] = {};
+    static thread_local LaneSet sets[kMaxDevices];
+    static thread_local bool ready[kMaxDevices] = {};
     int dev = 0;
     KPX_HIP(hipGetDevice(&dev));
     KPX_REQUIRE(dev >= 0 && dev < kMaxDevices, "lanes_get: device ordinal %d out of range", dev);
