@@ -1,0 +1,36 @@
+// kpx_fixed.h -- exact, order-independent accumulation of fp64 values in 128-bit fixed point (64 integer + 64
+// fractional bits; exact for 2^-64-aligned values, i.e. every double with |v| >= 2^-12 and every float32 with
+// |v| >= 2^-41; smaller magnitudes are truncated towards zero at 2^-64; |v| < 2^63).  Two 64-bit integer atomics per
+// add, carry propagated by whoever wraps the low word: integer addition is associative, so totals do not depend on the
+// order of the adds -- parallel sums stay bitwise reproducible.  The oracle restates the same conversion with __int128.
+#pragma once
+#include "kpx_common.h"
+
+namespace kpx {
+
+__device__ __forceinline__ void fixed_add(unsigned long long *acc2, double v)
+{
+    const bool neg = v < 0.0;
+    const double m = fabs(v);
+    const double ip = floor(m);
+    unsigned long long hi = (unsigned long long)ip;
+    unsigned long long lo = (unsigned long long)((m - ip) * 18446744073709551616.0);     // frac * 2^64, exact
+    if (neg) {                                              // two's complement of the 128-bit magnitude
+        lo = ~lo + 1ull;
+        hi = ~hi + (lo == 0ull ? 1ull : 0ull);
+    }
+    if (hi == 0ull && lo == 0ull) return;
+    const unsigned long long old = atomicAdd(acc2, lo);
+    const unsigned long long carry = (old + lo) < old ? 1ull : 0ull;
+    if (hi + carry != 0ull) atomicAdd(acc2 + 1, hi + carry);
+}
+// (lo, hi) two's complement -> double: (double)hi + (double)lo * 2^-64 on the magnitude
+__device__ __forceinline__ double fixed_value(unsigned long long lo, unsigned long long hi)
+{
+    const bool neg = (long long)hi < 0;
+    if (neg) { lo = ~lo + 1ull; hi = ~hi + (lo == 0ull ? 1ull : 0ull); }
+    const double v = (double)hi + (double)lo * 5.421010862427522170037e-20;              // 2^-64
+    return neg ? -v : v;
+}
+
+}  // namespace kpx

@@ -28,6 +28,7 @@
 
 #include "kpx_internal.h"
 #include "kpx_linalg.h"
+#include "kpx_fixed.h"
 
 namespace kpx {
 
@@ -707,29 +708,11 @@ __global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restric
 
 
 // ---- exact accumulation of the update sums (culled engine) --------------------------------------------------------
-// Every block turns its 44 fp64 partial sums into 128-bit fixed point (64 integer + 64 fractional bits: exact for
-// |v| >= 2^-12, truncated at 2^-64 below; |v| < 2^63) and adds them with two 64-bit integer atomics (carry propagated
-// by whoever wraps the low word).  Integer addition is associative: the total does not depend on the order of the
-// blocks, so the registration stays bitwise reproducible with ONE pair of words per sum instead of one partial row
-// per block -- the solve kernel reads 8 x 44 pairs instead of N/64 x 44 doubles.  kAccCopies copies (block & 7)
-// keep the same-address atomic traffic low.
+// Every block adds its 44 fp64 partial sums to 128-bit fixed-point accumulators (kpx_fixed.h): the totals do not
+// depend on the order of the blocks, so the registration stays bitwise reproducible with ONE pair of words per sum
+// instead of one partial row per block -- the solve kernel reads 8 x 44 pairs instead of N/64 x 44 doubles.
+// kAccCopies copies (block & 7) keep the same-address atomic traffic low.
 constexpr int kAccCopies = 8;
-__device__ __forceinline__ void fixed_add(unsigned long long *acc2, double v)
-{
-    const bool neg = v < 0.0;
-    const double m = fabs(v);
-    const double ip = floor(m);
-    unsigned long long hi = (unsigned long long)ip;
-    unsigned long long lo = (unsigned long long)((m - ip) * 18446744073709551616.0);     // frac * 2^64, exact
-    if (neg) {                                              // two's complement of the 128-bit magnitude
-        lo = ~lo + 1ull;
-        hi = ~hi + (lo == 0ull ? 1ull : 0ull);
-    }
-    if (hi == 0ull && lo == 0ull) return;
-    const unsigned long long old = atomicAdd(acc2, lo);
-    const unsigned long long carry = (old + lo) < old ? 1ull : 0ull;
-    if (hi + carry != 0ull) atomicAdd(acc2 + 1, hi + carry);
-}
 __device__ __forceinline__ double fixed_total(const unsigned long long *acc, int slot)
 {
     unsigned long long lo = 0ull, hi = 0ull;
@@ -739,10 +722,7 @@ __device__ __forceinline__ double fixed_total(const unsigned long long *acc, int
         lo += l;
         hi += h + (lo < l ? 1ull : 0ull);
     }
-    const bool neg = (long long)hi < 0;
-    if (neg) { lo = ~lo + 1ull; hi = ~hi + (lo == 0ull ? 1ull : 0ull); }
-    const double v = (double)hi + (double)lo * 5.421010862427522170037e-20;              // 2^-64
-    return neg ? -v : v;
+    return fixed_value(lo, hi);
 }
 // sums -> update step; clears the accumulators for the next iteration (single block: no race)
 __global__ __launch_bounds__(256) void icp_solve_fixed_kernel(unsigned long long *acc, int64_t n, int mode, int k, int max_iter, double rel_fit,
