@@ -218,6 +218,34 @@ def test_sor_duplicates_and_errors(ops, oracle):
             ops.sor(p, *bad)
 
 
+def test_sor_and_normals_on_lattice_ties(ops, oracle):
+    """integer lattice (raw Kinect XYZ is int16): many neighbours at exactly the k-th distance.  SOR counts ties at the
+    k-th value k - (#smaller) times; normals keep the lowest original indices among them -- both as the oracle does.
+    Sparse outliers next to the dense block exercise the truncated / radius-filtered gather passes."""
+    g = np.arange(0, 24, dtype=np.float32)
+    lat = np.stack(np.meshgrid(g, g, g[:6], indexing="ij"), -1).reshape(-1, 3) * 5.0
+    rng = np.random.default_rng(9)
+    far = rng.integers(-400, 600, size=(60, 3)).astype(np.float32)
+    p = np.concatenate([lat, far])[rng.permutation(len(lat) + 60)]
+    for k, ratio in ((6, 1.0), (20, 2.0), (27, 0.5), (200, 3.0)):
+        gi, gs, ga = ops.sor(p, k, ratio, want_avg=True)
+        ri, rs, ra = oracle.sor(p, k, ratio)
+        assert np.array_equal(npy(gi), ri)
+        assert np.allclose(npy(ga), ra, rtol=1e-13, atol=0)
+    for radius, nn in ((12.0, 10), (8.0, 30), (26.0, 40)):
+        gn = npy(ops.estimate_normals(p, radius, nn)).astype(np.float64)
+        rn, cov, cnt = oracle.estimate_normals(p, radius, nn)
+        A = np.zeros((len(p), 3, 3))
+        A[:, 0, 0], A[:, 1, 1], A[:, 2, 2] = cov[:, 0], cov[:, 3], cov[:, 5]
+        A[:, 0, 1] = A[:, 1, 0] = cov[:, 1]
+        A[:, 0, 2] = A[:, 2, 0] = cov[:, 2]
+        A[:, 1, 2] = A[:, 2, 1] = cov[:, 4]
+        w = np.linalg.eigvalsh(A)
+        well = (cnt >= 3) & ((w[:, 1] - w[:, 0]) > 1e-3 * np.maximum(w[:, 2], 1e-30))
+        assert (np.abs((gn * rn).sum(1))[well] > 1 - 1e-6).all()      # same neighbour sets -> same normal (up to sign)
+        assert np.allclose(gn[cnt < 3], [0, 0, 1])
+
+
 def test_normals_up_to_sign(ops, oracle, base_cloud):
     rng = np.random.default_rng(2)
     p = base_cloud[rng.choice(len(base_cloud), 30000, replace=False)]
