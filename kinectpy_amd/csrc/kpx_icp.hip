@@ -762,6 +762,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
                                                        const double *__restrict__ tbbox, const int32_t *__restrict__ row_of,
+                                                       const float *__restrict__ src_sorted, int32_t *__restrict__ idx_sorted,
                                                        int32_t *__restrict__ idx_cur, double *__restrict__ d2_cur, double max_d2, int mode,
                                                        int k, const IcpState *__restrict__ st, unsigned long long *acc,
                                                        unsigned long long *__restrict__ tile_visits)
@@ -777,15 +778,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int nacc = mode == 1 ? kAcc : 17;
 
     if (lane < 16) {
+        // (source rows and last iteration's partners are kept in sorted-row order too: no dependent gather in front
+        // of the partner lookup)
         const int64_t r = row_base + lane < last ? row_base + lane : last;
         const int64_t i = row_of[r];
         double s[3];
-        xform_row(st->T, src + 3 * i, s);
+        xform_row(st->T, src_sorted + 3 * r, s);
         const double seed = row_seed(s);
         double bv = INFINITY;
         int32_t bj = INT_MAX;
         if (k > 0) {
-            const int32_t p = idx_cur[i];
+            const int32_t p = idx_sorted[r];
             if (p >= 0) {
                 const float *tp = tgt + 3 * (int64_t)p;
                 const double tx = tp[0], ty = tp[1], tz = tp[2];
@@ -835,6 +838,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const int64_t i = rowi[wave][lane][1];
             const bool none = bj < 0 || bj == INT_MAX;
             idx_cur[i] = none ? -1 : bj;
+            idx_sorted[row_base + lane] = none ? -1 : bj;
             if (none) {
                 d2_cur[i] = INFINITY;
             } else {
@@ -966,7 +970,8 @@ struct NnBuffers {
     double *T0;
     // culled sweep
     double *Bs;
-    int32_t *orig_t, *row_of;
+    int32_t *orig_t, *row_of, *idx_sorted;
+    float *src_sorted;
     unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
     float *tile_box, *group_box;
     SortScratch sort_t, sort_s;
@@ -1004,6 +1009,8 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->cand = a.get<int32_t>(nn * kCand);
     b->overflow = a.get<int32_t>(nn);                   // list of overflowed rows
     b->row_of = a.get<int32_t>(nn);
+    b->idx_sorted = a.get<int32_t>(nn);
+    b->src_sorted = a.get<float>(nn * 3);
     b->acc_fixed = a.get<unsigned long long>((size_t)kAccCopies * kAcc * 2);
     sort_carve(a, n, &b->sort_s);
 }
@@ -1019,11 +1026,23 @@ static bool screening_enabled()
     if (on < 0) { const char *e = getenv("KPX_NN_SCREEN"); on = (e && e[0] == '0') ? 0 : 1; }
     return on != 0;
 }
+static __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t n, const int32_t *__restrict__ row_of,
+                                                                 float *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t i = row_of[r];
+    out[3 * r] = src[3 * i]; out[3 * r + 1] = src[3 * i + 1]; out[3 * r + 2] = src[3 * i + 2];
+}
 static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b, hipStream_t st)
 {
     if (!local_engine()) return KPX_OK;
     KPX_HIP(hipMemsetAsync(b.acc_fixed, 0, (size_t)kAccCopies * kAcc * 2 * sizeof(unsigned long long), st));
-    return morton_order(src, p.n_src, b.sort_s, b.row_of, st);
+    int rc = morton_order(src, p.n_src, b.sort_s, b.row_of, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(p.n_src, 256)), dim3(256), 0, st, src, p.n_src, b.row_of, b.src_sorted);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
 }
 // one ICP iteration (search k + update) of the culled engine: two launches
 static void icp_iter_launch(const float *src, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b, double max_d2, int mode,
@@ -1032,7 +1051,8 @@ static void icp_iter_launch(const float *src, const float *tgt, const float *tn,
     {
         ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
         hipLaunchKernelGGL(icp_iter_kernel, dim3((unsigned)cdiv(p.n_src, kIRows)), dim3(256), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t,
-                           b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.idx_cur, b.d2_cur, max_d2, mode, k, b.state,
+                           b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.idx_cur, b.d2_cur,
+                           max_d2, mode, k, b.state,
                            b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr);
     }
     hipLaunchKernelGGL(icp_solve_fixed_kernel, dim3(1), dim3(256), 0, st, b.acc_fixed, p.n_src, mode, k, max_iter, rel_fit, rel_rmse, b.state,
