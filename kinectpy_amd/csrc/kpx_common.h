@@ -201,6 +201,58 @@ __global__ __launch_bounds__(kCompactThreads) void compact_scatter_kernel(Pred p
         if (flags & (1u << k)) emit(base + k, frame, dst++);
 }
 
+// ---- index compaction over a float32 (n,3) cloud with a predicate on the coordinates ----------------------------
+// Same count -> scan -> scatter, specialised for the selections of the path: a thread loads its 8 points as six 16-byte
+// vectors (96 contiguous bytes) and the kept indices of a block are staged in LDS and written as consecutive dwords.
+template <class PredXYZ>
+__device__ __forceinline__ unsigned pts8_flags(const float *__restrict__ pts, int64_t n, int64_t base, const PredXYZ &pred, bool aligned)
+{
+    unsigned flags = 0;
+    if (base + kCompactItems <= n && aligned) {
+        union { float4 v[6]; float s[24]; } u;
+        const float4 *p4 = reinterpret_cast<const float4 *>(pts + 3 * base);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) u.v[q] = p4[q];
+#pragma unroll
+        for (int k = 0; k < kCompactItems; ++k)
+            if (pred(u.s[3 * k], u.s[3 * k + 1], u.s[3 * k + 2])) flags |= 1u << k;
+    } else {
+        for (int k = 0; k < kCompactItems; ++k) {
+            const int64_t i = base + k;
+            if (i < n && pred(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])) flags |= 1u << k;
+        }
+    }
+    return flags;
+}
+template <class PredXYZ>
+__global__ __launch_bounds__(kCompactThreads) void compact_pts_count_kernel(const float *__restrict__ pts, int64_t n, PredXYZ pred,
+                                                                            bool aligned, int32_t *__restrict__ block_counts)
+{
+    __shared__ int sh[kCompactThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
+    int c = base < n ? __builtin_popcount(pts8_flags(pts, n, base, pred, aligned)) : 0;
+    c = block_sum(c, sh);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
+}
+template <class PredXYZ>
+__global__ __launch_bounds__(kCompactThreads) void compact_pts_scatter_kernel(const float *__restrict__ pts, int64_t n, PredXYZ pred,
+                                                                              bool aligned, const int32_t *__restrict__ block_offsets,
+                                                                              int32_t *__restrict__ idx)
+{
+    __shared__ int sh[kCompactThreads / 64 + 1];
+    __shared__ int32_t si[kCompactTile];
+    const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
+    const unsigned flags = base < n ? pts8_flags(pts, n, base, pred, aligned) : 0u;
+    int tot;
+    int pos = block_excl_scan(__builtin_popcount(flags), sh, &tot);
+#pragma unroll
+    for (int k = 0; k < kCompactItems; ++k)
+        if (flags & (1u << k)) si[pos++] = (int32_t)(base + k);
+    __syncthreads();
+    const int64_t o = block_offsets[blockIdx.x];
+    for (int e = threadIdx.x; e < tot; e += kCompactThreads) idx[o + e] = si[e];
+}
+
 // Host driver.  ws_counts: int32 [frames * tiles(n)].
 static inline int64_t compact_tiles(int64_t n) { return cdiv(n > 0 ? n : 1, kCompactTile); }
 template <class Pred, class Emit>
@@ -212,6 +264,17 @@ int compact(Pred pred, Emit emit, int64_t n, int32_t frames, int32_t *ws_counts,
     hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(256), 0, st, ws_counts, tiles, d_count);
     hipLaunchKernelGGL((compact_scatter_kernel<Pred, Emit>), grid, dim3(kCompactThreads), 0, st, pred, emit, n,
                        ws_counts);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+template <class PredXYZ>
+int compact_points(const float *pts, int64_t n, PredXYZ pred, int32_t *idx, int32_t *ws_counts, int32_t *d_count, hipStream_t st)
+{
+    const int32_t tiles = (int32_t)compact_tiles(n);
+    const bool aligned = ((uintptr_t)pts % 16) == 0;
+    hipLaunchKernelGGL(compact_pts_count_kernel<PredXYZ>, dim3(tiles), dim3(kCompactThreads), 0, st, pts, n, pred, aligned, ws_counts);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, st, ws_counts, tiles, d_count);
+    hipLaunchKernelGGL(compact_pts_scatter_kernel<PredXYZ>, dim3(tiles), dim3(kCompactThreads), 0, st, pts, n, pred, aligned, ws_counts, idx);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

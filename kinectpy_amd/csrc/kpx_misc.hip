@@ -195,20 +195,28 @@ struct HalfspacePred {
         return !(v >= 0.0);
     }
 };
+struct HalfspaceXYZ {
+    double a, b, c, d;
+    __device__ bool operator()(float fx, float fy, float fz) const
+    {
+        const double x = fx, y = fy, z = fz;
+        const double v = ((a * x + b * y) + c * z) + d;     // floor_removal.py:43, left to right
+        return !(v >= 0.0);
+    }
+};
+struct SlabXYZ {
+    const double *bbox; double slab; int lower;
+    __device__ bool operator()(float, float fy, float) const
+    {
+        const double cut = bbox[4] - slab;                  // y.max() - 200 (floor_removal.py:65-66)
+        const double y = fy;
+        return lower ? (y >= cut) : (y < cut);
+    }
+};
 struct IndexEmit {
     int32_t *idx;
     __device__ void operator()(int64_t i, int, int32_t dst) const { idx[dst] = (int32_t)i; }
 };
-struct SlabPred {
-    const float *pts; const double *bbox; double slab; int lower;
-    __device__ bool operator()(int64_t i, int) const
-    {
-        double cut = bbox[4] - slab;                  // y.max() - 200 (floor_removal.py:65-66)
-        double y = pts[3 * i + 1];
-        return lower ? (y >= cut) : (y < cut);
-    }
-};
-
 static Affine affine_from(const double *T)
 {
     Affine A;
@@ -300,8 +308,9 @@ KPX_EXPORT int kpx_halfspace_select(const float *pts, int64_t n, const double *h
     a.get<uint8_t>((size_t)(n > 0 ? n : 1));
     int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
     KPX_ARENA_CHECK(a);
-    return compact(HalfspacePred{ pts, h_plane[0], h_plane[1], h_plane[2], h_plane[3] }, IndexEmit{ idx }, n, 1, counts,
-                   d_count, (hipStream_t)stream);
+    if (n == 0) return compact(HalfspacePred{ pts, h_plane[0], h_plane[1], h_plane[2], h_plane[3] }, IndexEmit{ idx }, n, 1, counts, d_count,
+                               (hipStream_t)stream);
+    return compact_points(pts, n, HalfspaceXYZ{ h_plane[0], h_plane[1], h_plane[2], h_plane[3] }, idx, counts, d_count, (hipStream_t)stream);
 }
 
 KPX_EXPORT int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t *lower_idx, int32_t *d_lower,
@@ -317,7 +326,7 @@ KPX_EXPORT int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t 
     double *bbox = part + (size_t)kBboxBlocks * 6;
     int rc = bbox_f32(pts, n, bbox, part, st);
     if (rc) return rc;
-    rc = compact(SlabPred{ pts, bbox, slab, 1 }, IndexEmit{ lower_idx }, n, 1, counts, d_lower, st);
+    rc = compact_points(pts, n, SlabXYZ{ bbox, slab, 1 }, lower_idx, counts, d_lower, st);
     if (rc) return rc;
-    return compact(SlabPred{ pts, bbox, slab, 0 }, IndexEmit{ upper_idx }, n, 1, counts, d_upper, st);
+    return compact_points(pts, n, SlabXYZ{ bbox, slab, 0 }, upper_idx, counts, d_upper, st);
 }
