@@ -176,6 +176,22 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const int16_t *__restr
 #pragma unroll
             for (int k = 0; k < 8; ++k) take(d.s[k]);
         }
+    } else if (stride == 3 && (n % 8 == 0) && (frame_stride % 8 == 0)) {
+        // int16 XYZ image, z channel: 8 pixels = 48 bytes = three 16-byte loads, z at elements 3k (v points at z of pixel 0)
+        const int64_t groups = n >> 3;
+        const int16_t *img = p - 2;                                     // frame base (x of pixel 0)
+        const bool ok = ((uintptr_t)img % 16) == 0;
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+            if (ok) {
+                union { uint4 q[3]; uint16_t s[24]; } d;
+                const uint4 *ip = reinterpret_cast<const uint4 *>(img + g * 24);
+                d.q[0] = ip[0]; d.q[1] = ip[1]; d.q[2] = ip[2];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) take(d.s[3 * k + 2]);
+            } else {
+                for (int k = 0; k < 8; ++k) take((uint32_t)(uint16_t)p[(g * 8 + k) * 3]);
+            }
+        }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
             take((uint32_t)(uint16_t)p[i * stride]);
