@@ -44,10 +44,13 @@ class SensorGroupPipeline:
         Returns (points (K,3) f32, colours (K,3) f32, transforms (S,4,4) f64 sub->group master)."""
         p = self.p
         S = depth.shape[0]
-        full = ops.depth_to_cloud(depth, self.xy, None, S, False, False)                 # registration input
-        masked = ops.depth_to_cloud(depth, self.xy, rgb, S, True, True, gate=p.gate)     # person clouds
+        # both extractions are queued before the first count is read back; the person clouds are only needed after the
+        # registration, so their counts are fetched then (no stall)
+        fp, _, _, fcnt = ops.depth_to_cloud(depth, self.xy, None, S, False, False, sync=False)                 # registration input
+        mp, mc, _, mcnt = ops.depth_to_cloud(depth, self.xy, rgb, S, True, True, gate=p.gate, sync=False)     # person clouds
+        fk = ops._count(fcnt)
         # -- registration: every sub onto the master, exactly execute_point_to_plane_registration
-        downs = [d[0] for d in ops.voxel_downsample_batch([full[i][0] for i in range(S)], p.reg_voxel)]
+        downs = [d[0] for d in ops.voxel_downsample_batch([fp[i, :fk[i]] for i in range(S)], p.reg_voxel)]
         tn = ops.estimate_normals(downs[0], 2.0 * p.reg_voxel, p.normals_nn) if p.icp_mode == "p2plane" else None
         Ts = [np.eye(4)]
         stats = []
@@ -57,6 +60,8 @@ class SensorGroupPipeline:
                 Ts.append(r["transformation"])
                 stats.append((r["iterations"], r["fitness"], r["inlier_rmse"]))
         # -- transform + fuse + filter
+        mk = ops._count(mcnt)
+        masked = [(mp[i, :mk[i]], mc[i, :mk[i]]) for i in range(S)]
         pts = [masked[0][0]] + [ops.transform(masked[i][0], Ts[i]) for i in range(1, S)]
         fused_p = torch.cat(pts, 0)
         fused_c = torch.cat([m[1] for m in masked], 0)
