@@ -112,7 +112,6 @@ def main():
     report("estimate_normals r=70 nn=40 on 100k (a11)", ms, 24 * 100000, n=100000)
 
     # ---- global registration (rows a11-a13) on two cluttered views, voxel 35
-    from oracle import oracle as O          # only to build the test views on the host
     xy2, ex = synth.xy_table(), synth.clutter()
     views = []
     for i, seed in ((0, 100), (1, 101)):
