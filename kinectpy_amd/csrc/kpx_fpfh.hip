@@ -17,37 +17,105 @@ namespace kpx {
 constexpr double kSentinelF = 1e300;
 
 // ---- neighbour lists ------------------------------------------------------------------------------------------
-__global__ void nbr_list_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
-                                const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t n, int k, double r2,
-                                int32_t *__restrict__ nbr, double *__restrict__ d2, int32_t *__restrict__ cnt)
+// Wave per query (wave_knn_select, kpx_gridknn.h): the selected neighbours are written in candidate order, except that
+// slot 0 receives the smallest (d^2, index) -- the entry the feature kernels skip as "the point itself".  The feature
+// sums do not depend on the order of the other slots beyond rounding.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void nbr_list_wave_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
+                                                                   const float *__restrict__ spts, const int32_t *__restrict__ sidx,
+                                                                   int64_t n, int k, int cap, double r2, int32_t *__restrict__ nbr,
+                                                                   double *__restrict__ d2, int32_t *__restrict__ cnt,
+                                                                   int32_t *__restrict__ fb_list, int32_t *__restrict__ fb_count)
 {
     extern __shared__ __align__(16) double lds[];
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
+    __shared__ uint32_t run_s0[WAVES][64];
+    __shared__ int32_t run_off[WAVES][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t *posbase = reinterpret_cast<uint32_t *>(lds + (size_t)WAVES * cap);
+    const WaveKnnScratch sc{ lds + (size_t)wave * cap, posbase + (size_t)wave * cap, run_s0[wave], run_off[wave], cap };
+    const GridParams g = *gp;
+    for (int64_t s = (int64_t)blockIdx.x * WAVES + wave; s < n; s += (int64_t)gridDim.x * WAVES) {
+        const double q[3] = { (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2] };
+        const int64_t me = sidx[s];
+        WaveKnnResult res;
+        if (!wave_knn_select<true>(g, cell_start, spts, q, k, r2, sc, res)) {
+            if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = (int32_t)s;
+            continue;
+        }
+        const int32_t idx_thr = wave_knn_tie_threshold(sc, res, sidx);
+        int base = 0;
+        double bd = INFINITY;                                  // smallest (d^2, index) written by this lane, and its slot
+        int32_t bi = INT_MAX, bslot = -1;
+        for (int t0 = 0; t0 < res.m; t0 += 64) {
+            const int t = t0 + lane;
+            const bool sel = t < res.m && wave_knn_is_selected(sc, res, sidx, idx_thr, t);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(sel);
+            if (sel) {
+                const int slot = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                const double d = sc.vals[t];
+                const int32_t oi = sidx[sc.pos[t]];
+                nbr[me * k + slot] = oi;
+                d2[me * k + slot] = d;
+                if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; bslot = slot; }
+            }
+            base += __builtin_popcountll(m);
+        }
+        // wave-wide minimum -> slot 0
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double od = __shfl_xor(bd, o, 64);
+            const int32_t oi = __shfl_xor(bi, o, 64), os = __shfl_xor(bslot, o, 64);
+            if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; bslot = os; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane == 0) {
+            cnt[me] = res.kk;
+            if (bslot > 0) {                                   // swap the minimum into slot 0
+                const int32_t i0 = nbr[me * k]; const double d0 = d2[me * k];
+                nbr[me * k] = bi; d2[me * k] = bd;
+                nbr[me * k + bslot] = i0; d2[me * k + bslot] = d0;
+            }
+        }
+        for (int t = res.kk + lane; t < k; t += 64) { nbr[me * k + t] = -1; d2[me * k + t] = 0.0; }
+        wave_lds_fence();
+    }
+}
+
+// Thread per query with a (d^2, index) heap; list != NULL: only the queries the wave kernel could not hold.
+__global__ void nbr_list_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
+                                const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t n, int k, double r2,
+                                int32_t *__restrict__ nbr, double *__restrict__ d2, int32_t *__restrict__ cnt,
+                                const int32_t *__restrict__ list, const int32_t *__restrict__ list_count)
+{
+    extern __shared__ __align__(16) double lds[];
+    const int64_t total = list ? (int64_t)*list_count : n;
     const GridParams g = *gp;
     int32_t *ilds = reinterpret_cast<int32_t *>(lds + (size_t)k * blockDim.x);
-    HeapDI heap{ lds + threadIdx.x, ilds + threadIdx.x, (int)blockDim.x, k, 0 };
-    grid_knn_scan(g, cell_start, spts, sidx, (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2], r2, heap);
-    const int64_t me = sidx[s];
-    const int m = heap.sz;
-    cnt[me] = m;
-    // heap-sort extraction: the maximum goes to the last free slot -> ascending (d2, idx)
-    for (int last = m - 1; last >= 0; --last) {
-        const double dm = heap.h[0]; const int32_t im = heap.ix[0];
-        const double dv = heap.h[last * heap.stride]; const int32_t iv = heap.ix[last * heap.stride];
-        int c = 0;
-        for (;;) {
-            int l = 2 * c + 1, r = l + 1;
-            if (l >= last) break;
-            int b = l; double hb = heap.h[l * heap.stride]; int32_t ib = heap.ix[l * heap.stride];
-            if (r < last) { double hr = heap.h[r * heap.stride]; int32_t ir = heap.ix[r * heap.stride]; if (HeapDI::less(hb, ib, hr, ir)) { b = r; hb = hr; ib = ir; } }
-            if (HeapDI::less(dv, iv, hb, ib)) { heap.h[c * heap.stride] = hb; heap.ix[c * heap.stride] = ib; c = b; } else break;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = list ? (int64_t)list[e] : e;
+        HeapDI heap{ lds + threadIdx.x, ilds + threadIdx.x, (int)blockDim.x, k, 0 };
+        grid_knn_scan(g, cell_start, spts, sidx, (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2], r2, heap);
+        const int64_t me = sidx[s];
+        const int m = heap.sz;
+        cnt[me] = m;
+        // heap-sort extraction: the maximum goes to the last free slot -> ascending (d2, idx)
+        for (int last = m - 1; last >= 0; --last) {
+            const double dm = heap.h[0]; const int32_t im = heap.ix[0];
+            const double dv = heap.h[last * heap.stride]; const int32_t iv = heap.ix[last * heap.stride];
+            int c = 0;
+            for (;;) {
+                int l = 2 * c + 1, r = l + 1;
+                if (l >= last) break;
+                int b = l; double hb = heap.h[l * heap.stride]; int32_t ib = heap.ix[l * heap.stride];
+                if (r < last) { double hr = heap.h[r * heap.stride]; int32_t ir = heap.ix[r * heap.stride]; if (HeapDI::less(hb, ib, hr, ir)) { b = r; hb = hr; ib = ir; } }
+                if (HeapDI::less(dv, iv, hb, ib)) { heap.h[c * heap.stride] = hb; heap.ix[c * heap.stride] = ib; c = b; } else break;
+            }
+            if (last > 0) { heap.h[c * heap.stride] = dv; heap.ix[c * heap.stride] = iv; }
+            nbr[me * k + last] = im;
+            d2[me * k + last] = dm;
         }
-        if (last > 0) { heap.h[c * heap.stride] = dv; heap.ix[c * heap.stride] = iv; }
-        nbr[me * k + last] = im;
-        d2[me * k + last] = dm;
+        for (int t = m; t < k; ++t) { nbr[me * k + t] = -1; d2[me * k + t] = 0.0; }
     }
-    for (int t = m; t < k; ++t) { nbr[me * k + t] = -1; d2[me * k + t] = 0.0; }
 }
 
 // ---- SPFH / FPFH ------------------------------------------------------------------------------------------------
@@ -106,32 +174,33 @@ __global__ __launch_bounds__(kFeatThreads) void spfh_kernel(const float *__restr
     for (int j = 0; j < 33; ++j) spfh[i * 33 + j] = hist[j][threadIdx.x];
 }
 
-__global__ __launch_bounds__(kFeatThreads) void fpfh_kernel(int64_t n, const int32_t *__restrict__ nbr, const double *__restrict__ d2,
-                                                            const int32_t *__restrict__ cnt, int k, const double *__restrict__ spfh,
-                                                            double *__restrict__ fpfh)
+// One wave per point: lane j < 33 owns component j, so every neighbour's SPFH row is one coalesced read.
+__global__ __launch_bounds__(256) void fpfh_kernel(int64_t n, const int32_t *__restrict__ nbr, const double *__restrict__ d2,
+                                                   const int32_t *__restrict__ cnt, int k, const double *__restrict__ spfh,
+                                                   double *__restrict__ fpfh)
 {
-    const int64_t i = (int64_t)blockIdx.x * kFeatThreads + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
-    double acc[33];
-#pragma unroll
-    for (int j = 0; j < 33; ++j) acc[j] = 0.0;
-    double sum[3] = { 0.0, 0.0, 0.0 };
     const int m = cnt[i];
+    double acc = 0.0;
     if (m > 1) {
-        for (int t = 1; t < m; ++t) {
+        for (int t = 1; t < m; ++t) {                      // slot 0 is the point itself
             const double dist = d2[i * k + t];
             if (dist == 0.0) continue;
             const double *sp = spfh + 33 * (int64_t)nbr[i * k + t];
-#pragma unroll
-            for (int j = 0; j < 33; ++j) { const double val = sp[j] / dist; sum[j / 11] += val; acc[j] += val; }
+            if (lane < 33) acc += sp[lane] / dist;
         }
+        // per-feature normalisation: 100 / (sum over the 11 bins of the feature)
+        const double a0 = lane < 11 ? acc : 0.0, a1 = (lane >= 11 && lane < 22) ? acc : 0.0, a2 = (lane >= 22 && lane < 33) ? acc : 0.0;
+        double s0 = a0, s1 = a1, s2 = a2;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) if (sum[j] != 0.0) sum[j] = 100.0 / sum[j];
-#pragma unroll
-        for (int j = 0; j < 33; ++j) acc[j] = acc[j] * sum[j / 11] + spfh[i * 33 + j];
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        double sum = lane < 11 ? s0 : (lane < 22 ? s1 : s2);
+        if (sum != 0.0) sum = 100.0 / sum;
+        if (lane < 33) acc = acc * sum + spfh[i * 33 + lane];
     }
-#pragma unroll
-    for (int j = 0; j < 33; ++j) fpfh[i * 33 + j] = acc[j];
+    if (lane < 33) fpfh[i * 33 + lane] = acc;
 }
 
 // ---- 33-D feature nearest neighbour -----------------------------------------------------------------------------
@@ -397,23 +466,32 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restri
 
 static int knn_lists(const float *pts, int64_t n, double radius, int k, Arena &a, Grid *g, int32_t **nbr, double **d2, int32_t **cnt, hipStream_t st)
 {
-    int rc = grid_build(pts, n, 24.0, a, g, st);
+    int rc = grid_build(pts, n, 16.0, a, g, st);
     if (rc) return rc;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     *nbr = a.get<int32_t>(nn * k);
     *d2 = a.get<double>(nn * k);
     *cnt = a.get<int32_t>(nn);
+    int32_t *fb_list = a.get<int32_t>(nn + 1);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
+    int32_t *fb_count = fb_list + nn;
     const int threads = k <= 48 ? 128 : 64;
     const size_t lds = (size_t)k * threads * (sizeof(double) + sizeof(int32_t));
     static bool attr_set = false;
     if (!attr_set) {
         KPX_HIP(hipFuncSetAttribute((const void *)nbr_list_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KPX_HIP(hipFuncSetAttribute((const void *)nbr_list_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(nbr_list_kernel, dim3((unsigned)cdiv(n, threads)), dim3(threads), lds, st, g->params, g->cell_start, g->sorted_pts,
-                       g->sorted_idx, n, k, radius * radius, *nbr, *d2, *cnt);
+    KPX_HIP(hipMemsetAsync(fb_count, 0, sizeof(int32_t), st));
+    // pass 1: one wave per query, 1024-candidate buffer; pass 2: the queries that did not fit, thread-per-query heap walk
+    const int cap = 1024;
+    hipLaunchKernelGGL(nbr_list_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256),
+                       (size_t)4 * cap * (sizeof(double) + sizeof(uint32_t)), st, g->params, g->cell_start, g->sorted_pts, g->sorted_idx, n, k, cap,
+                       radius * radius, *nbr, *d2, *cnt, fb_list, fb_count);
+    hipLaunchKernelGGL(nbr_list_kernel, dim3(256), dim3(threads), lds, st, g->params, g->cell_start, g->sorted_pts, g->sorted_idx, n, k,
+                       radius * radius, *nbr, *d2, *cnt, fb_list, fb_count);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
@@ -429,7 +507,7 @@ static int fpfh_impl(const float *pts, const float *nrm, int64_t n, double radiu
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     hipLaunchKernelGGL(spfh_kernel, dim3((unsigned)cdiv(n, kFeatThreads)), dim3(kFeatThreads), 0, st, pts, nrm, n, nbr, cnt, kk, spfh);
-    hipLaunchKernelGGL(fpfh_kernel, dim3((unsigned)cdiv(n, kFeatThreads)), dim3(kFeatThreads), 0, st, n, nbr, d2, cnt, kk, spfh, fpfh);
+    hipLaunchKernelGGL(fpfh_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, n, nbr, d2, cnt, kk, spfh, fpfh);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

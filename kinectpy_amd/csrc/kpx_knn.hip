@@ -147,185 +147,6 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     return KPX_OK;
 }
 
-// ---- wave-per-query neighbour selection (SOR, normals) -------------------------------------------------------
-// The lanes gather the squared distances (AC3, fp64) of the points of the (2r+1)^3 cell block around the query into
-// LDS (every (x, y) column of the block is one contiguous run of the cell-sorted points: 64 columns at a time, lane c
-// looks up run c, a wave scan places the runs, all candidates of the chunk are fetched together and the ones that pass
-// d^2 <= tau, d^2 < r2max are appended by ballot + popcount).  The k-th smallest is found by bisection on the IEEE
-// bit patterns (d^2 >= 0: the patterns order like the values; one ballot + popcount per 64 candidates and step) and
-// the search ends when that value lies inside the distance the block covers -- the termination rule of the ring walk
-// of kpx_gridknn.h.  Otherwise the k-th candidate found so far bounds the true k-th distance: the candidates are
-// gathered again, only those within it, from the block that covers it.  When the buffer fills, gathering stops; the
-// cap candidates held are still real points, so their k-th smallest is a valid bound too.
-__device__ __forceinline__ unsigned long long wave_all_min_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_all_max_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-    return v;
-}
-// squared distance the block [c-r, c+r] covers around q (infinity once it holds the whole grid)
-__device__ __forceinline__ double block_cover2(const GridParams &g, const double q[3], const int c[3], int r)
-{
-    double dcov = INFINITY;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double lo = g.org[a] + (double)(c[a] - r) * g.h;
-        const double hi = g.org[a] + (double)(c[a] + r + 1) * g.h;
-        const double dl = (c[a] - r <= 0) ? INFINITY : q[a] - lo;
-        const double dh = (c[a] + r + 1 >= g.dim[a]) ? INFINITY : hi - q[a];
-        dcov = fmin(dcov, fmin(dl, dh));
-    }
-    if (dcov == INFINITY) return INFINITY;
-    if (dcov < 0.0) dcov = 0.0;
-    return dcov * dcov * (1.0 - 1e-12);
-}
-
-struct WaveKnnScratch {        // LDS owned by one wave
-    double *vals;              // cap candidate distances
-    uint32_t *pos;             // cap sorted positions of the candidates (POS only)
-    uint32_t *run_s0;          // 64
-    int32_t *run_off;          // 64
-    int cap;
-};
-struct WaveKnnResult {
-    int m;                     // candidates in vals / pos
-    int kk;                    // neighbours selected: min(k, points within r2max)
-    int cnt;                   // candidates with pattern <= thr (>= kk: ties at the k-th value)
-    unsigned long long thr;    // bit pattern: the selected set is {d^2 pattern <= thr}
-    double top;                // largest selected d^2
-};
-// Returns false when the query does not fit the buffer (the caller hands it to the next pass).
-template <bool POS>
-__device__ __forceinline__ bool wave_knn_select(const GridParams &g, const uint32_t *__restrict__ cell_start, const float *__restrict__ spts,
-                                                const double q[3], int k, double r2max, const WaveKnnScratch &sc, WaveKnnResult &out)
-{
-    const int lane = threadIdx.x & 63;
-    int c[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) c[a] = cell_coord(q[a], g.org[a], g.h, g.dim[a]);
-    int maxr = g.dim[0] > g.dim[1] ? g.dim[0] : g.dim[1];
-    if (g.dim[2] > maxr) maxr = g.dim[2];
-    bool truncated = false;
-    auto gather_block = [&](int r, double tau) -> int {
-        const int xa = c[0] - r < 0 ? 0 : c[0] - r, xb = c[0] + r >= g.dim[0] ? g.dim[0] - 1 : c[0] + r;
-        const int ya = c[1] - r < 0 ? 0 : c[1] - r, yb = c[1] + r >= g.dim[1] ? g.dim[1] - 1 : c[1] + r;
-        const int za = c[2] - r < 0 ? 0 : c[2] - r, zb = c[2] + r >= g.dim[2] ? g.dim[2] - 1 : c[2] + r;
-        const int ny = yb - ya + 1, ncols = (xb - xa + 1) * ny;
-        int m = 0;
-        truncated = false;
-        for (int c0 = 0; c0 < ncols && !truncated; c0 += 64) {
-            const int nruns = ncols - c0 < 64 ? ncols - c0 : 64;
-            uint32_t s0 = 0;
-            int len = 0;
-            if (lane < nruns) {
-                const int x = xa + (c0 + lane) / ny, y = ya + (c0 + lane) % ny;
-                const int64_t col = ((int64_t)x * g.dim[1] + y) * g.dim[2];
-                s0 = cell_start[col + za];
-                len = (int)(cell_start[col + zb + 1] - s0);
-            }
-            const int incl = wave_incl_scan(len);
-            const int mc = __shfl(incl, 63, 64);
-            if (mc == 0) continue;
-            sc.run_s0[lane] = s0;
-            sc.run_off[lane] = incl - len;
-            wave_lds_fence();
-            for (int t0 = 0; t0 < mc; t0 += 64) {
-                const int t = t0 + lane;
-                double d = INFINITY;
-                uint32_t sp = 0;
-                if (t < mc) {
-                    int lo = 0, hi = nruns - 1;                                    // last run with off <= t
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (sc.run_off[mid] <= t) lo = mid; else hi = mid - 1;
-                    }
-                    sp = sc.run_s0[lo] + (uint32_t)(t - sc.run_off[lo]);
-                    const float *pp = spts + 3 * (int64_t)sp;
-                    const double dx = q[0] - (double)pp[0], dy = q[1] - (double)pp[1], dz = q[2] - (double)pp[2];
-                    d = fma(dz, dz, fma(dy, dy, dx * dx));
-                }
-                const bool keep = t < mc && d <= tau && d < r2max;
-                const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
-                const int pos = m + __builtin_popcountll(km & ((1ull << lane) - 1ull));
-                if (keep && pos < sc.cap) {
-                    sc.vals[pos] = d;
-                    if (POS) sc.pos[pos] = sp;
-                }
-                m += __builtin_popcountll(km);
-                if (m >= sc.cap) { m = sc.cap; truncated = true; break; }
-            }
-            wave_lds_fence();
-        }
-        return m;
-    };
-
-    double tau = INFINITY;
-    int r = 1;
-    for (int round = 0; round <= 24; ++round) {                // safety net: past it the query goes to the next pass
-        const int m = gather_block(r, tau);
-        wave_lds_fence();
-        const double cov2 = block_cover2(g, q, c, r);
-        const bool whole = cov2 == INFINITY || cov2 >= r2max;   // the block holds everything that may be selected
-        if (!truncated && m < k && !whole) {                    // too few candidates: grow by the density seen so far
-            const double f = cbrt((double)(k + 1) / (double)(m > 0 ? m : 1));
-            int rn = (int)((double)r * (f < 4.0 ? f : 4.0)) + 1;
-            r = rn > r ? rn : r + 1;
-            if (r > maxr) r = maxr;
-            continue;
-        }
-        const int kk = m < k ? m : k;
-        // k-th smallest by bisection between the smallest and the largest pattern
-        unsigned long long lo = ~0ull, hi = 0ull;
-        for (int t = lane; t < m; t += 64) {
-            const unsigned long long p = (unsigned long long)__double_as_longlong(sc.vals[t]);
-            lo = p < lo ? p : lo; hi = p > hi ? p : hi;
-        }
-        lo = wave_all_min_u64(lo); hi = wave_all_max_u64(hi);
-        if (m <= k) lo = hi;                                    // everything gathered is selected: no search needed
-        if (m == 0) { lo = hi = 0ull; }
-        while (lo < hi) {
-            const unsigned long long mid = lo + ((hi - lo) >> 1);
-            int cnt = 0;
-            for (int t0 = 0; t0 < m; t0 += 64) {
-                const int t = t0 + lane;
-                const bool le = t < m && (unsigned long long)__double_as_longlong(sc.vals[t]) <= mid;
-                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
-            }
-            if (cnt == kk) { lo = hi = mid; break; }           // the set is determined
-            if (cnt > kk) hi = mid; else lo = mid + 1;
-        }
-        double top = 0.0;
-        int cnt = 0;
-        for (int t0 = 0; t0 < m; t0 += 64) {
-            const int t = t0 + lane;
-            const bool le = t < m && (unsigned long long)__double_as_longlong(sc.vals[t]) <= lo;
-            if (le) top = fmax(top, sc.vals[t]);
-            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) top = fmax(top, __shfl_xor(top, o, 64));
-        if (!truncated && (whole || top < cov2)) {
-            out.m = m; out.kk = kk; out.cnt = cnt; out.thr = lo; out.top = top;
-            return true;
-        }
-        // the k-th candidate found so far bounds the true k-th distance: gather again, only what lies within it, from
-        // the block that covers it -- that settles the query unless even the ball overflows the buffer
-        if (truncated && top >= tau) return false;
-        tau = top;
-        int rn = (int)(sqrt(top) / g.h) + 1;
-        if (rn > maxr) rn = maxr;
-        r = rn;
-        wave_lds_fence();
-    }
-    return false;
-}
-
 // ---- a8 SOR ------------------------------------------------------------------------------------------
 // One WAVE per query; the mean needs no identities: sum of sqrt over the selected set, ties at the k-th value counted
 // k - (#smaller) times.  Queries whose candidates exceed the LDS buffer are listed for the next pass.
@@ -537,38 +358,10 @@ __global__ __launch_bounds__(WAVES * 64) void normals_wave_kernel(const GridPara
             if (lane == 0) { fb_list[atomicAdd(fb_count, 1)] = (int32_t)s; covbuf[10 * s + 9] = -1.0; }
             continue;
         }
-        const unsigned long long topp = (unsigned long long)__double_as_longlong(res.top);
-        int32_t idx_thr = INT_MAX;
-        if (res.cnt > res.kk) {
-            // more candidates at the k-th distance than slots: keep the `need` lowest original indices among them
-            int ntied = 0;
-            for (int t0 = 0; t0 < res.m; t0 += 64) {
-                const int t = t0 + lane;
-                const bool tie = t < res.m && (unsigned long long)__double_as_longlong(sc.vals[t]) == topp;
-                ntied += __builtin_popcountll(__builtin_amdgcn_ballot_w64(tie));
-            }
-            const int need = res.kk - (res.cnt - ntied);
-            int32_t last = -1;
-            for (int round = 0; round < need; ++round) {
-                int32_t cand = INT_MAX;
-                for (int t = lane; t < res.m; t += 64)
-                    if ((unsigned long long)__double_as_longlong(sc.vals[t]) == topp) {
-                        const int32_t oi = sidx[sc.pos[t]];
-                        if (oi > last && oi < cand) cand = oi;
-                    }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const int32_t t2 = __shfl_xor(cand, o, 64); cand = t2 < cand ? t2 : cand; }
-                last = cand;
-            }
-            idx_thr = last;
-        }
+        const int32_t idx_thr = wave_knn_tie_threshold(sc, res, sidx);
         double c[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
         for (int t = lane; t < res.m; t += 64) {
-            const unsigned long long p = (unsigned long long)__double_as_longlong(sc.vals[t]);
-            bool sel = p < topp || (p == topp && res.cnt == res.kk);
-            if (!sel && p == topp) sel = sidx[sc.pos[t]] <= idx_thr;
-            if (p > res.thr) sel = false;
-            if (sel) {
+            if (wave_knn_is_selected(sc, res, sidx, idx_thr, t)) {
                 const float *pp = spts + 3 * (int64_t)sc.pos[t];
                 const double x = pp[0], y = pp[1], z = pp[2];
                 c[0] += x; c[1] += y; c[2] += z;
