@@ -198,7 +198,9 @@ int kpx_fpfh(const float *pts, const float *normals, int64_t n, double radius, i
 
 /* 1-nearest neighbour of every row of fa among the rows of fb in the 33-D feature space (the matching stage of
  * registration_ransac_based_on_feature_matching, registration.py:50-57); ties to the lowest index. */
-int kpx_feature_nn(const double *fa, int64_t na, const double *fb, int64_t nb, int32_t *idx, void *stream);
+size_t kpx_feature_nn_workspace_bytes(int64_t na, int64_t nb);
+int kpx_feature_nn(const double *fa, int64_t na, const double *fb, int64_t nb, int32_t *idx, void *ws, size_t ws_bytes,
+                   void *stream);
 
 /* RegistrationRANSACBasedOnCorrespondence: ransac_n = 3 correspondences per hypothesis (Philox-seeded, with
  * replacement), Umeyama without scale, CorrespondenceCheckerBasedOnEdgeLength(edge_similarity) and

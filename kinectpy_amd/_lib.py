@@ -51,7 +51,8 @@ SIGNATURES = {
     "kpx_icp": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _f64, _vp, _i32, _i32, _f64, _f64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_fpfh_workspace_bytes": (_sz, [_i64, _i32]),
     "kpx_fpfh": (C.c_int, [_vp, _vp, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
-    "kpx_feature_nn": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "kpx_feature_nn_workspace_bytes": (_sz, [_i64, _i64]),
+    "kpx_feature_nn": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
     "kpx_ransac_workspace_bytes": (_sz, [_i64, _i64]),
     "kpx_ransac_corres": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _f64, _i32, _f64, _i32, _f64, _u64, _vp, _vp, _sz, _vp]),
     "kpx_nn_engine": (C.c_int, [_i32]),

@@ -213,8 +213,10 @@ __global__ __launch_bounds__(256) void fpfh_kernel(int64_t n, const int32_t *__r
 // conflict-free for the 16 columns a lane group reads), their norms are formed once per stage.
 typedef double fnn_d4 __attribute__((ext_vector_type(4)));
 constexpr int kFnnCols = 64, kFnnStride = 37;
+// gridDim.y column splits (stages of 64 columns dealt round-robin); split s writes (value, column) of its best to
+// part_val / part_idx [s][na]; feature_nn_merge_kernel takes the lexicographic minimum.
 __global__ __launch_bounds__(256) void feature_nn_kernel(const double *__restrict__ fa, int64_t na, const double *__restrict__ fb,
-                                                         int64_t nb, int32_t *__restrict__ idx)
+                                                         int64_t nb, double *__restrict__ part_val, int32_t *__restrict__ part_idx)
 {
     __shared__ double sb[kFnnCols][kFnnStride];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void feature_nn_kernel(const double *__restric
     }
     double best[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
     int32_t bcol[4] = { INT_MAX, INT_MAX, INT_MAX, INT_MAX };
-    for (int64_t j0 = 0; j0 < nb; j0 += kFnnCols) {
+    for (int64_t j0 = (int64_t)blockIdx.y * kFnnCols; j0 < nb; j0 += (int64_t)gridDim.y * kFnnCols) {
         const int cnt = nb - j0 < kFnnCols ? (int)(nb - j0) : kFnnCols;
         __syncthreads();
         for (int e = threadIdx.x; e < cnt * 33; e += 256) sb[e / 33][e % 33] = fb[j0 * 33 + e];
@@ -287,8 +289,22 @@ __global__ __launch_bounds__(256) void feature_nn_kernel(const double *__restric
             c = take ? oc : c;
         }
         const int64_t row = row_base + q + 4 * r;
-        if (j == 0 && row < na) idx[row] = c;
+        if (j == 0 && row < na) { part_val[(int64_t)blockIdx.y * na + row] = v; part_idx[(int64_t)blockIdx.y * na + row] = c; }
     }
+}
+__global__ __launch_bounds__(256) void feature_nn_merge_kernel(const double *__restrict__ part_val, const int32_t *__restrict__ part_idx,
+                                                               int64_t na, int splits, int32_t *__restrict__ idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    double bv = part_val[i];
+    int32_t bj = part_idx[i];
+    for (int s = 1; s < splits; ++s) {
+        const double v = part_val[(int64_t)s * na + i];
+        const int32_t c = part_idx[(int64_t)s * na + i];
+        if (v < bv || (v == bv && c < bj)) { bv = v; bj = c; }
+    }
+    idx[i] = bj;
 }
 
 // ---- RANSAC hypotheses -----------------------------------------------------------------------------------------
@@ -561,12 +577,36 @@ KPX_EXPORT int kpx_fpfh(const float *pts, const float *normals, int64_t n, doubl
     return fpfh_impl(pts, normals, n, radius, max_nn, fpfh, a, (hipStream_t)stream);
 }
 
-KPX_EXPORT int kpx_feature_nn(const double *fa, int64_t na, const double *fb, int64_t nb, int32_t *idx, void *stream)
+static int feature_nn_splits(int64_t na, int64_t nb)
+{
+    // aim for >= ~1024 blocks (4 per CU); a split needs at least one 64-column stage
+    const int64_t row_blocks = cdiv(na > 0 ? na : 1, 64), stages = cdiv(nb > 0 ? nb : 1, kFnnCols);
+    int64_t s = cdiv(1024, row_blocks);
+    if (s > stages) s = stages;
+    if (s > 16) s = 16;
+    return (int)(s < 1 ? 1 : s);
+}
+KPX_EXPORT size_t kpx_feature_nn_workspace_bytes(int64_t na, int64_t nb)
+{
+    Arena a(nullptr, 0);
+    const size_t e = (size_t)(na > 0 ? na : 1) * feature_nn_splits(na, nb);
+    a.get<double>(e);
+    a.get<int32_t>(e);
+    return a.off;
+}
+KPX_EXPORT int kpx_feature_nn(const double *fa, int64_t na, const double *fb, int64_t nb, int32_t *idx, void *ws, size_t ws_bytes, void *stream)
 {
     KPX_REQUIRE(na >= 0 && nb >= 1, "kpx_feature_nn: empty feature set");
     if (na == 0) return KPX_OK;
-    KPX_REQUIRE(fa && fb && idx, "kpx_feature_nn: null pointer");
-    hipLaunchKernelGGL(feature_nn_kernel, dim3((unsigned)cdiv(na, 64)), dim3(256), 0, (hipStream_t)stream, fa, na, fb, nb, idx);
+    KPX_REQUIRE(fa && fb && idx && ws, "kpx_feature_nn: null pointer");
+    const int splits = feature_nn_splits(na, nb);
+    Arena a(ws, ws_bytes);
+    double *pv = a.get<double>((size_t)na * splits);
+    int32_t *pi = a.get<int32_t>((size_t)na * splits);
+    KPX_ARENA_CHECK(a);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(feature_nn_kernel, dim3((unsigned)cdiv(na, 64), splits), dim3(256), 0, st, fa, na, fb, nb, pv, pi);
+    hipLaunchKernelGGL(feature_nn_merge_kernel, dim3((unsigned)cdiv(na, 256)), dim3(256), 0, st, pv, pi, na, splits, idx);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

@@ -341,7 +341,8 @@ def feature_nn(fa, fb):
     fa = _dev(fa, torch.float64).reshape(-1, 33)
     fb = _dev(fb, torch.float64).reshape(-1, 33)
     idx = torch.empty(fa.shape[0], dtype=torch.int32, device=fa.device)
-    L.check(lib.kpx_feature_nn(L.ptr(fa), fa.shape[0], L.ptr(fb), fb.shape[0], L.ptr(idx), L.stream_ptr()))
+    ws, wsz = L.workspace(lib.kpx_feature_nn_workspace_bytes(fa.shape[0], fb.shape[0]))
+    L.check(lib.kpx_feature_nn(L.ptr(fa), fa.shape[0], L.ptr(fb), fb.shape[0], L.ptr(idx), ws, wsz, L.stream_ptr()))
     return idx
 
 
