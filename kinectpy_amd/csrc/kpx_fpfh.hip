@@ -209,10 +209,10 @@ __global__ __launch_bounds__(256) void fpfh_kernel(int64_t n, const int32_t *__r
 //     A[i] = (a_0 .. a_32, 1, 0, 0)        B[j] = (-2 b_0 .. -2 b_32, |b_j|^2, 0, 0)        C[i] = |a_i|^2
 //     D_ij = fma chain over k = 0 .. 35 of A_ik B_kj seeded with C_i     (nine v_mfma_f64_16x16x4_f64 per tile;
 //     |x|^2 = fma chain x_k x_k from 0)  -> argmin_j, ties to the lowest j.  The oracle restates the same chain.
-// Block = 4 waves x 16 query rows; 64 target columns per stage go through LDS (row-major, stride 37 doubles:
-// conflict-free for the 16 columns a lane group reads), their norms are formed once per stage.
+// Block = 4 waves x 16 query rows; 128 target columns per stage go through LDS (row-major, stride 37 doubles:
+// conflict-free for the 16 columns a lane group reads) already scaled by -2, their norms are formed once per stage.
 typedef double fnn_d4 __attribute__((ext_vector_type(4)));
-constexpr int kFnnCols = 64, kFnnStride = 37;
+constexpr int kFnnCols = 128, kFnnStride = 37;
 // gridDim.y column splits (stages of 64 columns dealt round-robin); split s writes (value, column) of its best to
 // part_val / part_idx [s][na]; feature_nn_merge_kernel takes the lexicographic minimum.
 __global__ __launch_bounds__(256) void feature_nn_kernel(const double *__restrict__ fa, int64_t na, const double *__restrict__ fb,
@@ -244,29 +244,25 @@ __global__ __launch_bounds__(256) void feature_nn_kernel(const double *__restric
     for (int64_t j0 = (int64_t)blockIdx.y * kFnnCols; j0 < nb; j0 += (int64_t)gridDim.y * kFnnCols) {
         const int cnt = nb - j0 < kFnnCols ? (int)(nb - j0) : kFnnCols;
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt * 33; e += 256) sb[e / 33][e % 33] = fb[j0 * 33 + e];
+        for (int e = threadIdx.x; e < cnt * 33; e += 256) sb[e / 33][e % 33] = -2.0 * fb[j0 * 33 + e];    // B rows: -2 b (exact)
         __syncthreads();
         if ((int)threadIdx.x < kFnnCols) {
             double n2 = kSentinelF;                            // columns past the end can never win
             if ((int)threadIdx.x < cnt) {
                 n2 = 0.0;
-                for (int k = 0; k < 33; ++k) { const double v = sb[threadIdx.x][k]; n2 = fma(v, v, n2); }
+                for (int k = 0; k < 33; ++k) { const double v = -0.5 * sb[threadIdx.x][k]; n2 = fma(v, v, n2); }
             } else {
                 for (int k = 0; k < 33; ++k) sb[threadIdx.x][k] = 0.0;
             }
-            sb[threadIdx.x][33] = n2;
+            sb[threadIdx.x][33] = n2; sb[threadIdx.x][34] = 0.0; sb[threadIdx.x][35] = 0.0;
         }
         __syncthreads();
 #pragma unroll
         for (int ct = 0; ct < kFnnCols / 16; ++ct) {
             fnn_d4 acc = seed;
-            const double *col = sb[ct * 16 + j];
+            const double *col = sb[ct * 16 + j] + q;           // B[k = q + 4 s][column]: no arithmetic beside the MFMAs
 #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const int k = q + 4 * s;
-                const double b = k < 33 ? -2.0 * col[k] : (k == 33 ? col[33] : 0.0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
-            }
+            for (int s = 0; s < 9; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], col[4 * s], acc, 0, 0, 0);
             const int32_t c = (int32_t)(j0 + ct * 16 + j);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
