@@ -407,6 +407,9 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
                 for (int r = 0; r < 4; ++r) {
                     const unsigned h0 = hi32(best[0][r]), h1 = hi32(best[1][r]);
                     anyeq |= (bool)((int)(hi32(c00[r]) == h0) | (int)(hi32(c01[r]) == h0) | (int)(hi32(c10[r]) == h1) | (int)(hi32(c11[r]) == h1));
+                    // two candidates of one row with equal high words: the second must be compared exactly with the first
+                    // once that has become the running best (found by the random cross-engine test: far-apart line clouds)
+                    anyeq |= (bool)((int)(hi32(c00[r]) == hi32(c01[r])) | (int)(hi32(c10[r]) == hi32(c11[r])));
                 }
                 if (__builtin_amdgcn_ballot_w64(anyeq) == 0) {
                     // every high word differs from its bound: the high words alone decide "<" (no fp64 op)

@@ -340,6 +340,44 @@ def test_nn_far_apart_and_clustered(ops, oracle, base_cloud, engine):
         assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd)
 
 
+def test_nn_random_shapes_engines_and_oracle_agree(ops, oracle):
+    """sixty seeded random problems (sizes 1 .. 6000, blobs / sheets / lines / lattices / duplicates, random rigid motion):
+    culled engine == all-pairs engine == oracle, bit for bit"""
+    rng = np.random.default_rng(2025)
+
+    def cloud(n):
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            p = rng.normal(scale=rng.uniform(1, 800), size=(n, 3))
+        elif kind == 1:                                          # sheet with noise
+            p = np.stack([rng.uniform(-2000, 2000, n), rng.uniform(-1500, 1500, n), rng.normal(scale=2.0, size=n)], -1)
+        elif kind == 2:                                          # a few tight blobs far apart
+            c = rng.uniform(-5000, 5000, size=(rng.integers(1, 6), 3))
+            p = c[rng.integers(0, len(c), n)] + rng.normal(scale=3.0, size=(n, 3))
+        elif kind == 3:                                          # integer lattice with repeats
+            p = rng.integers(-20, 20, size=(n, 3)).astype(np.float64) * rng.integers(1, 9)
+        else:                                                    # line
+            t = rng.uniform(-3000, 3000, n)
+            p = np.stack([t, 0.5 * t + 10, np.full(n, 700.0)], -1)
+        return (p + rng.uniform(-3000, 3000, size=3)).astype(np.float32)
+
+    for case in range(60):
+        n, m = int(rng.integers(1, 6000)), int(rng.integers(1, 6000))
+        src, tgt = cloud(n), cloud(m)
+        ang = rng.uniform(-0.6, 0.6, 3)
+        cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+        R = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = rng.uniform(-500, 500, 3)
+        ri, rd, _ = oracle.nn(src, T, tgt)
+        for name in ("culled", "dense"):
+            prev = ops.nn_engine(name)
+            try:
+                gi, gd = ops.nn_search(src, tgt, T)
+            finally:
+                ops.nn_engine(prev)
+            assert np.array_equal(npy(gi), ri) and np.array_equal(npy(gd), rd), (case, name, n, m)
+
+
 def test_icp_without_any_correspondence(ops, oracle, base_cloud, engine):
     """nothing within max_correspondence_distance: fitness 0, the transform stays the initial one"""
     src, tgt, _ = synth.icp_pair(3000, base_cloud)
