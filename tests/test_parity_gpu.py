@@ -218,6 +218,55 @@ def test_sor_duplicates_and_errors(ops, oracle):
             ops.sor(p, *bad)
 
 
+def _random_cloud(rng, n):
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        p = rng.normal(scale=rng.uniform(1, 800), size=(n, 3))
+    elif kind == 1:                                              # sheet with noise
+        p = np.stack([rng.uniform(-2000, 2000, n), rng.uniform(-1500, 1500, n), rng.normal(scale=2.0, size=n)], -1)
+    elif kind == 2:                                              # a few tight blobs far apart + stragglers
+        c = rng.uniform(-5000, 5000, size=(rng.integers(1, 6), 3))
+        p = c[rng.integers(0, len(c), n)] + rng.normal(scale=3.0, size=(n, 3))
+        p[: max(1, n // 50)] = rng.uniform(-6000, 6000, size=(max(1, n // 50), 3))
+    elif kind == 3:                                              # integer lattice with repeats
+        p = rng.integers(-20, 20, size=(n, 3)).astype(np.float64) * rng.integers(1, 9)
+    else:                                                        # line
+        t = rng.uniform(-3000, 3000, n)
+        p = np.stack([t, 0.5 * t + 10, np.full(n, 700.0)], -1)
+    return (p + rng.uniform(-3000, 3000, size=3)).astype(np.float32)
+
+
+def test_filters_random_shapes_match_oracle(ops, oracle):
+    """forty seeded random clouds (blobs, sheets, lines, lattices with duplicates; 1 .. 8000 points) through voxel, SOR and
+    normals with random parameters: kept indices / voxel means bit-exact, statistics within tolerance"""
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        n = int(rng.integers(1, 8000))
+        p = _random_cloud(rng, n)
+        voxel = float(rng.choice([3.0, 10.0, 35.0, 120.0]))
+        gp = npy(ops.voxel_downsample(p, voxel)[0])
+        rp = oracle.voxel_downsample(p, voxel)[0]
+        assert np.array_equal(gp, rp), ("voxel", case, n, voxel)
+        k, ratio = int(rng.choice([1, 5, 20, 50, 200])), float(rng.choice([0.3, 1.0, 2.0, 3.0]))
+        gi, gs, ga = ops.sor(p, k, ratio, want_avg=True)
+        ri, rs, ra = oracle.sor(p, k, ratio)
+        assert np.allclose(npy(ga), ra, rtol=1e-12, atol=0), ("sor avg", case, n, k)
+        near = np.abs(ra - rs[2]) <= 1e-9 * max(abs(rs[2]), 1.0)      # means exactly at the threshold may fall either way
+        assert np.array_equal(np.setdiff1d(npy(gi), np.flatnonzero(near)), np.setdiff1d(ri, np.flatnonzero(near))), ("sor idx", case, n, k)
+        radius, nn = float(rng.choice([5.0, 40.0, 150.0])), int(rng.choice([3, 10, 40, 100]))
+        gn = npy(ops.estimate_normals(p, radius, nn)).astype(np.float64)
+        rn, cov, cnt = oracle.estimate_normals(p, radius, nn)
+        assert np.allclose(gn[cnt < 3], [0, 0, 1]), ("normals degenerate", case)
+        A = np.zeros((len(p), 3, 3))
+        A[:, 0, 0], A[:, 1, 1], A[:, 2, 2] = cov[:, 0], cov[:, 3], cov[:, 5]
+        A[:, 0, 1] = A[:, 1, 0] = cov[:, 1]
+        A[:, 0, 2] = A[:, 2, 0] = cov[:, 2]
+        A[:, 1, 2] = A[:, 2, 1] = cov[:, 4]
+        w = np.linalg.eigvalsh(A)
+        well = (cnt >= 3) & ((w[:, 1] - w[:, 0]) > 1e-3 * np.maximum(w[:, 2], 1e-30)) & (w[:, 2] > 1e-9)
+        assert (np.abs((gn * rn).sum(1))[well] > 1 - 1e-5).all(), ("normals", case, n, radius, nn)
+
+
 def test_sor_and_normals_on_lattice_ties(ops, oracle):
     """integer lattice (raw Kinect XYZ is int16): many neighbours at exactly the k-th distance.  SOR counts ties at the
     k-th value k - (#smaller) times; normals keep the lowest original indices among them -- both as the oracle does.
@@ -405,6 +454,29 @@ def test_icp_matches_oracle(ops, oracle, base_cloud, engine, mode):
         assert np.array_equal(npy(gi), idx) and np.array_equal(npy(gd), d2)
     if mode == "p2plane":
         assert np.abs(g["transformation"][:3, 3] - T[:3, 3]).max() < 3.0       # recovers the ground truth
+
+
+def test_icp_random_problems_match_oracle(ops, oracle, base_cloud):
+    """twelve seeded registrations (sizes 300 .. 6000, partial overlap, random motion up to ~8 deg / 60 mm, both estimators,
+    random max_correspondence_distance): iterations and fitness equal, transform within tolerance"""
+    rng = np.random.default_rng(31)
+    for case in range(12):
+        n, m = int(rng.integers(300, 6000)), int(rng.integers(300, 6000))
+        tgt = base_cloud[rng.choice(len(base_cloud), m, replace=False)]
+        src0 = base_cloud[rng.choice(len(base_cloud), n, replace=False)].astype(np.float64)
+        if case % 3 == 0:
+            src0 = src0[src0[:, 0] > np.median(src0[:, 0]) - 200]          # partial overlap
+        ang = rng.uniform(-0.14, 0.14, 3)
+        cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+        R = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        src = ((src0 - src0.mean(0)) @ R.T + src0.mean(0) + rng.uniform(-60, 60, 3)).astype(np.float32)
+        mode = "p2plane" if case % 2 else "p2p"
+        tn = oracle.estimate_normals(tgt, 70.0, 40)[0].astype(np.float32) if mode == "p2plane" else None
+        md = float(rng.choice([40.0, 100.0, 300.0]))
+        g = ops.icp(src, tgt, md, None, mode, tn, 20)
+        rT, rf, rr, rit = oracle.registration_icp(src, tgt, md, None, mode, tn, 20)
+        assert g["iterations"] == rit and g["fitness"] == rf, (case, mode, n, m, md)
+        assert np.abs(g["transformation"] - rT).max() < TOL_T, (case, mode)
 
 
 def test_icp_engines_agree(ops, base_cloud):
