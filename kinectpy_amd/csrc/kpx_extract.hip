@@ -145,9 +145,12 @@ struct MedianSel {
 // serialise.  Sixteen copies of every bin (lane & 15), laid out copy-minor so that equal bins of different copies fall
 // into different banks, cut the serialisation 16-fold; the copies are folded before the global add.
 constexpr int kHistCopies = 16;
+// xy != NULL (fused depth path, stride 1): the value of pixel i is the z the unprojection would store, i.e. 0 where a
+// table entry is NaN (unproject1), the raw depth otherwise.
 __global__ __launch_bounds__(256) void median_hist_kernel(const int16_t *__restrict__ v, int64_t n, int64_t stride,
                                                           int64_t frame_stride, const MedianSel *__restrict__ sel,
-                                                          uint32_t *__restrict__ hist /* [frames][2][256] */, int pass)
+                                                          uint32_t *__restrict__ hist /* [frames][2][256] */, int pass,
+                                                          const float *__restrict__ xy)
 {
     __shared__ uint32_t h[2][256][kHistCopies];
     const int frame = blockIdx.y;
@@ -167,12 +170,21 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const int16_t *__restr
             if (top == bb) atomicAdd(&h[1][key & 255u][cp], 1u);
         }
     };
-    const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0);
+    const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)xy % 16 == 0);
     if (vec) {
         const int64_t groups = n >> 3;
         for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
             union { uint4 q; uint16_t s[8]; } d;
             d.q = reinterpret_cast<const uint4 *>(p)[g];
+            if (xy) {
+                union { float4 v4[4]; float f[16]; } t;
+                const float4 *tp = reinterpret_cast<const float4 *>(xy + 16 * g);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) t.v4[q4] = tp[q4];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (__builtin_isnan(t.f[2 * k]) || __builtin_isnan(t.f[2 * k + 1])) d.s[k] = 0;
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) take(d.s[k]);
         }
@@ -193,8 +205,11 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const int16_t *__restr
             }
         }
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-            take((uint32_t)(uint16_t)p[i * stride]);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            uint32_t raw = (uint32_t)(uint16_t)p[i * stride];
+            if (xy && (__builtin_isnan(xy[2 * i]) || __builtin_isnan(xy[2 * i + 1]))) raw = 0;
+            take(raw);
+        }
     }
     __syncthreads();
     uint32_t *g = hist + (int64_t)frame * 512;
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(64) void median_select_kernel(uint32_t *__restrict_
 }
 
 static int median_impl(const int16_t *v, int64_t n, int64_t stride, int64_t frame_stride, int32_t frames,
-                       double *d_median, Arena &a, hipStream_t st)
+                       double *d_median, Arena &a, hipStream_t st, const float *xy = nullptr)
 {
     uint32_t *hist = a.get<uint32_t>((size_t)frames * 512);
     MedianSel *sel = a.get<MedianSel>((size_t)frames);
@@ -251,9 +266,9 @@ static int median_impl(const int16_t *v, int64_t n, int64_t stride, int64_t fram
     KPX_HIP(hipMemsetAsync(hist, 0, (size_t)frames * 512 * sizeof(uint32_t), st));
     int bx = (int)(cdiv(n, 256 * 16) < 1 ? 1 : (cdiv(n, 256 * 16) > 512 ? 512 : cdiv(n, 256 * 16)));
     dim3 grid(bx, frames);
-    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 0);
+    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 0, xy);
     hipLaunchKernelGGL(median_select_kernel, dim3(frames), dim3(64), 0, st, hist, n, sel, d_median, 0);
-    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 1);
+    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 1, xy);
     hipLaunchKernelGGL(median_select_kernel, dim3(frames), dim3(64), 0, st, hist, n, sel, d_median, 1);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
@@ -547,7 +562,7 @@ static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uin
     double *med = a.get<double>((size_t)frames);
     int rc = KPX_OK;
     if (flags & KPX_COMPACT_DEPTH_GATE || a.dry)
-        rc = median_impl(reinterpret_cast<const int16_t *>(depth), n, 1, n, frames, med, a, st);
+        rc = median_impl(reinterpret_cast<const int16_t *>(depth), n, 1, n, frames, med, a, st, xy);
     if (a.dry || rc) return rc;
     KPX_ARENA_CHECK(a);
     DepthPred pred{ depth, xy, rgb, med, n, flags, gate };

@@ -83,6 +83,35 @@ def test_compact_reference_kat(ops):
         assert np.allclose(np.asarray(pcd.colors), np.array(c["final_colors"]).reshape(-1, 3), atol=6e-8)
 
 
+def test_extract_random_frames_match_oracle(ops, oracle):
+    """thirty seeded random frame batches (pixel counts that do / do not take the 8-pixel vector path, 1 .. 5 frames, random
+    validity holes, NaN table entries, sparse colour masks, every flag combination, with / without index output): fused
+    depth->cloud and the int16-XYZ compaction against the oracle, bit for bit"""
+    rng = np.random.default_rng(123)
+    for case in range(30):
+        n = int(rng.choice([8, 64, 512, 1000, 4096, 5003, 20000, 36864]))
+        F = int(rng.integers(1, 6))
+        t = rng.normal(scale=0.5, size=(n, 2)).astype(np.float32)
+        t[rng.random(n) < 0.01] = np.nan
+        d = rng.integers(300, 6000, size=(F, n)).astype(np.uint16)
+        d[rng.random((F, n)) < rng.uniform(0.0, 0.6)] = 0
+        rgb = rng.integers(0, 255, size=(F, n, 3)).astype(np.uint8)
+        rgb[rng.random((F, n)) < rng.uniform(0.0, 0.9)] = 0
+        cm, dg, wi = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        use_rgb = bool(rng.integers(0, 2)) or cm
+        res = ops.depth_to_cloud(d, t, rgb if use_rgb else None, F, cm, dg, want_idx=wi)
+        xyz = np.stack([oracle.unproject_u16(d[f], t) for f in range(F)])
+        res2 = ops.rgbd_compact(xyz, rgb if use_rgb else None, F, cm, dg, want_idx=wi)
+        for f in range(F):
+            rp, rc, ri = oracle.rgbd_compact(xyz[f], rgb[f] if use_rgb else None, cm, dg, oracle.median_z(xyz[f]) + 750.0)
+            for (gp, gc, gi) in (res[f], res2[f]):
+                assert np.array_equal(npy(gp), rp), (case, n, F, cm, dg)
+                if use_rgb:
+                    assert np.array_equal(npy(gc), rc), (case, "colour")
+                if wi:
+                    assert np.array_equal(npy(gi), ri), (case, "idx")
+
+
 def test_fused_depth_to_cloud_batched_and_edge_cases(ops, oracle):
     xy = synth.xy_table()
     deps = np.stack([synth.render_depth(seed=s, xy=xy) for s in (1, 2, 3)] + [np.zeros(576 * 640, np.uint16)])
