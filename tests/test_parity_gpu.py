@@ -176,6 +176,33 @@ def test_select_halfspace_slab(ops, oracle, base_cloud):
         assert np.array_equal(np.asarray(kept.points), want.astype(np.float32).astype(np.float64))   # float32 storage
 
 
+def test_selections_random_sizes_and_unaligned_views(ops, oracle):
+    """half-space / slab selections, index selection and transforms on random sizes (tails that are not a multiple of the
+    8-point vector width) and on device views whose first element is not 16-byte aligned (scalar fallback)"""
+    rng = np.random.default_rng(19)
+    for case in range(24):
+        n = int(rng.choice([1, 7, 8, 9, 63, 2047, 2048, 2049, 10007, 65536 + 5]))
+        off = int(rng.integers(0, 4))                                # rows skipped: 12-byte steps break the alignment
+        host = rng.normal(scale=500, size=(n + off, 3)).astype(np.float32)
+        dev = torch.as_tensor(host).cuda()[off:]                     # contiguous view, possibly unaligned
+        p = host[off:]
+        pl = [float(x) for x in rng.normal(size=3)] + [float(rng.normal(scale=200))]
+        assert np.array_equal(npy(ops.halfspace_select(dev, pl)), oracle.halfspace_keep_idx(*pl, p)), (case, n, off)
+        slab = float(rng.uniform(1, 800))
+        lo, up = ops.slab_split(dev, slab)
+        y = p[:, 1].astype(np.float64)
+        assert np.array_equal(npy(lo), np.flatnonzero(y >= y.max() - slab)) and np.array_equal(npy(up), np.flatnonzero(y < y.max() - slab))
+        T = synth.t_star()
+        assert np.array_equal(npy(ops.transform(dev, T)), oracle.transform(p, T))
+        k = int(rng.integers(0, n + 1))
+        idx = np.sort(rng.choice(n, k, replace=False)).astype(np.int32)
+        g = ops.select_by_index([dev], idx)[0]
+        assert np.array_equal(npy(g), p[idx])
+        gi = ops.select_by_index([dev], idx, invert=True)[0]
+        m = np.ones(n, bool); m[idx] = False
+        assert np.array_equal(npy(gi), p[m])
+
+
 # ---------------------------------------------------------------------------------------------- filters
 @pytest.mark.parametrize("voxel", [0.02, 10.0, 35.0, 500.0])
 def test_voxel_bit_exact(ops, oracle, base_cloud, voxel):
