@@ -571,6 +571,25 @@ def test_icp_batch_equals_single_problems(ops, oracle, base_cloud, engine):
             assert rit == b["iterations"] and rf == b["fitness"] and np.abs(rT - b["transformation"]).max() < TOL_T
 
 
+def test_icp_batch_more_problems_than_lanes(ops, base_cloud):
+    """seven registrations onto one target (the library runs them on four internal lanes, two per lane at times): each
+    equals the single-problem call bit for bit, whatever the interleaving"""
+    rng = np.random.default_rng(8)
+    src, tgt, T = synth.icp_pair(9000, base_cloud)
+    srcs, inits = [], []
+    for i in range(7):
+        k = int(rng.integers(500, 9000))
+        srcs.append(src[rng.choice(len(src), k, replace=False)])
+        P = np.eye(4); P[:3, 3] = rng.uniform(-20, 20, 3)
+        inits.append(P)
+    for _ in range(2):                                            # twice: the lanes and pinned slots are reused
+        batch = ops.icp_batch(srcs, tgt, 100.0, inits, "p2p", None, 9)
+        for s_, i0, b in zip(srcs, inits, batch):
+            one = ops.icp(s_, tgt, 100.0, i0, "p2p", None, 9)
+            assert b["iterations"] == one["iterations"] and b["fitness"] == one["fitness"]
+            assert np.array_equal(b["transformation"], one["transformation"])
+
+
 def test_kabsch_pairs(ops, oracle, base_cloud):
     src, tgt, T = synth.icp_pair(5000, base_cloud)
     rng = np.random.default_rng(0)
