@@ -80,14 +80,15 @@ def _all_gather_flat(t: torch.Tensor) -> torch.Tensor:
 
 
 def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor):
-    """padded: (cap, C) float32 buffer whose first `count` rows are valid (same cap on every rank);
+    """padded: (cap, C) float32 buffer whose first min(count, cap) rows are valid (same cap on every rank; `count` may
+    exceed it: the header carries the true count so that the caller can resend with room);
     transforms: (k, 4, 4) float64 of this rank's sensors (same k on every rank).
     Returns (cloud (sum counts, C), all transforms (world*k, 4, 4), counts list).
     One collective: the header (count, transforms) travels as float64 bit patterns in extra rows of the buffer."""
     k = transforms.shape[0]
     hdr = torch.cat([torch.tensor([float(count)], dtype=torch.float64), transforms.reshape(-1).to("cpu", torch.float64)])
     if world_size() == 1:
-        return padded[:count], hdr[1:].reshape(-1, 4, 4).to(padded.device), [int(count)]
+        return padded[:min(count, padded.shape[0])], hdr[1:].reshape(-1, 4, 4).to(padded.device), [int(count)]
     cap, C = padded.shape
     words = hdr.numel() * 2                                     # float32 words carrying the float64 header
     hrows = (words + C - 1) // C
@@ -100,9 +101,34 @@ def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor)
     hdrs = allm[:, cap:].reshape(world_size(), -1)[:, :words].contiguous().cpu().view(torch.float64)   # one read-back
     counts = [int(c) for c in hdrs[:, 0].tolist()]
     all_T = hdrs[:, 1:].reshape(-1, 4, 4).to(padded.device)
-    cloud = torch.cat([allm[r, :c] for r, c in enumerate(counts)], 0)
+    cloud = torch.cat([allm[r, :min(c, cap)] for r, c in enumerate(counts)], 0)
     assert all_T.shape[0] == k * world_size()
     return cloud, all_T, counts
+
+
+class CloudExchange:
+    """Per-frame fuse exchange with an adaptive message size: the padded message holds `cap` rows, sized from the
+    counts every rank saw in the previous frame (+25 %, rounded to 4096: the same value on all ranks); a frame that
+    outgrows it is detected from the gathered header (which carries the true counts) and sent again with room."""
+
+    def __init__(self, initial_rows: int):
+        if initial_rows <= 0:
+            raise ValueError("cloud_capacity must be set for multi-GPU exchange")
+        self.cap = int(initial_rows)
+
+    def __call__(self, pts: torch.Tensor, col: torch.Tensor, transforms: torch.Tensor):
+        n = int(pts.shape[0])
+        while True:
+            cap = self.cap
+            buf = torch.empty((cap, 6), dtype=torch.float32, device=pts.device)
+            k = min(n, cap)
+            buf[:k, :3] = pts[:k]
+            buf[:k, 3:] = col[:k]
+            cloud, all_T, counts = allgather_clouds(buf, n, transforms)
+            need = max(counts)
+            self.cap = max(4096, -(-int(need * 1.25) // 4096) * 4096)      # every rank sees the same counts
+            if need <= cap:
+                return cloud[:, :3], cloud[:, 3:], all_T, counts
 
 
 def barrier():

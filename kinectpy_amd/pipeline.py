@@ -37,6 +37,7 @@ class SensorGroupPipeline:
         self.xy = ops._dev(xy_table, torch.float32).reshape(-1)
         self.init = [np.asarray(T, dtype=np.float64) for T in init_transforms]
         self.capacity = cloud_capacity
+        self._xchg = None
         self.last = {}
 
     def step(self, depth: torch.Tensor, rgb: torch.Tensor):
@@ -74,14 +75,10 @@ class SensorGroupPipeline:
 
     def exchange(self, out_p, out_c, Ts, to_global: np.ndarray):
         """Fuse across GPUs: clouds are moved into the global master frame with `to_global` (group master ->
-        global master, from calibration) and all-gathered together with the composed transforms."""
-        if self.capacity <= 0:
-            raise ValueError("cloud_capacity must be set for multi-GPU exchange")
+        global master, from calibration) and all-gathered together with the composed transforms
+        (parallel.CloudExchange: one collective per frame, message sized from the previous frame's counts)."""
+        if self._xchg is None:
+            self._xchg = parallel.CloudExchange(self.capacity)
         gp = ops.transform(out_p, to_global) if not np.allclose(to_global, np.eye(4)) else out_p
-        buf = torch.zeros((self.capacity, 6), dtype=torch.float32, device=out_p.device)
-        k = min(int(gp.shape[0]), self.capacity)
-        buf[:k, :3] = gp[:k]
-        buf[:k, 3:] = out_c[:k]
         comp = torch.as_tensor(np.stack([to_global @ T for T in Ts]))
-        cloud, all_T, counts = parallel.allgather_clouds(buf, k, comp)
-        return cloud[:, :3], cloud[:, 3:], all_T, counts
+        return self._xchg(gp, out_c, comp)

@@ -27,6 +27,13 @@ def _worker(rank, world, port, q):
     buf[:n] = torch.arange(n * 6, dtype=torch.float32).reshape(n, 6) + 1000 * rank
     Ts = torch.stack([torch.eye(4, dtype=torch.float64) * (1 + rank + 0.1 * k) for k in range(2)])
     cloud, all_T, counts = parallel.allgather_clouds(buf, n, Ts)
+    # adaptive exchange: the first message is too small for rank 1 (17 rows), the resend must deliver everything; the
+    # second frame then fits at once in the capacity learnt from the first
+    xc = parallel.CloudExchange(12)
+    px, cx, tx, cntx = xc(buf[:n, :3], buf[:n, 3:], Ts)
+    assert cntx == [10, 17] and px.shape == (27, 3) and xc.cap == 4096
+    px2, _, _, _ = xc(buf[:n, :3], buf[:n, 3:], Ts)
+    assert torch.equal(px, px2) and torch.equal(torch.cat([px, cx], 1), cloud)
     t = parallel.allreduce_max(1.0 + rank, "cpu")
     parallel.barrier()
     q.put((rank, sensors, cloud.numpy(), all_T.numpy(), counts, t))
