@@ -497,8 +497,8 @@ static int knn_lists(const float *pts, int64_t n, double radius, int k, Arena &a
         attr_set = true;
     }
     KPX_HIP(hipMemsetAsync(fb_count, 0, sizeof(int32_t), st));
-    // pass 1: one wave per query, 1024-candidate buffer; pass 2: the queries that did not fit, thread-per-query heap walk
-    const int cap = 1024;
+    // pass 1: one wave per query, 512- or 1024-candidate buffer; pass 2: the queries that did not fit, thread-per-query heap walk
+    const int cap = k <= 48 ? 512 : 1024;
     hipLaunchKernelGGL(nbr_list_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256),
                        (size_t)4 * cap * (sizeof(double) + sizeof(uint32_t)), st, g->params, g->cell_start, g->sorted_pts, g->sorted_idx, n, k, cap,
                        radius * radius, *nbr, *d2, *cnt, fb_list, fb_count);

@@ -278,8 +278,9 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
         ProfScope prof(KPX_PROF_SOR_KNN, 12.0 * (double)n + 8.0 * (double)n, st);     // read points, write mean distances
         const int32_t *none = nullptr;
         // pass 1: every query, 1024-candidate buffer (k <= KPX_SOR_MAX_K = 288 < 1024; many waves per CU)
-        hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256), (size_t)4 * 1024 * 8, st,
-                           g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk, 1024, avg, none, none, fb_list, fb_count);
+        const int cap1 = kk <= 32 ? 512 : 1024;               // small k: smaller buffers, more waves per CU
+        hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256), (size_t)4 * cap1 * 8, st,
+                           g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk, cap1, avg, none, none, fb_list, fb_count);
         // pass 2: the queries whose block did not fit (isolated points next to a dense sheet), 8192-candidate buffer
         hipLaunchKernelGGL(sor_wave_kernel<1>, dim3(2048), dim3(64), (size_t)8192 * 8, st, g.params, g.cell_start, g.sorted_pts,
                            g.sorted_idx, n, kk, 8192, avg, fb_list, fb_count, fb_list2, fb_count2);
@@ -429,8 +430,8 @@ static int normals_impl(const float *pts, int64_t n, double radius, int max_nn, 
         attr_set = true;
     }
     KPX_HIP(hipMemsetAsync(fb_count, 0, sizeof(int32_t), st));
-    // pass 1: one wave per query, 1024-candidate buffer; pass 2: the few queries that did not fit, thread-per-query heap walk
-    const int cap = 1024;
+    // pass 1: one wave per query, 512- or 1024-candidate buffer; pass 2: the few queries that did not fit, thread-per-query heap walk
+    const int cap = kk <= 48 ? 512 : 1024;
     hipLaunchKernelGGL(normals_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256),
                        (size_t)4 * cap * (sizeof(double) + sizeof(uint32_t)), st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk,
                        cap, radius * radius, covbuf, fb_list, fb_count);
