@@ -123,7 +123,15 @@ def registration_ransac_based_on_feature_matching(source, target, source_feature
         raise NotImplementedError("distance checker threshold must equal max_correspondence_distance (as in KinectPy)")
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
-    corres = ops.feature_correspondences(source_feature._dev, target_feature._dev, bool(mutual_filter), int(ransac_n))
+    # the correspondences depend only on the two feature sets: execute_global_registration calls this 15 times with the
+    # same features (registration.py:46-57), so they are computed once and kept on the source Feature
+    key = (id(target_feature), bool(mutual_filter), int(ransac_n))
+    cached = getattr(source_feature, "_corr_cache", None)
+    if cached is not None and cached[0] == key and cached[2] is target_feature:
+        corres = cached[1]
+    else:
+        corres = ops.feature_correspondences(source_feature._dev, target_feature._dev, bool(mutual_filter), int(ransac_n))
+        source_feature._corr_cache = (key, corres, target_feature)
     r = ops.ransac_corres(source._pts, target._pts, corres, float(max_correspondence_distance), int(ransac_n), edge,
                           crit.max_iteration, crit.confidence, seed)
     return RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], corres)
