@@ -411,10 +411,12 @@ struct Nearest1 {
 __global__ __launch_bounds__(256) void ransac_validate_kernel(const float *__restrict__ src, int64_t n, const GridParams *__restrict__ gp,
                                                               const uint32_t *__restrict__ cell_start, const float *__restrict__ tpts,
                                                               const int32_t *__restrict__ list, const double *__restrict__ Ts, double r2,
-                                                              int64_t *__restrict__ part_cnt, double *__restrict__ part_err)
+                                                              int64_t *__restrict__ part_cnt, double *__restrict__ part_err,
+                                                              const int32_t *__restrict__ n_list)
 {
     __shared__ double shd[4];
     __shared__ long long shc[4];
+    if (n_list && (int)blockIdx.y >= *n_list) return;       // speculative launch: fewer survivors than slots
     const int h = list[blockIdx.y];
     const double *T = Ts + (int64_t)h * 16;
     const GridParams g = *gp;
@@ -451,9 +453,11 @@ __global__ __launch_bounds__(256) void ransac_validate_kernel(const float *__res
 __global__ __launch_bounds__(256) void ransac_score_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
                                                            const int32_t *__restrict__ corres, int64_t nc, const int32_t *__restrict__ list,
                                                            const double *__restrict__ Ts, double max_dist, const int64_t *__restrict__ part_cnt,
-                                                           const double *__restrict__ part_err, int nblocks, double *__restrict__ score)
+                                                           const double *__restrict__ part_err, int nblocks, double *__restrict__ score,
+                                                           const int32_t *__restrict__ n_list)
 {
     __shared__ long long shc[4];
+    if (n_list && (int)blockIdx.x >= *n_list) return;
     const int h = list[blockIdx.x];
     const double *T = Ts + (int64_t)h * 16;
     long long inl = 0;
@@ -524,7 +528,7 @@ static int fpfh_impl(const float *pts, const float *nrm, int64_t n, double radiu
     return KPX_OK;
 }
 
-constexpr int kRansacBatch = 8192;
+constexpr int kRansacBatch = 32768;
 struct RansacBuffers {
     Grid g;
     uint8_t *pass;
@@ -634,28 +638,41 @@ KPX_EXPORT int kpx_ransac_corres(const float *src, int64_t n_src, const float *t
     const double r2 = max_dist * max_dist;
     double best_fit = 0.0, best_rmse = 0.0;
     int est_k = max_iteration, validations = 0, itr_done = 0;
+    // Per batch: hypotheses -> survivors compacted in iteration order -> the first kSpec survivors are validated and scored
+    // speculatively (kernels guarded by the device count) -> ONE read-back (count, list, scores) -> Open3D's loop body is
+    // replayed on the host in iteration order.  Batches with more than kSpec survivors validate the rest in further chunks.
+    constexpr int kSpec = 64;
     std::vector<int32_t> h_list(kRansacBatch);
-    std::vector<double> h_score((size_t)kMaxValidate * 4), h_T(16);
+    std::vector<double> h_score((size_t)kMaxValidate * 4);
     for (int itr0 = 0; itr0 < max_iteration && itr0 < est_k; itr0 += kRansacBatch) {
         const int count = max_iteration - itr0 < kRansacBatch ? max_iteration - itr0 : kRansacBatch;
         hipLaunchKernelGGL(ransac_hyp_kernel, dim3((unsigned)cdiv(count, 256)), dim3(256), 0, st, src, tgt, corres, n_corres, itr0, count,
                            (uint32_t)seed, (uint32_t)(seed >> 32), edge_similarity, max_dist, b.pass, b.Ts);
         rc = compact(PassPred{ b.pass }, PassEmit{ b.list }, count, 1, b.counts, b.n_pass, st);
         if (rc) return rc;
+        hipLaunchKernelGGL(ransac_validate_kernel, dim3(b.vblocks, kSpec), dim3(256), 0, st, src, n_src, b.g.params, b.g.cell_start,
+                           b.g.sorted_pts, b.list, b.Ts, r2, b.part_cnt, b.part_err, b.n_pass);
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(kSpec), dim3(256), 0, st, src, tgt, corres, n_corres, b.list, b.Ts, max_dist, b.part_cnt,
+                           b.part_err, b.vblocks, b.score, b.n_pass);
         int32_t n_pass = 0;
         KPX_HIP(hipMemcpyAsync(&n_pass, b.n_pass, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KPX_HIP(hipMemcpyAsync(h_score.data(), b.score, (size_t)kSpec * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
         KPX_HIP(hipStreamSynchronize(st));
-        if (n_pass) KPX_HIP(hipMemcpy(h_list.data(), b.list, (size_t)n_pass * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (n_pass > kSpec) KPX_HIP(hipMemcpy(h_list.data(), b.list, (size_t)n_pass * sizeof(int32_t), hipMemcpyDeviceToHost));
         bool stop = false;
-        for (int c0 = 0; c0 < n_pass && !stop; c0 += kMaxValidate) {
-            const int nv = n_pass - c0 < kMaxValidate ? n_pass - c0 : kMaxValidate;
-            if (itr0 + h_list[c0] >= est_k) break;                       // everything left is beyond the exit iteration
-            hipLaunchKernelGGL(ransac_validate_kernel, dim3(b.vblocks, nv), dim3(256), 0, st, src, n_src, b.g.params, b.g.cell_start,
-                               b.g.sorted_pts, b.list + c0, b.Ts, r2, b.part_cnt, b.part_err);
-            hipLaunchKernelGGL(ransac_score_kernel, dim3(nv), dim3(256), 0, st, src, tgt, corres, n_corres, b.list + c0, b.Ts, max_dist,
-                               b.part_cnt, b.part_err, b.vblocks, b.score);
-            KPX_HIP(hipMemcpyAsync(h_score.data(), b.score, (size_t)nv * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-            KPX_HIP(hipStreamSynchronize(st));
+        int best_in_batch = -1;
+        for (int c0 = 0; c0 < n_pass && !stop; c0 += (c0 == 0 ? kSpec : kMaxValidate)) {
+            int nv = n_pass - c0 < kSpec ? n_pass - c0 : kSpec;
+            if (c0 > 0) {                                               // beyond the speculative chunk
+                nv = n_pass - c0 < kMaxValidate ? n_pass - c0 : kMaxValidate;
+                if (itr0 + h_list[c0] >= est_k) break;                  // everything left is beyond the exit iteration
+                hipLaunchKernelGGL(ransac_validate_kernel, dim3(b.vblocks, nv), dim3(256), 0, st, src, n_src, b.g.params, b.g.cell_start,
+                                   b.g.sorted_pts, b.list + c0, b.Ts, r2, b.part_cnt, b.part_err, (const int32_t *)nullptr);
+                hipLaunchKernelGGL(ransac_score_kernel, dim3(nv), dim3(256), 0, st, src, tgt, corres, n_corres, b.list + c0, b.Ts, max_dist,
+                                   b.part_cnt, b.part_err, b.vblocks, b.score, (const int32_t *)nullptr);
+                KPX_HIP(hipMemcpyAsync(h_score.data(), b.score, (size_t)nv * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+                KPX_HIP(hipStreamSynchronize(st));
+            }
             for (int v = 0; v < nv; ++v) {                               // Open3D's loop body, in iteration order
                 const int itr = itr0 + (int)h_score[4 * v + 3];
                 if (itr >= est_k) { stop = true; break; }
@@ -664,13 +681,15 @@ KPX_EXPORT int kpx_ransac_corres(const float *src, int64_t n_src, const float *t
                 const double fit = cnt > 0 ? cnt / (double)n_src : 0.0, rmse = cnt > 0 ? sqrt(err / cnt) : 0.0;
                 if (fit > best_fit || (fit == best_fit && rmse < best_rmse)) {
                     best_fit = fit; best_rmse = rmse;
-                    KPX_HIP(hipMemcpy(h_result, b.Ts + (int64_t)h_score[4 * v + 3] * 16, 16 * sizeof(double), hipMemcpyDeviceToHost));
+                    best_in_batch = (int)h_score[4 * v + 3];
                     const double ratio = h_score[4 * v + 2] / (double)n_corres;
                     const double ek = log(1.0 - confidence) / log(1.0 - pow(ratio, (double)ransac_n));
                     if (ek < (double)est_k) est_k = (int)ceil(ek);
                 }
             }
         }
+        if (best_in_batch >= 0)                                         // the batch's transforms are overwritten by the next one
+            KPX_HIP(hipMemcpy(h_result, b.Ts + (int64_t)best_in_batch * 16, 16 * sizeof(double), hipMemcpyDeviceToHost));
         itr_done = itr0 + count < est_k ? itr0 + count : est_k;
         if (stop) break;
     }
