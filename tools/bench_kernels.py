@@ -130,6 +130,20 @@ def main():
     report("ransac feature matching 250k it (a13)", ms, corres=int(len(corr)), iterations=r["iterations"], validations=r["validations"],
            fitness=round(r["fitness"], 4))
 
+    from kinectpy_amd.geometry import PointCloud
+    from kinectpy_amd.preprocessing.registration import execute_global_registration
+    import time
+    pcs = []
+    for i, seed in ((0, 100), (1, 101)):
+        dep = synth.render_depth(synth.camera_pose(i, 16), seed=seed, xy=xy2, extra=ex)
+        pcs.append(PointCloud(ops.depth_to_cloud(dep, xy2, None, 1, False, False)[0][0]))
+    execute_global_registration(pcs[0], pcs[1], 35, 15, seed=1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    Tg = execute_global_registration(pcs[0], pcs[1], 35, 15, seed=1)
+    torch.cuda.synchronize()
+    report("execute_global_registration voxel 35, 15 trials x 250k it (registration.py:32-62, host wall time)", (time.perf_counter() - t0) * 1e3,
+           n_master=int(len(pcs[0].points)), n_sub=int(len(pcs[1].points)), found=Tg is not None)
+
     # ---- registration (config 2)
     def sweep(prof):
         """the sweep kernel that ran (culled by default, dense with KPX_NN_ENGINE=dense): avg ms, TFLOP/s issued"""
