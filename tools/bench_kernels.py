@@ -111,6 +111,21 @@ def main():
     ms, nrm = timed(lambda: ops.estimate_normals(vp[:100000].contiguous(), 70.0, 40), reps=3, warm=1)
     report("estimate_normals r=70 nn=40 on 100k (a11)", ms, 24 * 100000, n=100000)
 
+    # ---- config 3 as a whole: filter_outliers(voxel 10, k 20, ratio 2) + floor removal (floor_removal.py:61-73), host wall time
+    from kinectpy_amd.geometry import PointCloud as _PC
+    from kinectpy_amd.floor_removal import remove_floor
+    from kinectpy_amd.preprocessing.filtering import filter_outliers
+    import time as _time
+
+    def chain():
+        pc = _PC(c3)
+        f = filter_outliers(pc, 20, 2.0, 10.0)
+        return remove_floor(f, seed=7)
+    chain(); torch.cuda.synchronize(); t0 = _time.perf_counter()
+    outc = chain(); torch.cuda.synchronize()
+    report("config 3 chain: voxel 10 + SOR(20,2) + slab + segment_plane + SOR(50,0.3) on 1M points (host wall time)",
+           (_time.perf_counter() - t0) * 1e3, n_in=int(c3.shape[0]), n_out=int(len(outc.points)))
+
     # ---- global registration (rows a11-a13) on two cluttered views, voxel 35
     xy2, ex = synth.xy_table(), synth.clutter()
     views = []
