@@ -13,6 +13,45 @@ __device__ __forceinline__ void xform3(const Affine &A, double x, double y, doub
     for (int k = 0; k < 3; ++k) o[k] = fma(A.m[4 * k], x, fma(A.m[4 * k + 1], y, fma(A.m[4 * k + 2], z, A.m[4 * k + 3])));
 }
 
+// 4 points (48 B) per lane with every global access a contiguous KiB per wave: the three 16-byte pieces a lane owns are
+// 48 bytes apart, so loads and stores go through LDS (round r, lane l <-> piece 64 r + l of the wave's 3 KiB).  Covers
+// the first n - n % 256 points; the tail runs in transform_kernel.
+template <bool ROT_ONLY>
+__global__ __launch_bounds__(256) void transform_lds_kernel(const float *__restrict__ in, int64_t n, Affine A, float *__restrict__ out)
+{
+    __shared__ float4 stage[4][192];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t chunks = n >> 8;                                    // 256 points = 3 KiB per wave-trip
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < chunks; c += (int64_t)gridDim.x * 4) {
+        const float4 *src = reinterpret_cast<const float4 *>(in + c * 768);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) stage[wave][64 * r + lane] = src[64 * r + lane];
+        wave_lds_fence();
+        const float4 a = stage[wave][3 * lane], b = stage[wave][3 * lane + 1], cc = stage[wave][3 * lane + 2];
+        const float v[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, cc.x, cc.y, cc.z, cc.w };
+        float r12[12];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const double x = v[3 * p], y = v[3 * p + 1], z = v[3 * p + 2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double o = ROT_ONLY ? fma(A.m[4 * k], x, fma(A.m[4 * k + 1], y, A.m[4 * k + 2] * z))
+                                          : fma(A.m[4 * k], x, fma(A.m[4 * k + 1], y, fma(A.m[4 * k + 2], z, A.m[4 * k + 3])));
+                r12[3 * p + k] = (float)o;
+            }
+        }
+        wave_lds_fence();
+        stage[wave][3 * lane] = make_float4(r12[0], r12[1], r12[2], r12[3]);
+        stage[wave][3 * lane + 1] = make_float4(r12[4], r12[5], r12[6], r12[7]);
+        stage[wave][3 * lane + 2] = make_float4(r12[8], r12[9], r12[10], r12[11]);
+        wave_lds_fence();
+        float4 *dst = reinterpret_cast<float4 *>(out + c * 768);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) dst[64 * r + lane] = stage[wave][64 * r + lane];
+        wave_lds_fence();
+    }
+}
+
 // 4 points (48 B) per thread when aligned; rotate_only drops t and uses R_k2*z as the chain seed
 template <bool ROT_ONLY>
 __global__ __launch_bounds__(256) void transform_kernel(const float *__restrict__ in, int64_t n, Affine A,
@@ -239,6 +278,16 @@ KPX_EXPORT int kpx_transform(const float *pts, int64_t n, const double *h_T, flo
     if (n == 0) return KPX_OK;
     KPX_REQUIRE(pts && h_T && out, "kpx_transform: null pointer");
     int vec = (((uintptr_t)pts | (uintptr_t)out) % 16 == 0) ? 1 : 0;
+    const int64_t bulk = vec ? (n & ~(int64_t)255) : 0;
+    if (bulk >= 65536) {                                              // large aligned clouds: contiguous-KiB accesses
+        hipLaunchKernelGGL(transform_lds_kernel<false>, dim3(grid_for(bulk / 1024, 1, 4096)), dim3(256), 0, (hipStream_t)stream, pts, bulk,
+                           affine_from(h_T), out);
+        if (n > bulk)
+            hipLaunchKernelGGL(transform_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, pts + 3 * bulk, n - bulk, affine_from(h_T),
+                               out + 3 * bulk, vec);
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
     hipLaunchKernelGGL(transform_kernel<false>, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, pts, n,
                        affine_from(h_T), out, vec);
     KPX_LAUNCH_CHECK();
