@@ -94,14 +94,28 @@ def check(rc):
         raise KinectPxError(msg)
 
 
+_gpu_checked = False
+
+
 def device():
-    if not torch.cuda.is_available():
-        raise KinectPxError("no ROCm device visible: the kinectpx hot path runs on MI355X only (no CPU fallback)")
-    return torch.device("cuda", torch.cuda.current_device())
+    global _gpu_checked
+    if not _gpu_checked:
+        if not torch.cuda.is_available():
+            raise KinectPxError("no ROCm device visible: the kinectpx hot path runs on MI355X only (no CPU fallback)")
+        torch.cuda.current_device()                 # initialises the context
+        _gpu_checked = True
+    return torch.device("cuda", torch._C._cuda_getDevice())
+
+
+def _raw_stream():
+    """raw handle of the calling thread's current stream on the current device.  (torch.cuda.current_stream() costs ~30 us per
+    call -- it re-checks availability through os.environ -- and the ops ask for the stream ~20 times per frame.)"""
+    device()
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream())
 
 
 def ptr(t):
@@ -135,7 +149,7 @@ _ws = {}
 def workspace(nbytes):
     """scratch of the calling thread's current stream (ops of one stream run in order and may share it; another stream or
     host thread gets its own)"""
-    key = (threading.get_ident(), torch.cuda.current_stream().cuda_stream)
+    key = (threading.get_ident(), _raw_stream())
     ws = _ws.get(key)
     if ws is None:
         ws = _ws[key] = Workspace()
