@@ -96,6 +96,28 @@ def cpu_step(O, xy, depth, rgb, inits, P):
     return vp[keep], vc[keep], Ts
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed counter pass (profiles/rNN/pmc_summary.csv: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench, see profiles/README.md).  A counter pass cannot
+    run inside the timed bench, so this is the recorded figure, not a live one; FETCH_SIZE is the raw value (the gfx950
+    correction of MI355X_MICROARCH.md, x2 for 16 B/lane reads, does not apply to this kernel's 8 B/lane tile loads)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_summary.csv")))
+    if not files:
+        return {"traffic": None}
+    kb = {}
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if row["kernel"].split("::")[-1].strip() == kernel:
+                kb[row["counter"]] = float(row["avg_KB_per_dispatch_raw"])
+    if "FETCH_SIZE" not in kb or "WRITE_SIZE" not in kb:
+        return {"traffic": None}
+    return {"traffic": round((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), "traffic_unit": "B/launch",
+            "traffic_source": os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__))) +
+                              " (FETCH_SIZE + WRITE_SIZE, recorded counter pass)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +198,8 @@ def main():
             roof["note"] = ("achieved = SURVEY 8(d) algorithmic flops (8 per source-target pair) / launch duration; the kernel culls "
                             "the pair matrix by bounding boxes and issues only issued_flop_per_launch: it is latency-bound "
                             "(DESIGN.md 5); dense engine for comparison: KPX_NN_ENGINE=dense")
+    if roof is not None:
+        roof.update(pmc_traffic(kernel))
     other = {k: {"launches": v[1], "avg_us": round(v[0] / max(v[1], 1) * 1e3, 2)} for k, v in prof.items() if k != kname}
 
     cpu = None

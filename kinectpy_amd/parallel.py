@@ -79,15 +79,16 @@ def _all_gather_flat(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor):
+def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor, always_collective: bool = False):
     """padded: (cap, C) float32 buffer whose first min(count, cap) rows are valid (same cap on every rank; `count` may
     exceed it: the header carries the true count so that the caller can resend with room);
     transforms: (k, 4, 4) float64 of this rank's sensors (same k on every rank).
     Returns (cloud (sum counts, C), all transforms (world*k, 4, 4), counts list).
-    One collective: the header (count, transforms) travels as float64 bit patterns in extra rows of the buffer."""
+    One collective: the header (count, transforms) travels as float64 bit patterns in extra rows of the buffer.
+    `always_collective` runs the collective on a one-rank group too (the single-GPU RCCL test)."""
     k = transforms.shape[0]
     hdr = torch.cat([torch.tensor([float(count)], dtype=torch.float64), transforms.reshape(-1).to("cpu", torch.float64)])
-    if world_size() == 1:
+    if world_size() == 1 and not (always_collective and dist.is_initialized()):
         return padded[:min(count, padded.shape[0])], hdr[1:].reshape(-1, 4, 4).to(padded.device), [int(count)]
     cap, C = padded.shape
     words = hdr.numel() * 2                                     # float32 words carrying the float64 header

@@ -806,3 +806,35 @@ def test_full_size_filter_chain(ops, oracle):
     rpl, ridx = oracle.segment_plane(floor, 30.0, 30, 2000, seed=7)
     assert np.array_equal(npy(gidx), ridx) and np.abs(gpl - rpl).max() < TOL_PLANE
     assert abs(abs(gpl[1]) - 1) < 1e-4 and abs(abs(gpl[3]) - 900) < 3.0       # it is the floor
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, torch
+os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+import torch.distributed as dist
+from kinectpy_amd import parallel
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+g = torch.Generator().manual_seed(1)
+buf = torch.rand((4096, 6), generator=g).cuda()
+T = torch.rand((4, 4, 4), dtype=torch.float64, generator=g)
+cloud, all_T, counts = parallel.allgather_clouds(buf, 3000, T, always_collective=True)
+assert counts == [3000] and torch.equal(cloud, buf[:3000]) and torch.equal(all_T.cpu(), T)
+cloud, all_T, counts = parallel.allgather_clouds(buf, 5000, T, always_collective=True)      # overflow: header says 5000
+assert counts == [5000] and cloud.shape[0] == 4096
+parallel.barrier()
+assert parallel.allreduce_max(2.5, buf.device) == 2.5
+dist.destroy_process_group()
+print("rccl-ok")
+"""
+
+
+def test_rccl_exchange_on_one_rank():
+    """the fuse exchange through RCCL itself (backend "nccl"), on the one GPU a test box has: a one-rank group runs
+    the same all_gather_into_tensor / all_reduce / barrier calls the N-GPU bench makes (the multi-rank logic is
+    covered on CPU with gloo, tests/test_dist_cpu.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stderr[-2000:]
