@@ -232,6 +232,41 @@ int kpx_icp_batch(int32_t count, const float *const *h_src, const int64_t *h_n_s
 #define KPX_NN_ENGINE_DENSE 1
 int kpx_nn_engine(int32_t engine);
 
+/* ---- the sampler / normaliser after the path ------------------------------------ */
+/* select_points_randomly (utils/processing.py:259-275): number_of_points of the cloud without replacement.  The
+ * reference draws np.random.choice from NumPy's unseeded global generator; here point i gets the 64-bit key
+ * Philox4x32-10(ctr = (i_lo, i_hi, 'SAMP', 0), key = seed) words (1:0) and the sample is the k points with the
+ * smallest (key, i), in that order -- a uniformly random ordered k-subset.  k > n is an error (NumPy raises
+ * ValueError).  out_pts (k,3) f32 and/or out_idx (k) i32 on the device; either may be NULL. */
+size_t kpx_sample_workspace_bytes(int64_t n);
+int kpx_sample_points(const float *pts, int64_t n, int64_t k, uint64_t seed, float *out_pts, int32_t *out_idx, void *ws,
+                      size_t ws_bytes, void *stream);
+
+/* PointCloud.get_oriented_bounding_box() for `count` clouds of n points each, stored back to back (the batch arrays of
+ * utils/normalization.py:38-42, 74-77, 105-106; one cloud: utils/processing.py:341-344).  Open3D's CreateFromPoints:
+ * convex hull, PCA of the hull vertices (eigenvectors by descending eigenvalue, third = first x second; here each of
+ * the first two has its largest component positive), box of R^T (v - mean).  pts: f32 (pts_f64 = 0) or f64 (1)
+ * [count][n][3] on the device.  d_obb f64 [count][16]: R row-major (9) | centre (3) | extent (3) | number of hull
+ * vertices, or -1 (fewer than 3 distinct points / all on one line), -2 (hull did not close), -3 (flat hull: Qhull
+ * raises for these).  d_is_vertex: optional u8 [count][n] hull-vertex flags.  Asynchronous. */
+size_t kpx_obb_workspace_bytes(int32_t count, int64_t n);
+int kpx_obb_batch(const void *pts, int32_t pts_f64, int32_t count, int64_t n, double *d_obb, uint8_t *d_is_vertex, void *ws,
+                  size_t ws_bytes, void *stream);
+
+/* The normalisations, applied to `count` groups of `rows` f64 triples (points or joints) with the boxes of kpx_obb_batch:
+ *   KPX_NORM_OBB            (x @ M + centre) / max(extent), M = get_rotation_matrix_from_yxz([0, pi, 0])
+ *                           (obb_normalization_batch, utils/normalization.py:16-64, as written there)
+ *   KPX_NORM_OBB_ROT_TRANS  (x - centre) @ R @ M, M = Rz(90 deg)   (obb_rotation_translation_batch, :67-97)
+ *   KPX_NORM_TRANSLATE      x - centre                              (translation_normalization_batch, :100-126)
+ *   KPX_NORM_OBB_ROT        (x - centre) @ R                        (obb_normalization, utils/processing.py:329-354)
+ * h_M: host 3x3 row-major constant matrix of the mode (NULL where unused). */
+#define KPX_NORM_OBB 0
+#define KPX_NORM_OBB_ROT_TRANS 1
+#define KPX_NORM_TRANSLATE 2
+#define KPX_NORM_OBB_ROT 3
+int kpx_normalize_batch(const double *x, int32_t count, int64_t rows, const double *d_obb, int32_t mode, const double *h_M,
+                        double *out, void *stream);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it
  * (capacity = max launches recorded); every launch of a tagged kernel is bracketed by an event pair;

@@ -70,6 +70,35 @@ def _idx_array(indices):
     return np.ascontiguousarray(np.asarray(indices).reshape(-1), dtype=np.int32)
 
 
+class OrientedBoundingBox:
+    """the members the reference reads: R, extent, get_center(), get_rotation_matrix_from_yxz()"""
+
+    def __init__(self, center=None, R=None, extent=None):
+        self.center = np.zeros(3) if center is None else np.asarray(center, dtype=np.float64)
+        self.R = np.eye(3) if R is None else np.asarray(R, dtype=np.float64)
+        self.extent = np.zeros(3) if extent is None else np.asarray(extent, dtype=np.float64)
+
+    @classmethod
+    def _from_row(cls, row):
+        return cls(row[9:12].copy(), row[:9].reshape(3, 3).copy(), row[12:15].copy())
+
+    def get_center(self):
+        return self.center
+
+    @staticmethod
+    def get_rotation_matrix_from_yxz(rotation):
+        """Ry(rotation[0]) @ Rx(rotation[1]) @ Rz(rotation[2]) (utils/normalization.py:40)"""
+        a, b, c = (float(v) for v in np.asarray(rotation, dtype=np.float64).reshape(3))
+        ca, sa, cb, sb, cc, sc = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(c), np.sin(c)
+        Ry = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]])
+        Rx = np.array([[1, 0, 0], [0, cb, -sb], [0, sb, cb]])
+        Rz = np.array([[cc, -sc, 0], [sc, cc, 0], [0, 0, 1]])
+        return Ry @ Rx @ Rz
+
+    def __repr__(self):
+        return f"OrientedBoundingBox: center: {tuple(self.center)}, extent: {tuple(self.extent)}"
+
+
 class PointCloud:
     def __init__(self, points=None):
         self._pts = Vector3dVector(points).t
@@ -185,6 +214,11 @@ class PointCloud:
         if self.has_points():
             self._nrm = ops.estimate_normals(self._pts, sp.radius, min(sp.max_nn, 128))
         return self
+
+    def get_oriented_bounding_box(self, robust=False):
+        """utils/normalization.py:39, 74, 105; utils/processing.py:341"""
+        obb, _ = ops.obb_batch(self._pts)
+        return OrientedBoundingBox._from_row(obb[0].cpu().numpy())
 
     def __add__(self, other):
         both_c = self.has_colors() and other.has_colors()

@@ -1,6 +1,6 @@
 """Open3D-shaped namespace over the kinectpx hot path, so that KinectPy code written as
 `import open3d as o3d` keeps working with `from kinectpy_amd import o3d` for the calls on the
-path.  Anything off the path (visualisation, FPFH global registration this round)
+path.  Anything off the path (visualisation, coloured ICP)
 raises NotImplementedError loudly instead of silently computing on the CPU.
 """
 import types
@@ -8,7 +8,8 @@ import types
 import numpy as np
 
 from . import ops
-from .geometry import (KDTreeSearchParamHybrid, KDTreeSearchParamKNN, PointCloud, Vector2iVector, Vector3dVector)
+from .geometry import (KDTreeSearchParamHybrid, KDTreeSearchParamKNN, OrientedBoundingBox, PointCloud, Vector2iVector,
+                       Vector3dVector)
 from . import pcd_io
 
 
@@ -144,7 +145,7 @@ def _off_path(name):
     return f
 
 
-geometry = types.SimpleNamespace(PointCloud=PointCloud, KDTreeSearchParamHybrid=KDTreeSearchParamHybrid,
+geometry = types.SimpleNamespace(PointCloud=PointCloud, OrientedBoundingBox=OrientedBoundingBox, KDTreeSearchParamHybrid=KDTreeSearchParamHybrid,
                                  KDTreeSearchParamKNN=KDTreeSearchParamKNN)
 utility = types.SimpleNamespace(Vector3dVector=Vector3dVector, Vector2iVector=Vector2iVector)
 io = types.SimpleNamespace(read_point_cloud=pcd_io.read_point_cloud, write_point_cloud=pcd_io.write_point_cloud)

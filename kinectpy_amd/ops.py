@@ -430,3 +430,60 @@ def prof_end():
     work = np.zeros(len(PROF_KERNELS))
     L.check(L.load().kpx_prof_end(L.hptr(ms), cnt.ctypes.data_as(C.c_void_p), L.hptr(work)))
     return {k: (float(ms[i]), int(cnt[i]), float(work[i])) for i, k in enumerate(PROF_KERNELS)}
+
+
+# ---- sampler / normaliser ---------------------------------------------------------
+NORM_OBB, NORM_OBB_ROT_TRANS, NORM_TRANSLATE, NORM_OBB_ROT = 0, 1, 2, 3
+_OBB_ERRORS = {-1: "fewer than 3 distinct points, or all points on one line", -2: "the convex hull did not close",
+               -3: "the convex hull is flat (Qhull: initial simplex is flat)"}
+
+
+def sample_points(pts, k, seed, want_points=True):
+    """seeded select_points_randomly (utils/processing.py:259-275) -> (points f32 (k,3) | None, idx i32 (k))"""
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    n, k = pts.shape[0], int(k)
+    if k > n:
+        raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+    out = torch.empty((k, 3), dtype=torch.float32, device=pts.device) if want_points else None
+    idx = torch.empty(k, dtype=torch.int32, device=pts.device)
+    ws, wsz = L.workspace(lib.kpx_sample_workspace_bytes(n))
+    L.check(lib.kpx_sample_points(L.ptr(pts), n, k, C.c_uint64(int(seed) & (2 ** 64 - 1)), L.ptr(out), L.ptr(idx), ws, wsz,
+                                  L.stream_ptr()))
+    return out, idx
+
+
+def obb_batch(x, want_vertices=False, check=True):
+    """get_oriented_bounding_box() of every cloud of x: (count, n, 3) or (n, 3), f32 or f64 (other dtypes are read as
+    f64).  -> obb f64 (count, 16) on the device [R | centre | extent | hull vertices], u8 (count, n) vertex flags | None.
+    check=True reads the status back (one sync) and raises for degenerate clouds, as Qhull does."""
+    lib = L.load()
+    if not (isinstance(x, torch.Tensor) and x.dtype == torch.float32):
+        x = _dev(x, torch.float64)
+    x = _dev(x, x.dtype)
+    x = x.reshape((-1,) + tuple(x.shape[-2:]))
+    count, n = int(x.shape[0]), int(x.shape[1])
+    obb = torch.empty((count, 16), dtype=torch.float64, device=x.device)
+    flags = torch.empty((count, n), dtype=torch.uint8, device=x.device) if want_vertices else None
+    ws, wsz = L.workspace(lib.kpx_obb_workspace_bytes(count, n))
+    L.check(lib.kpx_obb_batch(L.ptr(x), 1 if x.dtype == torch.float64 else 0, count, n, L.ptr(obb), L.ptr(flags), ws, wsz,
+                              L.stream_ptr()))
+    if check and count:
+        st = obb[:, 15].cpu()
+        bad = torch.nonzero(st < 0).reshape(-1)
+        if bad.numel():
+            b = int(bad[0])
+            raise L.KinectPxError(f"get_oriented_bounding_box: cloud {b}: {_OBB_ERRORS.get(int(st[b]), 'error')}")
+    return obb, flags
+
+
+def normalize_batch(x, obb, mode, M=None):
+    """x f64 (count, rows, 3) -> the normalisation `mode` with the boxes of obb_batch (kpx_normalize_batch)"""
+    lib = L.load()
+    x = _dev(x, torch.float64)
+    count, rows = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty_like(x)
+    Mh = None if M is None else np.ascontiguousarray(M, dtype=np.float64).reshape(3, 3)
+    L.check(lib.kpx_normalize_batch(L.ptr(x), count, rows, L.ptr(obb), int(mode), None if Mh is None else L.hptr(Mh), L.ptr(out),
+                                    L.stream_ptr()))
+    return out

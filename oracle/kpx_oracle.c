@@ -984,3 +984,182 @@ KPO_API int kpo_num_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* the sampler / normaliser that follows the path.                            */
+/*                                                                                            */
+/* select_points_randomly (utils/processing.py:259-275) draws np.random.choice(N, k,            */
+/* replace=False) from NumPy's unseeded global generator: there is no reference stream to       */
+/* reproduce.  Contract used on both sides: point i gets the 64-bit key                         */
+/* Philox4x32-10(ctr = (i_lo, i_hi, 'SAMP', 0), key = seed) words (1:0); the sample is the k     */
+/* points with the smallest (key, i), in that order: a uniformly random ordered k-subset.       */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { uint64_t key; int64_t i; } samp_t;
+static int cmp_samp(const void *a, const void *b)
+{
+    const samp_t *x = (const samp_t *)a, *y = (const samp_t *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->i < y->i ? -1 : (x->i > y->i);
+}
+KPO_API int kpo_sample_indices(int64_t n, int64_t k, uint64_t seed, int32_t *idx)
+{
+    if (k < 0 || k > n) return -1;            /* np.random.choice: "Cannot take a larger sample than population" */
+    samp_t *s = (samp_t *)malloc(sizeof(samp_t) * (size_t)(n > 0 ? n : 1));
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t ctr[4] = { (uint32_t)i, (uint32_t)((uint64_t)i >> 32), 0x53414D50u, 0u }, out[4];
+        kpo_philox4x32(ctr, key, out);
+        s[i].key = ((uint64_t)out[1] << 32) | out[0];
+        s[i].i = i;
+    }
+    qsort(s, (size_t)n, sizeof(samp_t), cmp_samp);
+    for (int64_t j = 0; j < k; ++j) idx[j] = (int32_t)s[j].i;
+    free(s);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* PointCloud.get_oriented_bounding_box() (utils/normalization.py:38-42,74-77,105-106;          */
+/* utils/processing.py:341-344) is Open3D's OrientedBoundingBox::CreateFromPoints [O3D,          */
+/* recalled]: convex hull (Qhull), then mean / covariance of the HULL VERTICES, eigenvectors by   */
+/* descending eigenvalue as the columns of R (third = first x second), the axis-aligned box of   */
+/* R^T (v - mean) giving centre and extent.  Qhull is not in the reference tree; its published   */
+/* result for points in general position -- the set of extreme points -- is restated here by gift */
+/* wrapping, with this arithmetic contract (AC5, fp64, explicit fma, shared with the device):    */
+/*   wrap about the directed edge a->b of a facet (a, b, r) with outward normal                  */
+/*   n = e x g (e = b - a, g = r - a), t = e x n; for candidate c, d = c - a:                    */
+/*   u = t.d, w = max(-(n.d), 0), key2 = (u / |e|^2) u + w w (= |n|^2 x squared distance from the  */
+/*   edge line); c is skipped as lying on that line when key2 <= 2^-80 (n.n)(d.d); key1 = u / w    */
+/*   (w == 0: +-inf by the sign of u), key3 = e.d; the winner maximises (key1, key2, key3),        */
+/*   lowest index on full ties; it is the next extreme point also when several hull points are    */
+/*   coplanar (key2 / key3 walk the facet polygon).  New facet (b, a, c).                         */
+/* PARITY: unpinned against Open3D (absent here); the vertex set is pinned against Qhull itself   */
+/* (scipy.spatial.ConvexHull) in tests/test_oracle_cpu.py.                                        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { double k1, k2, k3; int32_t i; } wrapkey_t;
+static inline int wrap_better(const wrapkey_t *x, const wrapkey_t *y)      /* x beats y */
+{
+    if (y->i < 0) return x->i >= 0;
+    if (x->i < 0) return 0;
+    if (x->k1 != y->k1) return x->k1 > y->k1;
+    if (x->k2 != y->k2) return x->k2 > y->k2;
+    if (x->k3 != y->k3) return x->k3 > y->k3;
+    return x->i < y->i;
+}
+static inline double dot3f(const double a[3], const double b[3]) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
+static inline void cross3f(const double a[3], const double b[3], double o[3])
+{
+    o[0] = fma(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fma(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fma(a[0], b[1], -(a[1] * b[0]));
+}
+/* frame of one wrap: a, e, n (outward normal of the known facet), t, 1/|e|^2 */
+typedef struct { double a[3], e[3], n[3], t[3], inv_e2, n2s; } wrapframe_t;
+static void wrap_frame(const double a[3], const double b[3], const double r[3], wrapframe_t *f)
+{
+    double g[3];
+    for (int k = 0; k < 3; ++k) { f->a[k] = a[k]; f->e[k] = b[k] - a[k]; g[k] = r[k] - a[k]; }
+    cross3f(f->e, g, f->n);
+    cross3f(f->e, f->n, f->t);
+    f->inv_e2 = 1.0 / dot3f(f->e, f->e);
+    f->n2s = dot3f(f->n, f->n) * 0x1p-80;
+}
+static inline wrapkey_t wrap_key(const wrapframe_t *f, const double c[3], int32_t i)
+{
+    double d[3] = { c[0] - f->a[0], c[1] - f->a[1], c[2] - f->a[2] };
+    double u = dot3f(f->t, d), w = -dot3f(f->n, d);
+    wrapkey_t k; k.i = i;
+    if (w < 0.0) w = 0.0;
+    k.k2 = fma(u * f->inv_e2, u, w * w);
+    if (k.k2 <= f->n2s * dot3f(d, d)) { k.i = -1; k.k1 = k.k2 = k.k3 = 0.0; return k; }     /* on the edge line */
+    k.k1 = w == 0.0 ? (u > 0.0 ? INFINITY : -INFINITY) : u / w;
+    k.k3 = dot3f(f->e, d);
+    return k;
+}
+static int32_t wrap_scan(const wrapframe_t *f, const double *pts, int64_t n, int32_t ia, int32_t ib)
+{
+    wrapkey_t best; best.i = -1; best.k1 = best.k2 = best.k3 = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (i == ia || i == ib) continue;
+        wrapkey_t k = wrap_key(f, pts + 3 * i, (int32_t)i);
+        if (wrap_better(&k, &best)) best = k;
+    }
+    return best.i;
+}
+/* open-addressing set of directed edges */
+typedef struct { uint64_t *slot; uint64_t mask; } edgeset_t;
+static inline uint64_t edge_code(int32_t a, int32_t b) { return (((uint64_t)(uint32_t)a) << 32 | (uint32_t)b) + 1; }
+static inline uint64_t edge_hash(uint64_t c) { c *= 0x9E3779B97F4A7C15ull; return c ^ (c >> 29); }
+static int edge_has(const edgeset_t *s, int32_t a, int32_t b)
+{
+    uint64_t c = edge_code(a, b);
+    for (uint64_t h = edge_hash(c) & s->mask;; h = (h + 1) & s->mask) {
+        if (s->slot[h] == c) return 1;
+        if (s->slot[h] == 0) return 0;
+    }
+}
+static void edge_put(edgeset_t *s, int32_t a, int32_t b)
+{
+    uint64_t c = edge_code(a, b);
+    for (uint64_t h = edge_hash(c) & s->mask;; h = (h + 1) & s->mask) {
+        if (s->slot[h] == c) return;
+        if (s->slot[h] == 0) { s->slot[h] = c; return; }
+    }
+}
+/* is_vertex: u8 [n].  Returns the number of hull vertices, or -1 when the cloud has no proper first facet
+ * (fewer than 3 distinct points, or all of them on one line), -2 if the wrap did not close within 2n+64 facets.
+ * pts: f64 (n,3) -- float32 clouds are widened by the caller (exact). */
+KPO_API int64_t kpo_hull_vertices(const double *pts, int64_t n, uint8_t *is_vertex)
+{
+    memset(is_vertex, 0, (size_t)n);
+    if (n < 3) return -1;
+    int32_t p0 = 0;
+    for (int64_t i = 1; i < n; ++i) {
+        const double *a = pts + 3 * i, *b = pts + 3 * (int64_t)p0;
+        if (a[0] < b[0] || (a[0] == b[0] && (a[1] < b[1] || (a[1] == b[1] && a[2] < b[2])))) p0 = (int32_t)i;
+    }
+    double A[3] = { pts[3 * (int64_t)p0], pts[3 * (int64_t)p0 + 1], pts[3 * (int64_t)p0 + 2] };
+    /* virtual facet: the half plane {x = x0, y <= y0} bounded by the line through p0 along z */
+    wrapframe_t f;
+    for (int k = 0; k < 3; ++k) f.a[k] = A[k];
+    f.e[0] = 0; f.e[1] = 0; f.e[2] = -1; f.n[0] = -1; f.n[1] = 0; f.n[2] = 0; f.t[0] = 0; f.t[1] = 1; f.t[2] = 0; f.inv_e2 = 1.0; f.n2s = 0x1p-80;
+    int32_t c1 = wrap_scan(&f, pts, n, p0, p0);
+    if (c1 < 0) return -1;
+    double B[3] = { pts[3 * (int64_t)c1], pts[3 * (int64_t)c1 + 1], pts[3 * (int64_t)c1 + 2] };
+    double V[3] = { A[0], A[1], A[2] - 1.0 };            /* a + e of the virtual edge: the virtual facet is (v, p0, c1) */
+    wrap_frame(A, B, V, &f);
+    int32_t c2 = wrap_scan(&f, pts, n, p0, c1);
+    if (c2 < 0) return -1;
+    int64_t max_facets = 2 * n + 64, facets = 0;
+    uint64_t cap = 16; while (cap < (uint64_t)(8 * n)) cap <<= 1;
+    edgeset_t es; es.slot = (uint64_t *)calloc(cap, 8); es.mask = cap - 1;
+    int32_t *stack = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)(2 * max_facets + 8));
+    int64_t sp = 0;
+#define KPO_PUSH(x, y, z) do { stack[3 * sp] = (x); stack[3 * sp + 1] = (y); stack[3 * sp + 2] = (z); ++sp; } while (0)
+    /* first real facet (c1, p0, c2): all three of its edges are open */
+    edge_put(&es, c1, p0); edge_put(&es, p0, c2); edge_put(&es, c2, c1);
+    is_vertex[p0] = is_vertex[c1] = is_vertex[c2] = 1;
+    KPO_PUSH(c1, p0, c2); KPO_PUSH(p0, c2, c1); KPO_PUSH(c2, c1, p0);
+    facets = 1;
+    int64_t rc = 0;
+    while (sp > 0) {
+        --sp;
+        int32_t a = stack[3 * sp], b = stack[3 * sp + 1], r = stack[3 * sp + 2];
+        if (edge_has(&es, b, a)) continue;
+        if (++facets > max_facets) { rc = -2; break; }
+        double pa[3], pb[3], pr[3];
+        for (int k = 0; k < 3; ++k) { pa[k] = pts[3 * (int64_t)a + k]; pb[k] = pts[3 * (int64_t)b + k]; pr[k] = pts[3 * (int64_t)r + k]; }
+        wrap_frame(pa, pb, pr, &f);
+        int32_t c = wrap_scan(&f, pts, n, a, b);
+        if (c < 0) { rc = -2; break; }
+        edge_put(&es, b, a); edge_put(&es, a, c); edge_put(&es, c, b);
+        is_vertex[c] = 1;
+        KPO_PUSH(a, c, b); KPO_PUSH(c, b, a);
+    }
+#undef KPO_PUSH
+    free(stack); free(es.slot);
+    if (rc) return rc;
+    int64_t v = 0;
+    for (int64_t i = 0; i < n; ++i) v += is_vertex[i];
+    return v;
+}

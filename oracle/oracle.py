@@ -472,3 +472,108 @@ def floor_removal(pts, slab=200.0, thr=30.0, ransac_n=30, iters=2000, seed=0, so
 
 def num_threads():
     return int(lib().kpo_num_threads())
+
+
+# ---- sampler / normaliser --------------------------------------------------------
+def sample_indices(n, k, seed):
+    """seeded stand-in for np.random.choice(n, k, replace=False) (utils/processing.py:270-272)"""
+    idx = np.zeros(max(int(k), 0), dtype=np.int32)
+    if lib().kpo_sample_indices(C.c_int64(n), C.c_int64(k), C.c_uint64(seed), _p(idx)) != 0:
+        raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+    return idx
+
+
+def hull_vertices(pts):
+    """indices (ascending) of the extreme points of the cloud (gift wrapping, arithmetic contract AC5)"""
+    pts = np.ascontiguousarray(_f32(pts).reshape(-1, 3), dtype=np.float64)
+    return hull_vertices_f64(pts)
+
+
+def hull_vertices_f64(pts):
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    flag = np.zeros(len(pts), dtype=np.uint8)
+    lib().kpo_hull_vertices.restype = C.c_int64
+    v = lib().kpo_hull_vertices(_p(pts), C.c_int64(len(pts)), _p(flag))
+    if v < 0:
+        raise RuntimeError("hull_vertices: degenerate cloud" if v == -1 else "hull_vertices: the wrap did not close")
+    return np.flatnonzero(flag)
+
+
+def obb_from_vertices(verts):
+    """OrientedBoundingBox::CreateFromPoints after the hull [O3D, recalled]: cumulant mean / covariance of the hull
+    vertices, eigenvectors by descending eigenvalue (third = first x second), box of R^T (v - mean).  Eigenvector signs
+    are Eigen's in Open3D and unknowable here: each of the first two columns is given a positive largest component.
+    -> R (3,3), center (3,), extent (3,)"""
+    v = np.asarray(verts, dtype=np.float64)
+    mean = v.mean(0)
+    cov = (v[:, :, None] * v[:, None, :]).mean(0) - np.outer(mean, mean)
+    w, V = np.linalg.eigh(cov)
+    R = V[:, ::-1].copy()
+    for c in (0, 1):
+        j = int(np.argmax(np.abs(R[:, c])))
+        if R[j, c] < 0:
+            R[:, c] = -R[:, c]
+    R[:, 0] /= np.linalg.norm(R[:, 0])
+    R[:, 1] /= np.linalg.norm(R[:, 1])
+    R[:, 2] = np.cross(R[:, 0], R[:, 1])
+    q = (v - mean) @ R
+    lo, hi = q.min(0), q.max(0)
+    return R, R @ ((lo + hi) / 2) + mean, hi - lo
+
+
+def oriented_bounding_box(pts):
+    pts = _f32(pts).reshape(-1, 3)
+    return obb_from_vertices(pts[hull_vertices(pts)])
+
+
+def rotation_matrix_from_yxz(rot):
+    """Geometry3D::GetRotationMatrixFromYXZ [O3D, recalled]: Ry(rot[0]) Rx(rot[1]) Rz(rot[2])"""
+    def ax(axis, a):
+        c, s = np.cos(a), np.sin(a)
+        return {"x": np.array([[1, 0, 0], [0, c, -s], [0, s, c]]), "y": np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]),
+                "z": np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])}[axis]
+    return ax("y", rot[0]) @ ax("x", rot[1]) @ ax("z", rot[2])
+
+
+def obb_normalization_batch(x, y, obb=None):
+    """utils/normalization.py:16-64 (as written there: the rotation is the constant Rx(pi), the centre is ADDED)"""
+    x = np.asarray(x, dtype=np.float64)
+    x = x[None] if x.ndim == 2 else x
+    xs, ys = [], []
+    Rc = rotation_matrix_from_yxz([0, np.pi, 0])
+    for b in range(x.shape[0]):
+        R, c, ext = obb[b] if obb is not None else oriented_bounding_box(x[b])
+        L = np.max(ext)
+        xs.append((np.matmul(x[b], Rc) + c) / L)
+        ys.append(((np.matmul(np.asarray(y[b], dtype=np.float64).reshape(-1, 3), Rc) + c) / L).reshape(-1))
+    return np.array(xs), np.array(ys)
+
+
+def obb_rotation_translation_batch(x, y, obb=None):
+    """utils/normalization.py:67-97: (p - c) @ R @ Rz(90 deg)"""
+    x = np.asarray(x, dtype=np.float64)
+    r = rotation_matrix_from_yxz([0, 0, np.pi / 2])
+    xs, ys = [], []
+    for b in range(x.shape[0]):
+        R, c, ext = obb[b] if obb is not None else oriented_bounding_box(x[b])
+        xs.append((x[b] - c) @ R @ r)
+        ys.append(((np.asarray(y[b], dtype=np.float64).reshape(-1, 3) - c) @ R @ r).reshape(-1))
+    return np.array(xs), np.array(ys)
+
+
+def translation_normalization_batch(x, y, obb=None):
+    """utils/normalization.py:100-126: p - c"""
+    x = np.asarray(x, dtype=np.float64)
+    xs, ys = [], []
+    for b in range(x.shape[0]):
+        R, c, ext = obb[b] if obb is not None else oriented_bounding_box(x[b])
+        xs.append(x[b] - c)
+        ys.append((np.asarray(y[b], dtype=np.float64).reshape(-1, 3) - c).reshape(-1))
+    return np.array(xs), np.array(ys)
+
+
+def normalize_pointcloud(arr, min_range=-1.0, max_range=1.0):
+    """utils/processing.py:313-326"""
+    arr = np.asarray(arr, dtype=np.float64)
+    s = (max_range - min_range) / (np.max(arr) - np.min(arr))
+    return arr * s - np.min(arr) * s + min_range

@@ -151,3 +151,85 @@ def test_normals_of_a_plane(oracle):
     p = np.stack([rng.uniform(0, 500, 3000), rng.uniform(0, 500, 3000), np.full(3000, 100.0)], 1).astype(np.float32)
     n, cov, cnt = oracle.estimate_normals(p, 70.0, 40)
     assert np.allclose(np.abs(n[cnt >= 3, 2]), 1.0, atol=1e-9)
+
+
+# ---- sampler / oriented bounding box ---------------------------------------------------
+def _hull_cases():
+    rng = np.random.default_rng(11)
+    cases = {}
+    for n in (4, 9, 100, 4096):
+        cases[f"gauss{n}"] = (rng.normal(size=(n, 3)) * [300, 900, 200]).astype(np.float32)
+    s = rng.normal(size=(1500, 3))
+    cases["sphere"] = (s / np.linalg.norm(s, axis=1)[:, None]).astype(np.float32)           # every point is a vertex
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(5), np.arange(4), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    cases["lattice"] = g[rng.permutation(len(g))]                                               # coplanar / collinear ties
+    p = rng.normal(size=(400, 3)).astype(np.float32)
+    cases["duplicates"] = np.concatenate([p, p, p[:50]])
+    c3 = synth.filter_cloud(20000)
+    cases["scene"] = c3
+    cases["scene_int_mm"] = np.round(c3).astype(np.float32)                                     # sensor-like integer mm
+    return cases
+
+
+def test_hull_vertices_equal_qhull(oracle):
+    """the vertex set of the gift-wrapping restatement against Qhull itself (scipy.spatial.ConvexHull; Open3D's
+    get_oriented_bounding_box runs the same library)"""
+    from scipy.spatial import ConvexHull
+    for name, p in _hull_cases().items():
+        got = oracle.hull_vertices(p)
+        uniq, first = np.unique(p.astype(np.float64), axis=0, return_index=True)
+        ref = np.sort(first[ConvexHull(uniq).vertices])                  # duplicates: the lowest index stands for the point
+        assert np.array_equal(got, ref), name
+    with pytest.raises(RuntimeError):
+        oracle.hull_vertices(np.stack([np.arange(10.0)] * 3, 1))        # all on one line
+    with pytest.raises(RuntimeError):
+        oracle.hull_vertices(np.zeros((5, 3)))
+
+
+def test_obb_properties(oracle):
+    for name, p in _hull_cases().items():
+        if name == "lattice":
+            continue                                                     # equal eigenvalues: the axes are not unique
+        R, c, ext = oracle.oriented_bounding_box(p)
+        assert np.allclose(R.T @ R, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+        q = (p.astype(np.float64) - c) @ R                               # every point inside the box, the box is tight
+        assert (np.abs(q) <= ext / 2 * (1 + 1e-9) + 1e-9).all()
+        assert np.allclose(q.max(0) - q.min(0), ext, rtol=1e-9)
+        assert ext[0] >= ext[1] * 0.5                                    # principal axis first (PCA of the hull vertices)
+
+
+def test_sampler_is_a_seeded_uniform_subset(oracle):
+    idx = oracle.sample_indices(1000, 100, 7)
+    assert len(set(idx.tolist())) == 100 and idx.min() >= 0 and idx.max() < 1000
+    assert np.array_equal(idx, oracle.sample_indices(1000, 100, 7)) and not np.array_equal(idx, oracle.sample_indices(1000, 100, 8))
+    assert np.array_equal(oracle.sample_indices(1000, 1000, 3)[:100], oracle.sample_indices(1000, 100, 3))   # prefix property
+    assert sorted(oracle.sample_indices(50, 50, 1).tolist()) == list(range(50))
+    with pytest.raises(ValueError):
+        oracle.sample_indices(10, 11, 0)
+    # uniformity: inclusion counts of each index over many seeds ~ Binomial(S, k/n); first position uniform
+    S, n, k = 4000, 40, 10
+    draws = np.stack([oracle.sample_indices(n, k, s) for s in range(S)])
+    inc = np.bincount(draws.reshape(-1), minlength=n)
+    assert abs(inc - S * k / n).max() < 5 * np.sqrt(S * k / n * (1 - k / n))
+    first = np.bincount(draws[:, 0], minlength=n)
+    assert abs(first - S / n).max() < 5 * np.sqrt(S / n)
+
+
+def test_normalisation_restatements(oracle):
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(3, 500, 3)) * [300, 900, 200] + [10, -20, 2000]
+    y = rng.normal(size=(3, 12)) * 400
+    boxes = [oracle.oriented_bounding_box(x[b]) for b in range(3)]
+    xt, yt = oracle.translation_normalization_batch(x, y, boxes)
+    assert np.array_equal(xt[1], x[1] - boxes[1][1]) and yt.shape == (3, 12)
+    xr, yr = oracle.obb_rotation_translation_batch(x, y, boxes)
+    # in the box frame (then turned 90 degrees about z) the cloud is centred and spans the extents
+    span = xr[0].max(0) - xr[0].min(0)
+    assert np.allclose(sorted(span), sorted(boxes[0][2]), rtol=0.02)
+    xo, yo = oracle.obb_normalization_batch(x, y, boxes)
+    Rc = oracle.rotation_matrix_from_yxz([0, np.pi, 0])
+    assert np.allclose(Rc, np.diag([1, -1, -1]), atol=2e-16)
+    assert np.allclose(xo[2] * np.max(boxes[2][2]) - boxes[2][1], x[2] @ Rc, atol=1e-9)
+    a = rng.normal(size=(50, 3))
+    n = oracle.normalize_pointcloud(a)
+    assert abs(n.min() + 1) < 1e-12 and abs(n.max() - 1) < 1e-12

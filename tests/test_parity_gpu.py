@@ -838,3 +838,134 @@ def test_rccl_exchange_on_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stderr[-2000:]
+
+
+# ---- sampler / oriented bounding box / normalisers --------------------------------------
+def _hull_clouds():
+    rng = np.random.default_rng(11)
+    c = {}
+    for n in (4, 9, 100, 4096):
+        c[f"gauss{n}"] = (rng.normal(size=(n, 3)) * [300, 900, 200]).astype(np.float32)
+    s = rng.normal(size=(3000, 3))
+    c["sphere"] = (s / np.linalg.norm(s, axis=1)[:, None]).astype(np.float32)      # 5996 facets: the edge set leaves LDS
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(5), np.arange(4), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    c["lattice"] = g[rng.permutation(len(g))]
+    p = rng.normal(size=(400, 3)).astype(np.float32)
+    c["duplicates"] = np.concatenate([p, p, p[:50]])
+    c3 = synth.filter_cloud(60000)
+    c["scene"] = c3                                                                 # > 16384 points: 1024-thread block
+    c["scene_int_mm"] = np.round(c3[:30000]).astype(np.float32)
+    return c
+
+
+def test_sample_points_equal_oracle(ops, oracle, base_cloud):
+    for n, k, seed in [(1000, 100, 7), (len(base_cloud), 4096, 1234), (4096, 4096, 3), (5, 1, 0), (70000, 4096, 2 ** 63 + 5)]:
+        p = base_cloud[:n] if n <= len(base_cloud) else np.tile(base_cloud, (2, 1))[:n]
+        pts, idx = ops.sample_points(p, k, seed)
+        ref = oracle.sample_indices(n, k, seed)
+        assert np.array_equal(idx.cpu().numpy(), ref)
+        assert np.array_equal(pts.cpu().numpy(), p[ref])
+    _, idx = ops.sample_points(base_cloud[:100], 0, 1)
+    assert idx.numel() == 0
+    with pytest.raises(ValueError):
+        ops.sample_points(base_cloud[:10], 11, 0)
+
+
+def test_hull_vertices_bit_exact_and_obb(ops, oracle):
+    for name, p in _hull_clouds().items():
+        for dt in (np.float32, np.float64):
+            obb, flags = ops.obb_batch(torch.as_tensor(p.astype(dt))[None], want_vertices=True)
+            got = np.flatnonzero(flags[0].cpu().numpy())
+            ref = oracle.hull_vertices(p)
+            assert np.array_equal(got, ref), (name, dt)
+            row = obb[0].cpu().numpy()
+            assert row[15] == len(ref)
+            if name == "lattice":
+                continue
+            R, c, ext = oracle.obb_from_vertices(p[ref])
+            scale = np.abs(p).max()
+            assert np.allclose(row[:9].reshape(3, 3), R, atol=1e-7), name           # eigenvectors: gap-dependent conditioning
+            assert np.allclose(row[9:12], c, atol=1e-7 * scale) and np.allclose(row[12:15], ext, rtol=1e-7), name
+
+
+def test_obb_batch_of_training_clouds(ops, oracle, base_cloud):
+    rng = np.random.default_rng(4)
+    B, N = 24, 4096
+    x = np.stack([base_cloud[rng.choice(len(base_cloud), N, replace=False)] + rng.normal(size=3) * 100 for _ in range(B)]).astype(np.float64)
+    x += rng.normal(size=x.shape) * 1e-3                                            # float64 payload, not f32-representable
+    obb, flags = ops.obb_batch(x, want_vertices=True)
+    fl = flags.cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(np.flatnonzero(fl[b]), _hull_f64(oracle, x[b]))
+
+
+def _hull_f64(oracle, p):
+    """the oracle's hull on float64 points"""
+    return oracle.hull_vertices_f64(p)
+
+
+def test_obb_degenerate_clouds(ops):
+    from kinectpy_amd._lib import KinectPxError
+    line = np.stack([np.arange(10.0)] * 3, 1)
+    for bad in (line, np.zeros((5, 3)), np.zeros((2, 3)), np.c_[np.random.default_rng(0).normal(size=(50, 2)), np.zeros(50)]):
+        with pytest.raises(KinectPxError):
+            ops.obb_batch(bad)
+    good = np.random.default_rng(1).normal(size=(50, 3))
+    obb, _ = ops.obb_batch(np.stack([good, good * 2]))
+    assert (obb[:, 15] > 3).all()
+    obb, _ = ops.obb_batch(np.stack([good, np.zeros((50, 3))]), check=False)     # per-cloud status, no exception
+    st = obb[:, 15].cpu().numpy()
+    assert st[0] > 3 and st[1] == -1
+
+
+def test_normalisation_batches_match_oracle(oracle, base_cloud):
+    from kinectpy_amd.utils import normalization as Nz
+    rng = np.random.default_rng(9)
+    B, N, K = 6, 2048, 13
+    x = np.stack([base_cloud[rng.choice(len(base_cloud), N, replace=False)] for _ in range(B)]).astype(np.float64)
+    y = rng.normal(size=(B, 3 * K)) * 500
+    boxes = []
+    for b in range(B):
+        boxes.append(oracle.obb_from_vertices(x[b][oracle.hull_vertices_f64(x[b])]))
+    for name in ("obb_normalization_batch", "obb_rotation_translation_batch", "translation_normalization_batch"):
+        gx, gy = getattr(Nz, name)(x, y)
+        rx, ry = getattr(oracle, name)(x, y, boxes)
+        assert gx.shape == rx.shape and gy.shape == ry.shape and gx.dtype == np.float64
+        assert np.allclose(gx, rx, rtol=0, atol=1e-6 if "translation_norm" not in name else 1e-7), name
+        assert np.allclose(gy, ry, rtol=0, atol=1e-6), name
+    gx, gy = Nz.scale_batch(x, y)
+    assert np.array_equal(gx, x * (1 / 1000)) and np.array_equal(gy, y * (1 / 1000))
+    gx, gy = Nz.rotate_batch(x, y, degs=37)
+    a = np.deg2rad(37.0)
+    rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    assert np.allclose(gx, x @ rot, atol=1e-9) and np.allclose(gy.reshape(B, K, 3), y.reshape(B, K, 3) @ rot, atol=1e-9)
+    assert set(Nz.normalization_options) == {"obb_normalization", "obb_rotation_translation", "translation"}
+
+
+def test_processing_mirrors(oracle, base_cloud, tmp_path):
+    from kinectpy_amd import o3d
+    from kinectpy_amd.utils import processing as P
+    pcd = o3d.geometry.PointCloud(o3d.utility.Vector3dVector(base_cloud[:50000].astype(np.float64)))
+    s = P.select_points_randomly(pcd, 4096, seed=5)
+    assert s.shape == (4096, 3) and s.dtype == np.float64
+    assert np.array_equal(s, base_cloud[:50000][oracle.sample_indices(50000, 4096, 5)].astype(np.float64))
+    np.random.seed(3)
+    a = P.select_points_randomly(pcd, 100)
+    np.random.seed(3)
+    assert np.array_equal(a, P.select_points_randomly(pcd, 100))                  # np.random.seed governs the default draw
+    with pytest.raises(ValueError):
+        P.select_points_randomly(pcd, 50001)
+    box = pcd.get_oriented_bounding_box()
+    R, c, ext = oracle.oriented_bounding_box(base_cloud[:50000])
+    assert np.allclose(box.R, R, atol=1e-7) and np.allclose(box.get_center(), c, atol=1e-4) and np.allclose(box.extent, ext, rtol=1e-7)
+    assert np.allclose(box.get_rotation_matrix_from_yxz([0, np.pi, 0]), oracle.rotation_matrix_from_yxz([0, np.pi, 0]), atol=0)
+    xo, jo = P.obb_normalization(base_cloud[:3000], np.arange(12.0), 4)
+    Rb, cb, _ = oracle.oriented_bounding_box(base_cloud[:3000])
+    assert np.allclose(xo, (base_cloud[:3000].astype(np.float64) - cb) @ Rb, atol=1e-6) and jo.shape == (12,)
+    n = P.normalize_pointcloud(pcd.clone())
+    arr = np.asarray(n.points)
+    assert np.allclose(arr, oracle.normalize_pointcloud(base_cloud[:50000]), atol=1e-6)
+    sc = P.scale_point_cloud(pcd)
+    assert np.allclose(np.asarray(sc.points), base_cloud[:50000] * 0.001, rtol=1e-6)
+    P.save_points_npz(str(tmp_path / "1.npz"), pcd, 4096, seed=1)
+    assert np.load(str(tmp_path / "1.npz"))["points"][:4096].shape == (4096, 3)
