@@ -7,11 +7,18 @@
 //
 // Oriented bounding box = Open3D's CreateFromPoints: convex hull, then PCA of the hull VERTICES.  The hull vertices
 // are found by gift wrapping, ONE BLOCK PER CLOUD: every wrap is a block-wide arg-max of a three-part key over all
-// points (arithmetic contract AC5, oracle/kpx_oracle.c: the vertex set is bit-exact with the oracle because both
-// evaluate the same fp64 fma chains); thread 0 keeps the open-edge stack and the set of directed edges in LDS (spilling
-// to the workspace for hulls with more than ~2000 facets).  A wrap costs one pass over the cloud (L2 resident) plus two
-// block barriers, a hull of v vertices takes 2v-4 wraps: latency-bound by construction, which is fine for what it
-// serves -- batches of 4096-point training clouds run one per CU side by side.
+// points; thread 0 keeps the open-edge stack and the set of directed edges in LDS (spilling to the workspace for hulls
+// with more than ~2000 facets).  A wrap costs one pass over the cloud (L2 resident) plus two block barriers, a hull of
+// v vertices takes 2v-4 wraps: latency-bound by construction, which is fine for what it serves -- batches of
+// 4096-point training clouds run one per CU side by side.
+//
+// Arithmetic contract AC5 (fp64, every fma explicit): wrap about the directed edge a->b of a facet
+// (a, b, r) with outward normal n = e x g (e = b - a, g = r - a), t = e x n; for a candidate c, d = c - a:
+//   u = t.d,  w = max(-(n.d), 0),  key2 = (u / |e|^2) u + w w  (= |n|^2 x squared distance from the edge line);
+//   c is skipped as lying on that line when key2 <= 2^-80 (n.n)(d.d);  key1 = u / w (w == 0: +-inf by the sign of u),
+//   key3 = e.d;  the winner maximises (key1, key2, key3), lowest index on full ties -- it is the next extreme point
+//   also when several hull points are coplanar (key2 / key3 walk the facet polygon).  New facet (b, a, c).
+// The start is the lexicographically smallest point and the virtual half plane {x = x0, y <= y0} through it.
 #include <hipcub/hipcub.hpp>
 
 #include "kpx_internal.h"
