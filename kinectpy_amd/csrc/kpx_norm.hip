@@ -118,22 +118,6 @@ __device__ __forceinline__ void wrap_frame(const double a[3], const double b[3],
     f->inv_e2 = 1.0 / dot3f(f->e, f->e);
     f->n2s = dot3f(f->n, f->n) * 0x1p-80;
 }
-__device__ __forceinline__ WrapKey wrap_key(const WrapFrame &f, double cx, double cy, double cz, int32_t i)
-{
-    double d[3] = { cx - f.a[0], cy - f.a[1], cz - f.a[2] };
-    double u = dot3f(f.t, d), w = -dot3f(f.n, d);
-    WrapKey k;
-    k.i = i;
-    if (w < 0.0) w = 0.0;
-    k.k2 = fma(u * f.inv_e2, u, w * w);
-    if (k.k2 <= f.n2s * dot3f(d, d)) {              // on the edge line (or a duplicate of an end point)
-        k.i = -1; k.k1 = k.k2 = k.k3 = 0.0;
-        return k;
-    }
-    k.k1 = w == 0.0 ? (u > 0.0 ? INFINITY : -INFINITY) : u / w;
-    k.k3 = dot3f(f.e, d);
-    return k;
-}
 __device__ __forceinline__ WrapKey shfl_xor_key(const WrapKey &k, int o)
 {
     WrapKey r;
@@ -145,14 +129,15 @@ __device__ __forceinline__ WrapKey shfl_xor_key(const WrapKey &k, int o)
 }
 // best key of the block; valid in thread 0.  sh: one entry per wave.  wrap_better is a strict total order, so the
 // result does not depend on the shape of the reduction.
-__device__ __forceinline__ WrapKey block_best(WrapKey k, WrapKey *sh)
+// PRE = false: the caller guarantees that a barrier separates this call from the previous reader of sh.
+template <bool PRE = true> __device__ __forceinline__ WrapKey block_best(WrapKey k, WrapKey *sh)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         WrapKey t = shfl_xor_key(k, o);
         if (wrap_better(t, k)) k = t;
     }
-    __syncthreads();
+    if (PRE) __syncthreads();
     if (lane_id() == 0) sh[wave_id()] = k;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -231,15 +216,58 @@ template <class T> __device__ __forceinline__ void load_pt(const T *__restrict__
     p[2] = (double)pts[3 * i + 2];
 }
 
-template <class T> __device__ __forceinline__ WrapKey wrap_scan(const WrapFrame &f, const T *__restrict__ pts, int64_t n, int32_t ia, int32_t ib)
+// One candidate against the running best.  The quick reject skips the division for a candidate whose key1 = u / w is
+// certainly below the best so far (margin 2^-40 relative, far above the rounding of the product): it could not have
+// won, so the result is the arg-max of the full keys all the same.
+__device__ __forceinline__ void wrap_consider(const WrapFrame &f, double cx, double cy, double cz, int32_t i, WrapKey &best)
+{
+    const double d[3] = { cx - f.a[0], cy - f.a[1], cz - f.a[2] };
+    const double u = dot3f(f.t, d);
+    double w = -dot3f(f.n, d);
+    if (w < 0.0) w = 0.0;
+    if (best.i >= 0 && w > 0.0) {
+        const double bw = best.k1 * w;
+        if (u < bw - fabs(bw) * 0x1p-40) return;
+    }
+    WrapKey k;
+    k.k2 = fma(u * f.inv_e2, u, w * w);
+    if (k.k2 <= f.n2s * dot3f(d, d)) return;          // on the edge line (or a duplicate of an end point)
+    k.i = i;
+    k.k1 = w == 0.0 ? (u > 0.0 ? INFINITY : -INFINITY) : u / w;
+    k.k3 = dot3f(f.e, d);
+    if (wrap_better(k, best)) best = k;
+}
+
+constexpr int kHullCache = 4;      // points per thread held in registers (the first kHullCache * blockDim points)
+struct PtCache {
+    double x[kHullCache], y[kHullCache], z[kHullCache];
+};
+template <class T> __device__ __forceinline__ WrapKey wrap_scan(const WrapFrame &f, const PtCache &pc, const T *__restrict__ pts, int64_t n,
+                                                                int32_t ia, int32_t ib)
 {
     WrapKey best;
     best.i = -1; best.k1 = best.k2 = best.k3 = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        if (i == ia || i == ib) continue;
-        WrapKey k = wrap_key(f, (double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2], (int32_t)i);
-        if (wrap_better(k, best)) best = k;
+#pragma unroll
+    for (int j = 0; j < kHullCache; ++j) {
+        const int64_t i = threadIdx.x + (int64_t)j * blockDim.x;
+        if (i < n && i != ia && i != ib) wrap_consider(f, pc.x[j], pc.y[j], pc.z[j], (int32_t)i, best);
     }
+    int64_t i = threadIdx.x + (int64_t)kHullCache * blockDim.x;
+    for (; i + 3 * (int64_t)blockDim.x < n; i += 4 * (int64_t)blockDim.x) {      // four independent loads in flight
+        double c[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t iq = i + (int64_t)q * blockDim.x;
+            c[q][0] = (double)pts[3 * iq]; c[q][1] = (double)pts[3 * iq + 1]; c[q][2] = (double)pts[3 * iq + 2];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t iq = i + (int64_t)q * blockDim.x;
+            if (iq != ia && iq != ib) wrap_consider(f, c[q][0], c[q][1], c[q][2], (int32_t)iq, best);
+        }
+    }
+    for (; i < n; i += blockDim.x)
+        if (i != ia && i != ib) wrap_consider(f, (double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2], (int32_t)i, best);
     return best;
 }
 
@@ -265,6 +293,14 @@ __global__ __launch_bounds__(1024) void hull_obb_kernel(const T *__restrict__ pt
 
     for (int i = tid; i < kHullLdsSlots; i += blockDim.x) lds_slots[i] = 0;
     if (tid == 0) { S.go = 0; S.migrate = 0; S.status = 0; }
+    PtCache pc;
+#pragma unroll
+    for (int j = 0; j < kHullCache; ++j) {
+        const int64_t i = tid + (int64_t)j * blockDim.x;
+        pc.x[j] = i < n ? (double)pts[3 * i] : 0.0;
+        pc.y[j] = i < n ? (double)pts[3 * i + 1] : 0.0;
+        pc.z[j] = i < n ? (double)pts[3 * i + 2] : 0.0;
+    }
 
     // p0 = lexicographically smallest point (an extreme point); ties to the lowest index
     WrapKey k;
@@ -299,7 +335,7 @@ __global__ __launch_bounds__(1024) void hull_obb_kernel(const T *__restrict__ pt
     __syncthreads();
     if (S.status == 0) {                                        // first edge (p0, c1)
         const WrapFrame f = S.f;
-        k = wrap_scan(f, pts, n, S.ia, S.ib);
+        k = wrap_scan(f, pc, pts, n, S.ia, S.ib);
         k = block_best(k, S.best);
         if (tid == 0) {
             c1 = k.i;
@@ -315,7 +351,7 @@ __global__ __launch_bounds__(1024) void hull_obb_kernel(const T *__restrict__ pt
     }
     if (S.status == 0) {                                        // first facet (c1, p0, c2)
         const WrapFrame f = S.f;
-        k = wrap_scan(f, pts, n, S.ia, S.ib);
+        k = wrap_scan(f, pc, pts, n, S.ia, S.ib);
         k = block_best(k, S.best);
         if (tid == 0) {
             const int32_t c2 = k.i;
@@ -365,8 +401,8 @@ __global__ __launch_bounds__(1024) void hull_obb_kernel(const T *__restrict__ pt
         if (!S.go) break;
         const int32_t ia = S.ia, ib = S.ib;
         const WrapFrame f = S.f;
-        k = wrap_scan(f, pts, n, ia, ib);
-        k = block_best(k, S.best);
+        k = wrap_scan(f, pc, pts, n, ia, ib);
+        k = block_best<false>(k, S.best);      // the barrier at the top of the loop already separates the uses of S.best
         if (tid == 0) {
             const int32_t c = k.i;
             if (c < 0) S.status = -2;
@@ -567,7 +603,7 @@ KPX_EXPORT int kpx_obb_batch(const void *pts, int32_t pts_f64, int32_t count, in
     KPX_HIP(hipMemsetAsync(s.slots, 0, (size_t)count * p.glob_cap * 8, st));
     KPX_HIP(hipMemsetAsync(flags, 0, (size_t)count * (size_t)(n > 0 ? n : 1), st));
     const size_t lds = (size_t)kHullLdsSlots * 8 + (size_t)kHullLdsStack * 12;
-    const int threads = (count < 128 && n > 16384) ? 1024 : 256;      // a lone big cloud gets a full-size block
+    const int threads = 1024;      // the LDS tables allow one block per CU anyway
     if (pts_f64) {
         static bool once = false;
         if (!once) { KPX_HIP(hipFuncSetAttribute((const void *)hull_obb_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }

@@ -159,6 +159,27 @@ def main():
     report("execute_global_registration voxel 35, 15 trials x 250k it (registration.py:32-62, host wall time)", (time.perf_counter() - t0) * 1e3,
            n_master=int(len(pcs[0].points)), n_sub=int(len(pcs[1].points)), found=Tg is not None)
 
+    # ---- sampler / normaliser
+    fused = torch.as_tensor(synth.filter_cloud(260_000)).to(dev)
+    ms, _ = timed(lambda: ops.sample_points(fused, 4096, 7))
+    report("select_points_randomly 260k -> 4096 (utils/processing.py:259-275)", ms, nbytes=12 * 4096 + 12 * 4096 + 4 * 4096, n=260_000)
+    rng = np.random.default_rng(0)
+    host = synth.filter_cloud(260_000)
+    for B in (1, 32, 256):
+        xb = torch.as_tensor(np.stack([host[rng.choice(len(host), 4096, replace=False)] for _ in range(B)]).astype(np.float64)).to(dev)
+        ms, (obb, _) = timed(lambda: ops.obb_batch(xb, check=False))
+        v = obb[:, 15].cpu().numpy()
+        report(f"get_oriented_bounding_box, batch of {B} x 4096 points f64 (utils/normalization.py:38-42)", ms, clouds=B,
+               ms_per_cloud=round(ms / B, 4), hull_vertices_mean=float(v.mean()), wraps_mean=float(2 * v.mean() - 4))
+        if B == 256:
+            yb = torch.as_tensor(rng.normal(size=(B, 32, 3))).to(dev)
+            from kinectpy_amd.utils.normalization import OrientedBoundingBox
+            M = OrientedBoundingBox.get_rotation_matrix_from_yxz([0, 0, np.pi / 2])
+            ms, _ = timed(lambda: ops.normalize_batch(xb, obb, ops.NORM_OBB_ROT_TRANS, M))
+            report("obb_rotation_translation_batch apply, 256 x 4096 points f64 (utils/normalization.py:67-97)", ms, nbytes=2 * 24 * B * 4096)
+    ms, (obb, _) = timed(lambda: ops.obb_batch(fused, check=False), reps=3, warm=1)
+    report("get_oriented_bounding_box, one 260k-point cloud f32", ms, hull_vertices=float(obb[0, 15]))
+
     # ---- registration (config 2)
     def sweep(prof):
         """the sweep kernel that ran (culled by default, dense with KPX_NN_ENGINE=dense): avg ms, TFLOP/s issued"""
