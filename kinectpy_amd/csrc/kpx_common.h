@@ -161,18 +161,26 @@ __global__ __launch_bounds__(kCompactThreads) void compact_count_kernel(Pred pre
     if (threadIdx.x == 0) block_counts[(int64_t)frame * gridDim.x + blockIdx.x] = c;
 }
 
-// one block per frame: exclusive scan of the per-tile counts in place, total -> d_count[frame]
-static __global__ __launch_bounds__(256) void compact_scan_kernel(int32_t *block_counts, int32_t nblocks, int32_t *d_count)
+// one block per frame: exclusive scan of the per-tile counts in place, total -> d_count[frame].  A round scans 8 counts
+// per thread (one 3-barrier block scan per 8 x blockDim tiles; a 64M-point selection has 31250 tiles).
+static inline int compact_scan_threads(int64_t tiles) { return tiles > 2048 ? 1024 : 256; }
+static __global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t *block_counts, int32_t nblocks, int32_t *d_count)
 {
-    __shared__ int sh[256 / 64 + 1];
+    __shared__ int sh[1024 / 64 + 1];
     int32_t *bc = block_counts + (int64_t)blockIdx.x * nblocks;
     int carry = 0;
-    for (int32_t b0 = 0; b0 < nblocks; b0 += 256) {
-        int32_t b = b0 + threadIdx.x;
-        int v = b < nblocks ? bc[b] : 0;
+    for (int32_t b0 = 0; b0 < nblocks; b0 += 8 * (int32_t)blockDim.x) {
+        const int32_t b = b0 + 8 * (int32_t)threadIdx.x;
+        int v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = b + k < nblocks ? bc[b + k] : 0; sum += v[k]; }
         int tot;
-        int ex = block_excl_scan(v, sh, &tot);
-        if (b < nblocks) bc[b] = carry + ex;
+        int run = carry + block_excl_scan(sum, sh, &tot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (b + k < nblocks) bc[b + k] = run;
+            run += v[k];
+        }
         carry += tot;
         __syncthreads();
     }
@@ -202,47 +210,72 @@ __global__ __launch_bounds__(kCompactThreads) void compact_scatter_kernel(Pred p
 }
 
 // ---- index compaction over a float32 (n,3) cloud with a predicate on the coordinates ----------------------------
-// Same count -> scan -> scatter, specialised for the selections of the path: a thread loads its 8 points as six 16-byte
-// vectors (96 contiguous bytes) and the kept indices of a block are staged in LDS and written as consecutive dwords.
-template <class PredXYZ>
-__device__ __forceinline__ unsigned pts8_flags(const float *__restrict__ pts, int64_t n, int64_t base, const PredXYZ &pred, bool aligned)
+// The selections of the path (half space, slab split).  ONE pass over the points: a thread loads its 8 points as six
+// 16-byte vectors (96 contiguous bytes), evaluates the predicate -- which may feed two lists at once, bit 0 = list A,
+// bit 1 = list B -- and stores its 8 decisions per list as one byte; the scatter pass reads those bytes (n/8 bytes per
+// list instead of the 12 n of the points), stages the kept indices of a block in LDS and writes them as consecutive
+// dwords.  HBM traffic: 12 n + 4 K + n/4 per list, against 24 n + 4 K when the scatter pass re-evaluates the predicate.
+// The decisions are stored as ballots: bit i of the flag array <-> point i (so the scatter pass's thread t of a block
+// reads byte t = points 8 t .. 8 t + 7 of the tile).  A wave owns 512 points = 6 KiB: six lane-contiguous 16-byte loads
+// (every load instruction of the wave reads one contiguous KiB -- 96-byte strides per lane ran at 60 % of this) into
+// LDS, then lane l evaluates points 64 k + l, k = 0..7, read back with a 3-dword stride (conflict-free).
+// flags_*: tiles * kCompactThreads bytes; counts_*: one int per tile.  TWO = false: list A only.
+template <class PredXYZ, bool TWO>
+__global__ __launch_bounds__(kCompactThreads) void compact_pts_flag_kernel(const float *__restrict__ pts, int64_t n, PredXYZ pred, bool aligned,
+                                                                           uint8_t *__restrict__ flags_a, int32_t *__restrict__ counts_a,
+                                                                           uint8_t *__restrict__ flags_b, int32_t *__restrict__ counts_b)
 {
-    unsigned flags = 0;
-    if (base + kCompactItems <= n && aligned) {
-        union { float4 v[6]; float s[24]; } u;
-        const float4 *p4 = reinterpret_cast<const float4 *>(pts + 3 * base);
+    __shared__ __align__(16) float stage[kCompactThreads / 64][1536];
+    __shared__ int sh[2][kCompactThreads / 64];
+    const int wave = wave_id(), lane = lane_id();
+    const int64_t wbase = (int64_t)blockIdx.x * kCompactTile + (int64_t)wave * 512;
+    const bool full = aligned && wbase + 512 <= n;
+    if (full) {
+        const float4 *src = reinterpret_cast<const float4 *>(pts + 3 * wbase);
+        float4 *dst = reinterpret_cast<float4 *>(stage[wave]);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) u.v[q] = p4[q];
+        for (int r = 0; r < 6; ++r) dst[64 * r + lane] = src[64 * r + lane];
+        wave_lds_fence();
+    }
+    unsigned long long ma = 0, mb = 0;          // lane k < 8 keeps the ballot of row k
+    int ca = 0, cb = 0;
 #pragma unroll
-        for (int k = 0; k < kCompactItems; ++k)
-            if (pred(u.s[3 * k], u.s[3 * k + 1], u.s[3 * k + 2])) flags |= 1u << k;
-    } else {
-        for (int k = 0; k < kCompactItems; ++k) {
-            const int64_t i = base + k;
-            if (i < n && pred(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])) flags |= 1u << k;
+    for (int k = 0; k < 8; ++k) {
+        const int p = 64 * k + lane;
+        unsigned r = 0;
+        if (full) r = pred(stage[wave][3 * p], stage[wave][3 * p + 1], stage[wave][3 * p + 2]);
+        else if (wbase + p < n) r = pred(pts[3 * (wbase + p)], pts[3 * (wbase + p) + 1], pts[3 * (wbase + p) + 2]);
+        const unsigned long long qa = __ballot((r & 1u) != 0);
+        ca += __builtin_popcountll(qa);
+        if (lane == k) ma = qa;
+        if (TWO) {
+            const unsigned long long qb = __ballot((r & 2u) != 0);
+            cb += __builtin_popcountll(qb);
+            if (lane == k) mb = qb;
         }
     }
-    return flags;
+    const int64_t slot = ((int64_t)blockIdx.x * (kCompactThreads / 64) + wave) * 8 + lane;       // in units of 8 bytes
+    if (lane < 8) {
+        reinterpret_cast<unsigned long long *>(flags_a)[slot] = ma;
+        if (TWO) reinterpret_cast<unsigned long long *>(flags_b)[slot] = mb;
+    }
+    if (lane == 0) { sh[0][wave] = ca; sh[1][wave] = cb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ta = 0, tb = 0;
+        for (int w = 0; w < kCompactThreads / 64; ++w) { ta += sh[0][w]; tb += sh[1][w]; }
+        counts_a[blockIdx.x] = ta;
+        if (TWO) counts_b[blockIdx.x] = tb;
+    }
 }
-template <class PredXYZ>
-__global__ __launch_bounds__(kCompactThreads) void compact_pts_count_kernel(const float *__restrict__ pts, int64_t n, PredXYZ pred,
-                                                                            bool aligned, int32_t *__restrict__ block_counts)
-{
-    __shared__ int sh[kCompactThreads / 64];
-    const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
-    int c = base < n ? __builtin_popcount(pts8_flags(pts, n, base, pred, aligned)) : 0;
-    c = block_sum(c, sh);
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
-}
-template <class PredXYZ>
-__global__ __launch_bounds__(kCompactThreads) void compact_pts_scatter_kernel(const float *__restrict__ pts, int64_t n, PredXYZ pred,
-                                                                              bool aligned, const int32_t *__restrict__ block_offsets,
-                                                                              int32_t *__restrict__ idx)
+static __global__ __launch_bounds__(kCompactThreads) void compact_flags_scatter_kernel(const uint8_t *__restrict__ flag_bytes,
+                                                                                       const int32_t *__restrict__ block_offsets,
+                                                                                       int32_t *__restrict__ idx)
 {
     __shared__ int sh[kCompactThreads / 64 + 1];
     __shared__ int32_t si[kCompactTile];
     const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
-    const unsigned flags = base < n ? pts8_flags(pts, n, base, pred, aligned) : 0u;
+    const unsigned flags = flag_bytes[(int64_t)blockIdx.x * kCompactThreads + threadIdx.x];
     int tot;
     int pos = block_excl_scan(__builtin_popcount(flags), sh, &tot);
 #pragma unroll
@@ -261,20 +294,44 @@ int compact(Pred pred, Emit emit, int64_t n, int32_t frames, int32_t *ws_counts,
     const int32_t tiles = (int32_t)compact_tiles(n);
     dim3 grid(tiles, frames);
     hipLaunchKernelGGL(compact_count_kernel<Pred>, grid, dim3(kCompactThreads), 0, st, pred, n, ws_counts);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(256), 0, st, ws_counts, tiles, d_count);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(compact_scan_threads(tiles)), 0, st, ws_counts, tiles, d_count);
     hipLaunchKernelGGL((compact_scatter_kernel<Pred, Emit>), grid, dim3(kCompactThreads), 0, st, pred, emit, n,
                        ws_counts);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
+// Scratch of compact_points: per list one flag byte per thread and one count per tile.
+struct CompactPtsScratch {
+    uint8_t *flags[2];
+    int32_t *counts[2];
+};
+static inline void compact_pts_carve(Arena &a, int64_t n, CompactPtsScratch *s)
+{
+    const size_t tiles = (size_t)compact_tiles(n);
+    for (int l = 0; l < 2; ++l) {
+        s->flags[l] = a.get<uint8_t>(tiles * kCompactThreads);
+        s->counts[l] = a.get<int32_t>(tiles);
+    }
+}
+// idx_b / d_count_b == nullptr: one list (the predicate's bit 0).
 template <class PredXYZ>
-int compact_points(const float *pts, int64_t n, PredXYZ pred, int32_t *idx, int32_t *ws_counts, int32_t *d_count, hipStream_t st)
+int compact_points(const float *pts, int64_t n, PredXYZ pred, int32_t *idx_a, int32_t *d_count_a, int32_t *idx_b, int32_t *d_count_b,
+                   const CompactPtsScratch &s, hipStream_t st)
 {
     const int32_t tiles = (int32_t)compact_tiles(n);
     const bool aligned = ((uintptr_t)pts % 16) == 0;
-    hipLaunchKernelGGL(compact_pts_count_kernel<PredXYZ>, dim3(tiles), dim3(kCompactThreads), 0, st, pts, n, pred, aligned, ws_counts);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, st, ws_counts, tiles, d_count);
-    hipLaunchKernelGGL(compact_pts_scatter_kernel<PredXYZ>, dim3(tiles), dim3(kCompactThreads), 0, st, pts, n, pred, aligned, ws_counts, idx);
+    if (idx_b)
+        hipLaunchKernelGGL((compact_pts_flag_kernel<PredXYZ, true>), dim3(tiles), dim3(kCompactThreads), 0, st, pts, n, pred, aligned, s.flags[0],
+                           s.counts[0], s.flags[1], s.counts[1]);
+    else
+        hipLaunchKernelGGL((compact_pts_flag_kernel<PredXYZ, false>), dim3(tiles), dim3(kCompactThreads), 0, st, pts, n, pred, aligned, s.flags[0],
+                           s.counts[0], s.flags[1], s.counts[1]);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(compact_scan_threads(tiles)), 0, st, s.counts[0], tiles, d_count_a);
+    hipLaunchKernelGGL(compact_flags_scatter_kernel, dim3(tiles), dim3(kCompactThreads), 0, st, s.flags[0], s.counts[0], idx_a);
+    if (idx_b) {
+        hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(compact_scan_threads(tiles)), 0, st, s.counts[1], tiles, d_count_b);
+        hipLaunchKernelGGL(compact_flags_scatter_kernel, dim3(tiles), dim3(kCompactThreads), 0, st, s.flags[1], s.counts[1], idx_b);
+    }
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

@@ -541,7 +541,7 @@ static int px8_compact(const uint16_t *depth, const float *xy, const uint8_t *rg
     const int32_t tiles = (int32_t)compact_tiles(n);
     const dim3 grid(tiles, frames), thr(kCompactThreads);
     hipLaunchKernelGGL(depth_count_vec_kernel, grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(256), 0, st, counts, tiles, d_count);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(compact_scan_threads(tiles)), 0, st, counts, tiles, d_count);
     const bool wc = col && rgb;
 #define KPX_D2C(COL, IDX)                                                                                           \
     hipLaunchKernelGGL((depth_scatter_vec_kernel<COL, IDX>), grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts, pts, col, idx)

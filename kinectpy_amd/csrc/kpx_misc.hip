@@ -236,20 +236,20 @@ struct HalfspacePred {
 };
 struct HalfspaceXYZ {
     double a, b, c, d;
-    __device__ bool operator()(float fx, float fy, float fz) const
+    __device__ unsigned operator()(float fx, float fy, float fz) const
     {
         const double x = fx, y = fy, z = fz;
         const double v = ((a * x + b * y) + c * z) + d;     // floor_removal.py:43, left to right
-        return !(v >= 0.0);
+        return !(v >= 0.0) ? 1u : 0u;
     }
 };
-struct SlabXYZ {
-    const double *bbox; double slab; int lower;
-    __device__ bool operator()(float, float fy, float) const
+struct SlabXYZ {                                             // bit 0: lower list (y >= cut), bit 1: upper list (y < cut)
+    const double *bbox; double slab;
+    __device__ unsigned operator()(float, float fy, float) const
     {
         const double cut = bbox[4] - slab;                  // y.max() - 200 (floor_removal.py:65-66)
         const double y = fy;
-        return lower ? (y >= cut) : (y < cut);
+        return (y >= cut ? 1u : 0u) | (y < cut ? 2u : 0u);
     }
 };
 struct IndexEmit {
@@ -324,6 +324,8 @@ KPX_EXPORT size_t kpx_select_workspace_bytes(int64_t n)
     a.get<uint8_t>((size_t)(n > 0 ? n : 1));
     a.get<int32_t>((size_t)compact_tiles(n));
     a.get<double>((size_t)kBboxBlocks * 6 + 8);
+    CompactPtsScratch cs;
+    compact_pts_carve(a, n, &cs);
     return a.off;
 }
 KPX_EXPORT int kpx_select_by_index(const float *a0, const float *a1, const float *a2, int64_t n, const int32_t *idx,
@@ -356,10 +358,14 @@ KPX_EXPORT int kpx_halfspace_select(const float *pts, int64_t n, const double *h
     Arena a(ws, ws_bytes);
     a.get<uint8_t>((size_t)(n > 0 ? n : 1));
     int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    a.get<double>((size_t)kBboxBlocks * 6 + 8);
+    CompactPtsScratch cs;
+    compact_pts_carve(a, n, &cs);
     KPX_ARENA_CHECK(a);
     if (n == 0) return compact(HalfspacePred{ pts, h_plane[0], h_plane[1], h_plane[2], h_plane[3] }, IndexEmit{ idx }, n, 1, counts, d_count,
                                (hipStream_t)stream);
-    return compact_points(pts, n, HalfspaceXYZ{ h_plane[0], h_plane[1], h_plane[2], h_plane[3] }, idx, counts, d_count, (hipStream_t)stream);
+    return compact_points(pts, n, HalfspaceXYZ{ h_plane[0], h_plane[1], h_plane[2], h_plane[3] }, idx, d_count, nullptr, nullptr, cs,
+                          (hipStream_t)stream);
 }
 
 KPX_EXPORT int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t *lower_idx, int32_t *d_lower,
@@ -369,13 +375,13 @@ KPX_EXPORT int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t 
     hipStream_t st = (hipStream_t)stream;
     Arena a(ws, ws_bytes);
     a.get<uint8_t>((size_t)n);
-    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    a.get<int32_t>((size_t)compact_tiles(n));
     double *part = a.get<double>((size_t)kBboxBlocks * 6 + 8);
+    CompactPtsScratch cs;
+    compact_pts_carve(a, n, &cs);
     KPX_ARENA_CHECK(a);
     double *bbox = part + (size_t)kBboxBlocks * 6;
     int rc = bbox_f32(pts, n, bbox, part, st);
     if (rc) return rc;
-    rc = compact_points(pts, n, SlabXYZ{ bbox, slab, 1 }, lower_idx, counts, d_lower, st);
-    if (rc) return rc;
-    return compact_points(pts, n, SlabXYZ{ bbox, slab, 0 }, upper_idx, counts, d_upper, st);
+    return compact_points(pts, n, SlabXYZ{ bbox, slab }, lower_idx, d_lower, upper_idx, d_upper, cs, st);      // one pass feeds both lists
 }

@@ -86,6 +86,9 @@ def main():
     report("select_by_index gather", ms, n_big // 2 * (12 + 12 + 4), points=n_big // 2)
     ms, hs = timed(lambda: ops.halfspace_select(big, [0.1, -0.9, 0.2, 300.0]))
     report("halfspace_select (a19)", ms, n_big * 12 + int(hs.shape[0]) * 4, points=n_big)
+    ms, (lo_, up_) = timed(lambda: ops.slab_split(big, 200.0))
+    report("slab_split max(y)-200 (a18: bbox pass + one selection pass feeding both lists)", ms, n_big * 12 + n_big * 4, points=n_big,
+           lower=int(lo_.shape[0]))
     del big, idx, out
 
     # ---- filter chain (config 3)
