@@ -92,32 +92,35 @@ __global__ __launch_bounds__(256) void unproject_vec8_kernel(const uint16_t *__r
 // Same arithmetic; the 48 bytes a lane produces go through LDS so that each store instruction of a wave writes one
 // contiguous kilobyte (lane l of round r writes bytes (64 r + l) 16 .. of the wave's 3 KiB) instead of 16-byte pieces
 // 48 bytes apart.  Requires whole waves of groups: the host uses it when n_px is a multiple of 512.
+// blockIdx.y owns `fpb` consecutive frames: the table entries of a lane's 8 pixels are loaded once and reused for all
+// of them (the table is per camera, every frame of a batch uses the same one).
 __global__ __launch_bounds__(256) void unproject_vec8_lds_kernel(const uint16_t *__restrict__ depth, const float *__restrict__ xy,
-                                                                 int64_t n_px, int16_t *__restrict__ xyz)
+                                                                 int64_t n_px, int32_t frames, int32_t fpb, int16_t *__restrict__ xyz)
 {
     __shared__ uint4 stage[4][192];
-    const int frame = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f0 = blockIdx.y * fpb, f1 = min(frames, f0 + fpb);
     const int64_t groups = n_px >> 3;
-    const uint16_t *dp = depth + (int64_t)frame * n_px;
-    int16_t *op = xyz + (int64_t)frame * n_px * 3;
     for (int64_t g0 = ((int64_t)blockIdx.x * 4 + wave) * 64; g0 < groups; g0 += (int64_t)gridDim.x * 256) {
         const int64_t g = g0 + lane;
-        uint4 dv = *reinterpret_cast<const uint4 *>(dp + g * 8);
         const float4 *tp = reinterpret_cast<const float4 *>(xy + g * 16);
-        float4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
-        uint16_t d[8] = { (uint16_t)(dv.x & 0xffff), (uint16_t)(dv.x >> 16), (uint16_t)(dv.y & 0xffff), (uint16_t)(dv.y >> 16),
-                          (uint16_t)(dv.z & 0xffff), (uint16_t)(dv.z >> 16), (uint16_t)(dv.w & 0xffff), (uint16_t)(dv.w >> 16) };
-        float xt[8] = { t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z };
-        float yt[8] = { t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w };
-        union { int16_t s[24]; uint4 v[3]; } o;
+        const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+        const float xt[8] = { t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z };
+        const float yt[8] = { t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w };
+        for (int f = f0; f < f1; ++f) {
+            const uint4 dv = *reinterpret_cast<const uint4 *>(depth + (int64_t)f * n_px + g * 8);
+            const uint16_t d[8] = { (uint16_t)(dv.x & 0xffff), (uint16_t)(dv.x >> 16), (uint16_t)(dv.y & 0xffff), (uint16_t)(dv.y >> 16),
+                                    (uint16_t)(dv.z & 0xffff), (uint16_t)(dv.z >> 16), (uint16_t)(dv.w & 0xffff), (uint16_t)(dv.w >> 16) };
+            union { int16_t s[24]; uint4 v[3]; } o;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) unproject1(d[k], xt[k], yt[k], o.s[3 * k], o.s[3 * k + 1], o.s[3 * k + 2]);
-        stage[wave][3 * lane] = o.v[0]; stage[wave][3 * lane + 1] = o.v[1]; stage[wave][3 * lane + 2] = o.v[2];
-        wave_lds_fence();
-        uint4 *dst = reinterpret_cast<uint4 *>(op + g0 * 24);
+            for (int k = 0; k < 8; ++k) unproject1(d[k], xt[k], yt[k], o.s[3 * k], o.s[3 * k + 1], o.s[3 * k + 2]);
+            stage[wave][3 * lane] = o.v[0]; stage[wave][3 * lane + 1] = o.v[1]; stage[wave][3 * lane + 2] = o.v[2];
+            wave_lds_fence();
+            uint4 *dst = reinterpret_cast<uint4 *>(xyz + ((int64_t)f * n_px) * 3 + g0 * 24);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) dst[64 * r + lane] = stage[wave][64 * r + lane];
-        wave_lds_fence();
+            for (int r = 0; r < 3; ++r) dst[64 * r + lane] = stage[wave][64 * r + lane];
+            wave_lds_fence();
+        }
     }
 }
 
@@ -398,7 +401,8 @@ KPX_EXPORT int kpx_unproject_u16(const uint16_t *depth, const float *xy, int64_t
     if (vec && n_px % 512 == 0) {
         int64_t groups = n_px / 8;
         int bx = (int)(cdiv(groups, 256) > 2048 ? 2048 : cdiv(groups, 256));
-        hipLaunchKernelGGL(unproject_vec8_lds_kernel, dim3(bx, frames), dim3(256), 0, st, depth, xy, n_px, xyz);
+        const int fpb = frames >= 64 ? 8 : (frames >= 16 ? 4 : 1);          // keep >= 8 blocks per CU in flight for small batches
+        hipLaunchKernelGGL(unproject_vec8_lds_kernel, dim3(bx, (unsigned)cdiv(frames, fpb)), dim3(256), 0, st, depth, xy, n_px, frames, fpb, xyz);
     } else if (vec) {
         int64_t groups = n_px / 8;
         int bx = (int)(cdiv(groups, 256) > 2048 ? 2048 : cdiv(groups, 256));
