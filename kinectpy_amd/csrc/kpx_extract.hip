@@ -153,24 +153,39 @@ constexpr int kHistCopies = 16;
 __global__ __launch_bounds__(256) void median_hist_kernel(const int16_t *__restrict__ v, int64_t n, int64_t stride,
                                                           int64_t frame_stride, const MedianSel *__restrict__ sel,
                                                           uint32_t *__restrict__ hist /* [frames][2][256] */, int pass,
-                                                          const float *__restrict__ xy)
+                                                          const float *__restrict__ xy, const uint8_t *__restrict__ nanmask)
 {
     __shared__ uint32_t h[2][256][kHistCopies];
     const int frame = blockIdx.y;
     const int cp = threadIdx.x & (kHistCopies - 1);
-    for (int e = threadIdx.x; e < 2 * 256 * kHistCopies; e += 256) (&h[0][0][0])[e] = 0;
-    __syncthreads();
     const int16_t *p = v + (int64_t)frame * frame_stride;
     int ba = 0, bb = 0;
     if (pass == 1) { ba = sel[frame].bin_a; bb = sel[frame].bin_b; }
+    const int used = (pass == 1 && ba != bb) ? 2 : 1;                 // histograms in use (block-uniform)
+    for (int e = threadIdx.x; e < used * 256 * kHistCopies; e += 256) (&h[0][0][0])[e] = 0;
+    __syncthreads();
+    // Neighbouring pixels mostly fall into the same bin: a thread adds a run of equal bins with ONE atomic.  Pass 1 feeds
+    // the second histogram only when the two middle ranks lie in different top bins (median_select reads the first one
+    // for both otherwise).
+    const bool two = pass == 1 && ba != bb;
+    int run_bin = -1;                     // pass 0: top byte; pass 1: low byte + 256 * (which histogram)
+    uint32_t run_cnt = 0;
+    auto flush = [&]() {
+        if (run_cnt) atomicAdd(&h[run_bin >> 8][run_bin & 255][cp], run_cnt);
+    };
+    auto put = [&](int bin) {
+        if (bin == run_bin) { ++run_cnt; return; }
+        flush();
+        run_bin = bin; run_cnt = 1;
+    };
     auto take = [&](uint32_t raw) {
         const uint32_t key = (raw & 0xFFFFu) ^ 0x8000u;
         if (pass == 0) {
-            atomicAdd(&h[0][key >> 8][cp], 1u);
+            put((int)(key >> 8));
         } else {
             const int top = (int)(key >> 8);
-            if (top == ba) atomicAdd(&h[0][key & 255u][cp], 1u);
-            if (top == bb) atomicAdd(&h[1][key & 255u][cp], 1u);
+            if (top == ba) put((int)(key & 255u));
+            else if (two && top == bb) put(256 + (int)(key & 255u));
         }
     };
     const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)xy % 16 == 0);
@@ -179,14 +194,11 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const int16_t *__restr
         for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
             union { uint4 q; uint16_t s[8]; } d;
             d.q = reinterpret_cast<const uint4 *>(p)[g];
-            if (xy) {
-                union { float4 v4[4]; float f[16]; } t;
-                const float4 *tp = reinterpret_cast<const float4 *>(xy + 16 * g);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) t.v4[q4] = tp[q4];
+            if (xy) {                                       // one byte per 8 pixels instead of their 64 bytes of table
+                const unsigned m = nanmask[g];
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (__builtin_isnan(t.f[2 * k]) || __builtin_isnan(t.f[2 * k + 1])) d.s[k] = 0;
+                    if (m & (1u << k)) d.s[k] = 0;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) take(d.s[k]);
@@ -214,48 +226,89 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const int16_t *__restr
             take(raw);
         }
     }
+    flush();
     __syncthreads();
     uint32_t *g = hist + (int64_t)frame * 512;
     uint32_t s0 = 0, s1 = 0;
 #pragma unroll
-    for (int c = 0; c < kHistCopies; ++c) { s0 += h[0][threadIdx.x][c]; s1 += h[1][threadIdx.x][c]; }
+    for (int c = 0; c < kHistCopies; ++c) s0 += h[0][threadIdx.x][c];
     if (s0) atomicAdd(&g[threadIdx.x], s0);
-    if (pass == 1 && s1) atomicAdd(&g[256 + threadIdx.x], s1);
+    if (used == 2) {
+#pragma unroll
+        for (int c = 0; c < kHistCopies; ++c) s1 += h[1][threadIdx.x][c];
+        if (s1) atomicAdd(&g[256 + threadIdx.x], s1);
+    }
 }
 
-// one block (256 threads) per frame; finds the bin holding a rank by a serial walk (256 bins)
+// bit k of nanmask[g]: a table entry of pixel 8 g + k is NaN (the unprojection stores z = 0 there)
+__global__ __launch_bounds__(256) void xy_nanmask_kernel(const float *__restrict__ xy, int64_t groups, uint8_t *__restrict__ nanmask)
+{
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        union { float4 v4[4]; float f[16]; } t;
+        const float4 *tp = reinterpret_cast<const float4 *>(xy + 16 * g);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) t.v4[q4] = tp[q4];
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (__builtin_isnan(t.f[2 * k]) || __builtin_isnan(t.f[2 * k + 1])) m |= 1u << k;
+        nanmask[g] = (uint8_t)m;
+    }
+}
+
+// one wave per frame: lane l owns bins 4 l .. 4 l + 3; a wave scan of the lane sums locates the lane, which then walks
+// its four bins (a serial walk of the 256 bins by one thread took 23 us of dependent loads per pass)
+__device__ __forceinline__ void rank_to_bin(const uint32_t c[4], int64_t rank, int &bin, int64_t &within, int &owner)
+{
+    const int s = (int)(c[0] + c[1] + c[2] + c[3]);
+    const int64_t incl = wave_incl_scan(s), excl = incl - s;
+    const bool mine = rank >= excl && rank < incl;
+    const unsigned long long m = __ballot(mine);
+    owner = m ? __builtin_ctzll(m) : -1;
+    bin = 255; within = 0;
+    if (mine) {
+        int64_t cum = excl;
+        for (int q = 0; q < 4; ++q) {
+            if (rank < cum + c[q]) { bin = 4 * lane_id() + q; within = rank - cum; break; }
+            cum += c[q];
+        }
+    }
+}
 __global__ __launch_bounds__(64) void median_select_kernel(uint32_t *__restrict__ hist, int64_t n, MedianSel *sel,
                                                            double *d_median, int pass)
 {
-    const int frame = blockIdx.x;
-    if (threadIdx.x != 0) return;
+    const int frame = blockIdx.x, lane = lane_id();
     uint32_t *g = hist + (int64_t)frame * 512;
+    const uint4 v0 = reinterpret_cast<const uint4 *>(g)[lane];
+    const uint32_t c0[4] = { v0.x, v0.y, v0.z, v0.w };
     if (pass == 0) {
-        int64_t ra = (n - 1) / 2, rb = n / 2;
-        MedianSel s;
-        int64_t cum = 0;
-        s.bin_a = s.bin_b = 255; s.rank_a = s.rank_b = 0;
-        bool fa = false, fb = false;
-        for (int b = 0; b < 256; ++b) {
-            int64_t c = g[b];
-            if (!fa && ra < cum + c) { s.bin_a = b; s.rank_a = ra - cum; fa = true; }
-            if (!fb && rb < cum + c) { s.bin_b = b; s.rank_b = rb - cum; fb = true; }
-            cum += c;
-            g[b] = 0;                       // reused by pass 1
-        }
-        sel[frame] = s;
+        int bin_a, bin_b, own_a, own_b;
+        int64_t ra, rb;
+        rank_to_bin(c0, (n - 1) / 2, bin_a, ra, own_a);
+        rank_to_bin(c0, n / 2, bin_b, rb, own_b);
+        reinterpret_cast<uint4 *>(g)[lane] = make_uint4(0, 0, 0, 0);          // reused by pass 1
+        if (own_a < 0 && lane == 0) { sel[frame].bin_a = 255; sel[frame].rank_a = 0; }
+        if (own_b < 0 && lane == 0) { sel[frame].bin_b = 255; sel[frame].rank_b = 0; }
+        if (lane == own_a) { sel[frame].bin_a = bin_a; sel[frame].rank_a = ra; }
+        if (lane == own_b) { sel[frame].bin_b = bin_b; sel[frame].rank_b = rb; }
     } else {
-        MedianSel s = sel[frame];
-        int va = 0, vb = 0;
-        int64_t cum = 0;
-        bool fa = false;
-        for (int b = 0; b < 256; ++b) { int64_t c = g[b]; if (!fa && s.rank_a < cum + c) { va = b; fa = true; } cum += c; }
-        cum = 0;
-        bool fb = false;
-        for (int b = 0; b < 256; ++b) { int64_t c = g[256 + b]; if (!fb && s.rank_b < cum + c) { vb = b; fb = true; } cum += c; }
-        int ka = ((s.bin_a << 8) | va) ^ 0x8000, kb = ((s.bin_b << 8) | vb) ^ 0x8000;
-        double a = (double)(int16_t)(uint16_t)ka, b = (double)(int16_t)(uint16_t)kb;
-        d_median[frame] = 0.5 * (a + b);
+        const MedianSel s = sel[frame];
+        uint32_t c1[4] = { c0[0], c0[1], c0[2], c0[3] };
+        if (s.bin_a != s.bin_b) {
+            const uint4 v1 = reinterpret_cast<const uint4 *>(g + 256)[lane];
+            c1[0] = v1.x; c1[1] = v1.y; c1[2] = v1.z; c1[3] = v1.w;
+        }
+        int va, vb, own_a, own_b;
+        int64_t wa, wb;
+        rank_to_bin(c0, s.rank_a, va, wa, own_a);
+        rank_to_bin(c1, s.rank_b, vb, wb, own_b);
+        va = own_a >= 0 ? __shfl(va, own_a, 64) : 0;
+        vb = own_b >= 0 ? __shfl(vb, own_b, 64) : 0;
+        if (lane == 0) {
+            const int ka = ((s.bin_a << 8) | va) ^ 0x8000, kb = ((s.bin_b << 8) | vb) ^ 0x8000;
+            const double a = (double)(int16_t)(uint16_t)ka, b = (double)(int16_t)(uint16_t)kb;
+            d_median[frame] = 0.5 * (a + b);
+        }
     }
 }
 
@@ -264,14 +317,22 @@ static int median_impl(const int16_t *v, int64_t n, int64_t stride, int64_t fram
 {
     uint32_t *hist = a.get<uint32_t>((size_t)frames * 512);
     MedianSel *sel = a.get<MedianSel>((size_t)frames);
+    // carved for the fused depth path only (its size query runs dry with the frame size; kpx_median_i16 has no table)
+    uint8_t *nanmask = (xy || (a.dry && n > 0)) ? a.get<uint8_t>((size_t)(n / 8 + 1)) : nullptr;
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     KPX_HIP(hipMemsetAsync(hist, 0, (size_t)frames * 512 * sizeof(uint32_t), st));
-    int bx = (int)(cdiv(n, 256 * 16) < 1 ? 1 : (cdiv(n, 256 * 16) > 512 ? 512 : cdiv(n, 256 * 16)));
+    const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)xy % 16 == 0);
+    if (xy && vec)
+        hipLaunchKernelGGL(xy_nanmask_kernel, dim3((unsigned)(cdiv(n / 8, 256) > 1024 ? 1024 : cdiv(n / 8, 256))), dim3(256), 0, st, xy, n / 8, nanmask);
+    // values per thread: a block pays a fixed price for zeroing and folding its LDS histogram, so batches use fewer,
+    // longer blocks; a handful of frames keeps many short ones to fill the chip
+    const int per_thread = frames >= 64 ? 64 : (frames >= 16 ? 32 : 16);
+    int bx = (int)(cdiv(n, 256 * per_thread) < 1 ? 1 : (cdiv(n, 256 * per_thread) > 512 ? 512 : cdiv(n, 256 * per_thread)));
     dim3 grid(bx, frames);
-    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 0, xy);
+    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 0, xy, nanmask);
     hipLaunchKernelGGL(median_select_kernel, dim3(frames), dim3(64), 0, st, hist, n, sel, d_median, 0);
-    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 1, xy);
+    hipLaunchKernelGGL(median_hist_kernel, grid, dim3(256), 0, st, v, n, stride, frame_stride, sel, hist, 1, xy, nanmask);
     hipLaunchKernelGGL(median_select_kernel, dim3(frames), dim3(64), 0, st, hist, n, sel, d_median, 1);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
@@ -506,8 +567,9 @@ __global__ __launch_bounds__(kCompactThreads) void depth_scatter_vec_kernel(cons
                                                                             float *__restrict__ pts, float *__restrict__ col, int32_t *__restrict__ idx)
 {
     __shared__ int sh[kCompactThreads / 64 + 1];
-    __shared__ float sp[kCompactTile * 3];
-    __shared__ float sc[COL ? kCompactTile * 3 : 1];
+    // staged as the integers they are (converted when written): 18 KB instead of 48 KB per block, 8 blocks per CU instead of 3
+    __shared__ int16_t sp[kCompactTile * 3];
+    __shared__ uint8_t sc[COL ? kCompactTile * 3 : 1];
     __shared__ int32_t si[IDX ? kCompactTile : 1];
     const int f = blockIdx.y;
     const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
@@ -519,20 +581,16 @@ __global__ __launch_bounds__(kCompactThreads) void depth_scatter_vec_kernel(cons
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (p.keep & (1u << k)) {
-            sp[3 * pos] = (float)p.x[k]; sp[3 * pos + 1] = (float)p.y[k]; sp[3 * pos + 2] = (float)p.z[k];
-            if (COL) {
-                sc[3 * pos] = (float)((double)p.c[3 * k] / 255.0);
-                sc[3 * pos + 1] = (float)((double)p.c[3 * k + 1] / 255.0);
-                sc[3 * pos + 2] = (float)((double)p.c[3 * k + 2] / 255.0);
-            }
+            sp[3 * pos] = p.x[k]; sp[3 * pos + 1] = p.y[k]; sp[3 * pos + 2] = p.z[k];
+            if (COL) { sc[3 * pos] = p.c[3 * k]; sc[3 * pos + 1] = p.c[3 * k + 1]; sc[3 * pos + 2] = p.c[3 * k + 2]; }
             if (IDX) si[pos] = (int32_t)(base + k);
             ++pos;
         }
     __syncthreads();
     const int64_t o = (int64_t)f * n + block_offsets[(int64_t)f * gridDim.x + blockIdx.x];
     for (int e = threadIdx.x; e < tot * 3; e += kCompactThreads) {
-        pts[o * 3 + e] = sp[e];
-        if (COL) col[o * 3 + e] = sc[e];
+        pts[o * 3 + e] = (float)sp[e];
+        if (COL) col[o * 3 + e] = (float)((double)sc[e] / 255.0);
     }
     if (IDX)
         for (int e = threadIdx.x; e < tot; e += kCompactThreads) idx[o + e] = si[e];
