@@ -42,16 +42,40 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict
                                                          float *__restrict__ opts, float *__restrict__ ocol, float *__restrict__ onrm)
 {
     const int32_t m_total = *d_count;
+    // index overflow is reported through the count word (the host sees KPX_ERR_RANGE when it reads it); a block that reads
+    // the count after this store sees a negative total and does nothing -- the output is invalid in that case anyway
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *err) *d_count = KPX_ERR_RANGE;
     for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < m_total; m += (int64_t)gridDim.x * blockDim.x) {
         int64_t s0 = seg_start[m], s1 = (m + 1 < m_total) ? seg_start[m + 1] : n;
         double sp[3] = { 0, 0, 0 }, sc[3] = { 0, 0, 0 }, sn[3] = { 0, 0, 0 };
-        for (int64_t s = s0; s < s1; ++s) {
-            int64_t p = vals[s];
+        // The sums stay sequential in ascending point index (the contract); only the LOADS of 8 points are issued
+        // together -- a dense voxel (a wall patch close to the camera holds 50+ points) was a chain of 2 dependent
+        // global loads per point, and the longest voxel set the kernel's duration.
+        for (int64_t s = s0; s < s1; s += 8) {
+            const int cnt = (int)(s1 - s < 8 ? s1 - s : 8);
+            int64_t p[8];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                sp[a] += (double)pts[3 * p + a];
-                if (col) sc[a] += (double)col[3 * p + a];
-                if (nrm) sn[a] += (double)nrm[3 * p + a];
+            for (int k = 0; k < 8; ++k) p[k] = k < cnt ? vals[s + k] : -1;
+            float vp[8][3], vc[8][3], vn[8][3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (p[k] < 0) continue;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    vp[k][a] = pts[3 * p[k] + a];
+                    if (col) vc[k][a] = col[3 * p[k] + a];
+                    if (nrm) vn[k][a] = nrm[3 * p[k] + a];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (p[k] < 0) continue;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    sp[a] += (double)vp[k][a];
+                    if (col) sc[a] += (double)vc[k][a];
+                    if (nrm) sn[a] += (double)vn[k][a];
+                }
             }
         }
         double c = (double)(s1 - s0);
@@ -67,12 +91,6 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict
         }
     }
 }
-// index overflow is reported through the count word (host sees KPX_ERR_RANGE when it reads it)
-__global__ void voxel_flag_error_kernel(const int32_t *err, int32_t *d_count)
-{
-    if (*err) *d_count = KPX_ERR_RANGE;
-}
-
 static int voxel_impl(const float *pts, const float *col, const float *nrm, int64_t n, double voxel, float *opts,
                       float *ocol, float *onrm, int32_t *d_count, Arena &a, hipStream_t st)
 {
@@ -99,7 +117,6 @@ static int voxel_impl(const float *pts, const float *col, const float *nrm, int6
     if (rc) return rc;
     hipLaunchKernelGGL(voxel_mean_kernel, dim3(nb), dim3(256), 0, st, pts, col, nrm, n, vals_out, seg_start, d_count, err, opts,
                        ocol, onrm);
-    hipLaunchKernelGGL(voxel_flag_error_kernel, dim3(1), dim3(1), 0, st, err, d_count);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

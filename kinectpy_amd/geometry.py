@@ -197,7 +197,7 @@ class PointCloud:
         if not self.has_points():
             return PointCloud(), np.zeros(0, dtype=np.int32)
         idx, _, _ = ops.sor(self._pts, int(nb_neighbors), float(std_ratio))
-        p, c, n = ops.select_by_index(self._attrs(), idx, False)
+        p, c, n = ops.select_by_index(self._attrs(), idx, False, trusted=True)
         return PointCloud._make(p, c, n), idx.cpu().numpy()
 
     def segment_plane(self, distance_threshold, ransac_n, num_iterations, probability=0.99999999, seed=None):

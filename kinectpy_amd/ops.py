@@ -133,21 +133,23 @@ def joints_affine(x, A, t):
     return out
 
 
-def select_by_index(attrs, idx, invert=False):
-    """attrs: list of up to three (n,3) f32 tensors (None allowed).  Returns list of selected tensors."""
+def select_by_index(attrs, idx, invert=False, trusted=False):
+    """attrs: list of up to three (n,3) f32 tensors (None allowed).  Returns list of selected tensors.
+    trusted=True skips the range check of idx (two reductions and a host sync): for index lists that come straight from
+    another operator of this library (the keep list of sor, the inliers of segment_plane)."""
     lib = L.load()
     attrs = list(attrs) + [None] * (3 - len(attrs))
     ref = next(a for a in attrs if a is not None)
     n = ref.shape[0]
     idx = _dev(idx, torch.int32).reshape(-1)
     k = idx.numel()
-    if k and n:
+    if k and n and not trusted:
         lo, hi = int(idx.min()), int(idx.max())
         if lo < 0 or hi >= n:
             raise L.KinectPxError("select_by_index: index out of range")
     m = n if invert else k
     outs = [torch.empty((m, 3), dtype=torch.float32, device=ref.device) if a is not None else None for a in attrs]
-    cnt = torch.zeros(1, dtype=torch.int32, device=ref.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=ref.device) if invert else None
     ws, wsz = L.workspace(lib.kpx_select_workspace_bytes(n))
     L.check(lib.kpx_select_by_index(L.ptr(attrs[0]), L.ptr(attrs[1]), L.ptr(attrs[2]), n, L.ptr(idx), k, int(invert),
                                     L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(cnt), ws, wsz,

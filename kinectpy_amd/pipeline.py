@@ -68,7 +68,7 @@ class SensorGroupPipeline:
         fused_c = torch.cat([m[1] for m in masked], 0)
         vp, vc, _ = ops.voxel_downsample(fused_p, p.filt_voxel, fused_c)
         keep, _, _ = ops.sor(vp, p.filt_k, p.filt_ratio)
-        out_p, out_c, _ = ops.select_by_index([vp, vc], keep)
+        out_p, out_c, _ = ops.select_by_index([vp, vc], keep, trusted=True)
         self.last = {"icp": stats, "n_down": [int(d.shape[0]) for d in downs], "n_masked": [int(m[0].shape[0]) for m in masked],
                      "n_fused": int(fused_p.shape[0]), "n_out": int(out_p.shape[0])}
         return out_p, out_c, np.stack(Ts)
