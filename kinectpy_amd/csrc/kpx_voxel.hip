@@ -121,6 +121,213 @@ static int voxel_impl(const float *pts, const float *col, const float *nrm, int6
     return KPX_OK;
 }
 
+// ---- several clouds in ONE pass ---------------------------------------------------------------------------------
+// A voxel grid of an 85k-point cloud is ~28 short launches (bounding box, keys, the merge passes of the sort, head
+// compaction, means), and the pipeline down-samples 4 clouds per frame: queued on four lanes the work overlaps on the
+// GPU, but the host cannot issue 112 launches faster than ~0.6 ms.  Here the clouds are handled as one concatenated
+// array: per-cloud bounding boxes, the cloud number as the most significant digit of the key -- mixed radix
+// ((c DX + ix) DY + iy) DZ + iz with DX, DY, DZ the largest grid extents of the batch, so it fits 64 bits whenever the
+// single-cloud key does -- ONE stable sort, ONE head compaction, ONE mean kernel.  Results are identical to the
+// single-cloud path: same voxel indices (own origin per cloud), ascending (ix, iy, iz) per cloud, sums in ascending
+// point index.
+constexpr int kVoxelBatchMax = 8;
+constexpr int kVoxelBatchBboxBlocks = 64;
+struct VoxelBatch {
+    const float *pts[kVoxelBatchMax];
+    const float *col[kVoxelBatchMax];
+    float *opts[kVoxelBatchMax];
+    float *ocol[kVoxelBatchMax];
+    int64_t off[kVoxelBatchMax + 1];      // cloud c owns [off[c], off[c+1]) of the concatenated index space
+    int32_t count;
+};
+__device__ __forceinline__ int voxel_batch_cloud(const VoxelBatch &b, int64_t i)
+{
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < kVoxelBatchMax; ++k) c += (k < b.count && i >= b.off[k]) ? 1 : 0;
+    return c;
+}
+__global__ __launch_bounds__(256) void voxel_batch_bbox_partial_kernel(VoxelBatch b, double *__restrict__ part)
+{
+    __shared__ float sh[6][4];
+    const int c = blockIdx.y;
+    const float *pts = b.pts[c];
+    const int64_t n = b.off[c + 1] - b.off[c];
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { float v = pts[3 * i + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+    if (lane_id() == 0)
+        for (int a = 0; a < 3; ++a) { sh[a][wave_id()] = mn[a]; sh[3 + a][wave_id()] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[threadIdx.x][w]) : fmaxf(v, sh[threadIdx.x][w]);
+        part[((int64_t)c * kVoxelBatchBboxBlocks + blockIdx.x) * 6 + threadIdx.x] = (double)v;
+    }
+}
+// one wave per cloud: folds the partial boxes, bbox[c][0..5]; zeroes the cloud's error word
+__global__ __launch_bounds__(64) void voxel_batch_bbox_final_kernel(const double *__restrict__ part, double *__restrict__ bbox, int32_t *__restrict__ err)
+{
+    const int c = blockIdx.x, lane = lane_id();
+    double v[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a] = part[((int64_t)c * kVoxelBatchBboxBlocks + lane) * 6 + a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { v[a] = wave_min(v[a]); v[3 + a] = wave_max(v[3 + a]); }
+    if (lane == 0) {
+        for (int a = 0; a < 6; ++a) bbox[8 * c + a] = v[a];
+        err[c] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, const double *__restrict__ bbox, double voxel,
+                                                              uint64_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ err)
+{
+    __shared__ double dims[3];
+    __shared__ int overflow;
+    if (threadIdx.x == 0) {          // largest grid extents of the batch: index < floor((max - origin) / v) + 1
+        double d[3] = { 1.0, 1.0, 1.0 };
+        for (int c = 0; c < b.count; ++c) {
+            if (b.off[c + 1] == b.off[c]) continue;
+            for (int a = 0; a < 3; ++a) {
+                const double e = floor((bbox[8 * c + 3 + a] - (bbox[8 * c + a] - voxel * 0.5)) / voxel) + 1.0;
+                if (e > d[a] && e < 2097152.0) d[a] = e;          // out-of-range clouds are flagged per point below
+            }
+        }
+        dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
+        overflow = ((double)b.count * d[0]) * (d[1] * d[2]) >= 18446744073709551616.0 ? 1 : 0;
+    }
+    __syncthreads();
+    const uint64_t DX = (uint64_t)dims[0], DY = (uint64_t)dims[1], DZ = (uint64_t)dims[2];
+    const int64_t total = b.off[b.count];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = voxel_batch_cloud(b, i);
+        const float *pts = b.pts[c];
+        const int64_t j = i - b.off[c];
+        const double ox = bbox[8 * c] - voxel * 0.5, oy = bbox[8 * c + 1] - voxel * 0.5, oz = bbox[8 * c + 2] - voxel * 0.5;
+        double fx = floor(((double)pts[3 * j] - ox) / voxel);
+        double fy = floor(((double)pts[3 * j + 1] - oy) / voxel);
+        double fz = floor(((double)pts[3 * j + 2] - oz) / voxel);
+        const bool bad = overflow || !(fx >= 0.0) || !(fy >= 0.0) || !(fz >= 0.0) || fx >= 2097152.0 || fy >= 2097152.0 || fz >= 2097152.0;
+        if (bad) { err[c] = 1; fx = fy = fz = 0.0; }
+        keys[i] = (((uint64_t)c * DX + (uint64_t)fx) * DY + (uint64_t)fy) * DZ + (uint64_t)fz;
+        vals[i] = (int32_t)i;
+    }
+}
+// head[c] = number of voxels (segment heads) before cloud c in the sorted array; d_counts[c] = voxels of cloud c
+__global__ __launch_bounds__(64) void voxel_batch_locate_kernel(VoxelBatch b, const int32_t *__restrict__ seg_start, const int32_t *__restrict__ d_total,
+                                                                const int32_t *__restrict__ err, int32_t *__restrict__ head, int32_t *__restrict__ d_counts)
+{
+    __shared__ int32_t h[kVoxelBatchMax + 1];
+    const int c = threadIdx.x;
+    const int32_t m = *d_total;
+    if (c <= b.count) {
+        int32_t lo = 0, hi = m;                      // first head position >= off[c]
+        const int64_t want = b.off[c];
+        while (lo < hi) {
+            const int32_t mid = lo + (hi - lo) / 2;
+            if (seg_start[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        h[c] = c == b.count ? m : lo;
+        head[c] = h[c];
+    }
+    __syncthreads();
+    if (c < b.count) d_counts[c] = err[c] ? KPX_ERR_RANGE : h[c + 1] - h[c];
+}
+__global__ __launch_bounds__(256) void voxel_batch_mean_kernel(VoxelBatch b, const int32_t *__restrict__ vals, const int32_t *__restrict__ seg_start,
+                                                               const int32_t *__restrict__ d_total, const int32_t *__restrict__ head)
+{
+    const int32_t m_total = *d_total;
+    const int64_t total = b.off[b.count];
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < m_total; m += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s0 = seg_start[m], s1 = (m + 1 < m_total) ? seg_start[m + 1] : total;
+        const int c = voxel_batch_cloud(b, s0);      // the sorted array keeps the clouds' ranges: position s0 tells the cloud
+        const float *pts = b.pts[c], *col = b.col[c];
+        const int64_t base = b.off[c];
+        double sp[3] = { 0, 0, 0 }, sc[3] = { 0, 0, 0 };
+        for (int64_t s = s0; s < s1; s += 8) {       // loads of 8 points issued together, sums sequential (as voxel_mean_kernel)
+            const int cnt = (int)(s1 - s < 8 ? s1 - s : 8);
+            int64_t p[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = k < cnt ? (int64_t)vals[s + k] - base : -1;
+            float vp[8][3], vc[8][3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (p[k] < 0) continue;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    vp[k][a] = pts[3 * p[k] + a];
+                    if (col) vc[k][a] = col[3 * p[k] + a];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (p[k] < 0) continue;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    sp[a] += (double)vp[k][a];
+                    if (col) sc[a] += (double)vc[k][a];
+                }
+            }
+        }
+        const double cn = (double)(s1 - s0);
+        const int64_t o = m - head[c];
+        float *opts = b.opts[c], *ocol = b.ocol[c];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            opts[3 * o + a] = (float)(sp[a] / cn);
+            if (col && ocol) ocol[3 * o + a] = (float)(sc[a] / cn);
+        }
+    }
+}
+
+struct VoxelBatchScratch {
+    uint64_t *keys_in, *keys_out;
+    int32_t *vals_in, *vals_out, *seg_start, *counts, *err, *head, *d_total;
+    double *part, *bbox;
+    char *sort_tmp;
+    size_t sort_bytes;
+};
+static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
+{
+    const size_t nn = (size_t)(total > 0 ? total : 1);
+    s->keys_in = a.get<uint64_t>(nn); s->keys_out = a.get<uint64_t>(nn);
+    s->vals_in = a.get<int32_t>(nn); s->vals_out = a.get<int32_t>(nn);
+    s->seg_start = a.get<int32_t>(nn);
+    s->counts = a.get<int32_t>((size_t)compact_tiles(total));
+    s->err = a.get<int32_t>(kVoxelBatchMax);
+    s->head = a.get<int32_t>(kVoxelBatchMax + 1);
+    s->d_total = a.get<int32_t>(1);
+    s->part = a.get<double>((size_t)kVoxelBatchMax * kVoxelBatchBboxBlocks * 6);
+    s->bbox = a.get<double>((size_t)kVoxelBatchMax * 8);
+    s->sort_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->sort_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 64,
+                                             (hipStream_t) nullptr);
+    s->sort_tmp = a.get<char>(s->sort_bytes);
+}
+static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts, Arena &a, hipStream_t st)
+{
+    const int64_t total = b.off[b.count];
+    VoxelBatchScratch s;
+    voxel_batch_carve(a, total, &s);
+    KPX_ARENA_CHECK(a);
+    hipLaunchKernelGGL(voxel_batch_bbox_partial_kernel, dim3(kVoxelBatchBboxBlocks, b.count), dim3(256), 0, st, b, s.part);
+    hipLaunchKernelGGL(voxel_batch_bbox_final_kernel, dim3(b.count), dim3(64), 0, st, s.part, s.bbox, s.err);
+    const int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+    hipLaunchKernelGGL(voxel_batch_key_kernel, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err);
+    size_t bytes = s.sort_bytes;
+    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, 64, st));
+    int rc = compact(HeadPred{ s.keys_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(voxel_batch_locate_kernel, dim3(1), dim3(64), 0, st, b, s.seg_start, s.d_total, s.err, s.head, d_counts);
+    hipLaunchKernelGGL(voxel_batch_mean_kernel, dim3(nb), dim3(256), 0, st, b, s.vals_out, s.seg_start, s.d_total, s.head);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
 }  // namespace kpx
 
 using namespace kpx;
@@ -149,8 +356,15 @@ KPX_EXPORT size_t kpx_voxel_batch_workspace_bytes(int32_t count, const int64_t *
 {
     if (count < 1 || !h_n) return 0;
     Arena a(nullptr, 0);
-    for (int i = 0; i < count; ++i) voxel_impl(nullptr, nullptr, nullptr, h_n[i], 1.0, nullptr, nullptr, nullptr, nullptr, a, nullptr);
-    return a.off;
+    int64_t total = 0;
+    for (int i = 0; i < count; ++i) {
+        voxel_impl(nullptr, nullptr, nullptr, h_n[i], 1.0, nullptr, nullptr, nullptr, nullptr, a, nullptr);
+        total += h_n[i] > 0 ? h_n[i] : 0;
+    }
+    Arena one(nullptr, 0);
+    VoxelBatchScratch s;
+    voxel_batch_carve(one, total, &s);
+    return a.off > one.off ? a.off : one.off;
 }
 KPX_EXPORT int kpx_voxel_downsample_batch(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n,
                                           double voxel, float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws,
@@ -162,6 +376,23 @@ KPX_EXPORT int kpx_voxel_downsample_batch(int32_t count, const float *const *h_p
         KPX_REQUIRE(h_n[i] >= 0 && h_n[i] < ((int64_t)1 << 31) && (h_n[i] == 0 || (h_pts[i] && h_opts[i])),
                     "kpx_voxel_downsample_batch: bad cloud %d", i);
     hipStream_t st = (hipStream_t)stream;
+    int64_t total = 0;
+    for (int i = 0; i < count; ++i) total += h_n[i];
+    if (count <= kVoxelBatchMax && total > 0 && total < ((int64_t)1 << 31)) {         // one pass over the concatenated clouds
+        VoxelBatch b;
+        b.count = count;
+        b.off[0] = 0;
+        for (int i = 0; i < kVoxelBatchMax; ++i) {
+            const bool on = i < count;
+            b.pts[i] = on ? h_pts[i] : nullptr;
+            b.col[i] = (on && h_col) ? h_col[i] : nullptr;
+            b.opts[i] = on ? h_opts[i] : nullptr;
+            b.ocol[i] = (on && h_col && h_ocol) ? h_ocol[i] : nullptr;
+            b.off[i + 1] = b.off[i] + (on ? h_n[i] : 0);
+        }
+        Arena one(ws, ws_bytes);
+        return voxel_batch_impl(b, voxel, d_counts, one, st);
+    }
     LaneSet *ln = nullptr;
     int rc = lanes_get(&ln);
     if (rc) return rc;

@@ -230,6 +230,19 @@ def test_voxel_batch_equals_single_calls(ops, oracle, base_cloud):
         assert np.array_equal(npy(gp), rp) and np.array_equal(npy(gc), rc)
     nocol = ops.voxel_downsample_batch(clouds[:2], 10.0)
     assert nocol[0][1] is None and np.array_equal(npy(nocol[0][0]), oracle.voxel_downsample(clouds[0], 10.0)[0])
+    # up to 8 clouds go through ONE concatenated pass (cloud number = top digit of the key), more through the lanes
+    for k in (1, 2, 4, 8, 9):
+        sub = [clouds[i % len(clouds)] + np.float32(13.0 * i) for i in range(k)]
+        for (gp, _), c in zip(ops.voxel_downsample_batch(sub, 20.0), sub):
+            if len(c):
+                assert np.array_equal(npy(gp), oracle.voxel_downsample(c, 20.0)[0]), k
+            else:
+                assert gp.shape[0] == 0
+    # a cloud whose grid would overflow fails alone, with the same error as a single call
+    from kinectpy_amd._lib import KinectPxError
+    far = np.array([[0, 0, 0], [1e7, 0, 0]], np.float32)
+    with pytest.raises(KinectPxError, match="too small"):
+        ops.voxel_downsample_batch([clouds[0], far], 1.0)
 
 
 def test_voxel_edge_cases(ops, oracle):
