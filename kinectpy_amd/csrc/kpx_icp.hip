@@ -21,6 +21,7 @@
 // splits (lexicographic (value, column)), computes the direct squared distance (AC3) of the chosen pair
 // and accumulates the sums the update needs.  The ICP loop runs on the device; a small kernel solves the
 // 3x3 (Kabsch) or 6x6 (point-to-plane) system, updates T and raises `done`.
+#include <chrono>
 #include <limits.h>
 #include <stddef.h>
 #include <time.h>
@@ -667,11 +668,20 @@ __global__ __launch_bounds__(kSolveThreads) void icp_solve_kernel(const double *
     icp_finish(acc, n, mode, k, max_iter, rel_fit, rel_rmse, st, result);
 }
 
-__global__ void icp_init_kernel(IcpState *st, const double *__restrict__ T0)
+struct Mat16 {
+    double m[16];
+};
+__global__ void icp_init_kernel(IcpState *st, Mat16 T0)
 {
     if (threadIdx.x || blockIdx.x) return;
-    for (int q = 0; q < 16; ++q) st->T[q] = T0[q];
+    for (int q = 0; q < 16; ++q) st->T[q] = T0.m[q];
     st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0;
+}
+static Mat16 mat16_from(const double *h)
+{
+    Mat16 m;
+    for (int q = 0; q < 16; ++q) m.m[q] = h[q];
+    return m;
 }
 
 // ---- explicit-pair Kabsch (compute_transformation with a correspondence list) ------------------------------
@@ -728,8 +738,11 @@ __device__ __forceinline__ double fixed_total(const unsigned long long *acc, int
     return fixed_value(lo, hi);
 }
 // sums -> update step; clears the accumulators for the next iteration (single block: no race)
+// progress: optional word in pinned host memory, tag | done << 32 | iterations finished -- the batch driver reads it to keep
+// a window of iterations queued per problem without copies or events (system-scope release store by one thread)
 __global__ __launch_bounds__(256) void icp_solve_fixed_kernel(unsigned long long *acc, int64_t n, int mode, int k, int max_iter, double rel_fit,
-                                                              double rel_rmse, IcpState *st, double *__restrict__ result)
+                                                              double rel_rmse, IcpState *st, double *__restrict__ result,
+                                                              unsigned long long *progress, unsigned long long tag)
 {
     if (st->done) return;
     __shared__ double sums[kAcc];
@@ -739,6 +752,9 @@ __global__ __launch_bounds__(256) void icp_solve_fixed_kernel(unsigned long long
     for (int e = threadIdx.x; e < kAccCopies * kAcc * 2; e += 256) acc[e] = 0ull;
     if (threadIdx.x) return;
     icp_finish(sums, n, mode, k, max_iter, rel_fit, rel_rmse, st, result);
+    if (progress)
+        __hip_atomic_store(progress, tag | ((unsigned long long)(st->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace kpx
@@ -1049,7 +1065,8 @@ static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b,
 }
 // one ICP iteration (search k + update) of the culled engine: two launches
 static void icp_iter_launch(const float *src, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b, double max_d2, int mode,
-                            int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st)
+                            int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st,
+                            unsigned long long *progress = nullptr, unsigned long long tag = 0)
 {
     {
         ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
@@ -1059,7 +1076,7 @@ static void icp_iter_launch(const float *src, const float *tgt, const float *tn,
                            b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr);
     }
     hipLaunchKernelGGL(icp_solve_fixed_kernel, dim3(1), dim3(256), 0, st, b.acc_fixed, p.n_src, mode, k, max_iter, rel_fit, rel_rmse, b.state,
-                       d_result);
+                       d_result, progress, tag);
 }
 static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st)
 {
@@ -1233,8 +1250,7 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
     NnBuffers b;
     nn_carve(a, n_src, n_tgt, p, &b);
     KPX_ARENA_CHECK(a);
-    KPX_HIP(hipMemcpyAsync(b.T0, h_init, 16 * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, b.state, b.T0);
+    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, b.state, mat16_from(h_init));
     int rc = nn_prep(tgt, p, b, st);
     if (rc) return rc;
     rc = nn_prep_source(src, p, b, st);
@@ -1341,8 +1357,10 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     int rc = nn_prep(tgt, tplan, bufs[0], st);
     if (rc) return rc;
     hipEvent_t ev[64][2];
-    for (int i = 0; i < count; ++i)
-        for (int e = 0; e < 2; ++e) KPX_HIP(hipEventCreateWithFlags(&ev[i][e], hipEventDisableTiming));
+    const bool use_events = !local_engine();               // the all-pairs engine polls copies of the state through events
+    if (use_events)
+        for (int i = 0; i < count; ++i)
+            for (int e = 0; e < 2; ++e) KPX_HIP(hipEventCreateWithFlags(&ev[i][e], hipEventDisableTiming));
     const double md2 = max_dist * max_dist;
     ScreenPolicy policy[64];
     // A chunk = `chunk` iterations of one problem followed by a copy of its state to a pinned slot and an event.  The
@@ -1374,10 +1392,50 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     };
     const int used_lanes = count < kBatchLanes ? count : kBatchLanes;
     rc = lanes_fork(ln, st, used_lanes);
+    if (local_engine()) {
+        // Culled engine: every update kernel publishes "iterations finished | converged" in a pinned word of its problem.
+        // The driver keeps a window of iterations queued per problem and tops it up as the words advance: no copies, no
+        // events, and at most `window` launches wasted after a problem converges (they return at once on its flag).
+        static thread_local unsigned long long *h_progress = nullptr;
+        static thread_local unsigned long long generation = 0;
+        if (!h_progress) KPX_HIP(hipHostMalloc((void **)&h_progress, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+        generation = (generation + 1) & 0xFFFFFFull;
+        const unsigned long long tag = generation << 40;
+        constexpr int window = 6;
+        bool fin[64];
+        for (int i = 0; i < count && !rc; ++i) {
+            hipStream_t ls = lanes[i % kBatchLanes];
+            __atomic_store_n(&h_progress[i], 0ull, __ATOMIC_RELAXED);
+            hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, ls, bufs[i].state, mat16_from(h_init + 16 * i));
+            rc = nn_prep_source(h_src[i], plans[i], bufs[i], ls);
+            next_k[i] = 0;
+            fin[i] = false;
+        }
+        const auto t_start = std::chrono::steady_clock::now();
+        for (bool pending = true; pending && !rc;) {
+            pending = false;
+            for (int i = 0; i < count; ++i) {
+                if (fin[i]) continue;
+                const unsigned long long w = __atomic_load_n(&h_progress[i], __ATOMIC_ACQUIRE);
+                const bool mine = (w >> 40) == generation;
+                const int seen = mine ? (int)(w & 0xFFFFFFFFull) : 0;
+                if (mine && ((w >> 32) & 1ull)) { fin[i] = true; continue; }               // converged
+                hipStream_t ls = lanes[i % kBatchLanes];
+                while (next_k[i] <= max_iteration && next_k[i] - seen < window) {
+                    icp_iter_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], md2, mode, next_k[i], max_iteration, relative_fitness,
+                                    relative_rmse, d_results + 20 * i, ls, &h_progress[i], tag);
+                    ++next_k[i];
+                }
+                if (next_k[i] > max_iteration) { fin[i] = true; continue; }                // everything is queued
+                pending = true;
+            }
+            if (pending && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) rc = fail(KPX_ERR_HIP, "kpx_icp_batch: no progress");
+        }
+        if (hipGetLastError() != hipSuccess && !rc) rc = fail(KPX_ERR_HIP, "kpx_icp_batch: launch failed");
+    } else {
     for (int i = 0; i < count && !rc; ++i) {
         hipStream_t ls = lanes[i % kBatchLanes];
-        KPX_HIP(hipMemcpyAsync(bufs[i].T0, h_init + 16 * i, 16 * sizeof(double), hipMemcpyHostToDevice, ls));
-        hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, ls, bufs[i].state, bufs[i].T0);
+        hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, ls, bufs[i].state, mat16_from(h_init + 16 * i));
         rc = nn_prep_source(h_src[i], plans[i], bufs[i], ls);
         next_k[i] = 0; enq[i] = 0; polled[i] = 0;
         for (int c = 0; c < in_flight && !rc && next_k[i] <= max_iteration; ++c) rc = enqueue_chunk(i);
@@ -1396,13 +1454,15 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
             rc = enqueue_chunk(i);
         }
     }
+    }
     {
         const int jrc = lanes_join(ln, st, used_lanes);
         rc = rc ? rc : jrc;
     }
     if (rc) for (int l = 0; l < used_lanes; ++l) (void)hipStreamSynchronize(lanes[l]);     // leave nothing in flight on an error
-    for (int i = 0; i < count; ++i)
-        for (int e = 0; e < 2; ++e) (void)hipEventDestroy(ev[i][e]);
+    if (use_events)
+        for (int i = 0; i < count; ++i)
+            for (int e = 0; e < 2; ++e) (void)hipEventDestroy(ev[i][e]);
     if (rc) return rc;
     KPX_LAUNCH_CHECK();
     return KPX_OK;
