@@ -1053,11 +1053,12 @@ static __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__
     const int64_t i = row_of[r];
     out[3 * r] = src[3 * i]; out[3 * r + 1] = src[3 * i + 1]; out[3 * r + 2] = src[3 * i + 2];
 }
-static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b, hipStream_t st)
+// ordered: b.row_of already holds the Morton order (morton_order_batch)
+static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b, hipStream_t st, bool ordered = false)
 {
     if (!local_engine()) return KPX_OK;
     KPX_HIP(hipMemsetAsync(b.acc_fixed, 0, (size_t)kAccCopies * kAcc * 2 * sizeof(unsigned long long), st));
-    int rc = morton_order(src, p.n_src, b.sort_s, b.row_of, st);
+    int rc = ordered ? KPX_OK : morton_order(src, p.n_src, b.sort_s, b.row_of, st);
     if (rc) return rc;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(p.n_src, 256)), dim3(256), 0, st, src, p.n_src, b.row_of, b.src_sorted);
     KPX_LAUNCH_CHECK();
@@ -1078,10 +1079,11 @@ static void icp_iter_launch(const float *src, const float *tgt, const float *tn,
     hipLaunchKernelGGL(icp_solve_fixed_kernel, dim3(1), dim3(256), 0, st, b.acc_fixed, p.n_src, mode, k, max_iter, rel_fit, rel_rmse, b.state,
                        d_result, progress, tag);
 }
-static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st)
+// ordered: b.orig_t / b.sort_t.bbox already hold the target's Morton order and bounding box (morton_order_batch)
+static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st, bool ordered = false)
 {
     if (local_engine()) {
-        int rc = morton_order(tgt, p.n_tgt, b.sort_t, b.orig_t, st);
+        int rc = ordered ? KPX_OK : morton_order(tgt, p.n_tgt, b.sort_t, b.orig_t, st);
         if (rc) return rc;
         hipLaunchKernelGGL(nn_local_prep_kernel, dim3((unsigned)p.l_groups), dim3(256), 0, st, tgt, p.n_tgt, b.Bs, b.orig_t, b.tile_box,
                            b.group_box);
@@ -1309,7 +1311,12 @@ KPX_EXPORT size_t kpx_icp_batch_workspace_bytes(int32_t count, const int64_t *h_
         if (q.f_tiles_pad > tplan.f_tiles_pad) tplan.f_tiles_pad = q.f_tiles_pad;
     }
     nn_carve_target(a, tplan, &b);
-    for (int i = 0; i < count; ++i) nn_carve_source(a, h_n_src[i], nn_plan(h_n_src[i], n_tgt), &b);
+    int64_t total = n_tgt;
+    for (int i = 0; i < count; ++i) { nn_carve_source(a, h_n_src[i], nn_plan(h_n_src[i], n_tgt), &b); total += h_n_src[i]; }
+    if (count + 1 <= kMortonBatchMax && total < ((int64_t)1 << 31)) {
+        MortonBatchScratch ms;
+        morton_batch_carve(a, total, &ms);
+    }
     return a.off;
 }
 KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt,
@@ -1353,8 +1360,30 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         bufs[i].sort_t = bufs[0].sort_t;
         nn_carve_source(a, h_n_src[i], plans[i], &bufs[i]);
     }
+    int64_t total_pts = n_tgt;
+    for (int i = 0; i < count; ++i) total_pts += h_n_src[i];
+    const bool can_batch_sort = count + 1 <= kMortonBatchMax && total_pts < ((int64_t)1 << 31);
+    MortonBatchScratch ms;
+    if (can_batch_sort) morton_batch_carve(a, total_pts, &ms);
     KPX_ARENA_CHECK(a);
-    int rc = nn_prep(tgt, tplan, bufs[0], st);
+    // the shared target and every source are ordered along their Morton curves by ONE sort (cloud number above the code)
+    const bool ordered = can_batch_sort && local_engine();
+    int rc = KPX_OK;
+    if (ordered) {
+        MortonBatch mb;
+        mb.count = count + 1;
+        mb.off[0] = 0;
+        for (int c = 0; c < kMortonBatchMax; ++c) {
+            const bool on = c < mb.count;
+            mb.pts[c] = !on ? nullptr : (c == 0 ? tgt : h_src[c - 1]);
+            mb.perm[c] = !on ? nullptr : (c == 0 ? bufs[0].orig_t : bufs[c - 1].row_of);
+            mb.bbox[c] = !on ? nullptr : (c == 0 ? bufs[0].sort_t.bbox : bufs[c - 1].sort_s.bbox);
+            mb.off[c + 1] = mb.off[c] + (!on ? 0 : (c == 0 ? n_tgt : h_n_src[c - 1]));
+        }
+        rc = morton_order_batch(mb, ms, st);
+        if (rc) return rc;
+    }
+    rc = nn_prep(tgt, tplan, bufs[0], st, ordered);
     if (rc) return rc;
     hipEvent_t ev[64][2];
     const bool use_events = !local_engine();               // the all-pairs engine polls copies of the state through events
@@ -1407,7 +1436,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
             hipStream_t ls = lanes[i % kBatchLanes];
             __atomic_store_n(&h_progress[i], 0ull, __ATOMIC_RELAXED);
             hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, ls, bufs[i].state, mat16_from(h_init + 16 * i));
-            rc = nn_prep_source(h_src[i], plans[i], bufs[i], ls);
+            rc = nn_prep_source(h_src[i], plans[i], bufs[i], ls, ordered);
             next_k[i] = 0;
             fin[i] = false;
         }

@@ -101,4 +101,121 @@ static int morton_order(const float *pts, int64_t n, const SortScratch &s, int32
     return KPX_OK;
 }
 
+// ---- Morton order of several clouds with ONE sort -----------------------------------------------------------------
+// A registration batch orders its shared target and every source: four sorts of 20-30k keys are ~60 short launches,
+// and the host's launch rate, not the GPU, bounds such chains.  Here the clouds are concatenated, the cloud number sits
+// above the 30 Morton bits of the key, and one stable sort orders them all (the ordering inside each cloud is the one
+// morton_order produces).
+constexpr int kMortonBatchMax = 8;
+constexpr int kMortonBatchBboxBlocks = 32;
+struct MortonBatch {
+    const float *pts[kMortonBatchMax];
+    int32_t *perm[kMortonBatchMax];       // out: perm[c][r] = original index of the r-th point of cloud c along its curve
+    double *bbox[kMortonBatchMax];        // out: (min x,y,z, max x,y,z) of cloud c
+    int64_t off[kMortonBatchMax + 1];
+    int32_t count;
+};
+struct MortonBatchScratch {
+    uint64_t *keys_in, *keys_out;
+    int32_t *vals_in, *vals_out;
+    double *part;
+    void *tmp;
+    size_t tmp_bytes;
+};
+static void morton_batch_carve(Arena &a, int64_t total, MortonBatchScratch *s)
+{
+    const size_t nn = (size_t)(total > 0 ? total : 1);
+    s->keys_in = a.get<uint64_t>(nn);
+    s->keys_out = a.get<uint64_t>(nn);
+    s->vals_in = a.get<int32_t>(nn);
+    s->vals_out = a.get<int32_t>(nn);
+    s->part = a.get<double>((size_t)kMortonBatchMax * kMortonBatchBboxBlocks * 6);
+    s->tmp_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->tmp_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 34,
+                                             (hipStream_t) nullptr);
+    s->tmp = a.get<char>(s->tmp_bytes);
+}
+__device__ __forceinline__ int morton_batch_cloud(const MortonBatch &b, int64_t i)
+{
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < kMortonBatchMax; ++k) c += (k < b.count && i >= b.off[k]) ? 1 : 0;
+    return c;
+}
+static __global__ __launch_bounds__(256) void morton_batch_bbox_partial_kernel(MortonBatch b, double *__restrict__ part)
+{
+    __shared__ float sh[6][4];
+    const int c = blockIdx.y;
+    const float *pts = b.pts[c];
+    const int64_t n = b.off[c + 1] - b.off[c];
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { float v = pts[3 * i + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_all_min((double)mn[a]); mx[a] = wave_all_max((double)mx[a]); }
+    if (lane_id() == 0)
+        for (int a = 0; a < 3; ++a) { sh[a][wave_id()] = mn[a]; sh[3 + a][wave_id()] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[threadIdx.x][w]) : fmaxf(v, sh[threadIdx.x][w]);
+        part[((int64_t)c * kMortonBatchBboxBlocks + blockIdx.x) * 6 + threadIdx.x] = (double)v;
+    }
+}
+static __global__ __launch_bounds__(64) void morton_batch_bbox_final_kernel(MortonBatch b, const double *__restrict__ part)
+{
+    const int c = blockIdx.x, lane = lane_id();
+    double v[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+        v[a] = lane < kMortonBatchBboxBlocks ? part[((int64_t)c * kMortonBatchBboxBlocks + lane) * 6 + a] : (a < 3 ? (double)INFINITY : -(double)INFINITY);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { v[a] = wave_all_min(v[a]); v[3 + a] = wave_all_max(v[3 + a]); }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+        if (lane == a) b.bbox[c][a] = v[a];
+}
+static __global__ __launch_bounds__(256) void morton_batch_key_kernel(MortonBatch b, uint64_t *__restrict__ keys, int32_t *__restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.off[b.count]) return;
+    const int c = morton_batch_cloud(b, i);
+    const float *pts = b.pts[c];
+    const double *bbox = b.bbox[c];
+    const int64_t j = i - b.off[c];
+    const double ext = fmax(bbox[3] - bbox[0], fmax(bbox[4] - bbox[1], bbox[5] - bbox[2]));
+    const double scale = ext > 0.0 ? 1023.0 / ext : 0.0;
+    uint32_t q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double v = ((double)pts[3 * j + a] - bbox[a]) * scale;
+        q[a] = v >= 0.0 ? (uint32_t)(v < 1023.0 ? v : 1023.0) : 0u;          // NaN -> cell 0
+    }
+    const uint32_t m = morton_spread10(q[0]) | (morton_spread10(q[1]) << 1) | (morton_spread10(q[2]) << 2);
+    keys[i] = ((uint64_t)c << 30) | m;
+    vals[i] = (int32_t)i;
+}
+static __global__ __launch_bounds__(256) void morton_batch_split_kernel(MortonBatch b, const int32_t *__restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.off[b.count]) return;
+    const int c = morton_batch_cloud(b, i);          // sorted position i lies in cloud c's range
+    b.perm[c][i - b.off[c]] = vals[i] - (int32_t)b.off[c];
+}
+static int morton_order_batch(const MortonBatch &b, const MortonBatchScratch &s, hipStream_t st)
+{
+    const int64_t total = b.off[b.count];
+    hipLaunchKernelGGL(morton_batch_bbox_partial_kernel, dim3(kMortonBatchBboxBlocks, b.count), dim3(256), 0, st, b, s.part);
+    hipLaunchKernelGGL(morton_batch_bbox_final_kernel, dim3(b.count), dim3(64), 0, st, b, s.part);
+    const unsigned nb = (unsigned)cdiv(total, 256);
+    hipLaunchKernelGGL(morton_batch_key_kernel, dim3(nb), dim3(256), 0, st, b, s.keys_in, s.vals_in);
+    size_t bytes = s.tmp_bytes;
+    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, 34, st));
+    hipLaunchKernelGGL(morton_batch_split_kernel, dim3(nb), dim3(256), 0, st, b, s.vals_out);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
 }  // namespace kpx
