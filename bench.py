@@ -127,11 +127,12 @@ def main():
     ap.add_argument("--frames", type=int, default=2, help="distinct synthetic time frames cycled through")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--check", action="store_true", help="compare one GPU step against the oracle step")
+    ap.add_argument("--overlap", type=int, default=2, help="frames in flight per GPU (pipeline.FrameStream); 1 = one after the other")
     args = ap.parse_args()
 
     import torch
     from kinectpy_amd import ops, parallel
-    from kinectpy_amd.pipeline import PipelineParams, SensorGroupPipeline
+    from kinectpy_amd.pipeline import FrameStream, PipelineParams, SensorGroupPipeline
 
     rank, world, local = parallel.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -143,22 +144,38 @@ def main():
     rgb = torch.as_tensor(rgb_h).to(dev)
     pipe = SensorGroupPipeline(xy, inits, P, cloud_capacity=spg * 48 * 1024)
 
-    def step(k):
-        f = k % F
-        out_p, out_c, Ts = pipe.step(depth[f], rgb[f])
-        if world > 1:
+    def fuse(out):
+        out_p, out_c, Ts = out
+        if world > 1:                # the exchange stays on this thread, in frame order (one collective per frame)
             out_p, out_c, _, _ = pipe.exchange(out_p, out_c, Ts, to_global)
         return out_p, out_c, Ts
 
-    for k in range(args.warmup):
-        step(k)
+    def step(k):
+        f = k % F
+        return fuse(pipe.step(depth[f], rgb[f]))
+
+    frames = FrameStream(pipe, args.overlap) if args.overlap > 1 else None
+
+    def run_steps(first, count):
+        """`count` steps, all finished on return; with --overlap > 1 up to that many frames are in flight"""
+        if frames is None:
+            for k in range(first, first + count):
+                step(k)
+            return
+        for k in range(first, first + count):
+            if frames.full():
+                fuse(frames.pop())
+            frames.submit(depth[k % F], rgb[k % F])
+        while frames.pending:
+            fuse(frames.pop())
+
+    run_steps(0, args.warmup)
     parallel.barrier()
     torch.cuda.synchronize()
     ops.prof_stride(PROF_STRIDE)    # an event pair around EVERY launch of the 16 us iteration kernel costs ~10 % end to end
     ops.prof_begin(1 << 16)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
+    run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
@@ -166,6 +183,8 @@ def main():
     dt = parallel.allreduce_max(dt, dev)
 
     if rank != 0:
+        if frames is not None:
+            frames.close()
         return
     ms_step = dt / args.steps * 1e3
     value = world * spg * N_PX * args.steps / dt / 1e6
@@ -231,9 +250,11 @@ def main():
                                "step: extract -> pairwise point-to-plane ICP onto the group master -> fuse -> voxel+SOR",
                    "sensors_per_gpu": spg, "pixels_per_step_per_gpu": spg * N_PX, "icp": f"{P.icp_mode}, voxel {P.reg_voxel}, "
                    f"max_dist {P.icp_max_dist}, <= {P.icp_max_iteration} it", "filter": f"voxel {P.filt_voxel} + SOR({P.filt_k}, {P.filt_ratio})",
-                   "last_step": pipe.last},
+                   "frames_in_flight": args.overlap, "last_step": pipe.last},
         "roofline": roof, "cpu_baseline": cpu, "kernels": other,
     }
+    if frames is not None:
+        frames.close()
     print(json.dumps(line))
 
 

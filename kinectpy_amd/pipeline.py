@@ -7,6 +7,8 @@
 
 and, across GPUs, the exchange of parallel.py.  Everything on the device goes through kinectpy_amd.ops.
 """
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -82,3 +84,44 @@ class SensorGroupPipeline:
         gp = ops.transform(out_p, to_global) if not np.allclose(to_global, np.eye(4)) else out_p
         comp = torch.as_tensor(np.stack([to_global @ T for T in Ts]))
         return self._xchg(gp, out_c, comp)
+
+
+class FrameStream:
+    """Several frames of a stream in flight.  A frame is a chain of short, mostly latency-bound kernels (the ICP loop alone
+    is ~75 dependent launches that keep a fraction of the CUs busy), and consecutive frames are independent, so `depth`
+    of them run side by side: each on its own host thread (the library calls release the GIL; its lanes, workspaces and
+    progress words are per thread) and its own HIP stream.  Results come back in submission order."""
+
+    def __init__(self, pipe: SensorGroupPipeline, depth: int = 2):
+        self.pipe, self.depth = pipe, max(1, int(depth))
+        self.device = torch.cuda.current_device()
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self.pool = ThreadPoolExecutor(max_workers=self.depth)
+        self.pending = deque()
+        self.submitted = 0
+
+    def _run(self, stream, depth, rgb):
+        torch.cuda.set_device(self.device)
+        with torch.cuda.stream(stream):
+            out = self.pipe.step(depth, rgb)
+            stream.synchronize()                 # the outputs are consumed on the caller's stream
+        return out
+
+    def full(self) -> bool:
+        return len(self.pending) >= self.depth
+
+    def submit(self, depth: torch.Tensor, rgb: torch.Tensor):
+        """queue one frame (call pop() first when full())"""
+        assert not self.full()
+        stream = self.streams[self.submitted % self.depth]
+        self.submitted += 1
+        self.pending.append(self.pool.submit(self._run, stream, depth, rgb))
+
+    def pop(self):
+        """-> (points, colours, transforms) of the oldest frame in flight"""
+        return self.pending.popleft().result()
+
+    def close(self):
+        while self.pending:
+            self.pop()
+        self.pool.shutdown()

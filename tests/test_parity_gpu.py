@@ -982,3 +982,27 @@ def test_processing_mirrors(oracle, base_cloud, tmp_path):
     assert np.allclose(np.asarray(sc.points), base_cloud[:50000] * 0.001, rtol=1e-6)
     P.save_points_npz(str(tmp_path / "1.npz"), pcd, 4096, seed=1)
     assert np.load(str(tmp_path / "1.npz"))["points"][:4096].shape == (4096, 3)
+
+
+def test_frame_stream_equals_serial_steps():
+    """pipeline.FrameStream (two frames in flight, each on its own host thread and stream) returns, in order, exactly what
+    one step after the other returns"""
+    import bench
+    from kinectpy_amd.pipeline import FrameStream, PipelineParams, SensorGroupPipeline
+    xy, depth_h, rgb_h, inits, truth, _ = bench.make_group(0, 1, 4, 3)
+    depth = torch.as_tensor(depth_h).cuda()
+    rgb = torch.as_tensor(rgb_h).cuda()
+    pipe = SensorGroupPipeline(xy, inits, PipelineParams())
+    serial = [pipe.step(depth[f % 3], rgb[f % 3]) for f in range(7)]
+    fs = FrameStream(pipe, 2)
+    got = []
+    for f in range(7):
+        if fs.full():
+            got.append(fs.pop())
+        fs.submit(depth[f % 3], rgb[f % 3])
+    while fs.pending:
+        got.append(fs.pop())
+    fs.close()
+    assert len(got) == 7
+    for (p0, c0, T0), (p1, c1, T1) in zip(serial, got):
+        assert torch.equal(p0, p1) and torch.equal(c0, c1) and np.array_equal(T0, T1)
