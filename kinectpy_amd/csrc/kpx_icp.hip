@@ -622,8 +622,10 @@ __device__ void icp_finish(const double *acc, int64_t n, int mode, int k, int ma
         for (int c = 0; c < 16; ++c) st->T[c] = Tn[c];
     }
     if (done) st->done = 1;
-    for (int c = 0; c < 16; ++c) result[c] = st->T[c];
-    result[16] = fit; result[17] = rmse; result[18] = (double)k; result[19] = cnt;
+    if (result) {
+        for (int c = 0; c < 16; ++c) result[c] = st->T[c];
+        result[16] = fit; result[17] = rmse; result[18] = (double)k; result[19] = cnt;
+    }
 }
 
 // 1024 threads: thread (slot q = t & 63, slice = t >> 6) sums its slice of the per-block partials with eight
@@ -674,8 +676,10 @@ struct Mat16 {
 __global__ void icp_init_kernel(IcpState *st, Mat16 T0)
 {
     if (threadIdx.x || blockIdx.x) return;
-    for (int q = 0; q < 16; ++q) st->T[q] = T0.m[q];
-    st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0;
+    for (int slot = 0; slot < 2; ++slot) {               // both slots (see IcpFuse)
+        for (int q = 0; q < 16; ++q) st[slot].T[q] = T0.m[q];
+        st[slot].fitness = 0.0; st[slot].rmse = 0.0; st[slot].count = 0.0; st[slot].iter = 0; st[slot].done = 0;
+    }
 }
 static Mat16 mat16_from(const double *h)
 {
@@ -776,6 +780,21 @@ namespace kpx {
 // the boundary + the 1024-thread solve kernel.)
 constexpr int kIWaves = 4;
 constexpr int kIRows = kIWaves * kLRows;
+// One launch per iteration (used by kpx_icp_batch, whose chains are bound by the host's launch rate once several
+// registrations and two frames run side by side): launch k first performs the update of iteration k-1 -- every block
+// folds the accumulator set of the previous launch and runs the (deterministic) algebra itself, block 0 publishes the
+// state, the result and the progress word -- then sweeps with the new transform.  Three accumulator sets in a ring
+// (launch k reads set k-1, adds to set k, block 0 clears set k+1) and two state slots (launch k reads slot k-1, writes
+// slot k) keep the launches free of races.  pair == nullptr: two-kernel mode, icp_solve_fixed_kernel does the update.
+struct IcpFuse {
+    IcpState *pair;
+    unsigned long long *ring;
+    int max_iter;
+    double rel_fit, rel_rmse;
+    double *result;
+    unsigned long long *progress, tag;
+};
+constexpr int kAccSet = kAccCopies * kAcc * 2;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
@@ -784,9 +803,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                        const float *__restrict__ src_sorted, int32_t *__restrict__ idx_sorted,
                                                        int32_t *__restrict__ idx_cur, double *__restrict__ d2_cur, double max_d2, int mode,
                                                        int k, const IcpState *__restrict__ st, unsigned long long *acc,
-                                                       unsigned long long *__restrict__ tile_visits)
+                                                       unsigned long long *__restrict__ tile_visits, IcpFuse fuse)
 {
-    if (st->done) return;
+    __shared__ IcpState s_state;
+    __shared__ double s_sums[kAcc];
+    const double *Tk = st->T;
+    if (fuse.pair) {
+        const IcpState *in = fuse.pair + ((k + 1) & 1);
+        IcpState *out = fuse.pair + (k & 1);
+        if (in->done) {                                   // converged earlier: hand the state on, nothing else to do
+            if (blockIdx.x == 0 && threadIdx.x == 0) *out = *in;
+            return;
+        }
+        const unsigned long long *prev = fuse.ring + (int64_t)((k + 2) % 3) * kAccSet;
+        if (k > 0 && threadIdx.x < kAcc) s_sums[threadIdx.x] = (int)threadIdx.x < (mode == 1 ? kAcc : 17) ? fixed_total(prev, threadIdx.x) : 0.0;
+        if (threadIdx.x == 0) s_state = *in;
+        __syncthreads();
+        if (k > 0 && threadIdx.x == 0)
+            icp_finish(s_sums, n, mode, k - 1, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, &s_state, blockIdx.x == 0 ? fuse.result : (double *)nullptr);
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            unsigned long long *next = fuse.ring + (int64_t)((k + 1) % 3) * kAccSet;
+            for (int e = threadIdx.x; e < kAccSet; e += 256) next[e] = 0ull;
+            if (threadIdx.x == 0) {
+                *out = s_state;
+                if (k > 0 && fuse.progress)
+                    __hip_atomic_store(fuse.progress, fuse.tag | ((unsigned long long)(s_state.done ? 1 : 0) << 32) | (unsigned long long)(unsigned)k,
+                                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        if (s_state.done) return;
+        Tk = s_state.T;
+        acc = fuse.ring + (int64_t)(k % 3) * kAccSet;
+    } else if (st->done) return;
     __shared__ int32_t lists[kIWaves][kLList];
     __shared__ double rowd[kIWaves][16][5];          // s_x, s_y, s_z, K, bound / result value
     __shared__ int32_t rowi[kIWaves][16][2];         // partner (bound / result), original row
@@ -802,7 +851,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int64_t r = row_base + lane < last ? row_base + lane : last;
         const int64_t i = row_of[r];
         double s[3];
-        xform_row(st->T, src_sorted + 3 * r, s);
+        xform_row(Tk, src_sorted + 3 * r, s);
         const double seed = row_seed(s);
         double bv = INFINITY;
         int32_t bj = INT_MAX;
@@ -1018,7 +1067,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->init_idx = a.get<int32_t>(nn);
     b->idx_cur = a.get<int32_t>(nn);
     b->d2_cur = a.get<double>(nn);
-    b->state = a.get<IcpState>(1);
+    b->state = a.get<IcpState>(2);                     // two slots: the one-launch-per-iteration mode alternates between them
     b->T0 = a.get<double>(16);
     b->A64 = a.get<double>(nn * 4);
     b->K64 = a.get<double>(nn);
@@ -1030,7 +1079,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->row_of = a.get<int32_t>(nn);
     b->idx_sorted = a.get<int32_t>(nn);
     b->src_sorted = a.get<float>(nn * 3);
-    b->acc_fixed = a.get<unsigned long long>((size_t)kAccCopies * kAcc * 2);
+    b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * 2);      // ring of three sets (icp_iter_kernel, IcpFuse)
     sort_carve(a, n, &b->sort_s);
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
@@ -1057,7 +1106,7 @@ static __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__
 static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b, hipStream_t st, bool ordered = false)
 {
     if (!local_engine()) return KPX_OK;
-    KPX_HIP(hipMemsetAsync(b.acc_fixed, 0, (size_t)kAccCopies * kAcc * 2 * sizeof(unsigned long long), st));
+    KPX_HIP(hipMemsetAsync(b.acc_fixed, 0, (size_t)3 * kAccCopies * kAcc * 2 * sizeof(unsigned long long), st));
     int rc = ordered ? KPX_OK : morton_order(src, p.n_src, b.sort_s, b.row_of, st);
     if (rc) return rc;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(p.n_src, 256)), dim3(256), 0, st, src, p.n_src, b.row_of, b.src_sorted);
@@ -1074,10 +1123,23 @@ static void icp_iter_launch(const float *src, const float *tgt, const float *tn,
         hipLaunchKernelGGL(icp_iter_kernel, dim3((unsigned)cdiv(p.n_src, kIRows)), dim3(256), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t,
                            b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.idx_cur, b.d2_cur,
                            max_d2, mode, k, b.state,
-                           b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr);
+                           b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, IcpFuse{});
     }
     hipLaunchKernelGGL(icp_solve_fixed_kernel, dim3(1), dim3(256), 0, st, b.acc_fixed, p.n_src, mode, k, max_iter, rel_fit, rel_rmse, b.state,
                        d_result, progress, tag);
+}
+// one ICP iteration in ONE launch (IcpFuse): launch k = update of iteration k-1 + search k; k = max_iter + 1 is the closing
+// launch (update only: one block)
+static void icp_fused_launch(const float *src, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b, double max_d2, int mode,
+                             int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st,
+                             unsigned long long *progress, unsigned long long tag)
+{
+    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag };
+    const unsigned blocks = k > max_iter ? 1u : (unsigned)cdiv(p.n_src, kIRows);
+    ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
+    hipLaunchKernelGGL(icp_iter_kernel, dim3(blocks), dim3(256), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t, b.tile_box, b.group_box,
+                       p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.idx_cur, b.d2_cur, max_d2, mode, k, b.state,
+                       b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, fuse);
 }
 // ordered: b.orig_t / b.sort_t.bbox already hold the target's Morton order and bounding box (morton_order_batch)
 static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStream_t st, bool ordered = false)
@@ -1431,6 +1493,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         generation = (generation + 1) & 0xFFFFFFull;
         const unsigned long long tag = generation << 40;
         constexpr int window = 6;
+        static const bool fused = [] { const char *e = getenv("KPX_ICP_FUSE"); return !(e && e[0] == '0'); }();   // A/B switch: 0 = update in its own kernel
         bool fin[64];
         for (int i = 0; i < count && !rc; ++i) {
             hipStream_t ls = lanes[i % kBatchLanes];
@@ -1450,12 +1513,17 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                 const int seen = mine ? (int)(w & 0xFFFFFFFFull) : 0;
                 if (mine && ((w >> 32) & 1ull)) { fin[i] = true; continue; }               // converged
                 hipStream_t ls = lanes[i % kBatchLanes];
-                while (next_k[i] <= max_iteration && next_k[i] - seen < window) {
-                    icp_iter_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], md2, mode, next_k[i], max_iteration, relative_fitness,
-                                    relative_rmse, d_results + 20 * i, ls, &h_progress[i], tag);
+                const int last_k = fused ? max_iteration + 1 : max_iteration;               // the fused chain ends with an update-only launch
+                while (next_k[i] <= last_k && next_k[i] - seen < window) {
+                    if (fused)
+                        icp_fused_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], md2, mode, next_k[i], max_iteration, relative_fitness,
+                                         relative_rmse, d_results + 20 * i, ls, &h_progress[i], tag);
+                    else
+                        icp_iter_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], md2, mode, next_k[i], max_iteration, relative_fitness,
+                                        relative_rmse, d_results + 20 * i, ls, &h_progress[i], tag);
                     ++next_k[i];
                 }
-                if (next_k[i] > max_iteration) { fin[i] = true; continue; }                // everything is queued
+                if (next_k[i] > last_k) { fin[i] = true; continue; }                        // everything is queued
                 pending = true;
             }
             if (pending && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) rc = fail(KPX_ERR_HIP, "kpx_icp_batch: no progress");
