@@ -770,9 +770,11 @@ namespace kpx {
 // with last iteration's partner (clamped to the correspondence distance); the wave sweeps (sweep_wave); lanes 0..15
 // then form the chosen pair's direct distance (AC3) and the row's contribution to the update sums, which are added
 // in a fixed order per block and added to the exact fixed-point accumulators; icp_solve_fixed_kernel performs the
-// update step.  (Running the update redundantly in the prologue of the next launch -- one launch per iteration, a
-// ring of four accumulator sets -- was built and measured: the serial 6x6 / eigen algebra in front of every block's
-// sweep costs ~8 us against 5.7 us + 1.9 us for the solve kernel and its boundary; 100k x 100k got 20 % slower.)
+// update step (kpx_icp).  Running the update redundantly in the prologue of the next launch (IcpFuse below) puts the serial
+// 6x6 / eigen algebra (~5-8 us) in front of every block's sweep against 5.7 us + 1.9 us for the solve kernel and its
+// boundary: for one large registration (100k x 100k: five rounds of blocks per launch) it was 20 % slower, so kpx_icp
+// keeps two kernels per iteration; kpx_icp_batch, whose small problems fit one round of blocks and whose chains are
+// bound by the host's launch rate, uses the one-launch form.
 // ("Last block finishes the job" inside this launch was measured twice and lost both times: with plain stores +
 // __threadfence() the release writes back / invalidates the XCD's L2 once per block (10x slower); with write-through
 // device-scope stores, a drained vmcnt and a relaxed ticket it still adds ~13 us at 485 blocks -- the same-address
