@@ -14,7 +14,7 @@
 namespace kpx {
 
 // ---- grid construction ------------------------------------------------------------------------------
-__global__ void grid_params_kernel(const double *__restrict__ bbox, int64_t n, double target, GridParams *gp)
+__global__ void grid_params_kernel(const double *__restrict__ bbox, int64_t n, double target, int32_t cell_cap, GridParams *gp)
 {
     if (threadIdx.x || blockIdx.x) return;
     double ext[3], vol = 1.0;
@@ -33,7 +33,7 @@ __global__ void grid_params_kernel(const double *__restrict__ bbox, int64_t n, d
             if (d > 1000000.0) d = 1000000.0;
             dim[a] = (int)d; tot *= d;
         }
-        if (tot <= (double)kGridMaxCells) break;
+        if (tot <= (double)cell_cap) break;
         h *= 1.26;
     }
     gp->h = h;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void grid_occupancy_kernel(const uint32_t *__r
     if (threadIdx.x == 0 && c) atomicAdd(sumsq, c);
 }
 __global__ void grid_refine_kernel(const double *__restrict__ bbox, int64_t n, double target, const unsigned long long *__restrict__ sumsq,
-                                   GridParams *gp)
+                                   int32_t cell_cap, GridParams *gp)
 {
     if (threadIdx.x || blockIdx.x) return;
     const double occ = (double)*sumsq / (double)(n > 0 ? n : 1);
@@ -75,7 +75,7 @@ __global__ void grid_refine_kernel(const double *__restrict__ bbox, int64_t n, d
             if (d > 1000000.0) d = 1000000.0;
             dim[a] = (int)d; tot *= d;
         }
-        if (tot <= (double)kGridMaxCells) break;
+        if (tot <= (double)cell_cap) break;
         h *= 1.26;
     }
     gp->h = h;
@@ -128,20 +128,25 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     double *bbox = part + (size_t)kBboxBlocks * 6;
     int rc = bbox_f32(pts, n, bbox, part, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(1), 0, st, bbox, n, target_per_cell, g->params);
-    KPX_HIP(hipMemsetAsync(count, 0, ((size_t)kGridMaxCells + 1) * sizeof(uint32_t), st));
+    // The counters and the scan cover every cell the grid may have.  Small clouds get a smaller ceiling than the 4M the
+    // workspace holds (16 cells per point, at least 64k): clearing and scanning 16 MB twice per build cost ~50 us, more than
+    // the neighbour search of a 30k-point cloud; a grid that would need more cells just gets coarser (results do not depend on h).
+    int32_t cell_cap = 65536;
+    while (cell_cap < kGridMaxCells && (int64_t)cell_cap < 16 * n) cell_cap <<= 1;
+    hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(1), 0, st, bbox, n, target_per_cell, cell_cap, g->params);
+    KPX_HIP(hipMemsetAsync(count, 0, ((size_t)cell_cap + 1) * sizeof(uint32_t), st));
     int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
     hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->params, keys_in, vals_in, count);
     {   // one round of occupancy feedback, then the definitive binning
         unsigned long long *sumsq = reinterpret_cast<unsigned long long *>(part);   // scratch word (bbox partials are consumed)
         KPX_HIP(hipMemsetAsync(sumsq, 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(grid_occupancy_kernel, dim3(1024), dim3(256), 0, st, count, g->params, sumsq);
-        hipLaunchKernelGGL(grid_refine_kernel, dim3(1), dim3(1), 0, st, bbox, n, target_per_cell, sumsq, g->params);
-        KPX_HIP(hipMemsetAsync(count, 0, ((size_t)kGridMaxCells + 1) * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(grid_refine_kernel, dim3(1), dim3(1), 0, st, bbox, n, target_per_cell, sumsq, cell_cap, g->params);
+        KPX_HIP(hipMemsetAsync(count, 0, ((size_t)cell_cap + 1) * sizeof(uint32_t), st));
         hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->params, keys_in, vals_in, count);
     }
     KPX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, (int)n, 0, 22, st));
-    KPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, count, g->cell_start, kGridMaxCells + 1, st));
+    KPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, count, g->cell_start, cell_cap + 1, st));
     hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->sorted_idx, g->sorted_pts);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
