@@ -267,6 +267,13 @@ int kpx_obb_batch(const void *pts, int32_t pts_f64, int32_t count, int64_t n, do
 int kpx_normalize_batch(const double *x, int32_t count, int64_t rows, const double *d_obb, int32_t mode, const double *h_M,
                         double *out, void *stream);
 
+/* fuse_skeletons_gradient (utils/skeleton_fusion.py:21-74), SURVEY 8f rank 4: gradient- and centroid-weighted average of the
+ * joints seen by three cameras.  skeletons f64 [cams][frames][joints][3] on the device; the first initial_frame (reference: 20)
+ * frames are the mean over ALL cameras, later frames weight the FIRST THREE cameras (as the reference does) with
+ * w_c = 1 / (|p_c - fused[f-1]|^alpha |p_c - centroid|^beta).  out f64 [frames][joints][3]. */
+int kpx_fuse_skeletons(const double *skeletons, int32_t cams, int64_t frames, int32_t joints, double alpha, double beta,
+                       int32_t initial_frame, double *out, void *stream);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it
  * (capacity = max launches recorded); every launch of a tagged kernel is bracketed by an event pair;

@@ -103,6 +103,46 @@ __global__ __launch_bounds__(256) void joints_affine_kernel(const double *__rest
     }
 }
 
+
+// ---- skeleton fusion (utils/skeleton_fusion.py:21-74) ---------------------------------------------------------------
+// fused[f][j] = sum_c w_c p_c / sum_c w_c over the first three cameras, w_c = 1 / (|p_c - fused[f-1][j]|^alpha |p_c - centroid|^beta);
+// the first `initial` frames are the plain mean over all cameras.  A recurrence in f: one thread per joint walks the
+// frames (tiny data; the reference loops the same way).
+__global__ __launch_bounds__(64) void fuse_skeletons_kernel(const double *__restrict__ sk, int32_t cams, int64_t frames, int32_t joints,
+                                                            double alpha, double beta, int32_t initial, double *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= joints) return;
+    const int64_t cam_stride = frames * joints * 3;
+    const int64_t first = initial < frames ? initial : frames;
+    for (int64_t f = 0; f < first; ++f) {
+        for (int a = 0; a < 3; ++a) {
+            double sum = 0.0;
+            for (int c = 0; c < cams; ++c) sum += sk[c * cam_stride + (f * joints + j) * 3 + a];
+            out[(f * joints + j) * 3 + a] = sum / (double)cams;
+        }
+    }
+    for (int64_t f = first; f < frames; ++f) {
+        double last[3], p[3][3], cen[3];
+        for (int a = 0; a < 3; ++a) last[a] = out[((f - 1) * joints + j) * 3 + a];
+        for (int c = 0; c < 3; ++c)
+            for (int a = 0; a < 3; ++a) p[c][a] = sk[c * cam_stride + (f * joints + j) * 3 + a];
+        for (int a = 0; a < 3; ++a) cen[a] = ((p[0][a] + p[1][a]) + p[2][a]) / 3.0;
+        double w[3];
+        for (int c = 0; c < 3; ++c) {
+            double g2 = 0.0, d2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double dg = p[c][a] - last[a], dc = p[c][a] - cen[a];
+                g2 += dg * dg;
+                d2 += dc * dc;
+            }
+            w[c] = 1.0 / (pow(sqrt(g2), alpha) * pow(sqrt(d2), beta));
+        }
+        const double ws = (w[0] + w[1]) + w[2];
+        for (int a = 0; a < 3; ++a) out[(f * joints + j) * 3 + a] = ((w[0] * p[0][a] + w[1] * p[1][a]) + w[2] * p[2][a]) / ws;
+    }
+}
+
 // ---- bounding box --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restrict__ pts, int64_t n, double *__restrict__ part)
 {
@@ -314,6 +354,18 @@ KPX_EXPORT int kpx_joints_affine_f64(const double *x, int64_t rows, const double
     for (int k = 0; k < 9; ++k) A.m[k] = h_A[k];
     for (int k = 0; k < 3; ++k) A.m[9 + k] = h_t[k];
     hipLaunchKernelGGL(joints_affine_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, A, out);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+KPX_EXPORT int kpx_fuse_skeletons(const double *skeletons, int32_t cams, int64_t frames, int32_t joints, double alpha, double beta,
+                                  int32_t initial_frame, double *out, void *stream)
+{
+    KPX_REQUIRE(cams >= 3 && frames >= 0 && joints >= 0 && initial_frame >= 1, "kpx_fuse_skeletons: needs >= 3 cameras, initial_frame >= 1");
+    if (frames == 0 || joints == 0) return KPX_OK;
+    KPX_REQUIRE(skeletons && out, "kpx_fuse_skeletons: null pointer");
+    hipLaunchKernelGGL(fuse_skeletons_kernel, dim3((unsigned)cdiv(joints, 64)), dim3(64), 0, (hipStream_t)stream, skeletons, cams, frames, joints,
+                       alpha, beta, initial_frame, out);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

@@ -489,3 +489,15 @@ def normalize_batch(x, obb, mode, M=None):
     L.check(lib.kpx_normalize_batch(L.ptr(x), count, rows, L.ptr(obb), int(mode), None if Mh is None else L.hptr(Mh), L.ptr(out),
                                     L.stream_ptr()))
     return out
+
+
+def fuse_skeletons(skeletons, alpha=1.4, beta=1.4, initial_frame=20):
+    """utils/skeleton_fusion.py:21-74.  skeletons (cams, frames, joints, 3) -> fused (frames, joints, 3) f64 on the device"""
+    lib = L.load()
+    sk = _dev(skeletons, torch.float64)
+    if sk.dim() != 4 or sk.shape[3] != 3:
+        raise ValueError("skeletons must have shape (cameras, frames, joints, 3)")
+    cams, frames, joints = int(sk.shape[0]), int(sk.shape[1]), int(sk.shape[2])
+    out = torch.empty((frames, joints, 3), dtype=torch.float64, device=sk.device)
+    L.check(lib.kpx_fuse_skeletons(L.ptr(sk), cams, frames, joints, float(alpha), float(beta), int(initial_frame), L.ptr(out), L.stream_ptr()))
+    return out

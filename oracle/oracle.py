@@ -577,3 +577,19 @@ def normalize_pointcloud(arr, min_range=-1.0, max_range=1.0):
     arr = np.asarray(arr, dtype=np.float64)
     s = (max_range - min_range) / (np.max(arr) - np.min(arr))
     return arr * s - np.min(arr) * s + min_range
+
+
+def fuse_skeletons_gradient(skeletons, alpha=1.4, beta=1.4, initial_frame=20):
+    """utils/skeleton_fusion.py:21-74 (pinned by tests/golden/ref_skeleton_fusion.json)"""
+    sk = np.asarray(skeletons, dtype=np.float64)
+    C_, F, J, _ = sk.shape
+    out = np.zeros((F, J, 3))
+    out[:initial_frame] = np.mean(sk[:, :initial_frame], axis=0)
+    for f in range(initial_frame, F):
+        for j in range(J):
+            last = out[f - 1, j]
+            p = [sk[c, f, j] for c in range(3)]
+            cen = (p[0] + p[1] + p[2]) / 3
+            w = [1.0 / ((np.linalg.norm(q - last) ** alpha) * (np.linalg.norm(q - cen) ** beta)) for q in p]
+            out[f, j] = (w[0] * p[0] + w[1] * p[1] + w[2] * p[2]) / (w[0] + w[1] + w[2])
+    return out

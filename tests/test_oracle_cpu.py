@@ -233,3 +233,11 @@ def test_normalisation_restatements(oracle):
     a = rng.normal(size=(50, 3))
     n = oracle.normalize_pointcloud(a)
     assert abs(n.min() + 1) < 1e-12 and abs(n.max() - 1) < 1e-12
+
+
+def test_skeleton_fusion_kat(oracle):
+    """fuse_skeletons_gradient against the reference's own outputs (tests/golden/make_ref_skeleton_kat.py)"""
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_skeleton_fusion.json")))
+    for c in kat["fuse_skeletons_gradient"]:
+        got = oracle.fuse_skeletons_gradient(np.array(c["skeletons"]), c["alpha"], c["beta"])
+        assert np.allclose(got, np.array(c["fused"]), rtol=1e-13, atol=1e-10)

@@ -1006,3 +1006,20 @@ def test_frame_stream_equals_serial_steps():
     assert len(got) == 7
     for (p0, c0, T0), (p1, c1, T1) in zip(serial, got):
         assert torch.equal(p0, p1) and torch.equal(c0, c1) and np.array_equal(T0, T1)
+
+
+def test_skeleton_fusion_matches_reference_outputs(ops, oracle):
+    """kpx_fuse_skeletons against the reference's own results (golden vectors) and the oracle on a longer sequence"""
+    from kinectpy_amd.utils.skeleton_fusion import fuse_skeletons_gradient
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_skeleton_fusion.json")))
+    for c in kat["fuse_skeletons_gradient"]:
+        got = fuse_skeletons_gradient(np.array(c["skeletons"]), c["alpha"], c["beta"])
+        assert got.dtype == np.float64 and np.allclose(got, np.array(c["fused"]), rtol=1e-10, atol=1e-8)
+    rng = np.random.default_rng(3)
+    truth = np.cumsum(rng.normal(scale=4.0, size=(400, 32, 3)), axis=0)
+    sk = np.stack([truth + rng.normal(scale=s, size=truth.shape) for s in (2.0, 6.0, 12.0, 50.0)])      # a fourth camera is ignored after frame 20
+    got = ops.fuse_skeletons(sk, 1.4, 1.4).cpu().numpy()
+    assert np.allclose(got, oracle.fuse_skeletons_gradient(sk, 1.4, 1.4), rtol=1e-9, atol=1e-7)
+    from kinectpy_amd._lib import KinectPxError
+    with pytest.raises(KinectPxError):
+        ops.fuse_skeletons(sk[:2], 1.4, 1.4)
