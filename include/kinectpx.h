@@ -267,6 +267,23 @@ int kpx_obb_batch(const void *pts, int32_t pts_f64, int32_t count, int64_t n, do
 int kpx_normalize_batch(const double *x, int32_t count, int64_t rows, const double *d_obb, int32_t mode, const double *h_M,
                         double *out, void *stream);
 
+/* a15: coloured ICP (execute_colored_ICP_registration, preprocessing/registration.py:89-114), SURVEY 8f rank 4.
+ * kpx_color_gradient = [O3D] InitializePointCloudForColoredICP: per target point the least-squares gradient of the
+ * intensity (r + g + b) / 3 in its tangent plane over the hybrid neighbourhood (radius, max_nn; Open3D passes
+ * 2 x max_correspondence_distance and 30); grad f64 [n][3] on the device.
+ * kpx_colored_icp = [O3D] registration_colored_icp: the registration_icp loop (correspondences, fitness, inlier rmse,
+ * convergence as kpx_icp) with TransformationEstimationForColoredICP(lambda_geometric, Open3D default 0.968) as the
+ * update: per pair a geometric row sqrt(lambda) ((s - t).n) and a photometric row sqrt(1 - lambda) (I_s - I_t - g.(s' - t)).
+ * colours f32 [n][3]; d_result as kpx_icp. */
+size_t kpx_color_gradient_workspace_bytes(int64_t n, int32_t max_nn);
+int kpx_color_gradient(const float *pts, const float *normals, const float *colors, int64_t n, double radius, int32_t max_nn,
+                       double *grad, void *ws, size_t ws_bytes, void *stream);
+size_t kpx_colored_icp_workspace_bytes(int64_t n_src, int64_t n_tgt);
+int kpx_colored_icp(const float *src, const float *src_colors, int64_t n_src, const float *tgt, const float *tgt_colors,
+                    const float *tgt_normals, const double *tgt_gradient, int64_t n_tgt, double max_dist, const double *h_init,
+                    double lambda_geometric, int32_t max_iteration, double relative_fitness, double relative_rmse,
+                    int32_t poll_interval, double *d_result, void *ws, size_t ws_bytes, void *stream);
+
 /* fuse_skeletons_gradient (utils/skeleton_fusion.py:21-74), SURVEY 8f rank 4: gradient- and centroid-weighted average of the
  * joints seen by three cameras.  skeletons f64 [cams][frames][joints][3] on the device; the first initial_frame (reference: 20)
  * frames are the mean over ALL cameras, later frames weight the FIRST THREE cameras (as the reference does) with

@@ -60,6 +60,10 @@ SIGNATURES = {
     "kpx_obb_workspace_bytes": (_sz, [_i32, _i64]),
     "kpx_obb_batch": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "kpx_normalize_batch": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "kpx_color_gradient_workspace_bytes": (_sz, [_i64, _i32]),
+    "kpx_color_gradient": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
+    "kpx_colored_icp_workspace_bytes": (_sz, [_i64, _i64]),
+    "kpx_colored_icp": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _f64, _i32, _f64, _f64, _i32, _vp, _vp, _sz, _vp]),
     "kpx_fuse_skeletons": (C.c_int, [_vp, _i32, _i64, _i32, _f64, _f64, _i32, _vp, _vp]),
     "kpx_nn_engine": (C.c_int, [_i32]),
     "kpx_icp_batch_workspace_bytes": (_sz, [_i32, _vp, _i64]),

@@ -528,6 +528,60 @@ static int fpfh_impl(const float *pts, const float *nrm, int64_t n, double radiu
     return KPX_OK;
 }
 
+
+// ---- colour gradient of the target of a coloured ICP ([O3D] InitializePointCloudForColoredICP) ----------------------------
+// Per point: least squares over its hybrid neighbourhood (the list's first entry, the point itself, is skipped) of
+// intensity difference against the offset projected onto the tangent plane, plus the row (nn - 1) n = 0 that keeps the
+// gradient in that plane; fewer than 4 neighbours: zero.  Normal equations A^T A x = A^T b, 3x3, solved by cofactors.
+__global__ __launch_bounds__(256) void color_gradient_kernel(const float *__restrict__ pts, const float *__restrict__ nrm, const float *__restrict__ col,
+                                                             int64_t n, const int32_t *__restrict__ nbr, const int32_t *__restrict__ cnt, int k,
+                                                             double *__restrict__ grad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x[3] = { 0.0, 0.0, 0.0 };
+    const int nn = cnt[i];
+    if (nn >= 4) {
+        const double vt[3] = { pts[3 * i], pts[3 * i + 1], pts[3 * i + 2] }, nt[3] = { nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2] };
+        const double it = ((double)col[3 * i] + (double)col[3 * i + 1] + (double)col[3 * i + 2]) / 3.0;
+        double a = 0, b = 0, c = 0, d = 0, e = 0, f = 0, r0 = 0, r1 = 0, r2 = 0;       // A^T A = [a b c; b d e; c e f], A^T b = r
+        for (int t = 1; t < nn; ++t) {
+            const int64_t j = nbr[i * k + t];
+            const double q[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
+            const double dp = (q[0] - vt[0]) * nt[0] + (q[1] - vt[1]) * nt[1] + (q[2] - vt[2]) * nt[2];
+            const double u[3] = { (q[0] - dp * nt[0]) - vt[0], (q[1] - dp * nt[1]) - vt[1], (q[2] - dp * nt[2]) - vt[2] };
+            const double bi = ((double)col[3 * j] + (double)col[3 * j + 1] + (double)col[3 * j + 2]) / 3.0 - it;
+            a += u[0] * u[0]; b += u[0] * u[1]; c += u[0] * u[2]; d += u[1] * u[1]; e += u[1] * u[2]; f += u[2] * u[2];
+            r0 += u[0] * bi; r1 += u[1] * bi; r2 += u[2] * bi;
+        }
+        const double w = (double)(nn - 1), w2 = w * w;
+        a += w2 * nt[0] * nt[0]; b += w2 * nt[0] * nt[1]; c += w2 * nt[0] * nt[2];
+        d += w2 * nt[1] * nt[1]; e += w2 * nt[1] * nt[2]; f += w2 * nt[2] * nt[2];
+        const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+        const double det = a * c00 + b * c01 + c * c02;
+        if (det != 0.0 && isfinite(det)) {
+            const double c11 = a * f - c * c, c12 = b * c - a * e, c22 = a * d - b * b;
+            x[0] = (c00 * r0 + c01 * r1 + c02 * r2) / det;
+            x[1] = (c01 * r0 + c11 * r1 + c12 * r2) / det;
+            x[2] = (c02 * r0 + c12 * r1 + c22 * r2) / det;
+        }
+    }
+    grad[3 * i] = x[0]; grad[3 * i + 1] = x[1]; grad[3 * i + 2] = x[2];
+}
+static int color_gradient_impl(const float *pts, const float *nrm, const float *col, int64_t n, double radius, int max_nn, double *grad, Arena &a,
+                               hipStream_t st)
+{
+    Grid g;
+    int32_t *nbr, *cnt; double *d2;
+    const int kk = (int64_t)max_nn < n ? max_nn : (int)(n > 0 ? n : 1);
+    int rc = knn_lists(pts, n, radius, kk, a, &g, &nbr, &d2, &cnt, st);
+    if (rc || a.dry) return rc;
+    KPX_ARENA_CHECK(a);
+    hipLaunchKernelGGL(color_gradient_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, pts, nrm, col, n, nbr, cnt, kk, grad);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
 constexpr int kRansacBatch = 32768;
 struct RansacBuffers {
     Grid g;
@@ -557,6 +611,23 @@ constexpr int kMaxValidate = 512;      // validations per launch (surviving hypo
 }  // namespace kpx
 
 using namespace kpx;
+
+KPX_EXPORT size_t kpx_color_gradient_workspace_bytes(int64_t n, int32_t max_nn)
+{
+    Arena a(nullptr, 0);
+    color_gradient_impl(nullptr, nullptr, nullptr, n, 1.0, max_nn < 1 ? 1 : max_nn, nullptr, a, nullptr);
+    return a.off;
+}
+KPX_EXPORT int kpx_color_gradient(const float *pts, const float *normals, const float *colors, int64_t n, double radius, int32_t max_nn,
+                                  double *grad, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(radius > 0.0 && max_nn >= 1 && max_nn <= KPX_NORMALS_MAX_NN, "kpx_color_gradient: radius / max_nn out of range");
+    KPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) / 128, "kpx_color_gradient: bad size");
+    if (n == 0) return KPX_OK;
+    KPX_REQUIRE(pts && normals && colors && grad && ws, "kpx_color_gradient: null pointer");
+    Arena a(ws, ws_bytes);
+    return color_gradient_impl(pts, normals, colors, n, radius, max_nn, grad, a, (hipStream_t)stream);
+}
 
 KPX_EXPORT size_t kpx_fpfh_workspace_bytes(int64_t n, int32_t max_nn)
 {

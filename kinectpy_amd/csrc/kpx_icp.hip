@@ -464,6 +464,14 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
 // ---- merge splits, direct distance, accumulation ---------------------------------------------------------
 // mode: -2 = write (value, column) as the bound of the next sweep, -1 = correspondences only,
 //        0 = point-to-point sums, 1 = + point-to-plane normal equations
+//        2 = coloured ICP ([O3D] TransformationEstimationForColoredICP): the normal equations hold a geometric row
+//            sqrt(lambda) (s x n, n | (s - t).n) and a photometric row sqrt(1 - lambda) (s x g', g' | I_s - (I_t + g.(s' - t))),
+//            s' = s projected onto the target's tangent plane, g the target's colour gradient, g' = -(I - n n^T) g
+struct ColorTerms {
+    const float *src_col, *tgt_col;
+    const double *tgt_grad;
+    double sqrt_lg, sqrt_lp;
+};
 constexpr int kMergeThreads = 64;
 __global__ __launch_bounds__(kMergeThreads) void nn_merge_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ T,
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(kMergeThreads) void nn_merge_kernel(const float *__
                                                        const int32_t *__restrict__ part_idx, int splits, double max_d2, int mode,
                                                        int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
                                                        double *__restrict__ val_out, double *__restrict__ part_acc,
-                                                       const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand)
+                                                       const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, ColorTerms ct)
 {
     if (done && *done) return;
     __shared__ double sh[kAcc][kMergeThreads + 1];
@@ -541,6 +549,31 @@ __global__ __launch_bounds__(kMergeThreads) void nn_merge_kernel(const float *__
                         for (int c = p; c < 6; ++c) acc[q++] = J[p] * J[c];
 #pragma unroll
                     for (int p = 0; p < 6; ++p) acc[38 + p] = J[p] * r;
+                } else if (mode == 2) {
+                    const float *np_ = tn + 3 * (int64_t)bj;
+                    const double nv[3] = { np_[0], np_[1], np_[2] };
+                    const double rg = (s[0] - t[0]) * nv[0] + (s[1] - t[1]) * nv[1] + (s[2] - t[2]) * nv[2];
+                    const double is = ((double)ct.src_col[3 * i] + (double)ct.src_col[3 * i + 1] + (double)ct.src_col[3 * i + 2]) / 3.0;
+                    const float *tc = ct.tgt_col + 3 * (int64_t)bj;
+                    const double it = ((double)tc[0] + (double)tc[1] + (double)tc[2]) / 3.0;
+                    const double *gp = ct.tgt_grad + 3 * (int64_t)bj;
+                    const double g[3] = { gp[0], gp[1], gp[2] };
+                    const double sp[3] = { s[0] - rg * nv[0], s[1] - rg * nv[1], s[2] - rg * nv[2] };
+                    const double is0 = (g[0] * (sp[0] - t[0]) + g[1] * (sp[1] - t[1]) + g[2] * (sp[2] - t[2])) + it;
+                    const double gn = g[0] * nv[0] + g[1] * nv[1] + g[2] * nv[2];
+                    const double gm[3] = { -(g[0] - gn * nv[0]), -(g[1] - gn * nv[1]), -(g[2] - gn * nv[2]) };
+                    const double JG[6] = { ct.sqrt_lg * (s[1] * nv[2] - s[2] * nv[1]), ct.sqrt_lg * (s[2] * nv[0] - s[0] * nv[2]),
+                                           ct.sqrt_lg * (s[0] * nv[1] - s[1] * nv[0]), ct.sqrt_lg * nv[0], ct.sqrt_lg * nv[1], ct.sqrt_lg * nv[2] };
+                    const double JI[6] = { ct.sqrt_lp * (s[1] * gm[2] - s[2] * gm[1]), ct.sqrt_lp * (s[2] * gm[0] - s[0] * gm[2]),
+                                           ct.sqrt_lp * (s[0] * gm[1] - s[1] * gm[0]), ct.sqrt_lp * gm[0], ct.sqrt_lp * gm[1], ct.sqrt_lp * gm[2] };
+                    const double rG = ct.sqrt_lg * rg, rI = ct.sqrt_lp * (is - is0);
+                    int q = 17;
+#pragma unroll
+                    for (int p = 0; p < 6; ++p)
+#pragma unroll
+                        for (int c = p; c < 6; ++c) acc[q++] = JG[p] * JG[c] + JI[p] * JI[c];
+#pragma unroll
+                    for (int p = 0; p < 6; ++p) acc[38 + p] = JG[p] * rG + JI[p] * rI;
                 }
             }
         }
@@ -549,10 +582,10 @@ __global__ __launch_bounds__(kMergeThreads) void nn_merge_kernel(const float *__
     // fixed-order block sums through LDS: slot q of lane l at sh[q][l] (row stride 65 doubles: conflict-free
     // column walks), lane q then adds its row in lane order -- no cross-lane shuffles (a 64-lane fp64 shuffle
     // tree for 44 slots costs ~500 ds_bpermutes per wave)
-    const int nacc = mode == 1 ? kAcc : 17;
+    const int nacc = mode >= 1 ? kAcc : 17;
 #pragma unroll
     for (int q = 0; q < kAcc; ++q)
-        if (q < 17 || mode == 1) sh[q][threadIdx.x] = acc[q];
+        if (q < 17 || mode >= 1) sh[q][threadIdx.x] = acc[q];
     __syncthreads();
     if ((int)threadIdx.x < nacc) {
         double v = 0.0;
@@ -1173,7 +1206,8 @@ static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStr
 // One correspondence search.  have_prev: b.idx_cur holds the partners of the previous search (bound from them),
 // otherwise a seed sweep over every 64th target tile provides the bound.
 static int nn_search_launch(const float *src, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b,
-                            const double *T, const int32_t *done, bool have_prev, bool allow_screen, double max_d2, int mode, hipStream_t st)
+                            const double *T, const int32_t *done, bool have_prev, bool allow_screen, double max_d2, int mode, hipStream_t st,
+                            ColorTerms ct = ColorTerms{})
 {
     const int64_t n = p.n_src;
     const dim3 thr(256);
@@ -1189,7 +1223,7 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
         }
         hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done,
                            b.part_val, b.part_idx, 1, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc,
-                           (const int32_t *)nullptr, (const int32_t *)nullptr);
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, ct);
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
@@ -1206,7 +1240,7 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
         hipLaunchKernelGGL(nn_overflow_kernel, dim3(1024), thr, 0, st, src, n, tgt,
                            p.n_tgt, T, done, b.cand_cnt, b.cand, b.overflow);
         hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.init_val, b.init_idx, 1,
-                           max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, b.cand_cnt, b.cand);
+                           max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, b.cand_cnt, b.cand, ct);
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
@@ -1214,7 +1248,8 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
         hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, 1), thr, 0, st, n, b.Bseed, (int32_t)p.seed_tiles_pad, (int32_t)kSeedStride,
                            done, b.A64, b.K64, (const double *)nullptr, (const int32_t *)nullptr, b.part_val, b.part_idx);
         hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx, 1,
-                           0.0, -2, b.init_idx, (double *)nullptr, b.init_val, b.part_acc, (const int32_t *)nullptr, (const int32_t *)nullptr);
+                           0.0, -2, b.init_idx, (double *)nullptr, b.init_val, b.part_acc, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                           ColorTerms{});
     }
     {
         ProfScope prof(KPX_PROF_NN_MFMA, 8.0 * (double)p.n_src * (double)p.n_tgt, st);     // 4 MAC per (source, target) pair
@@ -1223,7 +1258,7 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
     }
     hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
                        p.splits, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr);
+                       (const int32_t *)nullptr, ct);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
@@ -1353,6 +1388,53 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
     }
     if (idx) KPX_HIP(hipMemcpyAsync(idx, b.idx_cur, (size_t)n_src * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     if (d2) KPX_HIP(hipMemcpyAsync(d2, b.d2_cur, (size_t)n_src * sizeof(double), hipMemcpyDeviceToDevice, st));
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+// ---- coloured ICP (preprocessing/registration.py:89-114) -----------------------------------------------------
+// [O3D] registration_colored_icp = the registration_icp loop (same correspondences, fitness, inlier rmse and convergence
+// test) with TransformationEstimationForColoredICP as the update; the target's colour gradient comes from
+// kpx_color_gradient.  Search -> sums -> solve are three launches per iteration (nn_merge_kernel mode 2 + icp_solve_kernel):
+// the function is unused in the reference, so this path is built for parity, not for speed.
+KPX_EXPORT size_t kpx_colored_icp_workspace_bytes(int64_t n_src, int64_t n_tgt) { return kpx_icp_workspace_bytes(n_src, n_tgt); }
+KPX_EXPORT int kpx_colored_icp(const float *src, const float *src_colors, int64_t n_src, const float *tgt, const float *tgt_colors,
+                               const float *tgt_normals, const double *tgt_gradient, int64_t n_tgt, double max_dist, const double *h_init,
+                               double lambda_geometric, int32_t max_iteration, double relative_fitness, double relative_rmse,
+                               int32_t poll_interval, double *d_result, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(tgt_normals, "TransformationEstimationPointToPlane and TransformationEstimationColoredICP require pre-computed normal vectors for target PointCloud.");
+    KPX_REQUIRE(src_colors && tgt_colors && tgt_gradient, "kpx_colored_icp: colours of both clouds and the target's colour gradient are required");
+    KPX_REQUIRE(max_dist > 0.0, "Invalid max_correspondence_distance.");
+    KPX_REQUIRE(lambda_geometric >= 0.0 && lambda_geometric <= 1.0, "kpx_colored_icp: lambda_geometric must lie in [0, 1]");
+    KPX_REQUIRE(n_src >= 1 && n_tgt >= 1 && max_iteration >= 0, "kpx_colored_icp: empty cloud");
+    KPX_REQUIRE(n_src < ((int64_t)1 << 31) && n_tgt < ((int64_t)1 << 31) - 65536, "kpx_colored_icp: cloud too large");
+    KPX_REQUIRE(src && tgt && h_init && d_result && ws, "kpx_colored_icp: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    NnPlan p = nn_plan(n_src, n_tgt);
+    NnBuffers b;
+    nn_carve(a, n_src, n_tgt, p, &b);
+    KPX_ARENA_CHECK(a);
+    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, b.state, mat16_from(h_init));
+    int rc = nn_prep(tgt, p, b, st);
+    if (rc) return rc;
+    rc = nn_prep_source(src, p, b, st);
+    if (rc) return rc;
+    const ColorTerms ct{ src_colors, tgt_colors, tgt_gradient, sqrt(lambda_geometric), sqrt(1.0 - lambda_geometric) };
+    const double md2 = max_dist * max_dist;
+    for (int k = 0; k <= max_iteration; ++k) {
+        rc = nn_search_launch(src, tgt, tgt_normals, p, b, b.state->T, &b.state->done, k > 0, false, md2, 2, st, ct);
+        if (rc) return rc;
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(kSolveThreads), 0, st, b.part_acc, (int)cdiv(n_src, kMergeThreads), n_src, 1, k,
+                           max_iteration, relative_fitness, relative_rmse, b.state, d_result);
+        if (poll_interval > 0 && (k + 1) % poll_interval == 0 && k < max_iteration) {
+            int32_t h_done = 0;
+            KPX_HIP(hipMemcpyAsync(&h_done, &b.state->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            KPX_HIP(hipStreamSynchronize(st));
+            if (h_done) break;
+        }
+    }
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

@@ -1,6 +1,6 @@
 """Open3D-shaped namespace over the kinectpx hot path, so that KinectPy code written as
 `import open3d as o3d` keeps working with `from kinectpy_amd import o3d` for the calls on the
-path.  Anything off the path (visualisation, coloured ICP)
+path.  Anything off the path (visualisation)
 raises NotImplementedError loudly instead of silently computing on the CPU.
 """
 import types
@@ -44,6 +44,29 @@ class TransformationEstimationPointToPoint:
 
 class TransformationEstimationPointToPlane:
     mode = "p2plane"
+
+
+class TransformationEstimationForColoredICP:
+    mode = "colored"
+
+    def __init__(self, lambda_geometric=0.968):
+        self.lambda_geometric = float(lambda_geometric)
+
+
+def registration_colored_icp(source, target, max_correspondence_distance, init=None, estimation_method=None, criteria=None):
+    """preprocessing/registration.py:107-113"""
+    est = estimation_method if estimation_method is not None else TransformationEstimationForColoredICP()
+    crit = criteria if criteria is not None else ICPConvergenceCriteria()
+    if max_correspondence_distance <= 0:
+        raise RuntimeError("Invalid max_correspondence_distance.")
+    if not target.has_normals():
+        raise RuntimeError("TransformationEstimationPointToPlane and TransformationEstimationColoredICP "
+                           "require pre-computed normal vectors for target PointCloud.")
+    if not (source.has_colors() and target.has_colors()):
+        raise RuntimeError("ColoredICP requires colored point clouds.")
+    r = ops.colored_icp(source._pts, source._col, target._pts, target._col, target._nrm, float(max_correspondence_distance), init,
+                        est.lambda_geometric, crit.max_iteration, crit.relative_fitness, crit.relative_rmse)
+    return RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], None)
 
 
 def registration_icp(source, target, max_correspondence_distance, init=None, estimation_method=None, criteria=None):
@@ -161,7 +184,8 @@ pipelines = types.SimpleNamespace(registration=types.SimpleNamespace(
     CorrespondenceCheckerBasedOnEdgeLength=CorrespondenceCheckerBasedOnEdgeLength,
     CorrespondenceCheckerBasedOnDistance=CorrespondenceCheckerBasedOnDistance,
     RANSACConvergenceCriteria=RANSACConvergenceCriteria,
-    registration_colored_icp=_off_path("registration_colored_icp"),
+    registration_colored_icp=registration_colored_icp,
+    TransformationEstimationForColoredICP=TransformationEstimationForColoredICP,
 ))
 visualization = types.SimpleNamespace(VisualizerWithEditing=_off_path("VisualizerWithEditing"),
                                       draw_geometries=_off_path("draw_geometries"))

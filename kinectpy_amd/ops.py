@@ -501,3 +501,41 @@ def fuse_skeletons(skeletons, alpha=1.4, beta=1.4, initial_frame=20):
     out = torch.empty((frames, joints, 3), dtype=torch.float64, device=sk.device)
     L.check(lib.kpx_fuse_skeletons(L.ptr(sk), cams, frames, joints, float(alpha), float(beta), int(initial_frame), L.ptr(out), L.stream_ptr()))
     return out
+
+
+# ---- coloured ICP (SURVEY 8f rank 4) -------------------------------------------------------------------
+def color_gradient(pts, normals, colors, radius, max_nn=30):
+    """[O3D] InitializePointCloudForColoredICP: tangent-plane intensity gradient per point, (n, 3) f64 on the device"""
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    nrm = _dev(normals, torch.float32).reshape(-1, 3)
+    col = _dev(colors, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    grad = torch.zeros((n, 3), dtype=torch.float64, device=pts.device)
+    ws, wsz = L.workspace(lib.kpx_color_gradient_workspace_bytes(n, int(max_nn)))
+    L.check(lib.kpx_color_gradient(L.ptr(pts), L.ptr(nrm), L.ptr(col), n, float(radius), int(max_nn), L.ptr(grad), ws, wsz, L.stream_ptr()))
+    return grad
+
+
+def colored_icp(src, src_colors, tgt, tgt_colors, tgt_normals, max_dist, init=None, lambda_geometric=0.968, max_iteration=30,
+                relative_fitness=1e-6, relative_rmse=1e-6, poll_interval=4, tgt_gradient=None):
+    """[O3D] registration_colored_icp.  Returns dict(transformation, fitness, inlier_rmse, iterations, count)."""
+    lib = L.load()
+    src = _dev(src, torch.float32).reshape(-1, 3)
+    tgt = _dev(tgt, torch.float32).reshape(-1, 3)
+    sc = _dev(src_colors, torch.float32).reshape(-1, 3)
+    tc = _dev(tgt_colors, torch.float32).reshape(-1, 3)
+    tn = _dev(tgt_normals, torch.float32).reshape(-1, 3)
+    n, m = src.shape[0], tgt.shape[0]
+    if tgt_gradient is None:
+        tgt_gradient = color_gradient(tgt, tn, tc, 2.0 * float(max_dist), 30)       # Open3D: KDTreeSearchParamHybrid(2 max_distance, 30)
+    tg = _dev(tgt_gradient, torch.float64).reshape(-1, 3)
+    res = torch.zeros(20, dtype=torch.float64, device=src.device)
+    init = _T(np.eye(4) if init is None else init)
+    ws, wsz = L.workspace(lib.kpx_colored_icp_workspace_bytes(n, m))
+    L.check(lib.kpx_colored_icp(L.ptr(src), L.ptr(sc), n, L.ptr(tgt), L.ptr(tc), L.ptr(tn), L.ptr(tg), m, float(max_dist), L.hptr(init),
+                                float(lambda_geometric), int(max_iteration), float(relative_fitness), float(relative_rmse), int(poll_interval),
+                                L.ptr(res), ws, wsz, L.stream_ptr()))
+    r = res.cpu().numpy()
+    return {"transformation": r[:16].reshape(4, 4).copy(), "fitness": float(r[16]), "inlier_rmse": float(r[17]),
+            "iterations": int(r[18]), "count": int(r[19])}

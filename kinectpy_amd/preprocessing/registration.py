@@ -64,5 +64,22 @@ def execute_point_to_plane_registration(pcd_master, pcd_sub, initial_transformat
 
 
 def execute_colored_ICP_registration(pcd_master, pcd_sub, initial_transformation):
-    """registration.py:89-114: unused by the reference's pipeline and defective there."""
-    raise NotImplementedError("coloured ICP is unused by KinectPy's pipeline (SURVEY.md 8f rank 4)")
+    """registration.py:89-114, as written there: master is the source, sub the target; three scales (voxel 80 / 40 / 20 with
+    50 / 30 / 14 iterations), every scale starts again from `initial_transformation`, the last scale's result is returned."""
+    source = copy.deepcopy(pcd_master)
+    target = copy.deepcopy(pcd_sub)
+    voxel_radius = [80, 40, 20]
+    max_iter = [50, 30, 14]
+    result_icp = None
+    for scale in range(len(max_iter)):
+        iters = max_iter[scale]
+        radius = voxel_radius[scale]
+        source_down = source.voxel_down_sample(radius)
+        target_down = target.voxel_down_sample(radius)
+        source_down.estimate_normals(o3d.geometry.KDTreeSearchParamHybrid(radius=radius * 2, max_nn=30))
+        target_down.estimate_normals(o3d.geometry.KDTreeSearchParamHybrid(radius=radius * 2, max_nn=30))
+        result_icp = o3d.pipelines.registration.registration_colored_icp(
+            source_down, target_down, radius, initial_transformation,
+            o3d.pipelines.registration.TransformationEstimationForColoredICP(),
+            o3d.pipelines.registration.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=iters))
+    return result_icp.transformation

@@ -204,3 +204,19 @@ def filter_cloud(n=1_000_000, seed=3):
     out = np.stack([rng.uniform(-2000, 2000, no), rng.uniform(-1500, FLOOR_Y, no), rng.uniform(1000, 3500, no)], -1)
     pts = np.concatenate([floor, person, wall, out])
     return pts[rng.permutation(len(pts))].astype(np.float32)
+
+
+def coloured_pair(n, seed=0):
+    """a smooth colour field painted on the scene: target samples + a displaced, noisy second sampling"""
+    rng = np.random.default_rng(seed)
+    c = filter_cloud(4 * n)
+    c = c[(c[:, 1] < 880)][: 2 * n]                      # drop the floor plane: the person and the wall carry the colour
+    field = lambda p: np.stack([0.5 + 0.4 * np.sin(p[:, 0] / 90.0) * np.cos(p[:, 1] / 120.0),
+                                0.5 + 0.4 * np.cos(p[:, 2] / 150.0 + p[:, 0] / 200.0),
+                                0.5 + 0.3 * np.sin(p[:, 1] / 70.0)], 1).astype(np.float32)
+    tgt = c[:n].copy()
+    src0 = c[n:2 * n].copy()
+    T = t_star()
+    Ti = np.linalg.inv(T)
+    src = (src0.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+    return src, field(src0), tgt, field(tgt), T

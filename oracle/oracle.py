@@ -593,3 +593,84 @@ def fuse_skeletons_gradient(skeletons, alpha=1.4, beta=1.4, initial_frame=20):
             w = [1.0 / ((np.linalg.norm(q - last) ** alpha) * (np.linalg.norm(q - cen) ** beta)) for q in p]
             out[f, j] = (w[0] * p[0] + w[1] * p[1] + w[2] * p[2]) / (w[0] + w[1] + w[2])
     return out
+
+
+# ---- coloured ICP ([O3D] ColoredICP, recalled; parity unpinned) -------------------------------------------
+def color_gradient(pts, normals, colors, radius, max_nn=30):
+    """InitializePointCloudForColoredICP: per point, least squares of the neighbours' intensity differences against their
+    offsets projected onto the tangent plane, plus the row (nn - 1) n = 0; fewer than 4 neighbours: zero."""
+    pts = _f32(pts).reshape(-1, 3).astype(np.float64)
+    nrm = _f32(normals).reshape(-1, 3).astype(np.float64)
+    inten = _f32(colors).reshape(-1, 3).astype(np.float64).sum(1) / 3.0
+    nbr, cnt = hybrid_knn(pts, radius, max_nn)
+    grad = np.zeros_like(pts)
+    for k in range(len(pts)):
+        nn_ = int(cnt[k])
+        if nn_ < 4:
+            continue
+        j = nbr[k, 1:nn_]
+        q = pts[j]
+        dp = (q - pts[k]) @ nrm[k]
+        A = np.vstack([q - dp[:, None] * nrm[k] - pts[k], (nn_ - 1) * nrm[k]])
+        b = np.append(inten[j] - inten[k], 0.0)
+        M = A.T @ A
+        if np.linalg.det(M) != 0:
+            grad[k] = np.linalg.solve(M, A.T @ b)
+    return grad
+
+
+def registration_colored_icp(src, src_colors, tgt, tgt_colors, tgt_normals, max_dist, init=None, lambda_geometric=0.968,
+                             max_iteration=30, relative_fitness=1e-6, relative_rmse=1e-6):
+    """registration_icp loop with TransformationEstimationForColoredICP as the update -> T, fitness, rmse, iterations"""
+    src = _f32(src).reshape(-1, 3)
+    tgt = _f32(tgt).reshape(-1, 3)
+    n = src.shape[0]
+    tn = _f32(tgt_normals).reshape(-1, 3).astype(np.float64)
+    Is = _f32(src_colors).reshape(-1, 3).astype(np.float64).sum(1) / 3.0
+    It = _f32(tgt_colors).reshape(-1, 3).astype(np.float64).sum(1) / 3.0
+    grad = color_gradient(tgt, tgt_normals, tgt_colors, 2.0 * max_dist, 30)
+    slg, slp = np.sqrt(lambda_geometric), np.sqrt(1.0 - lambda_geometric)
+    T = np.eye(4) if init is None else np.array(init, dtype=np.float64).reshape(4, 4)
+
+    def search(Tc):
+        idx, d2, _ = nn(src, Tc, tgt, grid=True)
+        ok = d2 < max_dist * max_dist
+        cnt = int(ok.sum())
+        fit = cnt / n if n else 0.0
+        rmse = np.sqrt(d2[ok].sum() / cnt) if cnt else 0.0
+        return idx, ok, fit, rmse
+
+    def update(Tc, idx, ok):
+        if not ok.any():
+            return np.eye(4)
+        s = (src[ok].astype(np.float64) @ Tc[:3, :3].T) + Tc[:3, 3]
+        j = idx[ok]
+        t, nv, g = tgt[j].astype(np.float64), tn[j], grad[j]
+        rg = ((s - t) * nv).sum(1)
+        sp = s - rg[:, None] * nv
+        is0 = (g * (sp - t)).sum(1) + It[j]
+        gm = -(g - (g * nv).sum(1)[:, None] * nv)
+        JG = slg * np.hstack([np.cross(s, nv), nv])
+        JI = slp * np.hstack([np.cross(s, gm), gm])
+        rG, rI = slg * rg, slp * (Is[ok] - is0)
+        A = JG.T @ JG + JI.T @ JI
+        rhs = -(JG.T @ rG + JI.T @ rI)
+        try:
+            x = np.linalg.solve(A, rhs)
+        except np.linalg.LinAlgError:
+            return np.eye(4)
+        U = np.eye(4)
+        U[:3, :3] = _rot_zyx(x[0], x[1], x[2])
+        U[:3, 3] = x[3:6]
+        return U
+
+    idx, ok, fit, rmse = search(T)
+    it = 0
+    for it in range(1, max_iteration + 1):
+        T = update(T, idx, ok) @ T
+        idx, ok, nfit, nrmse = search(T)
+        done = abs(fit - nfit) < relative_fitness and abs(rmse - nrmse) < relative_rmse
+        fit, rmse = nfit, nrmse
+        if done:
+            break
+    return T, fit, rmse, it

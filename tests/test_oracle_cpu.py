@@ -241,3 +241,24 @@ def test_skeleton_fusion_kat(oracle):
     for c in kat["fuse_skeletons_gradient"]:
         got = oracle.fuse_skeletons_gradient(np.array(c["skeletons"]), c["alpha"], c["beta"])
         assert np.allclose(got, np.array(c["fused"]), rtol=1e-13, atol=1e-10)
+
+
+_coloured_pair = synth.coloured_pair
+
+
+def test_colour_gradient_of_a_linear_field_on_a_plane(oracle):
+    rng = np.random.default_rng(1)
+    p = np.stack([rng.uniform(0, 500, 4000), rng.uniform(0, 500, 4000), np.full(4000, 100.0)], 1).astype(np.float32)
+    n = np.tile(np.array([0, 0, 1.0], np.float32), (4000, 1))
+    inten = 0.2 + 0.001 * p[:, 0] - 0.0005 * p[:, 1]
+    col = np.stack([inten] * 3, 1).astype(np.float32)
+    g = oracle.color_gradient(p, n, col, 40.0, 30)
+    inner = (p[:, 0] > 60) & (p[:, 0] < 440) & (p[:, 1] > 60) & (p[:, 1] < 440)
+    assert np.allclose(g[inner], [0.001, -0.0005, 0.0], atol=2e-6)       # float32 colours
+
+
+def test_coloured_icp_recovers_transform(oracle):
+    src, sc, tgt, tc, T = _coloured_pair(6000)
+    tn = oracle.estimate_normals(tgt, 70.0, 30)[0].astype(np.float32)
+    Tr, fit, rmse, it = oracle.registration_colored_icp(src, sc, tgt, tc, tn, 80.0, None, 0.968, 40)
+    assert fit > 0.9 and np.abs(Tr[:3, :3] - T[:3, :3]).max() < 5e-3 and np.abs(Tr[:3, 3] - T[:3, 3]).max() < 6.0

@@ -1023,3 +1023,46 @@ def test_skeleton_fusion_matches_reference_outputs(ops, oracle):
     from kinectpy_amd._lib import KinectPxError
     with pytest.raises(KinectPxError):
         ops.fuse_skeletons(sk[:2], 1.4, 1.4)
+
+
+_coloured_pair = synth.coloured_pair
+
+
+def test_colour_gradient_and_coloured_icp_match_oracle(ops, oracle, engine):
+    src, sc, tgt, tc, T = _coloured_pair(6000)
+    tn = oracle.estimate_normals(tgt, 70.0, 30)[0].astype(np.float32)
+    g = ops.color_gradient(tgt, tn, tc, 160.0, 30).cpu().numpy()
+    rg = oracle.color_gradient(tgt, tn, tc, 160.0, 30)
+    assert np.allclose(g, rg, rtol=1e-7, atol=1e-10)
+    for lam, iters, init in ((0.968, 25, None), (0.5, 8, np.linalg.inv(np.linalg.inv(T))), (1.0, 6, None)):
+        r = ops.colored_icp(src, sc, tgt, tc, tn, 80.0, init, lam, iters)
+        rT, rf, rr, rit = oracle.registration_colored_icp(src, sc, tgt, tc, tn, 80.0, init, lam, iters)
+        assert r["iterations"] == rit and r["fitness"] == rf and abs(r["inlier_rmse"] - rr) < 1e-8
+        assert np.abs(r["transformation"] - rT).max() < TOL_T
+    r = ops.colored_icp(src, sc, tgt, tc, tn, 80.0, None, 0.968, 40)
+    assert np.abs(r["transformation"][:3, :3] - T[:3, :3]).max() < 5e-3 and np.abs(r["transformation"][:3, 3] - T[:3, 3]).max() < 6.0
+    # lambda = 1 drops the photometric row: the update is the point-to-plane one
+    a = ops.colored_icp(src, sc, tgt, tc, tn, 80.0, None, 1.0, 5)
+    b = ops.icp(src, tgt, 80.0, None, "p2plane", tn, 5)
+    assert a["iterations"] == b["iterations"] and np.abs(a["transformation"] - b["transformation"]).max() < 1e-9
+
+
+def test_coloured_icp_api_mirrors(oracle):
+    from kinectpy_amd import o3d
+    from kinectpy_amd.preprocessing.registration import execute_colored_ICP_registration
+    src, sc, tgt, tc, T = _coloured_pair(20000)
+    a = o3d.geometry.PointCloud(o3d.utility.Vector3dVector(src.astype(np.float64)))
+    b = o3d.geometry.PointCloud(o3d.utility.Vector3dVector(tgt.astype(np.float64)))
+    with pytest.raises(RuntimeError):
+        o3d.pipelines.registration.registration_colored_icp(a, b, 80.0, np.eye(4))       # no normals
+    b.estimate_normals(o3d.geometry.KDTreeSearchParamHybrid(radius=70.0, max_nn=30))
+    with pytest.raises(RuntimeError):
+        o3d.pipelines.registration.registration_colored_icp(a, b, 80.0, np.eye(4))       # no colours
+    a.colors = o3d.utility.Vector3dVector(sc.astype(np.float64))
+    b.colors = o3d.utility.Vector3dVector(tc.astype(np.float64))
+    res = o3d.pipelines.registration.registration_colored_icp(
+        a, b, 80.0, np.eye(4), o3d.pipelines.registration.TransformationEstimationForColoredICP(),
+        o3d.pipelines.registration.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30))
+    assert res.fitness > 0.9 and np.abs(res.transformation[:3, 3] - T[:3, 3]).max() < 8.0
+    Tm = execute_colored_ICP_registration(a, b, np.eye(4))                                   # the reference's three-scale loop
+    assert Tm.shape == (4, 4) and np.abs(Tm[:3, :3] - T[:3, :3]).max() < 2e-2
