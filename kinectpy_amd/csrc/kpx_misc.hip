@@ -220,8 +220,34 @@ int lanes_join(LaneSet *l, hipStream_t caller, int used)
     return KPX_OK;
 }
 
+// small clouds: one block does the whole reduction (one launch instead of two; the chains these boxes sit in are bound by
+// the host's launch rate)
+__global__ __launch_bounds__(1024) void bbox_small_kernel(const float *__restrict__ pts, int64_t n, double *__restrict__ bbox)
+{
+    __shared__ float sh[6][16];
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { float v = pts[3 * i + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+    if (lane_id() == 0)
+        for (int a = 0; a < 3; ++a) { sh[a][wave_id()] = mn[a]; sh[3 + a][wave_id()] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[threadIdx.x][0];
+        for (int w = 1; w < 16; ++w) v = threadIdx.x < 3 ? fminf(v, sh[threadIdx.x][w]) : fmaxf(v, sh[threadIdx.x][w]);
+        bbox[threadIdx.x] = (double)v;
+    }
+}
 int bbox_f32(const float *pts, int64_t n, double *d_bbox6, double *ws_partials, hipStream_t st)
 {
+    if (n <= 65536) {
+        hipLaunchKernelGGL(bbox_small_kernel, dim3(1), dim3(1024), 0, st, pts, n, d_bbox6);
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > kBboxBlocks ? kBboxBlocks : cdiv(n, 256 * 8)));
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, st, pts, n, ws_partials);
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, st, ws_partials, nb, d_bbox6);
