@@ -183,22 +183,45 @@ __global__ __launch_bounds__(64) void voxel_batch_bbox_final_kernel(const double
         err[c] = 0;
     }
 }
+// largest grid extents of the batch (index < floor((max - origin) / v) + 1) and whether count x DX x DY x DZ fits 64 bits
+__device__ __forceinline__ void voxel_batch_dims(const VoxelBatch &b, const double *__restrict__ bbox, double voxel, double d[3], int *overflow)
+{
+    d[0] = d[1] = d[2] = 1.0;
+    for (int c = 0; c < b.count; ++c) {
+        if (b.off[c + 1] == b.off[c]) continue;
+        for (int a = 0; a < 3; ++a) {
+            const double e = floor((bbox[8 * c + 3 + a] - (bbox[8 * c + a] - voxel * 0.5)) / voxel) + 1.0;
+            if (e > d[a] && e < 2097152.0) d[a] = e;              // out-of-range clouds are flagged per point by the key kernel
+        }
+    }
+    *overflow = ((double)b.count * d[0]) * (d[1] * d[2]) >= 18446744073709551616.0 ? 1 : 0;
+}
+// bits the keys of this batch occupy: batches above rocPRIM's merge-sort limit are sorted by Onesweep, one pass per 8 bits --
+// a 4-sensor frame needs ~24 of the 64
+__global__ void voxel_batch_bits_kernel(VoxelBatch b, const double *__restrict__ bbox, double voxel, int32_t *__restrict__ bits)
+{
+    double d[3];
+    int overflow;
+    voxel_batch_dims(b, bbox, voxel, d, &overflow);
+    int n = 64;
+    if (!overflow) {
+        const unsigned long long range = (((unsigned long long)b.count * (unsigned long long)d[0]) * (unsigned long long)d[1]) * (unsigned long long)d[2];
+        n = 1;
+        while (n < 64 && (range >> n) != 0ull) ++n;
+    }
+    *bits = n;
+}
 __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, const double *__restrict__ bbox, double voxel,
                                                               uint64_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ err)
 {
     __shared__ double dims[3];
     __shared__ int overflow;
-    if (threadIdx.x == 0) {          // largest grid extents of the batch: index < floor((max - origin) / v) + 1
-        double d[3] = { 1.0, 1.0, 1.0 };
-        for (int c = 0; c < b.count; ++c) {
-            if (b.off[c + 1] == b.off[c]) continue;
-            for (int a = 0; a < 3; ++a) {
-                const double e = floor((bbox[8 * c + 3 + a] - (bbox[8 * c + a] - voxel * 0.5)) / voxel) + 1.0;
-                if (e > d[a] && e < 2097152.0) d[a] = e;          // out-of-range clouds are flagged per point below
-            }
-        }
+    if (threadIdx.x == 0) {
+        double d[3];
+        int ov;
+        voxel_batch_dims(b, bbox, voxel, d, &ov);
         dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
-        overflow = ((double)b.count * d[0]) * (d[1] * d[2]) >= 18446744073709551616.0 ? 1 : 0;
+        overflow = ov;
     }
     __syncthreads();
     const uint64_t DX = (uint64_t)dims[0], DY = (uint64_t)dims[1], DZ = (uint64_t)dims[2];
@@ -318,8 +341,19 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
     hipLaunchKernelGGL(voxel_batch_bbox_final_kernel, dim3(b.count), dim3(64), 0, st, s.part, s.bbox, s.err);
     const int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
     hipLaunchKernelGGL(voxel_batch_key_kernel, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err);
+    int end_bit = 64;
+    if (total > (int64_t)1024 * 1024) {
+        // above rocPRIM's merge-sort limit the sort is an Onesweep with one pass per 8 key bits: reading the width back (one
+        // small round trip; the caller waits for the counts anyway) saves four or five of the eight ~27 us passes
+        static thread_local int32_t *h_bits = nullptr;
+        if (!h_bits) KPX_HIP(hipHostMalloc((void **)&h_bits, sizeof(int32_t), hipHostMallocDefault));
+        hipLaunchKernelGGL(voxel_batch_bits_kernel, dim3(1), dim3(1), 0, st, b, s.bbox, voxel, s.head);
+        KPX_HIP(hipMemcpyAsync(h_bits, s.head, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KPX_HIP(hipStreamSynchronize(st));
+        end_bit = *h_bits < 1 ? 1 : (*h_bits > 64 ? 64 : *h_bits);
+    }
     size_t bytes = s.sort_bytes;
-    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, 64, st));
+    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, end_bit, st));
     int rc = compact(HeadPred{ s.keys_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st);
     if (rc) return rc;
     hipLaunchKernelGGL(voxel_batch_locate_kernel, dim3(1), dim3(64), 0, st, b, s.seg_start, s.d_total, s.err, s.head, d_counts);

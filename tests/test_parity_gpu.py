@@ -238,6 +238,11 @@ def test_voxel_batch_equals_single_calls(ops, oracle, base_cloud):
                 assert np.array_equal(npy(gp), oracle.voxel_downsample(c, 20.0)[0]), k
             else:
                 assert gp.shape[0] == 0
+    # more than a million points together: the sort is an Onesweep over the key bits the batch really uses (read back)
+    rngb = np.random.default_rng(8)
+    big = [(rngb.random((n_, 3)) * [4000, 2500, 3800] + [-2000, -1200, 300]).astype(np.float32) for n_ in (300_000, 280_000, 310_000, 290_000)]
+    for (gp, _), c in zip(ops.voxel_downsample_batch(big, 35.0), big):
+        assert np.array_equal(npy(gp), oracle.voxel_downsample(c, 35.0)[0])
     # a cloud whose grid would overflow fails alone, with the same error as a single call
     from kinectpy_amd._lib import KinectPxError
     far = np.array([[0, 0, 0], [1e7, 0, 0]], np.float32)
