@@ -121,8 +121,8 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sensors-per-gpu", type=int, default=4)
     ap.add_argument("--frames", type=int, default=2, help="distinct synthetic time frames cycled through")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="0 disables the cpu_baseline leg")
