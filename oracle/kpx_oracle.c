@@ -7,14 +7,16 @@
  *
  * PARITY STATUS: **parity unpinned** for everything whose arithmetic lives inside Open3D
  * (voxel_down_sample, remove_statistical_outlier, segment_plane, registration_icp,
- * estimate_normals).  Open3D is an un-vendored, un-pinned dependency of the reference
+ * estimate_normals, compute_fpfh_feature, registration_ransac_based_on_feature_matching,
+ * registration_colored_icp, get_oriented_bounding_box -- the last one's integer part, WHICH points
+ * are hull vertices, is pinned against Qhull itself through scipy).  Open3D is an un-vendored, un-pinned dependency of the reference
  * (`import open3d as o3d`, /root/reference/preprocessing/registration.py:4, filtering.py:7,
  * floor_removal.py:4; API usage bounds it to >= 0.12), it is not installed here and the
  * reference has no tests or golden vectors.  Those functions restate Open3D's published
  * algorithms ([O3D], recalled) and are anchored on the reference's call sites.  The pure-NumPy
  * reference functions (load_depth, rgbd_to_pointcloud masks, equation_plane, pcd_above_plane,
- * kalman_filter, transform_joints) ARE pinned by the known answers captured from the reference
- * itself (tests/golden/ref_kat.json).
+ * kalman_filter, transform_joints, fuse_skeletons_gradient) ARE pinned by the known answers captured
+ * from the reference itself (tests/golden/ref_kat.json, ref_skeleton_fusion.json).
  *
  * Storage contract shared with the GPU product (DESIGN.md "arithmetic contract"): clouds are
  * float32 (N,3) arrays; every decision scalar is computed in fp64 from the promoted values with

@@ -2,7 +2,8 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 PARITY STATUS: parity unpinned for the Open3D-internal algorithms (no golden vectors exist in the
-reference); the NumPy-only reference functions are pinned by tests/golden/ref_kat.json.
+reference; the hull-vertex part of the oriented bounding box is pinned against Qhull through scipy); the
+NumPy-only reference functions are pinned by tests/golden/ref_kat.json and ref_skeleton_fusion.json.
 """
 import ctypes as C
 import os
