@@ -35,6 +35,32 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_ctypes_signatures_match_the_header():
+    """argument count and the C type class of every parameter (pointer / 64-bit integer / 32-bit integer / double / size_t)
+    of each prototype in include/kinectpx.h (size_t counts as a 64-bit integer) against kinectpy_amd/_lib.py::SIGNATURES"""
+    from kinectpy_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "kinectpx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = re.findall(r"\b(?:int|size_t|const char \*)\s*\**\s*(kpx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) == len(_lib.SIGNATURES)
+
+    def cls(param):
+        param = " ".join(param.split())
+        if "*" in param:
+            return "ptr"
+        for key, name in (("uint64_t", "i64"), ("int64_t", "i64"), ("size_t", "i64"), ("int32_t", "i32"), ("double", "f64"), ("int ", "i32")):
+            if key in param + " ":
+                return name
+        raise AssertionError(param)
+
+    ctype_cls = {C.c_void_p: "ptr", C.c_int64: "i64", C.c_uint64: "i64", C.c_int32: "i32", C.c_int: "i32", C.c_double: "f64", C.c_size_t: "i64"}      # LP64: size_t is a 64-bit integer
+    for name, params in protos:
+        params = params.strip()
+        want = [] if params in ("", "void") else [cls(q) for q in params.split(",")]
+        got = [ctype_cls[t] for t in _lib.SIGNATURES[name][1]]
+        assert got == want, (name, got, want)
+
+
 def test_version_and_error_channel(lib):
     assert lib.kpx_version() == 100
     rc = lib.kpx_voxel_downsample(None, None, None, 10, C.c_double(0.0), None, None, None, None, None, 0, None)
