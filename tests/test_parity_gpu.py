@@ -1071,3 +1071,28 @@ def test_coloured_icp_api_mirrors(oracle):
     assert res.fitness > 0.9 and np.abs(res.transformation[:3, 3] - T[:3, 3]).max() < 8.0
     Tm = execute_colored_ICP_registration(a, b, np.eye(4))                                   # the reference's three-scale loop
     assert Tm.shape == (4, 4) and np.abs(Tm[:3, :3] - T[:3, :3]).max() < 2e-2
+
+
+def test_two_ranks_share_one_gpu(tmp_path):
+    """the N > 1 path on device tensors: two ranks (gloo, both on this GPU) run the frame pipeline with two frames in flight and
+    exchange every frame; each rank must end up with rank 0's cloud followed by rank 1's, moved into the global frame"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KPX_DIST_BACKEND="gloo", OUT_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29591", os.path.join(root, "tests", "dist_gpu_worker.py")], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(str(tmp_path / "rank0.npz")), np.load(str(tmp_path / "rank1.npz"))
+    for i in range(3):
+        assert np.array_equal(a[f"all_p{i}"], b[f"all_p{i}"]) and np.array_equal(a[f"all_c{i}"], b[f"all_c{i}"])
+        assert np.array_equal(a[f"all_T{i}"], b[f"all_T{i}"]) and a[f"counts{i}"].tolist() == b[f"counts{i}"].tolist()
+        n0, n1 = a[f"counts{i}"].tolist()
+        assert n0 == len(a[f"own_p{i}"]) and n1 == len(b[f"own_p{i}"]) and len(a[f"all_p{i}"]) == n0 + n1
+        for rank, own in ((0, a), (1, b)):
+            G = own["to_global"]
+            want = (own[f"own_p{i}"].astype(np.float64) @ G[:3, :3].T + G[:3, 3]).astype(np.float32)
+            part = a[f"all_p{i}"][:n0] if rank == 0 else a[f"all_p{i}"][n0:]
+            assert np.abs(part - want).max() < 1e-2
+            assert np.allclose(a[f"all_T{i}"][2 * rank:2 * rank + 2], np.stack([G @ T for T in own[f"own_T{i}"]]), atol=1e-12)
