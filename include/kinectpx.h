@@ -92,9 +92,16 @@ int kpx_rotate(const float *nrm, int64_t n, const double *h_T, float *out, void 
 int kpx_joints_affine_f64(const double *x, int64_t rows, const double *h_A, const double *h_t, double *out,
                           void *stream);
 
-/* select_by_index (floor_removal.py:50,69,71,72): gather of up to three (n,3) f32 attributes.
- * invert == 0: out[k] = in[idx[k]] for k < n_idx (idx taken in the given order).
- * invert != 0: ascending complement of idx; d_count receives its length. */
+/* select_by_index (floor_removal.py:50,69,71,72): selection of up to three (n,3) f32 attributes.
+ * [O3D] SelectByIndex marks the listed points in a mask and emits the marked (or, inverted, the unmarked) points in
+ * ascending original order: duplicates collapse, the order of the list does not matter.
+ * KPX_SELECT_GATHER (0): out[k] = in[idx[k]] for k < n_idx -- equal to Open3D for ascending duplicate-free lists (the
+ *                        keep lists / inlier lists this library produces, np.argwhere results), one gather, no count;
+ * KPX_SELECT_INVERT (1): ascending complement of idx; d_count receives its length;
+ * KPX_SELECT_MASK   (2): the mask semantics for arbitrary lists (unsorted, repeated); d_count receives the length. */
+#define KPX_SELECT_GATHER 0
+#define KPX_SELECT_INVERT 1
+#define KPX_SELECT_MASK 2
 size_t kpx_select_workspace_bytes(int64_t n);
 int kpx_select_by_index(const float *a0, const float *a1, const float *a2, int64_t n, const int32_t *idx,
                         int64_t n_idx, int32_t invert, float *o0, float *o1, float *o2, int32_t *d_count,

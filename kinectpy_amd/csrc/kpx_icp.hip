@@ -1587,9 +1587,13 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
             next_k[i] = 0;
             fin[i] = false;
         }
-        const auto t_start = std::chrono::steady_clock::now();
+        // "no progress" = no progress word advanced and nothing could be queued for `stall_limit` seconds (the clock restarts
+        // on every advance: the lanes first wait for whatever the caller already queued on `stream`, and a large batch runs long)
+        static const double stall_limit = [] { const char *e = getenv("KPX_ICP_STALL_SECONDS"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 60.0; }();
+        auto t_last = std::chrono::steady_clock::now();
         for (bool pending = true; pending && !rc;) {
             pending = false;
+            bool advanced = false;
             for (int i = 0; i < count; ++i) {
                 if (fin[i]) continue;
                 const unsigned long long w = __atomic_load_n(&h_progress[i], __ATOMIC_ACQUIRE);
@@ -1599,6 +1603,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                 hipStream_t ls = lanes[i % kBatchLanes];
                 const int last_k = fused ? max_iteration + 1 : max_iteration;               // the fused chain ends with an update-only launch
                 while (next_k[i] <= last_k && next_k[i] - seen < window) {
+                    advanced = true;
                     if (fused)
                         icp_fused_launch(h_src[i], tgt, tgt_normals, plans[i], bufs[i], md2, mode, next_k[i], max_iteration, relative_fitness,
                                          relative_rmse, d_results + 20 * i, ls, &h_progress[i], tag);
@@ -1610,7 +1615,12 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                 if (next_k[i] > last_k) { fin[i] = true; continue; }                        // everything is queued
                 pending = true;
             }
-            if (pending && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) rc = fail(KPX_ERR_HIP, "kpx_icp_batch: no progress");
+            if (advanced) t_last = std::chrono::steady_clock::now();
+            else if (pending) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > stall_limit)
+                    rc = fail(KPX_ERR_HIP, "kpx_icp_batch: no progress for %.0f s (KPX_ICP_STALL_SECONDS)", stall_limit);
+                __builtin_ia32_pause();
+            }
         }
         if (hipGetLastError() != hipSuccess && !rc) rc = fail(KPX_ERR_HIP, "kpx_icp_batch: launch failed");
     } else {

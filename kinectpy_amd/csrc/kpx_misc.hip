@@ -279,6 +279,10 @@ struct UnmarkedPred {
     const uint8_t *flag;
     __device__ bool operator()(int64_t i, int) const { return flag[i] == 0; }
 };
+struct MarkedPred {
+    const uint8_t *flag;
+    __device__ bool operator()(int64_t i, int) const { return flag[i] != 0; }
+};
 struct Gather3Emit {
     const float *a0, *a1, *a2; float *o0, *o1, *o2;
     __device__ void operator()(int64_t i, int, int32_t dst) const
@@ -419,13 +423,15 @@ KPX_EXPORT int kpx_select_by_index(const float *a0, const float *a1, const float
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
-    KPX_REQUIRE(ws && d_count, "kpx_select_by_index: invert needs workspace and d_count");
+    KPX_REQUIRE(invert == KPX_SELECT_INVERT || invert == KPX_SELECT_MASK, "kpx_select_by_index: unknown mode %d", invert);
+    KPX_REQUIRE(ws && d_count, "kpx_select_by_index: the mask modes need workspace and d_count");
     Arena a(ws, ws_bytes);
     uint8_t *flag = a.get<uint8_t>((size_t)(n > 0 ? n : 1));
     int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
     KPX_ARENA_CHECK(a);
     KPX_HIP(hipMemsetAsync(flag, 0, (size_t)(n > 0 ? n : 1), st));
     if (n_idx) hipLaunchKernelGGL(mark_kernel, dim3(grid_for(n_idx, 256)), dim3(256), 0, st, idx, n_idx, n, flag);
+    if (invert == KPX_SELECT_MASK) return compact(MarkedPred{ flag }, Gather3Emit{ a0, a1, a2, o0, o1, o2 }, n, 1, counts, d_count, st);
     return compact(UnmarkedPred{ flag }, Gather3Emit{ a0, a1, a2, o0, o1, o2 }, n, 1, counts, d_count, st);
 }
 

@@ -212,7 +212,7 @@ class PointCloud:
     def estimate_normals(self, search_param=None, fast_normal_computation=True):
         sp = search_param if search_param is not None else KDTreeSearchParamKNN()
         if self.has_points():
-            self._nrm = ops.estimate_normals(self._pts, sp.radius, min(sp.max_nn, 128))
+            self._nrm = ops.estimate_normals(self._pts, sp.radius, sp.max_nn)       # max_nn > 128: the library raises
         return self
 
     def get_oriented_bounding_box(self, robust=False):

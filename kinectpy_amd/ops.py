@@ -135,8 +135,10 @@ def joints_affine(x, A, t):
 
 def select_by_index(attrs, idx, invert=False, trusted=False):
     """attrs: list of up to three (n,3) f32 tensors (None allowed).  Returns list of selected tensors.
-    trusted=True skips the range check of idx (two reductions and a host sync): for index lists that come straight from
-    another operator of this library (the keep list of sor, the inliers of segment_plane)."""
+    [O3D] SelectByIndex has mask semantics: the result is in ascending original order without duplicates whatever the
+    order of idx.  trusted=True is for index lists that come straight from another operator of this library (the keep
+    list of sor, the inliers of segment_plane: ascending, duplicate-free, in range): it skips the range check (two
+    reductions and a host sync) and selects with one gather."""
     lib = L.load()
     attrs = list(attrs) + [None] * (3 - len(attrs))
     ref = next(a for a in attrs if a is not None)
@@ -147,14 +149,16 @@ def select_by_index(attrs, idx, invert=False, trusted=False):
         lo, hi = int(idx.min()), int(idx.max())
         if lo < 0 or hi >= n:
             raise L.KinectPxError("select_by_index: index out of range")
-    m = n if invert else k
+    # trusted lists are ascending and duplicate-free by construction: a plain gather equals Open3D's mask selection
+    mode = 1 if invert else (0 if trusted else 2)
+    m = n if mode else k
     outs = [torch.empty((m, 3), dtype=torch.float32, device=ref.device) if a is not None else None for a in attrs]
-    cnt = torch.zeros(1, dtype=torch.int32, device=ref.device) if invert else None
+    cnt = torch.zeros(1, dtype=torch.int32, device=ref.device) if mode else None
     ws, wsz = L.workspace(lib.kpx_select_workspace_bytes(n))
-    L.check(lib.kpx_select_by_index(L.ptr(attrs[0]), L.ptr(attrs[1]), L.ptr(attrs[2]), n, L.ptr(idx), k, int(invert),
+    L.check(lib.kpx_select_by_index(L.ptr(attrs[0]), L.ptr(attrs[1]), L.ptr(attrs[2]), n, L.ptr(idx), k, mode,
                                     L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(cnt), ws, wsz,
                                     L.stream_ptr()))
-    if invert:
+    if mode:
         m = _count(cnt)[0]
         outs = [o[:m] if o is not None else None for o in outs]
     return outs

@@ -118,8 +118,16 @@ class FrameStream:
         self.pending.append(self.pool.submit(self._run, stream, depth, rgb))
 
     def pop(self):
-        """-> (points, colours, transforms) of the oldest frame in flight"""
-        return self.pending.popleft().result()
+        """-> (points, colours, transforms) of the oldest frame in flight.  The tensors were allocated on the frame's side
+        stream: they are handed to the caller's current stream with record_stream(), so that the caching allocator does not
+        give their blocks back to the side stream (whose next frame would overwrite them) while kernels the caller queued
+        asynchronously are still reading them."""
+        out = self.pending.popleft().result()
+        cur = torch.cuda.current_stream(self.device)
+        for t in out:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
+        return out
 
     def close(self):
         while self.pending:

@@ -51,7 +51,7 @@ class MKVFilesProcessing(object):
                     return
                 xyz = ops.unproject_u16(np.stack(buf).reshape(-1), xy, len(buf)).cpu().numpy()
                 for ts, a in zip(stamps, xyz):
-                    if str(ts).startswith('0'):            # "0_*" files are empty frames (extractor.py:150-154)
+                    if f'{ts}_depth.dat'.startswith('0_'):  # "0_*" files (timestamp exactly 0) are empty frames (extractor.py:150-154)
                         continue
                     a.tofile(os.path.join(output_dir, 'depths', f'{ts}_depth.dat'))
                 stamps.clear(); buf.clear()

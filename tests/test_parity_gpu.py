@@ -157,8 +157,13 @@ def test_select_halfspace_slab(ops, oracle, base_cloud):
     pc = PointCloud(base_cloud)
     pc.colors = rng.random(base_cloud.shape)
     col32 = npy(pc._col)
-    sel = pc.select_by_index(idx.reshape(-1, 1))                     # (K,1) argwhere-style
-    assert np.array_equal(npy(sel._pts), base_cloud[idx]) and np.array_equal(npy(sel._col), col32[idx])
+    # [O3D] SelectByIndex has mask semantics: ascending original order, duplicates collapse, whatever the list's order
+    sel = pc.select_by_index(idx.reshape(-1, 1))                     # (K,1) argwhere-style, here unsorted
+    srt = np.sort(idx)
+    assert np.array_equal(npy(sel._pts), base_cloud[srt]) and np.array_equal(npy(sel._col), col32[srt])
+    dup = pc.select_by_index(np.concatenate([idx, idx[:100], idx[::-1]]))
+    assert np.array_equal(npy(dup._pts), base_cloud[srt]) and np.array_equal(npy(dup._col), col32[srt])
+    assert np.array_equal(npy(ops.select_by_index([pc._pts], srt, trusted=True)[0]), base_cloud[srt])   # the one-gather path
     inv = pc.select_by_index(idx, invert=True)
     m = np.ones(len(base_cloud), bool)
     m[idx] = False
@@ -785,12 +790,15 @@ def test_extract_writes_dat_files(tmp_path, oracle):
     from kinectpy_amd.preprocessing.extractor import MKVFilesProcessing
     from kinectpy_amd.utils.io import load_depth
     xy = synth.xy_table()
+    # timestamps: ordinary, zero-padded ("0123": kept -- only the NAME "0_..." marks an empty frame, extractor.py:150-154), and 0
     frames = [(1000 + 33 * i, synth.render_depth(seed=i, xy=xy)) for i in range(3)]
+    frames += [("0123", synth.render_depth(seed=7, xy=xy)), (0, synth.render_depth(seed=8, xy=xy))]
     m = MKVFilesProcessing(["a.mkv"], [str(tmp_path / "master_1")], frame_source=lambda fp: (xy, iter(frames)))
     m.extract(pointcloud=True, batch=2)
-    for ts, d in frames:
+    for ts, d in frames[:4]:
         got = load_depth(str(tmp_path / "master_1" / "depths" / str(ts)))
         assert np.array_equal(got, oracle.unproject_u16(d, xy))
+    assert not (tmp_path / "master_1" / "depths" / "0_depth.dat").exists()
 
 
 # ----------------------------------------------------------------------------- BASELINE.json full sizes
