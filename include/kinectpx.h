@@ -144,6 +144,19 @@ size_t kpx_sor_workspace_bytes(int64_t n, int32_t nb_neighbors);
 int kpx_sor(const float *pts, int64_t n, int32_t nb_neighbors, double std_ratio, int32_t *keep_idx,
             int32_t *d_count, double *d_stats, double *d_avg, void *ws, size_t ws_bytes, void *stream);
 
+/* The same filter sharded over GPUs (the fused-cloud filter_outliers of preprocessing/data.py:61 when every GPU holds the
+ * fused cloud): the grid order of the cloud is the same on every GPU, each searches only the queries at
+ * cell-sorted positions [q_begin, q_end) -- a spatial slab -- and writes their mean distances, in that order, to
+ * d_avg_sorted f64 [q_end - q_begin]; d_order i32 [n] (optional) receives the cell-sorted position -> point index map.
+ * After the slabs have been exchanged (one all-gather), kpx_sor_finish(avg of all n positions, d_order) computes mean / std /
+ * threshold and the ascending keep list with the same kernels and the same reduction order as kpx_sor: the result is
+ * bit-identical to the one-GPU call.  Workspace of kpx_sor_partial: kpx_sor_workspace_bytes(n, nb_neighbors). */
+int kpx_sor_partial(const float *pts, int64_t n, int32_t nb_neighbors, int64_t q_begin, int64_t q_end, double *d_avg_sorted,
+                    int32_t *d_order, void *ws, size_t ws_bytes, void *stream);
+size_t kpx_sor_finish_workspace_bytes(int64_t n);
+int kpx_sor_finish(const double *d_avg_sorted, const int32_t *d_order, int64_t n, double std_ratio, int32_t *keep_idx,
+                   int32_t *d_count, double *d_stats, double *d_avg, void *ws, size_t ws_bytes, void *stream);
+
 /* estimate_normals(KDTreeSearchParamHybrid(radius, max_nn)) (preprocessing/registration.py:9-13):
  * neighbours = up to max_nn nearest with d2 < radius^2; < 3 neighbours -> (0,0,1); else the
  * eigenvector of the smallest eigenvalue of the neighbourhood covariance.  max_nn <= 128. */

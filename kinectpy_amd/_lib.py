@@ -39,6 +39,9 @@ SIGNATURES = {
     "kpx_voxel_downsample_batch": (C.c_int, [_i32, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_sor_workspace_bytes": (_sz, [_i64, _i32]),
     "kpx_sor": (C.c_int, [_vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_sor_partial": (C.c_int, [_vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_sor_finish_workspace_bytes": (_sz, [_i64]),
+    "kpx_sor_finish": (C.c_int, [_vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_normals_workspace_bytes": (_sz, [_i64, _i32]),
     "kpx_estimate_normals": (C.c_int, [_vp, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
     "kpx_segment_plane_workspace_bytes": (_sz, [_i64, _i32, _i32]),

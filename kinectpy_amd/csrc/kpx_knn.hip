@@ -158,19 +158,21 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
                                                               const float *__restrict__ spts, const int32_t *__restrict__ sidx,
-                                                              int64_t n, int k, int cap, double *__restrict__ avg,
+                                                              int64_t q0, int64_t q1, int k, int cap, double *__restrict__ avg,
                                                               const int32_t *__restrict__ in_list, const int32_t *__restrict__ in_count,
                                                               int32_t *__restrict__ fb_list, int32_t *__restrict__ fb_count)
 {
+    // queries = the cell-sorted positions [q0, q1) (all of them: 0, n; a slab of the grid order for kpx_sor_partial).
+    // sidx != NULL: avg is indexed by the caller's point index; sidx == NULL: by sorted position relative to q0.
     extern __shared__ __align__(16) double lds[];
     __shared__ uint32_t run_s0[WAVES][64];
     __shared__ int32_t run_off[WAVES][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const WaveKnnScratch sc{ lds + (size_t)wave * cap, nullptr, run_s0[wave], run_off[wave], cap };
     const GridParams g = *gp;
-    const int64_t nq = in_list ? (int64_t)*in_count : n;         // in_list: the queries an earlier pass could not hold
+    const int64_t nq = in_list ? (int64_t)*in_count : q1 - q0;   // in_list: the queries an earlier pass could not hold
     for (int64_t e = (int64_t)blockIdx.x * WAVES + wave; e < nq; e += (int64_t)gridDim.x * WAVES) {
-        const int64_t s = in_list ? (int64_t)in_list[e] : e;
+        const int64_t s = in_list ? (int64_t)in_list[e] : q0 + e;
         const double q[3] = { (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2] };
         WaveKnnResult res;
         if (!wave_knn_select<false>(g, cell_start, spts, q, k, INFINITY, sc, res)) {
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         const double total = sum - (double)(res.cnt - res.kk) * sqrt(res.top);      // ties beyond the k-th slot
-        if (lane == 0) avg[sidx[s]] = res.kk > 0 ? total / (double)res.kk : -1.0;
+        if (lane == 0) avg[sidx ? (int64_t)sidx[s] : s - q0] = res.kk > 0 ? total / (double)res.kk : -1.0;
         wave_lds_fence();
     }
 }
@@ -193,20 +195,20 @@ __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *
 // Exact ring walk, one thread per query (queries in cell order: neighbouring threads walk neighbouring cells).
 // list != NULL: only the queries list[0 .. *list_count) (the wave kernel's overflow list).
 __global__ void sor_knn_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
-                               const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t n, int k,
+                               const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t q0, int64_t q1, int k,
                                double *__restrict__ avg, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count)
 {
     extern __shared__ __align__(16) double lds[];
     const GridParams g = *gp;
-    const int64_t total = list ? (int64_t)*list_count : n;
+    const int64_t total = list ? (int64_t)*list_count : q1 - q0;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = list ? (int64_t)list[t] : t;
+        const int64_t s = list ? (int64_t)list[t] : q0 + t;
         HeapD heap{ lds + threadIdx.x, (int)blockDim.x, k, 0 };
         grid_knn_scan(g, cell_start, spts, (const int32_t *)nullptr, (double)spts[3 * s], (double)spts[3 * s + 1],
                       (double)spts[3 * s + 2], -1.0, heap);
         double sum = 0.0;
         for (int e = 0; e < heap.sz; ++e) sum += sqrt(heap.h[e * heap.stride]);
-        avg[sidx[s]] = heap.sz > 0 ? sum / (double)heap.sz : -1.0;
+        avg[sidx ? (int64_t)sidx[s] : s - q0] = heap.sz > 0 ? sum / (double)heap.sz : -1.0;
     }
 }
 
@@ -248,10 +250,33 @@ static int sor_block_threads(int k)
     return 64;
 }
 
+// statistics over avg (caller's point order) + ascending keep list -- shared by kpx_sor and kpx_sor_finish, so that the
+// sharded filter folds the very same reduction tree over the very same array as the one-GPU call
+static int sor_stats_compact(const double *avg, int64_t n, double std_ratio, double *part, int32_t *counts, int32_t *keep_idx,
+                             int32_t *d_count, double *d_stats, hipStream_t st)
+{
+    int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(sor_sum_kernel, dim3(nb), dim3(256), 0, st, avg, n, d_stats, pass, part);
+        hipLaunchKernelGGL(sor_final_kernel, dim3(1), dim3(1), 0, st, part, nb, n, std_ratio, pass, d_stats);
+    }
+    KPX_LAUNCH_CHECK();
+    return compact(SorPred{ avg, d_stats }, IdxEmit{ keep_idx }, n, 1, counts, d_count, st);
+}
+
+__global__ __launch_bounds__(256) void sor_unsort_kernel(const double *__restrict__ avg_sorted, const int32_t *__restrict__ order, int64_t n,
+                                                         double *__restrict__ avg)
+{
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) avg[order[s]] = avg_sorted[s];
+}
+
+// q0 <= q1: only the queries at cell-sorted positions [q0, q1) are searched (kpx_sor_partial: avg_out is indexed by sorted
+// position - q0 and the statistics / keep list are skipped); full == true: the whole filter (kpx_sor)
 static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_t *keep_idx, int32_t *d_count, double *d_stats,
-                    double *d_avg, Arena &a, hipStream_t st)
+                    double *d_avg, Arena &a, hipStream_t st, bool full = true, int64_t q0 = 0, int64_t q1 = 0, int32_t *d_order = nullptr)
 {
     Grid g;
+    if (full) { q0 = 0; q1 = n; }
     int kk = (int64_t)k < n ? k : (int)(n > 0 ? n : 1);
     // cell occupancy (as seen by a point) ~0.4 k: the 27-cell block then holds ~10 k candidates and usually covers the
     // k-th neighbour
@@ -267,6 +292,8 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     if (d_avg) avg = d_avg;
+    const int32_t *out_idx = full ? g.sorted_idx : nullptr;
+    const int64_t nq = q1 - q0;
     int32_t *fb_count = fb_list + (n > 0 ? n : 1), *fb_count2 = fb_list2 + (n > 0 ? n : 1);
     const int threads = sor_block_threads(kk);
     const size_t lds = (size_t)kk * threads * sizeof(double);
@@ -284,22 +311,22 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
         const int32_t *none = nullptr;
         // pass 1: every query, 1024-candidate buffer (k <= KPX_SOR_MAX_K = 288 < 1024; many waves per CU)
         const int cap1 = kk <= 32 ? 512 : 1024;               // small k: smaller buffers, more waves per CU
-        hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256), (size_t)4 * cap1 * 8, st,
-                           g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk, cap1, avg, none, none, fb_list, fb_count);
+        if (nq > 0)
+            hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(nq, 4) > 8192 ? 8192 : cdiv(nq, 4))), dim3(256), (size_t)4 * cap1 * 8, st,
+                               g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk, cap1, avg, none, none, fb_list, fb_count);
         // pass 2: the queries whose block did not fit (isolated points next to a dense sheet), 8192-candidate buffer
         hipLaunchKernelGGL(sor_wave_kernel<1>, dim3(2048), dim3(64), (size_t)8192 * 8, st, g.params, g.cell_start, g.sorted_pts,
-                           g.sorted_idx, n, kk, 8192, avg, fb_list, fb_count, fb_list2, fb_count2);
+                           out_idx, q0, q1, kk, 8192, avg, fb_list, fb_count, fb_list2, fb_count2);
         // pass 3: whatever is left: thread-per-query ring walk with a k-heap
-        hipLaunchKernelGGL(sor_knn_kernel, dim3(256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk,
+        hipLaunchKernelGGL(sor_knn_kernel, dim3(256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk,
                            avg, fb_list2, fb_count2);
     }
-    int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
-    for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(sor_sum_kernel, dim3(nb), dim3(256), 0, st, avg, n, d_stats, pass, part);
-        hipLaunchKernelGGL(sor_final_kernel, dim3(1), dim3(1), 0, st, part, nb, n, std_ratio, pass, d_stats);
+    if (!full) {
+        if (d_order) KPX_HIP(hipMemcpyAsync(d_order, g.sorted_idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
     }
-    KPX_LAUNCH_CHECK();
-    return compact(SorPred{ avg, d_stats }, IdxEmit{ keep_idx }, n, 1, counts, d_count, st);
+    return sor_stats_compact(avg, n, std_ratio, part, counts, keep_idx, d_count, d_stats, st);
 }
 
 // ---- estimate_normals ---------------------------------------------------------------------------------
@@ -470,6 +497,42 @@ KPX_EXPORT int kpx_sor(const float *pts, int64_t n, int32_t nb_neighbors, double
     KPX_REQUIRE(pts && keep_idx, "kpx_sor: null pointer");
     Arena a(ws, ws_bytes);
     return sor_impl(pts, n, nb_neighbors, std_ratio, keep_idx, d_count, d_stats, d_avg, a, st);
+}
+
+KPX_EXPORT int kpx_sor_partial(const float *pts, int64_t n, int32_t nb_neighbors, int64_t q_begin, int64_t q_end, double *d_avg_sorted,
+                               int32_t *d_order, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(nb_neighbors >= 1, "remove_statistical_outlier: nb_neighbors and std_ratio must be positive");
+    KPX_REQUIRE(nb_neighbors <= KPX_SOR_MAX_K, "remove_statistical_outlier: nb_neighbors > %d is not supported", KPX_SOR_MAX_K);
+    KPX_REQUIRE(n >= 1 && n < ((int64_t)1 << 31), "kpx_sor_partial: bad size");
+    KPX_REQUIRE(q_begin >= 0 && q_begin <= q_end && q_end <= n, "kpx_sor_partial: bad query range");
+    KPX_REQUIRE(pts && ws && (d_avg_sorted || q_begin == q_end), "kpx_sor_partial: null pointer");
+    Arena a(ws, ws_bytes);
+    return sor_impl(pts, n, nb_neighbors, 1.0, nullptr, nullptr, nullptr, d_avg_sorted, a, (hipStream_t)stream, false, q_begin, q_end, d_order);
+}
+KPX_EXPORT size_t kpx_sor_finish_workspace_bytes(int64_t n)
+{
+    Arena a(nullptr, 0);
+    a.get<double>((size_t)(n > 0 ? n : 1));
+    a.get<double>(1024);
+    a.get<int32_t>((size_t)compact_tiles(n));
+    return a.off;
+}
+KPX_EXPORT int kpx_sor_finish(const double *d_avg_sorted, const int32_t *d_order, int64_t n, double std_ratio, int32_t *keep_idx,
+                              int32_t *d_count, double *d_stats, double *d_avg, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(std_ratio > 0.0, "remove_statistical_outlier: nb_neighbors and std_ratio must be positive");
+    KPX_REQUIRE(n >= 1 && n < ((int64_t)1 << 31), "kpx_sor_finish: bad size");
+    KPX_REQUIRE(d_avg_sorted && d_order && keep_idx && d_count && d_stats && ws, "kpx_sor_finish: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    double *avg = a.get<double>((size_t)n);
+    double *part = a.get<double>(1024);
+    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    KPX_ARENA_CHECK(a);
+    if (d_avg) avg = d_avg;
+    hipLaunchKernelGGL(sor_unsort_kernel, dim3((unsigned)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256))), dim3(256), 0, st, d_avg_sorted, d_order, n, avg);
+    return sor_stats_compact(avg, n, std_ratio, part, counts, keep_idx, d_count, d_stats, st);
 }
 
 KPX_EXPORT size_t kpx_normals_workspace_bytes(int64_t n, int32_t max_nn)

@@ -248,6 +248,39 @@ def sor(pts, nb_neighbors, std_ratio, want_avg=False):
     return idx[:k], stats, (avg[:n] if avg is not None else None)
 
 
+def sor_partial(pts, nb_neighbors, q_begin, q_end, want_order=True):
+    """Sharded a8, first half: mean kNN distances of the queries at cell-sorted positions [q_begin, q_end) of the cloud's
+    grid order -> (avg f64 (q_end - q_begin) in that order, order i32 (N) sorted position -> point index | None)."""
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    avg = torch.empty(max(int(q_end - q_begin), 1), dtype=torch.float64, device=pts.device)
+    order = torch.empty(n, dtype=torch.int32, device=pts.device) if want_order else None
+    ws, wsz = L.workspace(lib.kpx_sor_workspace_bytes(n, int(nb_neighbors)))
+    L.check(lib.kpx_sor_partial(L.ptr(pts), n, int(nb_neighbors), int(q_begin), int(q_end), L.ptr(avg), L.ptr(order), ws, wsz,
+                                L.stream_ptr()))
+    return avg[: int(q_end - q_begin)], order
+
+
+def sor_finish(avg_sorted, order, std_ratio, want_avg=False):
+    """Sharded a8, second half: the slabs' mean distances (all N, grid order) -> keep_idx, stats, avg | None as sor()."""
+    lib = L.load()
+    avg_sorted = _dev(avg_sorted, torch.float64).reshape(-1)
+    order = _dev(order, torch.int32).reshape(-1)
+    n = order.numel()
+    assert avg_sorted.numel() == n
+    dev = order.device
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    avg = torch.empty(n, dtype=torch.float64, device=dev) if want_avg else None
+    ws, wsz = L.workspace(lib.kpx_sor_finish_workspace_bytes(n))
+    L.check(lib.kpx_sor_finish(L.ptr(avg_sorted), L.ptr(order), n, float(std_ratio), L.ptr(idx), L.ptr(cnt), L.ptr(stats), L.ptr(avg),
+                               ws, wsz, L.stream_ptr()))
+    k = _count(cnt)[0]
+    return idx[:k], stats, avg
+
+
 def estimate_normals(pts, radius, max_nn):
     lib = L.load()
     pts = _dev(pts, torch.float32).reshape(-1, 3)

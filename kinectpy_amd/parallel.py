@@ -39,8 +39,16 @@ def shard_sensors(n_sensors: int, rank: int, world: int) -> List[int]:
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
-def world_size() -> int:
-    return dist.get_world_size() if dist.is_initialized() else 1
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def new_group():
+    """another communicator over all ranks (one per frame slot of pipeline.FrameStream: collectives of different frames in
+    flight must not share a communicator, their issue order differs between ranks); None on a single rank"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    return dist.new_group(ranks=list(range(dist.get_world_size())), backend=dist.get_backend())
 
 
 def _all_gather(t: torch.Tensor):
@@ -61,25 +69,41 @@ def allgather_header(header: torch.Tensor) -> torch.Tensor:
     return torch.stack(_all_gather(header))
 
 
-def _all_gather_flat(t: torch.Tensor) -> torch.Tensor:
+def _all_gather_flat(t: torch.Tensor, group=None) -> torch.Tensor:
     """(...)-> (world, ...) with one all_gather_into_tensor (host-staged under gloo when the tensor is on a GPU)"""
-    w = world_size()
-    if dist.get_backend() == "gloo" and t.is_cuda:
+    w = world_size(group)
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
         out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype)
         try:
-            dist.all_gather_into_tensor(out, t.cpu().contiguous())
+            dist.all_gather_into_tensor(out, t.cpu().contiguous(), group=group)
         except (RuntimeError, NotImplementedError):
-            out = torch.stack(_all_gather(t.cpu()))
+            parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(w)]
+            dist.all_gather(parts, t.cpu().contiguous(), group=group)
+            out = torch.stack(parts)
         return out.to(t.device)
     out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     try:
-        dist.all_gather_into_tensor(out, t.contiguous())
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
     except (RuntimeError, NotImplementedError):
-        out = torch.stack(_all_gather(t))
+        parts = [torch.empty_like(t) for _ in range(w)]
+        dist.all_gather(parts, t.contiguous(), group=group)
+        out = torch.stack(parts)
     return out
 
 
-def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor, always_collective: bool = False):
+def _broadcast(t: torch.Tensor, src: int, group=None) -> torch.Tensor:
+    """in-place broadcast from global rank `src` (host-staged under gloo when the tensor is on a GPU)"""
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src, group=group)
+        if dist.get_rank() != src:
+            t.copy_(h)
+        return t
+    dist.broadcast(t, src, group=group)
+    return t
+
+
+def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor, always_collective: bool = False, group=None):
     """padded: (cap, C) float32 buffer whose first min(count, cap) rows are valid (same cap on every rank; `count` may
     exceed it: the header carries the true count so that the caller can resend with room);
     transforms: (k, 4, 4) float64 of this rank's sensors (same k on every rank).
@@ -88,7 +112,8 @@ def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor,
     `always_collective` runs the collective on a one-rank group too (the single-GPU RCCL test)."""
     k = transforms.shape[0]
     hdr = torch.cat([torch.tensor([float(count)], dtype=torch.float64), transforms.reshape(-1).to("cpu", torch.float64)])
-    if world_size() == 1 and not (always_collective and dist.is_initialized()):
+    W = world_size(group)
+    if W == 1 and not (always_collective and dist.is_initialized()):
         return padded[:min(count, padded.shape[0])], hdr[1:].reshape(-1, 4, 4).to(padded.device), [int(count)]
     cap, C = padded.shape
     words = hdr.numel() * 2                                     # float32 words carrying the float64 header
@@ -98,12 +123,12 @@ def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor,
     tail = torch.zeros(hrows * C, dtype=torch.float32)
     tail[:words] = hdr.view(torch.float32)
     msg[cap:] = tail.reshape(hrows, C).to(padded.device, non_blocking=True)
-    allm = _all_gather_flat(msg)                                # (world, cap + hrows, C)
-    hdrs = allm[:, cap:].reshape(world_size(), -1)[:, :words].contiguous().cpu().view(torch.float64)   # one read-back
+    allm = _all_gather_flat(msg, group)                         # (world, cap + hrows, C)
+    hdrs = allm[:, cap:].reshape(W, -1)[:, :words].contiguous().cpu().view(torch.float64)   # one read-back
     counts = [int(c) for c in hdrs[:, 0].tolist()]
     all_T = hdrs[:, 1:].reshape(-1, 4, 4).to(padded.device)
     cloud = torch.cat([allm[r, :min(c, cap)] for r, c in enumerate(counts)], 0)
-    assert all_T.shape[0] == k * world_size()
+    assert all_T.shape[0] == k * W
     return cloud, all_T, counts
 
 
@@ -112,10 +137,11 @@ class CloudExchange:
     counts every rank saw in the previous frame (+25 %, rounded to 4096: the same value on all ranks); a frame that
     outgrows it is detected from the gathered header (which carries the true counts) and sent again with room."""
 
-    def __init__(self, initial_rows: int):
+    def __init__(self, initial_rows: int, group=None):
         if initial_rows <= 0:
             raise ValueError("cloud_capacity must be set for multi-GPU exchange")
         self.cap = int(initial_rows)
+        self.group = group
 
     def __call__(self, pts: torch.Tensor, col: torch.Tensor, transforms: torch.Tensor):
         n = int(pts.shape[0])
@@ -125,11 +151,70 @@ class CloudExchange:
             k = min(n, cap)
             buf[:k, :3] = pts[:k]
             buf[:k, 3:] = col[:k]
-            cloud, all_T, counts = allgather_clouds(buf, n, transforms)
+            cloud, all_T, counts = allgather_clouds(buf, n, transforms, group=self.group)
             need = max(counts)
             self.cap = max(4096, -(-int(need * 1.25) // 4096) * 4096)      # every rank sees the same counts
             if need <= cap:
                 return cloud[:, :3], cloud[:, 3:], all_T, counts
+
+
+class MasterBroadcast:
+    """Calibration broadcast of the north-star partition (preprocessing/data.py:140-157 registers every sub device
+    onto the master's cloud): rank 0 sends the master's down-sampled cloud and its normals, ONE collective per calibration.
+    The message has `cap` rows of 6 floats (xyz | normal) plus one header row carrying the true count as float64 bits;
+    `cap` follows the last count seen (+25 %, rounded to 4096, the same on all ranks); a cloud that outgrows it is detected
+    from the header by every rank and sent again with room."""
+
+    def __init__(self, initial_rows: int, group=None, src: int = 0):
+        self.cap = max(4096, int(initial_rows))
+        self.group, self.src = group, src
+
+    def __call__(self, pts, nrm, device=None):
+        """rank src: pts (n,3), nrm (n,3) | None; other ranks: None, None (+ device) -> (pts, nrm | None) on every rank"""
+        if world_size(self.group) == 1:
+            return pts, nrm
+        me = dist.get_rank()
+        if me == self.src:
+            device = pts.device
+        while True:
+            cap = self.cap
+            msg = torch.empty((cap + 1, 6), dtype=torch.float32, device=device)
+            if me == self.src:
+                n = int(pts.shape[0])
+                k = min(n, cap)
+                msg[:k, :3] = pts[:k]
+                if nrm is not None:
+                    msg[:k, 3:] = nrm[:k]
+                hdr = torch.tensor([float(n), 1.0 if nrm is not None else 0.0], dtype=torch.float64).view(torch.float32)   # 4 words
+                msg[cap, :4] = hdr.to(device)
+            _broadcast(msg, self.src, self.group)
+            h = msg[cap, :4].cpu().view(torch.float64)                       # one read-back: the receivers need n on the host anyway
+            n, has_n = int(h[0]), bool(h[1])
+            self.cap = max(4096, -(-int(n * 1.25) // 4096) * 4096)
+            if n <= cap:
+                if me == self.src:
+                    return pts, nrm
+                return msg[:n, :3].contiguous(), (msg[:n, 3:].contiguous() if has_n else None)
+
+
+def allgather_slabs(part: torch.Tensor, rows: int, group=None) -> torch.Tensor:
+    """part: this rank's 1-D slab, at most `rows` long (the same `rows` on every rank) -> (world, rows) after one all-gather
+    (the tail of a short slab is padding).  Used by the sharded fused filter for the per-slab mean kNN distances."""
+    buf = torch.zeros(rows, dtype=part.dtype, device=part.device)
+    buf[: part.numel()] = part
+    if world_size(group) == 1:
+        return buf[None]
+    return _all_gather_flat(buf, group)
+
+
+def warm(group, device):
+    """create the communicator of `group` now, from the calling thread (a tiny all-reduce): the frame slots use their
+    groups from worker threads, and every rank has to build its communicators in the same order"""
+    if dist.is_initialized() and world_size(group) > 1:
+        t = torch.zeros(1, dtype=torch.float32, device="cpu" if dist.get_backend(group) == "gloo" else device)
+        dist.all_reduce(t, group=group)
+        if t.is_cuda:
+            torch.cuda.synchronize()
 
 
 def barrier():

@@ -86,24 +86,160 @@ class SensorGroupPipeline:
         return self._xchg(gp, out_c, comp)
 
 
+class SensorShardPipeline:
+    """The north-star partition of the reference's DataProcessor across GPUs (BASELINE.json configs[3] / [4]):
+    sensor g lives on GPU g (with fewer GPUs than sensors a rank owns a contiguous block of them, same code path).
+
+    calibration (preprocessing/data.py:127-161 -- the master's cloud is the target of every sub device's registration):
+        every rank   depth -> full cloud -> voxel_down_sample(35) of its own sensors
+        rank 0       + normals of the master's down-sampled cloud, then ONE broadcast of (cloud, normals)
+        every rank   execute_point_to_plane_registration of its own sub sensors onto the master cloud (kpx_icp_batch)
+    per frame (data.py:35-61):
+        every rank   depth + person mask -> masked, gated clouds of its sensors; pcd.transform(T_i) for the subs
+                     ONE all-gather of the transformed clouds, in sensor order (= np.vstack of data.py:55-58), with the
+                     4x4 transforms and the counts in the header rows
+        filter_outliers on the FUSED cloud (data.py:61), `fused_filter`:
+          "rank0"    rank 0 filters alone (the others return None and go on with the next frame);
+          "sharded"  every rank down-samples the fused cloud (cheap, identical everywhere), searches the k neighbours of its
+                     own slab of the grid order only (kpx_sor_partial), ONE all-gather of the slabs' mean distances
+                     (8 B per point), then the statistics and the keep list with the one-GPU kernels (kpx_sor_finish): the
+                     result is on every rank and bit-identical to the single-GPU filter.
+
+    step() = calibration + frame (the bench's unit: unproject + filter + ICP).  `ops_module` is the operator namespace
+    (kinectpy_amd.ops; the CPU rehearsal of the multi-rank logic in tests/ injects its own)."""
+
+    def __init__(self, xy_table, n_sensors: int, init_transforms: List[np.ndarray], params: Optional[PipelineParams] = None,
+                 group=None, fused_filter: str = "sharded", cloud_capacity: int = 64 * 1024, ops_module=None, rank=None, world=None):
+        self.ops = ops_module or ops
+        self.p = params or PipelineParams()
+        self.group = group
+        self.world = parallel.world_size(group) if world is None else world
+        self.rank = (torch.distributed.get_rank() if self.world > 1 else 0) if rank is None else rank
+        self.n_sensors = int(n_sensors)
+        if self.world > self.n_sensors:
+            raise ValueError(f"{self.world} ranks for {self.n_sensors} sensors: a rank needs at least one sensor")
+        self.sensors = parallel.shard_sensors(self.n_sensors, self.rank, self.world)     # contiguous: rank order = sensor order
+        self.k_max = -(-self.n_sensors // self.world)                                  # transforms per rank in the exchange header
+        if len(init_transforms) != self.n_sensors - 1:
+            raise ValueError("init_transforms: one 4x4 per sub sensor (sensors 1 .. n-1)")
+        self.init = [np.asarray(T, dtype=np.float64) for T in init_transforms]
+        if fused_filter not in ("rank0", "sharded"):
+            raise ValueError("fused_filter must be 'rank0' or 'sharded'")
+        self.fused_filter = fused_filter
+        self.xy = self.ops._dev(xy_table, torch.float32).reshape(-1)
+        self._bcast = parallel.MasterBroadcast(cloud_capacity, group)
+        self._xchg = parallel.CloudExchange(max(4096, cloud_capacity * self.k_max), group)     # the same on every rank
+        self.transforms = None            # (len(self.sensors), 4, 4) sub -> master of the sensors this rank owns
+        self.last = {}
+
+    # -- calibration ------------------------------------------------------------------------------------------------
+    def calibrate(self, depth: torch.Tensor):
+        """depth (S_local, n_px) u16 of this rank's sensors -> transforms (S_local, 4, 4) f64 (identity for the master)"""
+        return self._calibrate(depth, None)[0]
+
+    def _calibrate(self, depth, queue_next):
+        o, p = self.ops, self.p
+        S = depth.shape[0]
+        assert S == len(self.sensors)
+        fp, _, _, fcnt = o.depth_to_cloud(depth, self.xy, None, S, False, False, sync=False)
+        nxt = queue_next() if queue_next is not None else None     # queued behind the extraction, before the first read-back
+        fk = o._count(fcnt)
+        downs = [d[0] for d in o.voxel_downsample_batch([fp[i, :fk[i]] for i in range(S)], p.reg_voxel)]
+        owns_master = self.sensors[0] == 0
+        master = downs[0] if owns_master else None
+        tn = o.estimate_normals(master, 2.0 * p.reg_voxel, p.normals_nn) if (owns_master and p.icp_mode == "p2plane") else None
+        master, tn = self._bcast(master, tn, device=fp.device)                          # collective 1 (world > 1)
+        subs = downs[1:] if owns_master else downs
+        ids = [g for g in self.sensors if g != 0]
+        Ts = [np.eye(4)] if owns_master else []
+        stats = []
+        if subs:
+            rs = o.icp_batch(subs, master, p.icp_max_dist, [self.init[g - 1] for g in ids], p.icp_mode, tn, p.icp_max_iteration)
+            for r in rs:
+                Ts.append(r["transformation"])
+                stats.append((r["iterations"], r["fitness"], r["inlier_rmse"]))
+        self.transforms = np.stack(Ts)
+        self.last = {"icp": stats, "n_down": [int(d.shape[0]) for d in downs], "n_master": int(master.shape[0])}
+        return self.transforms, nxt
+
+    # -- frame --------------------------------------------------------------------------------------------------------
+    def fuse(self, depth: torch.Tensor, rgb: torch.Tensor, extracted=None):
+        """depth (S_local, n_px) u16, rgb (S_local, n_px, 3) u8 -> (points, colours, transforms (n_sensors, 4, 4)) of the
+        fused, filtered frame; points / colours are None on ranks > 0 with fused_filter == "rank0"."""
+        o, p = self.ops, self.p
+        if self.transforms is None:
+            raise RuntimeError("calibrate() first (or load transforms)")
+        S = depth.shape[0]
+        mp, mc, _, mcnt = extracted if extracted is not None else o.depth_to_cloud(depth, self.xy, rgb, S, True, True, gate=p.gate, sync=False)
+        mk = o._count(mcnt)
+        pts, cols = [], []
+        for i, g in enumerate(self.sensors):
+            q = mp[i, :mk[i]]
+            pts.append(q if g == 0 else o.transform(q, self.transforms[i]))
+            cols.append(mc[i, :mk[i]])
+        loc_p = pts[0] if S == 1 else torch.cat(pts, 0)
+        loc_c = cols[0] if S == 1 else torch.cat(cols, 0)
+        Tpad = np.stack(list(self.transforms) + [np.eye(4)] * (self.k_max - S))
+        if self.world > 1:                                                                # collective 2
+            fused_p, fused_c, all_T, counts = self._xchg(loc_p, loc_c, torch.as_tensor(Tpad))
+            all_T = all_T.cpu().numpy().reshape(self.world, self.k_max, 4, 4)
+            Ts = np.concatenate([all_T[r, :len(parallel.shard_sensors(self.n_sensors, r, self.world))] for r in range(self.world)])
+            fused_p, fused_c = fused_p.contiguous(), fused_c.contiguous()
+        else:
+            fused_p, fused_c, Ts, counts = loc_p, loc_c, self.transforms, [int(loc_p.shape[0])]
+        self.last.update(n_masked=[int(k) for k in mk], n_fused=int(fused_p.shape[0]), counts=counts)
+        if self.world > 1 and self.fused_filter == "rank0" and self.rank != 0:
+            return None, None, Ts
+        vp, vc, _ = o.voxel_downsample(fused_p, p.filt_voxel, fused_c)
+        M = int(vp.shape[0])
+        if self.world > 1 and self.fused_filter == "sharded" and M > 0:
+            rows = -(-M // self.world)                                                    # slab r = grid-order positions [r rows, (r+1) rows)
+            q0, q1 = min(M, self.rank * rows), min(M, (self.rank + 1) * rows)
+            part, order = o.sor_partial(vp, p.filt_k, q0, q1)
+            slabs = parallel.allgather_slabs(part, rows, self.group)                       # collective 3
+            keep, _, _ = o.sor_finish(slabs.reshape(-1)[:M], order, p.filt_ratio)
+        else:
+            keep, _, _ = o.sor(vp, p.filt_k, p.filt_ratio)
+        out_p, out_c, _ = o.select_by_index([vp, vc], keep, trusted=True)
+        self.last.update(n_voxel=M, n_out=int(out_p.shape[0]))
+        return out_p, out_c, Ts
+
+    def step(self, depth: torch.Tensor, rgb: torch.Tensor):
+        """calibration + frame on the same depth images (the bench's unit).  Both extractions are queued before the first
+        count is read back; the person clouds are only needed after the registration, so their counts are fetched then."""
+        o, p = self.ops, self.p
+        S = depth.shape[0]
+        _, masked = self._calibrate(depth, lambda: o.depth_to_cloud(depth, self.xy, rgb, S, True, True, gate=p.gate, sync=False))
+        return self.fuse(depth, rgb, masked)
+
+
 class FrameStream:
     """Several frames of a stream in flight.  A frame is a chain of short, mostly latency-bound kernels (the ICP loop alone
     is ~75 dependent launches that keep a fraction of the CUs busy), and consecutive frames are independent, so `depth`
     of them run side by side: each on its own host thread (the library calls release the GIL; its lanes, workspaces and
     progress words are per thread) and its own HIP stream.  Results come back in submission order."""
 
-    def __init__(self, pipe: SensorGroupPipeline, depth: int = 2):
-        self.pipe, self.depth = pipe, max(1, int(depth))
+    def __init__(self, pipe, depth: int = 2):
+        """pipe: one pipeline shared by the slots (single-GPU pipelines keep no per-frame state), or a list with one pipeline
+        per slot -- required for SensorShardPipeline on several ranks: every slot needs its own communicator
+        (parallel.new_group()), because the collectives of different frames in flight interleave differently on each rank."""
+        self.pipes = list(pipe) if isinstance(pipe, (list, tuple)) else None
+        self.depth = len(self.pipes) if self.pipes else max(1, int(depth))
+        self.pipe = self.pipes[0] if self.pipes else pipe
         self.device = torch.cuda.current_device()
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.pool = ThreadPoolExecutor(max_workers=self.depth)
         self.pending = deque()
         self.submitted = 0
 
-    def _run(self, stream, depth, rgb):
+    def _run(self, slot, depth, rgb):
         torch.cuda.set_device(self.device)
+        stream = self.streams[slot]
         with torch.cuda.stream(stream):
-            out = self.pipe.step(depth, rgb)
+            if not depth.is_cuda:                # frames handed over in pinned host memory: the copy is part of the frame
+                depth = depth.to(self.device, non_blocking=True)
+                rgb = rgb.to(self.device, non_blocking=True)
+            out = (self.pipes[slot] if self.pipes else self.pipe).step(depth, rgb)
             stream.synchronize()                 # the outputs are consumed on the caller's stream
         return out
 
@@ -113,9 +249,9 @@ class FrameStream:
     def submit(self, depth: torch.Tensor, rgb: torch.Tensor):
         """queue one frame (call pop() first when full())"""
         assert not self.full()
-        stream = self.streams[self.submitted % self.depth]
+        slot = self.submitted % self.depth
         self.submitted += 1
-        self.pending.append(self.pool.submit(self._run, stream, depth, rgb))
+        self.pending.append(self.pool.submit(self._run, slot, depth, rgb))
 
     def pop(self):
         """-> (points, colours, transforms) of the oldest frame in flight.  The tensors were allocated on the frame's side
@@ -128,6 +264,10 @@ class FrameStream:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(cur)
         return out
+
+    @property
+    def last(self):
+        return self.pipe.last
 
     def close(self):
         while self.pending:

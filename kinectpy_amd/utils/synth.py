@@ -220,3 +220,48 @@ def coloured_pair(n, seed=0):
     Ti = np.linalg.inv(T)
     src = (src0.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
     return src, field(src0), tgt, field(tgt), T
+
+
+def perturb(T, deg=3.0, mm=50.0, seed=0):
+    """initial guess = ground-truth extrinsic perturbed by 3 deg / 50 mm"""
+    rng = np.random.default_rng(seed)
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    a = np.deg2rad(deg)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+    t = rng.normal(size=3)
+    t *= mm / np.linalg.norm(t)
+    P = np.eye(4)
+    P[:3, :3] = R
+    P[:3, 3] = t
+    return P @ T
+
+
+def sensor_ring(n_sensors, n_frames=1, xy=None, sensors=None, first_frame=0):
+    """BASELINE configs 4/5: `n_sensors` cameras on a circle around the person, `n_frames` time frames (the person moves
+    5 mm per frame).  `sensors`: the global sensor ids to render (default all).  Sensor 0 is the master.
+    -> xy, depth (F, len(sensors), n_px) u16, rgb (F, len(sensors), n_px, 3) u8 (person mask colours),
+       inits (n_sensors - 1 perturbed sub -> master transforms), truth (the exact ones)"""
+    if xy is None:
+        xy = xy_table()
+    sensors = list(range(n_sensors)) if sensors is None else list(sensors)
+    poses = [camera_pose(g, n_sensors) for g in range(n_sensors)]
+    n_px = len(xy)
+    depth = np.zeros((n_frames, len(sensors), n_px), np.uint16)
+    rgb = np.zeros((n_frames, len(sensors), n_px, 3), np.uint8)
+    for f in range(n_frames):
+        t = first_frame + f
+        for i, g in enumerate(sensors):
+            d, person = render_depth(poses[g], person_shift=(5.0 * t, 0.0, 0.0), seed=100 + g + 1000 * t, xy=xy, return_person=True)
+            depth[f, i] = d
+            rgb[f, i] = mask_rgb(person, seed=7 + g)
+    Einv = np.linalg.inv(poses[0])
+    truth = [Einv @ poses[g] for g in range(1, n_sensors)]
+    inits = [perturb(T, seed=g) for g, T in enumerate(truth)]
+    return xy, depth, rgb, inits, truth
+
+
+def small_xy(scale=4):
+    """a 1/scale-resolution camera (144 x 160 for scale 4) with the same field of view: CPU-sized frames for rehearsals"""
+    return xy_table(h=H // scale, w=W // scale, fx=FX / scale, fy=FY / scale, cx=CX / scale, cy=CY / scale)

@@ -36,6 +36,18 @@
 
 #define KPO_API __attribute__((visibility("default")))
 
+/* Cloud storage type.  float (default) is the contract shared with the GPU product: clouds, colours and normals are
+ * float32 arrays and every decision scalar is fp64.  -DKPO_STORAGE_F64 builds the reference-faithful variant
+ * (_build/libkpx_oracle_f64.so): clouds stay float64 between stages, as the reference keeps them
+ * (/root/reference/utils/io.py:29-41, preprocessing/data.py:55-56); tests/test_oracle_cpu.py measures what the float32
+ * storage changes (coordinates and index decisions).  The depth unprojection is float32 in both (the [K4A] formula). */
+#ifdef KPO_STORAGE_F64
+typedef double real_t;
+#else
+typedef float real_t;
+#endif
+KPO_API int kpo_storage_bytes(void) { return (int)sizeof(real_t); }
+
 /* ------------------------------------------------------------------------------------------ */
 /* Philox4x32-10 counter RNG (Salmon et al. 2011).  Used for every random draw so that the     */
 /* CPU and GPU RANSACs consume identical streams (the reference's RANSAC is unseeded:          */
@@ -116,7 +128,7 @@ KPO_API double kpo_median_i16(const int16_t *v, int64_t n, int64_t stride)
 /* gate_hi is median+750 computed by the caller in float64.                                     */
 KPO_API int64_t kpo_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t n,
                                  int use_color_mask, int use_gate, double gate_hi,
-                                 float *pts, float *col, int32_t *idx)
+                                 real_t *pts, real_t *col, int32_t *idx)
 {
     int64_t k = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -126,9 +138,9 @@ KPO_API int64_t kpo_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t
             keep = keep && rgb[3 * i] != 0 && rgb[3 * i + 1] != 0 && rgb[3 * i + 2] != 0;
         if (use_gate) keep = keep && ((double)z <= gate_hi);
         if (!keep) continue;
-        if (pts) { pts[3 * k] = (float)x; pts[3 * k + 1] = (float)y; pts[3 * k + 2] = (float)z; }
+        if (pts) { pts[3 * k] = (real_t)x; pts[3 * k + 1] = (real_t)y; pts[3 * k + 2] = (real_t)z; }
         if (col && rgb)
-            for (int c = 0; c < 3; ++c) col[3 * k + c] = (float)((double)rgb[3 * i + c] / 255.0);
+            for (int c = 0; c < 3; ++c) col[3 * k + c] = (real_t)((double)rgb[3 * i + c] / 255.0);
         if (idx) idx[k] = (int32_t)i;
         ++k;
     }
@@ -145,21 +157,21 @@ static inline void xform3(const double *T, double x, double y, double z, double 
     for (int k = 0; k < 3; ++k)
         o[k] = fma(T[4 * k + 0], x, fma(T[4 * k + 1], y, fma(T[4 * k + 2], z, T[4 * k + 3])));
 }
-KPO_API void kpo_transform(const float *pts, int64_t n, const double *T, float *out)
+KPO_API void kpo_transform(const real_t *pts, int64_t n, const double *T, real_t *out)
 {
     for (int64_t i = 0; i < n; ++i) {
         double o[3];
         xform3(T, (double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2], o);
-        out[3 * i] = (float)o[0]; out[3 * i + 1] = (float)o[1]; out[3 * i + 2] = (float)o[2];
+        out[3 * i] = (real_t)o[0]; out[3 * i + 1] = (real_t)o[1]; out[3 * i + 2] = (real_t)o[2];
     }
 }
 /* normals rotate only (Open3D PointCloud::Transform) */
-KPO_API void kpo_rotate(const float *nrm, int64_t n, const double *T, float *out)
+KPO_API void kpo_rotate(const real_t *nrm, int64_t n, const double *T, real_t *out)
 {
     for (int64_t i = 0; i < n; ++i) {
         double x = nrm[3 * i], y = nrm[3 * i + 1], z = nrm[3 * i + 2];
         for (int k = 0; k < 3; ++k)
-            out[3 * i + k] = (float)fma(T[4 * k + 0], x, fma(T[4 * k + 1], y, T[4 * k + 2] * z));
+            out[3 * i + k] = (real_t)fma(T[4 * k + 0], x, fma(T[4 * k + 1], y, T[4 * k + 2] * z));
     }
 }
 
@@ -178,9 +190,9 @@ static int cmp_kv(const void *a, const void *b)
     if (x->key != y->key) return (x->key > y->key) - (x->key < y->key);
     return (x->idx > y->idx) - (x->idx < y->idx);
 }
-KPO_API int64_t kpo_voxel_downsample(const float *pts, const float *col, const float *nrm,
-                                     int64_t n, double voxel, float *opts, float *ocol,
-                                     float *onrm, int32_t *ocnt)
+KPO_API int64_t kpo_voxel_downsample(const real_t *pts, const real_t *col, const real_t *nrm,
+                                     int64_t n, double voxel, real_t *opts, real_t *ocol,
+                                     real_t *onrm, int32_t *ocnt)
 {
     if (!(voxel > 0.0)) return -1;
     if (n == 0) return 0;
@@ -216,12 +228,12 @@ KPO_API int64_t kpo_voxel_downsample(const float *pts, const float *col, const f
         }
         double c = (double)(j - i);
         for (int a = 0; a < 3; ++a) {
-            opts[3 * m + a] = (float)(sp[a] / c);
-            if (col && ocol) ocol[3 * m + a] = (float)(sc[a] / c);
+            opts[3 * m + a] = (real_t)(sp[a] / c);
+            if (col && ocol) ocol[3 * m + a] = (real_t)(sc[a] / c);
         }
         if (nrm && onrm) {
             double nn = sqrt(fma(sn[2], sn[2], fma(sn[1], sn[1], sn[0] * sn[0])));
-            for (int a = 0; a < 3; ++a) onrm[3 * m + a] = (float)(nn > 0 ? sn[a] / nn : sn[a]);
+            for (int a = 0; a < 3; ++a) onrm[3 * m + a] = (real_t)(nn > 0 ? sn[a] / nn : sn[a]);
         }
         if (ocnt) ocnt[m] = (int32_t)(j - i);
         ++m; i = j;
@@ -245,7 +257,7 @@ typedef struct {
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-static void grid_build(grid_t *g, const float *pts, int64_t n, double target_per_cell)
+static void grid_build(grid_t *g, const real_t *pts, int64_t n, double target_per_cell)
 {
     double mn[3] = { DBL_MAX, DBL_MAX, DBL_MAX }, mx[3] = { -DBL_MAX, -DBL_MAX, -DBL_MAX };
     for (int64_t i = 0; i < n; ++i)
@@ -328,7 +340,7 @@ static int cmp_di(const void *a, const void *b)
 /* exact k nearest (by (d2, idx)) of query q among the gridded points; result sorted ascending.
  * If r2max >= 0 only points with d2 < r2max are returned ([O3D] SearchHybrid: knn then
  * lower_bound(radius^2), i.e. strict <).  Returns the number found. */
-static int grid_knn(const grid_t *g, const float *pts, double qx, double qy, double qz,
+static int grid_knn(const grid_t *g, const real_t *pts, double qx, double qy, double qz,
                     int k, double r2max, di_t *heap)
 {
     int c[3];
@@ -385,7 +397,25 @@ static int grid_knn(const grid_t *g, const float *pts, double qx, double qy, dou
  *   keep   = avg_i > 0 && avg_i < mean + std_ratio*std ; indices ascending.
  * stats[0..2] = mean, std, threshold.  Returns kept count, -1 on invalid arguments.
  * brute != 0 uses the O(N^2) scan (validation of the grid search). */
-KPO_API int64_t kpo_sor(const float *pts, int64_t n, int k, double std_ratio, int brute,
+/* second half of [O3D] RemoveStatisticalOutliers: mean / Bessel std over the per-point mean distances (sum over avg > 0,
+ * divisor = all points: every point finds itself, so Open3D's valid_distances == n), keep avg > 0 && avg < mean + r std */
+KPO_API int64_t kpo_sor_from_avg(const double *avg, int64_t n, double std_ratio, int32_t *keep_idx, double *stats)
+{
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; ++i) if (avg[i] > 0) sum += avg[i];
+    double mean = sum / (double)n;
+    double sq = 0.0;
+    for (int64_t i = 0; i < n; ++i) if (avg[i] > 0) sq += (avg[i] - mean) * (avg[i] - mean);
+    double sd = sqrt(sq / (double)(n - 1));
+    double thr = mean + std_ratio * sd;
+    if (stats) { stats[0] = mean; stats[1] = sd; stats[2] = thr; }
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (avg[i] > 0 && avg[i] < thr) { if (keep_idx) keep_idx[cnt] = (int32_t)i; ++cnt; }
+    return cnt;
+}
+
+KPO_API int64_t kpo_sor(const real_t *pts, int64_t n, int k, double std_ratio, int brute,
                         int32_t *keep_idx, double *stats, double *avg_out)
 {
     if (k < 1 || !(std_ratio > 0.0)) return -1;
@@ -417,17 +447,7 @@ KPO_API int64_t kpo_sor(const float *pts, int64_t n, int k, double std_ratio, in
         free(heap);
     }
     if (!brute) grid_free(&g);
-    double sum = 0.0;
-    for (int64_t i = 0; i < n; ++i) if (avg[i] > 0) sum += avg[i];
-    double mean = sum / (double)n;
-    double sq = 0.0;
-    for (int64_t i = 0; i < n; ++i) if (avg[i] > 0) sq += (avg[i] - mean) * (avg[i] - mean);
-    double sd = sqrt(sq / (double)(n - 1));
-    double thr = mean + std_ratio * sd;
-    if (stats) { stats[0] = mean; stats[1] = sd; stats[2] = thr; }
-    int64_t cnt = 0;
-    for (int64_t i = 0; i < n; ++i)
-        if (avg[i] > 0 && avg[i] < thr) { if (keep_idx) keep_idx[cnt] = (int32_t)i; ++cnt; }
+    int64_t cnt = kpo_sor_from_avg(avg, n, std_ratio, keep_idx, stats);
     if (!avg_out) free(avg);
     return cnt;
 }
@@ -435,14 +455,14 @@ KPO_API int64_t kpo_sor(const float *pts, int64_t n, int k, double std_ratio, in
 /* [O3D] KDTreeFlann::SearchHybrid(radius, max_nn) for every point of the cloud against itself
  * (estimate_normals, preprocessing/registration.py:9-13).  nbr: n*max_nn indices ascending by
  * (d2, idx); cnt: number found.  */
-KPO_API int kpo_hybrid_knn_d2(const float *pts, int64_t n, double radius, int max_nn,
+KPO_API int kpo_hybrid_knn_d2(const real_t *pts, int64_t n, double radius, int max_nn,
                               int32_t *nbr, int32_t *cnt, double *d2out);
-KPO_API int kpo_hybrid_knn(const float *pts, int64_t n, double radius, int max_nn,
+KPO_API int kpo_hybrid_knn(const real_t *pts, int64_t n, double radius, int max_nn,
                            int32_t *nbr, int32_t *cnt)
 {
     return kpo_hybrid_knn_d2(pts, n, radius, max_nn, nbr, cnt, NULL);
 }
-KPO_API int kpo_hybrid_knn_d2(const float *pts, int64_t n, double radius, int max_nn,
+KPO_API int kpo_hybrid_knn_d2(const real_t *pts, int64_t n, double radius, int max_nn,
                               int32_t *nbr, int32_t *cnt, double *d2out)
 {
     if (max_nn < 1 || !(radius > 0)) return -1;
@@ -470,7 +490,7 @@ KPO_API int kpo_hybrid_knn_d2(const float *pts, int64_t n, double radius, int ma
 /* [O3D] utility::ComputeCovariance over the hybrid neighbourhood (cumulant form):
  *   c[0..8] = mean of x,y,z,xx,xy,xz,yy,yz,zz (sequential, neighbour order), then
  *   cov = E[ab] - E[a]E[b].  Output 6 doubles per point: xx,xy,xz,yy,yz,zz; cnt<3 -> zeros. */
-KPO_API void kpo_covariances(const float *pts, int64_t n, const int32_t *nbr, const int32_t *cnt,
+KPO_API void kpo_covariances(const real_t *pts, int64_t n, const int32_t *nbr, const int32_t *cnt,
                              int max_nn, double *cov6)
 {
 #pragma omp parallel for schedule(static)
@@ -508,7 +528,7 @@ KPO_API void kpo_covariances(const float *pts, int64_t n, const int32_t *nbr, co
 /*        iterations with index > break_iteration are skipped.                                  */
 /* Final: inliers of the best plane (ascending), plane re-fitted to them.                       */
 /* ------------------------------------------------------------------------------------------ */
-static void plane_from_points(const float *pts, const int32_t *ids, int64_t m, double pl[4])
+static void plane_from_points(const real_t *pts, const int32_t *ids, int64_t m, double pl[4])
 {
     pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
     if (m < 3) return;
@@ -531,9 +551,9 @@ static void plane_from_points(const float *pts, const int32_t *ids, int64_t m, d
     a /= nn; b /= nn; c /= nn;
     pl[0] = a; pl[1] = b; pl[2] = c; pl[3] = -(a * cx + b * cy + c * cz);
 }
-static void plane_from_triangle(const float *pts, const int32_t *ids, double pl[4])
+static void plane_from_triangle(const real_t *pts, const int32_t *ids, double pl[4])
 {
-    const float *p0 = pts + 3 * ids[0], *p1 = pts + 3 * ids[1], *p2 = pts + 3 * ids[2];
+    const real_t *p0 = pts + 3 * ids[0], *p1 = pts + 3 * ids[1], *p2 = pts + 3 * ids[2];
     double e0[3], e1[3];
     for (int a = 0; a < 3; ++a) { e0[a] = (double)p1[a] - p0[a]; e1[a] = (double)p2[a] - p0[a]; }
     double a = e0[1] * e1[2] - e0[2] * e1[1], b = e0[2] * e1[0] - e0[0] * e1[2], c = e0[0] * e1[1] - e0[1] * e1[0];
@@ -558,16 +578,16 @@ KPO_API void kpo_ransac_sample(int64_t n, int ransac_n, uint64_t seed, uint32_t 
         }
     }
 }
-KPO_API void kpo_plane_fit(const float *pts, const int32_t *ids, int64_t m, double pl[4])
+KPO_API void kpo_plane_fit(const real_t *pts, const int32_t *ids, int64_t m, double pl[4])
 {
     if (m == 3 && ids) plane_from_triangle(pts, ids, pl); else plane_from_points(pts, ids, m, pl);
 }
-static inline double plane_dist(const double pl[4], const float *p)
+static inline double plane_dist(const double pl[4], const real_t *p)
 {
     return fabs(fma(pl[0], (double)p[0], fma(pl[1], (double)p[1], fma(pl[2], (double)p[2], pl[3]))));
 }
 /* per-hypothesis table hyp[h*6 + {a,b,c,d,count,error}] is optional (debug / GPU cross-check) */
-KPO_API int kpo_segment_plane(const float *pts, int64_t n, double thr, int ransac_n, int iters,
+KPO_API int kpo_segment_plane(const real_t *pts, int64_t n, double thr, int ransac_n, int iters,
                               double probability, uint64_t seed, double plane[4],
                               int32_t *inl_idx, int64_t *inl_count, double *hyp)
 {
@@ -623,7 +643,7 @@ KPO_API int kpo_segment_plane(const float *pts, int64_t n, double thr, int ransa
 /* k-ordered fma chain, which is what the f64 MFMA computes), |t|^2 = fma(tx,tx,fma(ty,ty,tz*tz)); */
 /* argmin, ties -> lowest j.  The reported d2 is the direct form AC3 of the chosen pair.        */
 /* ------------------------------------------------------------------------------------------ */
-static inline double nn_metric(const double s[3], const float *t)
+static inline double nn_metric(const double s[3], const real_t *t)
 {
     double tx = t[0], ty = t[1], tz = t[2];
     double t2 = fma(tx, tx, fma(ty, ty, tz * tz));
@@ -634,7 +654,7 @@ static inline double nn_metric(const double s[3], const float *t)
     m = fma(1.0, t2, m);
     return m;
 }
-KPO_API int kpo_nn_brute(const float *src, int64_t n, const double *T, const float *tgt, int64_t m,
+KPO_API int kpo_nn_brute(const real_t *src, int64_t n, const double *T, const real_t *tgt, int64_t m,
                          int32_t *idx, double *d2, double *metric)
 {
     if (m <= 0) return -1;
@@ -655,7 +675,7 @@ KPO_API int kpo_nn_brute(const float *src, int64_t n, const double *T, const flo
 }
 /* Same answer through the grid: ring search on the direct distance with a safety margin, the
  * AC2 metric decides among everything within the margin of the best. */
-KPO_API int kpo_nn_grid(const float *src, int64_t n, const double *T, const float *tgt, int64_t m,
+KPO_API int kpo_nn_grid(const real_t *src, int64_t n, const double *T, const real_t *tgt, int64_t m,
                         int32_t *idx, double *d2, double *metric)
 {
     if (m <= 0) return -1;
@@ -725,8 +745,8 @@ KPO_API int kpo_nn_grid(const float *src, int64_t n, const double *T, const floa
  * If tn (target normals) != NULL also the point-to-plane normal equations:
  * out[17..37] = upper triangle of J^T J (6x6 row-major upper), out[38..43] = J^T r,
  * with r = (s - t).n, J = [s x n, n]  ([O3D] TransformationEstimationPointToPlane). */
-KPO_API void kpo_icp_accumulate(const float *src, int64_t n, const double *T, const float *tgt,
-                                const float *tn, const int32_t *idx, const double *d2,
+KPO_API void kpo_icp_accumulate(const real_t *src, int64_t n, const double *T, const real_t *tgt,
+                                const real_t *tn, const int32_t *idx, const double *d2,
                                 double max_dist, double *out)
 {
     for (int a = 0; a < 44; ++a) out[a] = 0.0;
@@ -735,12 +755,12 @@ KPO_API void kpo_icp_accumulate(const float *src, int64_t n, const double *T, co
         if (!(d2[i] < md2)) continue;
         double s[3];
         xform3(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], s);
-        const float *t = tgt + 3 * (int64_t)idx[i];
+        const real_t *t = tgt + 3 * (int64_t)idx[i];
         out[0] += 1.0; out[1] += d2[i];
         for (int a = 0; a < 3; ++a) { out[2 + a] += s[a]; out[5 + a] += (double)t[a]; }
         for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) out[8 + 3 * a + b] += (double)t[a] * s[b];
         if (tn) {
-            const float *nf = tn + 3 * (int64_t)idx[i];
+            const real_t *nf = tn + 3 * (int64_t)idx[i];
             double nx = nf[0], ny = nf[1], nz = nf[2];
             double r = (s[0] - t[0]) * nx + (s[1] - t[1]) * ny + (s[2] - t[2]) * nz;
             double J[6] = { s[1] * nz - s[2] * ny, s[2] * nx - s[0] * nz, s[0] * ny - s[1] * nx, nx, ny, nz };
@@ -785,7 +805,7 @@ static inline int bin11(double x)
     int h = (int)floor(x);
     return h < 0 ? 0 : (h >= 11 ? 10 : h);
 }
-KPO_API void kpo_fpfh(const float *pts, const float *nrm, int64_t n, const int32_t *nbr, const int32_t *cnt,
+KPO_API void kpo_fpfh(const real_t *pts, const real_t *nrm, int64_t n, const int32_t *nbr, const int32_t *cnt,
                       const double *d2, int max_nn, double *spfh, double *fpfh)
 {
     memset(spfh, 0, (size_t)n * 33 * sizeof(double));
@@ -910,7 +930,7 @@ KPO_API void kpo_kabsch_pairs(const double *s, const double *t, int m, double *T
 /*   OpenMP loop in unspecified order: the reference result is not reproducible).                       */
 /* stats[0] = iterations run, [1] = validations, [2] = fitness, [3] = rmse.  Returns 0, T = identity if  */
 /* nothing passed.                                                                                       */
-KPO_API int kpo_ransac_corres(const float *src, int64_t n, const float *tgt, int64_t m, const int32_t *corres, int64_t nc,
+KPO_API int kpo_ransac_corres(const real_t *src, int64_t n, const real_t *tgt, int64_t m, const int32_t *corres, int64_t nc,
                               double max_dist, int ransac_n, double edge_sim, int max_iter, double confidence,
                               uint64_t seed, double *Tbest, double *stats)
 {
@@ -963,7 +983,7 @@ KPO_API int kpo_ransac_corres(const float *src, int64_t n, const float *tgt, int
             int64_t inl = 0;
             for (int64_t c = 0; c < nc; ++c) {
                 double o[3], e2 = 0;
-                const float *s = src + 3 * (int64_t)corres[2 * c], *t = tgt + 3 * (int64_t)corres[2 * c + 1];
+                const real_t *s = src + 3 * (int64_t)corres[2 * c], *t = tgt + 3 * (int64_t)corres[2 * c + 1];
                 xform3(T, s[0], s[1], s[2], o);
                 for (int a = 0; a < 3; ++a) e2 += (o[a] - t[a]) * (o[a] - t[a]);
                 if (sqrt(e2) < max_dist) ++inl;

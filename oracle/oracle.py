@@ -12,38 +12,78 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libkpx_oracle.so")
+# KPO_BUILD_DIR=_build/asan selects the sanitizer builds (make asan; tools/asan_cpu_suite.sh)
+_DIR = os.path.join(_HERE, os.environ.get("KPO_BUILD_DIR", "_build"))
+_SOS = {"f32": os.path.join(_DIR, "libkpx_oracle.so"), "f64": os.path.join(_DIR, "libkpx_oracle_f64.so")}
+_SO = _SOS["f32"]
 
 
 def build(force=False):
     src = os.path.join(_HERE, "kpx_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    stale = any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) for so in _SOS.values())
+    if force or stale:
+        target = ["asan"] if _DIR.endswith("asan") else []
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"] + target, stdout=subprocess.DEVNULL)
     return _SO
 
 
-_lib = None
+# ---- cloud storage mode ---------------------------------------------------------------------------------------------
+# "f32" (default): clouds / colours / normals are float32 arrays between stages -- the storage contract of the GPU product
+# (DESIGN.md 3).  "f64": they stay float64, as in the reference (utils/io.py:29-41, preprocessing/data.py:55-56: every
+# Vector3dVector is float64).  Same C source compiled twice (real_t); `with storage("f64"):` switches every function below.
+_STORAGE = "f32"
+_libs = {}
+
+
+class storage:
+    def __init__(self, mode):
+        if mode not in _SOS:
+            raise ValueError("storage mode must be 'f32' or 'f64'")
+        self.mode = mode
+
+    def __enter__(self):
+        global _STORAGE
+        self.prev, _STORAGE = _STORAGE, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _STORAGE
+        _STORAGE = self.prev
+
+
+def storage_mode():
+    return _STORAGE
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_SO):
+    l = _libs.get(_STORAGE)
+    if l is None:
+        if not os.path.exists(_SOS[_STORAGE]):
             build()
-        _lib = C.CDLL(_SO)
-        _lib.kpo_median_i16.restype = C.c_double
-        _lib.kpo_rgbd_compact.restype = C.c_int64
-        _lib.kpo_voxel_downsample.restype = C.c_int64
-        _lib.kpo_sor.restype = C.c_int64
-    return _lib
+        l = C.CDLL(_SOS[_STORAGE])
+        l.kpo_median_i16.restype = C.c_double
+        l.kpo_rgbd_compact.restype = C.c_int64
+        l.kpo_voxel_downsample.restype = C.c_int64
+        l.kpo_sor.restype = C.c_int64
+        l.kpo_sor_from_avg.restype = C.c_int64
+        l.kpo_hull_vertices.restype = C.c_int64
+        assert l.kpo_storage_bytes() == (4 if _STORAGE == "f32" else 8)
+        _libs[_STORAGE] = l
+    return l
 
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _rt():
+    """dtype of stored clouds in the active storage mode"""
+    return np.float32 if _STORAGE == "f32" else np.float64
+
+
 def _f32(a):
-    return np.ascontiguousarray(a, dtype=np.float32)
+    """cloud array in the active storage dtype (float32 unless `with storage("f64")`)"""
+    return np.ascontiguousarray(a, dtype=_rt())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -64,7 +104,7 @@ def xy_table_pinhole(H, W, fx, fy, cx, cy):
 
 def unproject_u16(depth, xy):
     depth = np.ascontiguousarray(depth, dtype=np.uint16).reshape(-1)
-    xy = _f32(xy).reshape(-1, 2)
+    xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)          # the table is float32 in every storage mode
     out = np.zeros((depth.size, 3), dtype=np.int16)
     lib().kpo_unproject_u16(_p(depth), _p(xy), C.c_int64(depth.size), _p(out))
     return out
@@ -82,8 +122,8 @@ def rgbd_compact(xyz, rgb=None, use_color_mask=False, use_gate=False, gate_hi=0.
     n = xyz.shape[0]
     if rgb is not None:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
-    pts = np.zeros((n, 3), dtype=np.float32)
-    col = np.zeros((n, 3), dtype=np.float32) if rgb is not None else None
+    pts = np.zeros((n, 3), dtype=_rt())
+    col = np.zeros((n, 3), dtype=_rt()) if rgb is not None else None
     idx = np.zeros(n, dtype=np.int32)
     k = lib().kpo_rgbd_compact(_p(xyz), _p(rgb), C.c_int64(n), C.c_int(int(use_color_mask)),
                                C.c_int(int(use_gate)), C.c_double(gate_hi), _p(pts), _p(col), _p(idx))
@@ -111,9 +151,9 @@ def voxel_downsample(pts, voxel, col=None, nrm=None, return_counts=False):
     n = pts.shape[0]
     col = _f32(col).reshape(-1, 3) if col is not None else None
     nrm = _f32(nrm).reshape(-1, 3) if nrm is not None else None
-    op = np.zeros((max(n, 1), 3), dtype=np.float32)
-    oc = np.zeros((max(n, 1), 3), dtype=np.float32) if col is not None else None
-    on = np.zeros((max(n, 1), 3), dtype=np.float32) if nrm is not None else None
+    op = np.zeros((max(n, 1), 3), dtype=_rt())
+    oc = np.zeros((max(n, 1), 3), dtype=_rt()) if col is not None else None
+    on = np.zeros((max(n, 1), 3), dtype=_rt()) if nrm is not None else None
     cnt = np.zeros(max(n, 1), dtype=np.int32)
     m = lib().kpo_voxel_downsample(_p(pts), _p(col), _p(nrm), C.c_int64(n), C.c_double(voxel), _p(op),
                                    _p(oc), _p(on), _p(cnt))
@@ -139,6 +179,17 @@ def sor(pts, nb_neighbors, std_ratio, brute=False):
     if k < 0:
         raise RuntimeError("invalid nb_neighbors / std_ratio")
     return idx[:k].copy(), tuple(st.tolist()), avg[:n].copy()
+
+
+def sor_from_avg(avg, std_ratio):
+    """statistics + keep list of a8 from the per-point mean distances -> keep_idx, (mean, std, thr)"""
+    avg = np.ascontiguousarray(avg, dtype=np.float64).reshape(-1)
+    n = avg.size
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    st = np.zeros(3, dtype=np.float64)
+    lib().kpo_sor_from_avg.restype = C.c_int64
+    k = lib().kpo_sor_from_avg(_p(avg), C.c_int64(n), C.c_double(std_ratio), _p(idx), _p(st))
+    return idx[:k].copy(), tuple(st.tolist())
 
 
 def hybrid_knn(pts, radius, max_nn):
@@ -675,3 +726,29 @@ def registration_colored_icp(src, src_colors, tgt, tgt_colors, tgt_normals, max_
         if done:
             break
     return T, fit, rmse, it
+
+
+# ---- the frame step of the pipeline (preprocessing/data.py:35-61, 127-161) through the oracle -----------------------------
+def pipeline_step(xy, depth, rgb, inits, P):
+    """One step of kinectpy_amd.pipeline over S sensors in ONE process: depth (S, n_px) u16, rgb (S, n_px, 3) u8, inits =
+    the S-1 initial transforms, P = PipelineParams-like (reg_voxel, normals_nn, icp_max_dist, icp_mode, icp_max_iteration,
+    gate, filt_voxel, filt_k, filt_ratio).  Sensor 0 is the master.  -> (points, colours, [T_0 .. T_{S-1}], intermediates)"""
+    S = depth.shape[0]
+    full, masked = [], []
+    for i in range(S):
+        xyz = unproject_u16(depth[i], xy)
+        full.append(rgbd_compact(xyz)[0])
+        p, c, _ = rgbd_compact(xyz, rgb[i], True, True, median_z(xyz) + P.gate)
+        masked.append((p, c))
+    downs = [voxel_downsample(f, P.reg_voxel)[0] for f in full]
+    tn = estimate_normals(downs[0], 2 * P.reg_voxel, P.normals_nn)[0].astype(_rt()) if P.icp_mode == "p2plane" else None
+    Ts, icp_stats = [np.eye(4)], []
+    for i in range(1, S):
+        T, fit, rmse, it = registration_icp(downs[i], downs[0], P.icp_max_dist, inits[i - 1], P.icp_mode, tn, P.icp_max_iteration, grid=True)
+        Ts.append(T)
+        icp_stats.append((it, fit, rmse))
+    pts = np.concatenate([masked[0][0]] + [transform(masked[i][0], Ts[i]) for i in range(1, S)])
+    col = np.concatenate([m[1] for m in masked])
+    vp, vc, _ = voxel_downsample(pts, P.filt_voxel, col)
+    keep, stats, _ = sor(vp, P.filt_k, P.filt_ratio)
+    return vp[keep], vc[keep], Ts, {"downs": downs, "normals": tn, "icp": icp_stats, "fused": pts, "voxel": vp, "keep": keep, "sor_stats": stats}
