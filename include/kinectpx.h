@@ -135,6 +135,18 @@ int kpx_voxel_downsample_batch(int32_t count, const float *const *h_pts, const f
                                double voxel, float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws,
                                size_t ws_bytes, void *stream);
 
+/* a17 + a7 in one pass -- the fuse of the frame loop, preprocessing/data.py:44-61: cloud c is moved by its registration
+ * h_T[c] (pcd.transform(T), :48; 4x4 row-major f64 on the host, identity for the master), the clouds are stacked in the given
+ * order (np.vstack, :55-58) and the stack is voxel_down_sample'd (filter_outliers, filtering.py:23).  The stacked cloud is
+ * never materialised: the reference holds it in float64, so the minimum bound, the voxel index and the per-voxel sums use the
+ * fp64 value of the moved point recomputed from the float32 sensor point -- voxel membership is the float64 path's, which a
+ * float32 copy of the moved points does not guarantee.  Up to 16 clouds; h_col (and ocol) may be NULL; colours must be on all
+ * non-empty clouds or on none.  opts / ocol: f32 [sum n][3] worst case; d_count = voxels.  Output order as kpx_voxel_downsample. */
+size_t kpx_fuse_voxel_workspace_bytes(int64_t total_points);
+int kpx_fuse_voxel_downsample(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n,
+                              const double *h_T, double voxel, float *opts, float *ocol, int32_t *d_count, void *ws,
+                              size_t ws_bytes, void *stream);
+
 /* a8: PointCloud.remove_statistical_outlier(nb_neighbors, std_ratio) (filtering.py:24,
  * floor_removal.py:73, utils/processing.py:309).  keep_idx ascending, d_count = kept,
  * d_stats f64 [3] = (mean, std, threshold), d_avg f64 [n] (optional) = per-point mean kNN distance.

@@ -37,6 +37,8 @@ SIGNATURES = {
     "kpx_voxel_downsample": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_voxel_batch_workspace_bytes": (_sz, [_i32, _vp]),
     "kpx_voxel_downsample_batch": (C.c_int, [_i32, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_fuse_voxel_workspace_bytes": (_sz, [_i64]),
+    "kpx_fuse_voxel_downsample": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_sor_workspace_bytes": (_sz, [_i64, _i32]),
     "kpx_sor": (C.c_int, [_vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_sor_partial": (C.c_int, [_vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),

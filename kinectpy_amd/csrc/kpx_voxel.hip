@@ -362,9 +362,221 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
     return KPX_OK;
 }
 
+// ---- transform + fuse + voxel grid in one pass (preprocessing/data.py:44-61) ----------------------------------------
+// Cloud c of the frame is moved by its registration T[c] (identity for the master), the clouds are stacked and the stack is
+// down-sampled.  The reference keeps the moved points as float64 arrays; storing them as float32 first would move points
+// that lie within 2^-24 |x| of a voxel face into the neighbouring voxel (measured: ~1e-5 of the points,
+// oracle/storage_deviation.py).  So the stack is never materialised: the bounding box, the voxel index and the per-voxel
+// sums all use the fp64 value p' = AC1(T[c], p), recomputed from the float32 sensor point wherever it is needed (9 fma).
+// That is also one pass less over HBM and three launches less per sensor than transform -> concat -> voxel.
+constexpr int kFuseMax = 16;
+constexpr int kFuseBboxBlocks = 32;
+struct FuseBatch {
+    const float *pts[kFuseMax];
+    const float *col[kFuseMax];
+    int64_t off[kFuseMax + 1];
+    double T[kFuseMax][12];               // rows of [R | t]
+    int32_t count;
+};
+__device__ __forceinline__ int fuse_cloud(const FuseBatch &b, int64_t i)
+{
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < kFuseMax; ++k) c += (k < b.count && i >= b.off[k]) ? 1 : 0;
+    return c;
+}
+__device__ __forceinline__ void fuse_point(const FuseBatch &b, int c, int64_t j, double o[3])
+{
+    const float *p = b.pts[c] + 3 * j;
+    const double x = p[0], y = p[1], z = p[2];
+    const double *T = b.T[c];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = fma(T[4 * k], x, fma(T[4 * k + 1], y, fma(T[4 * k + 2], z, T[4 * k + 3])));
+}
+__global__ __launch_bounds__(256) void fuse_bbox_partial_kernel(FuseBatch b, double *__restrict__ part)
+{
+    __shared__ double sh[6][4];
+    const int c = blockIdx.y;
+    const int64_t n = b.off[c + 1] - b.off[c];
+    double mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double q[3];
+        fuse_point(b, c, i, q);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fmin(mn[a], q[a]); mx[a] = fmax(mx[a], q[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+    if (lane_id() == 0)
+        for (int a = 0; a < 3; ++a) { sh[a][wave_id()] = mn[a]; sh[3 + a][wave_id()] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = sh[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fmin(v, sh[threadIdx.x][w]) : fmax(v, sh[threadIdx.x][w]);
+        part[((int64_t)c * kFuseBboxBlocks + blockIdx.x) * 6 + threadIdx.x] = v;
+    }
+}
+// folds the count x kFuseBboxBlocks partial boxes (min / max: exact, order-free) -> bbox[0..5]; zeroes the error word
+__global__ __launch_bounds__(64) void fuse_bbox_final_kernel(const double *__restrict__ part, int rows, double *__restrict__ bbox, int32_t *__restrict__ err)
+{
+    const int lane = lane_id();
+    double v[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    for (int r = lane; r < rows; r += 64) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { v[a] = fmin(v[a], part[(int64_t)r * 6 + a]); v[3 + a] = fmax(v[3 + a], part[(int64_t)r * 6 + 3 + a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { v[a] = wave_min(v[a]); v[3 + a] = wave_max(v[3 + a]); }
+    if (lane == 0) {
+        for (int a = 0; a < 6; ++a) bbox[a] = v[a];
+        *err = 0;
+    }
+}
+__global__ __launch_bounds__(256) void fuse_key_kernel(FuseBatch b, const double *__restrict__ bbox, double voxel, uint64_t *__restrict__ keys,
+                                                       int32_t *__restrict__ vals, int32_t *__restrict__ err)
+{
+    const double ox = bbox[0] - voxel * 0.5, oy = bbox[1] - voxel * 0.5, oz = bbox[2] - voxel * 0.5;
+    const int64_t total = b.off[b.count];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = fuse_cloud(b, i);
+        double q[3];
+        fuse_point(b, c, i - b.off[c], q);
+        double fx = floor((q[0] - ox) / voxel), fy = floor((q[1] - oy) / voxel), fz = floor((q[2] - oz) / voxel);
+        const bool bad = !(fx >= 0.0) || !(fy >= 0.0) || !(fz >= 0.0) || fx >= 2097152.0 || fy >= 2097152.0 || fz >= 2097152.0;
+        if (bad) { *err = 1; fx = fy = fz = 0.0; }
+        keys[i] = ((uint64_t)fx << 42) | ((uint64_t)fy << 21) | (uint64_t)fz;
+        vals[i] = (int32_t)i;
+    }
+}
+__global__ __launch_bounds__(256) void fuse_mean_kernel(FuseBatch b, const int32_t *__restrict__ vals, const int32_t *__restrict__ seg_start,
+                                                        int32_t *__restrict__ d_count, const int32_t *__restrict__ err, float *__restrict__ opts,
+                                                        float *__restrict__ ocol)
+{
+    const int32_t m_total = *d_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *err) *d_count = KPX_ERR_RANGE;      // as voxel_mean_kernel
+    const int64_t total = b.off[b.count];
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < m_total; m += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s0 = seg_start[m], s1 = (m + 1 < m_total) ? seg_start[m + 1] : total;
+        double sp[3] = { 0, 0, 0 }, sc[3] = { 0, 0, 0 };
+        for (int64_t s = s0; s < s1; s += 8) {       // loads of 8 points issued together, sums sequential in ascending stacked index
+            const int cnt = (int)(s1 - s < 8 ? s1 - s : 8);
+            int64_t p[8];
+            int cl[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                p[k] = k < cnt ? (int64_t)vals[s + k] : -1;
+                cl[k] = p[k] >= 0 ? fuse_cloud(b, p[k]) : 0;
+            }
+            double vq[8][3];
+            float vc[8][3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (p[k] < 0) continue;
+                const int64_t j = p[k] - b.off[cl[k]];
+                fuse_point(b, cl[k], j, vq[k]);
+                const float *col = b.col[cl[k]];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) vc[k][a] = col ? col[3 * j + a] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (p[k] < 0) continue;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { sp[a] += vq[k][a]; sc[a] += (double)vc[k][a]; }
+            }
+        }
+        const double cn = (double)(s1 - s0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            opts[3 * m + a] = (float)(sp[a] / cn);
+            if (ocol) ocol[3 * m + a] = (float)(sc[a] / cn);
+        }
+    }
+}
+struct FuseScratch {
+    uint64_t *keys_in, *keys_out;
+    int32_t *vals_in, *vals_out, *seg_start, *counts, *err;
+    double *part, *bbox;
+    char *sort_tmp;
+    size_t sort_bytes;
+};
+static void fuse_carve(Arena &a, int64_t total, FuseScratch *s)
+{
+    const size_t nn = (size_t)(total > 0 ? total : 1);
+    s->keys_in = a.get<uint64_t>(nn); s->keys_out = a.get<uint64_t>(nn);
+    s->vals_in = a.get<int32_t>(nn); s->vals_out = a.get<int32_t>(nn);
+    s->seg_start = a.get<int32_t>(nn);
+    s->counts = a.get<int32_t>((size_t)compact_tiles(total));
+    s->err = a.get<int32_t>(1);
+    s->part = a.get<double>((size_t)kFuseMax * kFuseBboxBlocks * 6);
+    s->bbox = a.get<double>(8);
+    s->sort_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->sort_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 63,
+                                             (hipStream_t) nullptr);
+    s->sort_tmp = a.get<char>(s->sort_bytes);
+}
+static int fuse_voxel_impl(const FuseBatch &b, double voxel, float *opts, float *ocol, int32_t *d_count, Arena &a, hipStream_t st)
+{
+    const int64_t total = b.off[b.count];
+    FuseScratch s;
+    fuse_carve(a, total, &s);
+    KPX_ARENA_CHECK(a);
+    hipLaunchKernelGGL(fuse_bbox_partial_kernel, dim3(kFuseBboxBlocks, b.count), dim3(256), 0, st, b, s.part);
+    hipLaunchKernelGGL(fuse_bbox_final_kernel, dim3(1), dim3(64), 0, st, s.part, b.count * kFuseBboxBlocks, s.bbox, s.err);
+    const int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+    hipLaunchKernelGGL(fuse_key_kernel, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err);
+    size_t bytes = s.sort_bytes;
+    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, 63, st));
+    int rc = compact(HeadPred{ s.keys_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, d_count, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fuse_mean_kernel, dim3(nb), dim3(256), 0, st, b, s.vals_out, s.seg_start, d_count, s.err, opts, ocol);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
 }  // namespace kpx
 
 using namespace kpx;
+
+KPX_EXPORT size_t kpx_fuse_voxel_workspace_bytes(int64_t total)
+{
+    Arena a(nullptr, 0);
+    FuseScratch s;
+    fuse_carve(a, total, &s);
+    return a.off;
+}
+KPX_EXPORT int kpx_fuse_voxel_downsample(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n,
+                                         const double *h_T, double voxel, float *opts, float *ocol, int32_t *d_count, void *ws,
+                                         size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(voxel > 0.0, "voxel_size <= 0");
+    KPX_REQUIRE(count >= 1 && count <= kFuseMax, "kpx_fuse_voxel_downsample: 1 .. %d clouds", kFuseMax);
+    KPX_REQUIRE(h_pts && h_n && h_T && d_count && ws, "kpx_fuse_voxel_downsample: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    FuseBatch b;
+    b.count = count;
+    b.off[0] = 0;
+    bool any_col = false, all_col = true;
+    for (int i = 0; i < kFuseMax; ++i) {
+        const bool on = i < count;
+        if (on) {
+            KPX_REQUIRE(h_n[i] >= 0 && (h_n[i] == 0 || h_pts[i]), "kpx_fuse_voxel_downsample: bad cloud %d", i);
+            if (h_n[i] > 0) { const bool hc = h_col && h_col[i]; any_col |= hc; all_col &= hc; }
+        }
+        b.pts[i] = on ? h_pts[i] : nullptr;
+        b.col[i] = (on && h_col) ? h_col[i] : nullptr;
+        b.off[i + 1] = b.off[i] + (on ? h_n[i] : 0);
+        for (int k = 0; k < 12; ++k) b.T[i][k] = on ? h_T[16 * i + k] : 0.0;
+    }
+    const int64_t total = b.off[count];
+    KPX_REQUIRE(total < ((int64_t)1 << 31), "kpx_fuse_voxel_downsample: bad size");
+    // [O3D] operator+= keeps colours only when both clouds have them
+    KPX_REQUIRE(!ocol || !any_col || all_col, "kpx_fuse_voxel_downsample: colours on some clouds only");
+    if (total == 0) { KPX_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return KPX_OK; }
+    KPX_REQUIRE(opts, "kpx_fuse_voxel_downsample: null pointer");
+    Arena a(ws, ws_bytes);
+    return fuse_voxel_impl(b, voxel, opts, (any_col && all_col) ? ocol : nullptr, d_count, a, st);
+}
 
 KPX_EXPORT size_t kpx_voxel_workspace_bytes(int64_t n)
 {

@@ -26,7 +26,7 @@ def equation_plane(p1, p2, p3):
 def pcd_above_plane(a, b, c, d, pcd: PointCloud) -> PointCloud:
     """floor_removal.py:39-51: despite the name it keeps the points whose plane value is < 0."""
     idx = ops.halfspace_select(pcd._pts, [a, b, c, d])
-    return pcd.select_by_index(idx)
+    return pcd._select(idx)
 
 
 def remove_floor(pcd: PointCloud, slab=200, distance_threshold=30, ransac_n=30, num_iterations=2000,
@@ -34,10 +34,10 @@ def remove_floor(pcd: PointCloud, slab=200, distance_threshold=30, ransac_n=30, 
     """Body of the reference's per-file loop (floor_removal.py:61-73): split at max(y)-slab, RANSAC
     plane on the lower slab, drop its inliers, concatenate with the upper part, SOR(50, 0.30)."""
     idx_lower, idx_upper = ops.slab_split(pcd._pts, float(slab))
-    floor = pcd.select_by_index(idx_lower)
+    floor = pcd._select(idx_lower)
     _, inliers = floor.segment_plane(distance_threshold=distance_threshold, ransac_n=ransac_n,
                                      num_iterations=num_iterations, seed=seed)
     outlier_cloud = floor.select_by_index(inliers, invert=True)
-    filtered = outlier_cloud + pcd.select_by_index(idx_upper)
+    filtered = outlier_cloud + pcd._select(idx_upper)
     filtered, _ = filtered.remove_statistical_outlier(nb_neighbors, std_ratio)
     return filtered

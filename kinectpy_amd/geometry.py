@@ -184,6 +184,11 @@ class PointCloud:
         p, c, n = ops.select_by_index(self._attrs(), idx, invert)
         return PointCloud._make(p, c, n)
 
+    def _select(self, idx):
+        """select_by_index for an index list produced by this library (ascending, duplicate-free, in range): one gather"""
+        p, c, n = ops.select_by_index(self._attrs(), idx, False, trusted=True)
+        return PointCloud._make(p, c, n)
+
     def voxel_down_sample(self, voxel_size):
         if not voxel_size > 0:
             raise RuntimeError("voxel_size <= 0.")

@@ -231,6 +231,29 @@ def voxel_downsample_batch(clouds, voxel, cols=None):
     return [(outs[i][: ms[i]], ocols[i][: ms[i]] if ocols is not None else None) for i in range(cnt)]
 
 
+def fuse_voxel_downsample(clouds, cols, Ts, voxel):
+    """preprocessing/data.py:44-61 in one pass: cloud c moved by Ts[c], stacked in order, voxel_down_sample(voxel) of the
+    stack on the fp64 values of the moved points (kpx_fuse_voxel_downsample).  cols: list of colour tensors or None.
+    -> (points f32 (M,3), colours f32 (M,3) | None)"""
+    lib = L.load()
+    clouds = [_dev(p, torch.float32).reshape(-1, 3) for p in clouds]
+    cnt = len(clouds)
+    dev = clouds[0].device if cnt else L.device()
+    cols = [_dev(c, torch.float32).reshape(-1, 3) for c in cols] if cols is not None else None
+    n_arr = np.array([p.shape[0] for p in clouds], dtype=np.int64)
+    total = int(n_arr.sum())
+    T = np.ascontiguousarray(np.stack([_T(t) for t in Ts]))
+    arr = lambda ts: C.cast((C.c_void_p * cnt)(*[t.data_ptr() for t in ts]), C.c_void_p) if ts is not None else None
+    op = torch.empty((max(total, 1), 3), dtype=torch.float32, device=dev)
+    oc = torch.empty_like(op) if cols is not None else None
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws, wsz = L.workspace(lib.kpx_fuse_voxel_workspace_bytes(total))
+    L.check(lib.kpx_fuse_voxel_downsample(cnt, arr(clouds), arr(cols), n_arr.ctypes.data_as(C.c_void_p), L.hptr(T), float(voxel), L.ptr(op),
+                                          L.ptr(oc), L.ptr(d_cnt), ws, wsz, L.stream_ptr()))
+    m = _count(d_cnt)[0]
+    return op[:m], (oc[:m] if oc is not None else None)
+
+
 def sor(pts, nb_neighbors, std_ratio, want_avg=False):
     """a8.  Returns keep_idx i32 (K), stats f64 (3) [mean, std, thr] (device), avg f64 (N)|None."""
     lib = L.load()

@@ -158,6 +158,67 @@ class CloudExchange:
                 return cloud[:, :3], cloud[:, 3:], all_T, counts
 
 
+class SensorExchange:
+    """Per-frame fuse exchange of the north-star partition (preprocessing/data.py:44-58: the sub devices' clouds are moved by
+    their transforms and stacked behind the master's): every rank contributes the masked clouds of the sensors it owns,
+    UNMOVED (float32 values of int16 sensor data: exact), together with their point counts and 4x4 transforms -- ONE
+    all-gather per frame.  The receiver applies the transforms inside the fused voxel grid in fp64
+    (kpx_fuse_voxel_downsample), so no float32 rounding of a moved point ever crosses the wire or decides a voxel.
+    Message of a rank: `cap` rows of xyz, `cap` rows of rgb (planar, so that every sensor's cloud is a contiguous (n,3) view
+    of the gathered buffer), then the header rows: k_max counts and k_max transforms as float64 bit patterns.  `cap` follows
+    the largest total of the previous frame (+25 %, rounded to 4096, the same on all ranks); a frame that outgrows it is
+    seen by every rank in the gathered header and sent again with room."""
+
+    def __init__(self, initial_rows: int, k_max: int, group=None):
+        self.cap = max(4096, int(initial_rows))
+        self.k_max = int(k_max)
+        self.group = group
+
+    def __call__(self, clouds, transforms):
+        """clouds: [(pts (n_i,3) f32, col (n_i,3) f32)] of this rank's sensors (at most k_max); transforms: (len(clouds),4,4) f64.
+        -> segments [[(pts, col)] per rank], T (world, k_max, 4, 4) numpy, counts (world, k_max) numpy int64"""
+        import numpy as np
+        W, K = world_size(self.group), self.k_max
+        ns = [int(p.shape[0]) for p, _ in clouds]
+        hdr = np.zeros(K * 17, dtype=np.float64)
+        hdr[:len(ns)] = ns
+        Tl = np.tile(np.eye(4), (K, 1, 1))
+        Tl[:len(ns)] = np.asarray(transforms, dtype=np.float64).reshape(-1, 4, 4)
+        hdr[K:] = Tl.reshape(-1)
+        if W == 1:
+            return [list(clouds)], Tl[None], np.array([ns + [0] * (K - len(ns))], dtype=np.int64)
+        dev = clouds[0][0].device
+        words = hdr.size * 2
+        hrows = -(-words // 3)
+        tail = torch.zeros(hrows * 3, dtype=torch.float32)
+        tail[:words] = torch.from_numpy(hdr).view(torch.float32)
+        while True:
+            cap = self.cap
+            msg = torch.empty((2 * cap + hrows, 3), dtype=torch.float32, device=dev)
+            off = 0
+            for (p, c), n in zip(clouds, ns):
+                k = max(0, min(n, cap - off))
+                msg[off:off + k] = p[:k]
+                msg[cap + off:cap + off + k] = c[:k]
+                off += k
+            msg[2 * cap:] = tail.reshape(hrows, 3).to(dev, non_blocking=True)
+            allm = _all_gather_flat(msg, self.group)                                  # (world, 2 cap + hrows, 3)
+            h = allm[:, 2 * cap:].reshape(W, -1)[:, :words].contiguous().cpu().view(torch.float64).numpy()   # one read-back
+            counts = h[:, :K].astype(np.int64)
+            need = int(counts.sum(1).max())
+            self.cap = max(4096, -(-int(need * 1.25) // 4096) * 4096)
+            if need <= cap:
+                segs = []
+                for r in range(W):
+                    o, row = 0, []
+                    for j in range(K):
+                        n = int(counts[r, j])
+                        row.append((allm[r, o:o + n], allm[r, cap + o:cap + o + n]))          # k_max entries per rank (empty ones included)
+                        o += n
+                    segs.append(row)
+                return segs, h[:, K:].reshape(W, K, 4, 4).copy(), counts
+
+
 class MasterBroadcast:
     """Calibration broadcast of the north-star partition (preprocessing/data.py:140-157 registers every sub device
     onto the master's cloud): rank 0 sends the master's down-sampled cloud and its normals, ONE collective per calibration.

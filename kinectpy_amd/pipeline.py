@@ -65,14 +65,12 @@ class SensorGroupPipeline:
         # -- transform + fuse + filter
         mk = ops._count(mcnt)
         masked = [(mp[i, :mk[i]], mc[i, :mk[i]]) for i in range(S)]
-        pts = [masked[0][0]] + [ops.transform(masked[i][0], Ts[i]) for i in range(1, S)]
-        fused_p = torch.cat(pts, 0)
-        fused_c = torch.cat([m[1] for m in masked], 0)
-        vp, vc, _ = ops.voxel_downsample(fused_p, p.filt_voxel, fused_c)
+        # pcd.transform(T_i) + np.vstack + voxel_down_sample (data.py:44-61) in one pass, on the fp64 values of the moved points
+        vp, vc = ops.fuse_voxel_downsample([m[0] for m in masked], [m[1] for m in masked], Ts, p.filt_voxel)
         keep, _, _ = ops.sor(vp, p.filt_k, p.filt_ratio)
         out_p, out_c, _ = ops.select_by_index([vp, vc], keep, trusted=True)
         self.last = {"icp": stats, "n_down": [int(d.shape[0]) for d in downs], "n_masked": [int(m[0].shape[0]) for m in masked],
-                     "n_fused": int(fused_p.shape[0]), "n_out": int(out_p.shape[0])}
+                     "n_fused": int(sum(mk)), "n_voxel": int(vp.shape[0]), "n_out": int(out_p.shape[0])}
         return out_p, out_c, np.stack(Ts)
 
     def exchange(self, out_p, out_c, Ts, to_global: np.ndarray):
@@ -95,9 +93,10 @@ class SensorShardPipeline:
         rank 0       + normals of the master's down-sampled cloud, then ONE broadcast of (cloud, normals)
         every rank   execute_point_to_plane_registration of its own sub sensors onto the master cloud (kpx_icp_batch)
     per frame (data.py:35-61):
-        every rank   depth + person mask -> masked, gated clouds of its sensors; pcd.transform(T_i) for the subs
-                     ONE all-gather of the transformed clouds, in sensor order (= np.vstack of data.py:55-58), with the
-                     4x4 transforms and the counts in the header rows
+        every rank   depth + person mask -> masked, gated clouds of its sensors
+                     ONE all-gather of those clouds (unmoved: exact float32 of int16 data), in sensor order (= np.vstack of
+                     data.py:55-58), with their counts and 4x4 transforms in the header rows; pcd.transform(T_i) happens
+                     inside the fused voxel grid, in fp64 (kpx_fuse_voxel_downsample)
         filter_outliers on the FUSED cloud (data.py:61), `fused_filter`:
           "rank0"    rank 0 filters alone (the others return None and go on with the next frame);
           "sharded"  every rank down-samples the fused cloud (cheap, identical everywhere), searches the k neighbours of its
@@ -128,7 +127,7 @@ class SensorShardPipeline:
         self.fused_filter = fused_filter
         self.xy = self.ops._dev(xy_table, torch.float32).reshape(-1)
         self._bcast = parallel.MasterBroadcast(cloud_capacity, group)
-        self._xchg = parallel.CloudExchange(max(4096, cloud_capacity * self.k_max), group)     # the same on every rank
+        self._xchg = parallel.SensorExchange(max(4096, cloud_capacity * self.k_max), self.k_max, group)     # the same on every rank
         self.transforms = None            # (len(self.sensors), 4, 4) sub -> master of the sensors this rank owns
         self.last = {}
 
@@ -172,25 +171,16 @@ class SensorShardPipeline:
         S = depth.shape[0]
         mp, mc, _, mcnt = extracted if extracted is not None else o.depth_to_cloud(depth, self.xy, rgb, S, True, True, gate=p.gate, sync=False)
         mk = o._count(mcnt)
-        pts, cols = [], []
-        for i, g in enumerate(self.sensors):
-            q = mp[i, :mk[i]]
-            pts.append(q if g == 0 else o.transform(q, self.transforms[i]))
-            cols.append(mc[i, :mk[i]])
-        loc_p = pts[0] if S == 1 else torch.cat(pts, 0)
-        loc_c = cols[0] if S == 1 else torch.cat(cols, 0)
-        Tpad = np.stack(list(self.transforms) + [np.eye(4)] * (self.k_max - S))
-        if self.world > 1:                                                                # collective 2
-            fused_p, fused_c, all_T, counts = self._xchg(loc_p, loc_c, torch.as_tensor(Tpad))
-            all_T = all_T.cpu().numpy().reshape(self.world, self.k_max, 4, 4)
-            Ts = np.concatenate([all_T[r, :len(parallel.shard_sensors(self.n_sensors, r, self.world))] for r in range(self.world)])
-            fused_p, fused_c = fused_p.contiguous(), fused_c.contiguous()
-        else:
-            fused_p, fused_c, Ts, counts = loc_p, loc_c, self.transforms, [int(loc_p.shape[0])]
-        self.last.update(n_masked=[int(k) for k in mk], n_fused=int(fused_p.shape[0]), counts=counts)
+        local = [(mp[i, :mk[i]], mc[i, :mk[i]]) for i in range(S)]
+        segs, all_T, counts = self._xchg(local, self.transforms)                          # collective 2 (world > 1)
+        owned = [len(parallel.shard_sensors(self.n_sensors, r, self.world)) for r in range(self.world)]
+        Ts = np.concatenate([all_T[r, :owned[r]] for r in range(self.world)])             # sensor order
+        clouds = [seg for r in range(self.world) for seg in segs[r][:owned[r]]]
+        self.last.update(n_masked=[int(k) for k in mk], n_fused=int(counts.sum()), counts=[int(c) for c in counts.sum(1)])
         if self.world > 1 and self.fused_filter == "rank0" and self.rank != 0:
             return None, None, Ts
-        vp, vc, _ = o.voxel_downsample(fused_p, p.filt_voxel, fused_c)
+        # pcd.transform(T_i) + np.vstack + voxel_down_sample (data.py:44-61) in one pass, on the fp64 values of the moved points
+        vp, vc = o.fuse_voxel_downsample([c[0] for c in clouds], [c[1] for c in clouds], Ts, p.filt_voxel)
         M = int(vp.shape[0])
         if self.world > 1 and self.fused_filter == "sharded" and M > 0:
             rows = -(-M // self.world)                                                    # slab r = grid-order positions [r rows, (r+1) rows)

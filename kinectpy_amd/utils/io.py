@@ -9,13 +9,16 @@ DEPTH_SUFFIX = "_depth.dat"
 
 
 def load_color(color_fp: str) -> np.ndarray:
-    """utils/io.py:6-12 (PNG decode is host I/O and needs OpenCV, as in the reference)."""
-    try:
-        import cv2
-    except ImportError as e:          # not a compute fallback: the reference has the same dependency
-        raise ImportError("load_color needs OpenCV (cv2), exactly like KinectPy's utils/io.py") from e
+    """utils/io.py:6-12: the PNG as an RGB (H, W, 3) uint8 array.  Host file I/O: OpenCV as in the reference when it is
+    installed, otherwise Pillow (both decode PNG losslessly, so the array is the same)."""
     if not color_fp.endswith(COLOR_SUFFIX):
         color_fp += COLOR_SUFFIX
+    try:
+        import cv2
+    except ImportError:
+        from PIL import Image
+        with Image.open(color_fp) as im:
+            return np.array(im.convert("RGB"))
     return cv2.cvtColor(cv2.imread(color_fp), cv2.COLOR_BGR2RGB)
 
 

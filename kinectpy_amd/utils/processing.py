@@ -10,6 +10,12 @@ from .. import ops
 from ..geometry import PointCloud
 
 
+def sort_filenames_by_timestamp(list_of_files):
+    """utils/processing.py:12-20: sort by the integer made of all digits in the name (in place, as the reference)"""
+    list_of_files.sort(key=lambda x: int(''.join(filter(str.isdigit, x))))
+    return np.array(list_of_files)
+
+
 def select_points_randomly(pointcloud, number_of_points, seed=None):
     """utils/processing.py:259-275: `number_of_points` of the cloud, without replacement, as a float64 (k,3) array.
     The reference draws from NumPy's global generator; `seed` fixes the draw (default: a seed drawn from that same

@@ -243,6 +243,70 @@ KPO_API int64_t kpo_voxel_downsample(const real_t *pts, const real_t *col, const
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Transform + fuse + voxel_down_sample of preprocessing/data.py:44-61 in one step:            */
+/* cloud c is moved by T[c] (pcd.transform, :48; identity for the master), the clouds are      */
+/* stacked in order (np.vstack, :55-58) and the stack is down-sampled (filter_outliers ->      */
+/* voxel_down_sample, filtering.py:23).  In the reference the moved points are float64 arrays, */
+/* so here every decision (min bound, voxel index) and every sum uses the fp64 value           */
+/* p' = AC1(T[c], p) itself, never a float32 rounding of it -- in both storage modes.  Only    */
+/* the per-voxel means are stored (real_t).  Same order rules as kpo_voxel_downsample.         */
+/* ------------------------------------------------------------------------------------------ */
+KPO_API int64_t kpo_fuse_voxel_downsample(int32_t count, const real_t *const *pts, const real_t *const *col, const int64_t *n,
+                                          const double *T, double voxel, real_t *opts, real_t *ocol, int32_t *ocnt)
+{
+    if (!(voxel > 0.0)) return -1;
+    int64_t total = 0;
+    for (int c = 0; c < count; ++c) total += n[c];
+    if (total == 0) return 0;
+    double *q = (double *)malloc((size_t)total * 3 * sizeof(double));
+    const real_t **cp = (const real_t **)malloc((size_t)total * sizeof(real_t *));
+    int64_t w = 0;
+    for (int c = 0; c < count; ++c)
+        for (int64_t i = 0; i < n[c]; ++i, ++w) {
+            xform3(T + 16 * c, (double)pts[c][3 * i], (double)pts[c][3 * i + 1], (double)pts[c][3 * i + 2], q + 3 * w);
+            cp[w] = (col && col[c]) ? col[c] + 3 * i : NULL;
+        }
+    double mn[3] = { q[0], q[1], q[2] };
+    for (int64_t i = 1; i < total; ++i)
+        for (int a = 0; a < 3; ++a) if (q[3 * i + a] < mn[a]) mn[a] = q[3 * i + a];
+    double org[3];
+    for (int a = 0; a < 3; ++a) org[a] = mn[a] - voxel * 0.5;
+    kv_t *kv = (kv_t *)malloc((size_t)total * sizeof(kv_t));
+    for (int64_t i = 0; i < total; ++i) {
+        uint64_t key = 0;
+        for (int a = 0; a < 3; ++a) {
+            double f = floor((q[3 * i + a] - org[a]) / voxel);
+            if (!(f >= 0.0) || f >= 2097152.0) { free(kv); free(q); free(cp); return -2; }
+            key = (key << 21) | (uint64_t)f;
+        }
+        kv[i].key = key; kv[i].idx = i;
+    }
+    qsort(kv, (size_t)total, sizeof(kv_t), cmp_kv);
+    int64_t m = 0, i = 0;
+    while (i < total) {
+        int64_t j = i;
+        double sp[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
+        while (j < total && kv[j].key == kv[i].key) {
+            int64_t p = kv[j].idx;
+            for (int a = 0; a < 3; ++a) {
+                sp[a] += q[3 * p + a];
+                if (cp[p]) sc[a] += (double)cp[p][a];
+            }
+            ++j;
+        }
+        double c = (double)(j - i);
+        for (int a = 0; a < 3; ++a) {
+            opts[3 * m + a] = (real_t)(sp[a] / c);
+            if (ocol) ocol[3 * m + a] = (real_t)(sc[a] / c);
+        }
+        if (ocnt) ocnt[m] = (int32_t)(j - i);
+        ++m; i = j;
+    }
+    free(kv); free(q); free(cp);
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Uniform grid used to accelerate the exact neighbour searches (stand-in for Open3D's         */
 /* KD-tree: any exact search returns the same neighbour distances).                             */
 /* Contract AC3 (direct squared distance): d2 = fma(dz,dz, fma(dy,dy, dx*dx)), dx = xi - xj.   */

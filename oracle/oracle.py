@@ -167,6 +167,33 @@ def voxel_downsample(pts, voxel, col=None, nrm=None, return_counts=False):
     return tuple(res)
 
 
+def fuse_voxel_downsample(clouds, cols, Ts, voxel, return_counts=False):
+    """preprocessing/data.py:44-61 in one step: cloud c moved by Ts[c] (4x4; identity for the master), stacked in order,
+    voxel_down_sample(voxel) of the stack -- every decision on the fp64 value of the moved point (the reference's arrays are
+    float64), only the means are stored.  cols: list of colour arrays or None.  -> points, colours | None [, counts]"""
+    clouds = [_f32(p).reshape(-1, 3) for p in clouds]
+    cnt = len(clouds)
+    cols = [_f32(c).reshape(-1, 3) for c in cols] if cols is not None else None
+    n = np.array([len(p) for p in clouds], dtype=np.int64)
+    total = int(n.sum())
+    T = np.ascontiguousarray(np.stack([np.asarray(t, dtype=np.float64).reshape(4, 4) for t in Ts]))
+    pp = (C.c_void_p * cnt)(*[p.ctypes.data for p in clouds])
+    cc = (C.c_void_p * cnt)(*[c.ctypes.data for c in cols]) if cols is not None else None
+    op = np.zeros((max(total, 1), 3), dtype=_rt())
+    oc = np.zeros((max(total, 1), 3), dtype=_rt()) if cols is not None else None
+    ocnt = np.zeros(max(total, 1), dtype=np.int32)
+    lib().kpo_fuse_voxel_downsample.restype = C.c_int64
+    m = lib().kpo_fuse_voxel_downsample(C.c_int32(cnt), pp, cc, _p(n), _p(T), C.c_double(voxel), _p(op), _p(oc), _p(ocnt))
+    if m == -1:
+        raise RuntimeError("voxel_size <= 0")
+    if m == -2:
+        raise RuntimeError("voxel_size is too small")
+    res = [op[:m].copy(), oc[:m].copy() if oc is not None else None]
+    if return_counts:
+        res.append(ocnt[:m].copy())
+    return tuple(res)
+
+
 def sor(pts, nb_neighbors, std_ratio, brute=False):
     """a8.  Returns keep_idx i32 (K), (mean, std, thr), avg f64 (N)."""
     pts = _f32(pts).reshape(-1, 3)
@@ -747,8 +774,10 @@ def pipeline_step(xy, depth, rgb, inits, P):
         T, fit, rmse, it = registration_icp(downs[i], downs[0], P.icp_max_dist, inits[i - 1], P.icp_mode, tn, P.icp_max_iteration, grid=True)
         Ts.append(T)
         icp_stats.append((it, fit, rmse))
+    # transform + vstack + voxel_down_sample (data.py:44-61) on the fp64 values of the moved points, as the reference's
+    # float64 arrays carry them (fuse_voxel_downsample); the stacked cloud itself is kept only for inspection
+    vp, vc = fuse_voxel_downsample([m[0] for m in masked], [m[1] for m in masked], Ts, P.filt_voxel)
     pts = np.concatenate([masked[0][0]] + [transform(masked[i][0], Ts[i]) for i in range(1, S)])
-    col = np.concatenate([m[1] for m in masked])
-    vp, vc, _ = voxel_downsample(pts, P.filt_voxel, col)
     keep, stats, _ = sor(vp, P.filt_k, P.filt_ratio)
-    return vp[keep], vc[keep], Ts, {"downs": downs, "normals": tn, "icp": icp_stats, "fused": pts, "voxel": vp, "keep": keep, "sor_stats": stats}
+    return vp[keep], vc[keep], Ts, {"downs": downs, "normals": tn, "icp": icp_stats, "fused": pts, "masked": masked, "voxel": vp, "keep": keep,
+                                   "sor_stats": stats}

@@ -54,6 +54,11 @@ def voxel_downsample(pts, voxel, col=None, nrm=None):
     return torch.as_tensor(vp), (torch.as_tensor(vc) if vc is not None else None), None
 
 
+def fuse_voxel_downsample(clouds, cols, Ts, voxel):
+    vp, vc = O.fuse_voxel_downsample([_np(p) for p in clouds], [_np(c) for c in cols] if cols is not None else None, Ts, voxel)
+    return torch.as_tensor(vp), (torch.as_tensor(vc) if vc is not None else None)
+
+
 def estimate_normals(pts, radius, max_nn):
     return torch.as_tensor(O.estimate_normals(_np(pts), radius, max_nn)[0].astype(np.float32))
 

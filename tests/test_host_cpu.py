@@ -70,3 +70,53 @@ def test_synthetic_scene_is_deterministic():
     assert 0.15 < (a == 0).mean() < 0.45
     E = synth.camera_pose(1, 4)
     assert np.allclose(E[:3, :3] @ E[:3, :3].T, np.eye(3)) and abs(np.linalg.norm(E[:3, 3]) - 2500) < 1e-9
+
+
+# ---- on-disk formats: the PCD v0.7 binary layout Open3D writes, field by field ------------------------
+def test_pcd_header_fields_and_rgb_packing():
+    """preprocessing/data.py:69 / floor_removal.py:61,78 exchange clouds through o3d.io: header text, field order (normals before
+    rgb), SIZE/TYPE/COUNT, WIDTH = POINTS, HEIGHT 1, VIEWPOINT, DATA binary, float32 records, rgb = (r<<16)|(g<<8)|b as float bits"""
+    from kinectpy_amd import pcd_io
+    pts = np.array([[1.5, -2.25, 3.0], [1e3, 2e3, -3e3]])
+    nrm = np.array([[0.0, 0.0, 1.0], [0.6, 0.8, 0.0]])
+    col = np.array([[1.0, 0.5, 0.0], [0.2, 1.7, -0.3]])                 # out-of-range channels clamp
+    raw = pcd_io.encode_pcd(pts, nrm, col)
+    want = (b"# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z normal_x normal_y normal_z rgb\n"
+            b"SIZE 4 4 4 4 4 4 4\nTYPE F F F F F F F\nCOUNT 1 1 1 1 1 1 1\nWIDTH 2\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 2\nDATA binary\n")
+    assert raw.startswith(want) and len(raw) == len(want) + 2 * 7 * 4
+    rec = np.frombuffer(raw[len(want):], dtype="<f4").reshape(2, 7)
+    assert np.array_equal(rec[:, :3], pts.astype(np.float32)) and np.array_equal(rec[:, 3:6], nrm.astype(np.float32))
+    packed = np.ascontiguousarray(rec[:, 6]).view(np.uint32)
+    assert packed[0] == (255 << 16) | (128 << 8) | 0                   # round(0.5 * 255) = 128
+    assert packed[1] == (51 << 16) | (255 << 8) | 0
+    assert pcd_io.pcd_header(["x", "y", "z"], 0).endswith("WIDTH 0\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 0\nDATA binary\n")
+    p, n, c = pcd_io.decode_pcd(raw)
+    assert np.array_equal(p, pts.astype(np.float32).astype(np.float64)) and np.array_equal(n, nrm.astype(np.float32).astype(np.float64))
+    assert np.array_equal(c, np.array([[255, 128, 0], [51, 255, 0]]) / 255.0)
+    p, n, c = pcd_io.decode_pcd(pcd_io.encode_pcd(pts))
+    assert n is None and c is None and len(p) == 2
+
+
+def test_pcd_reader_accepts_other_writers():
+    """a PCL-style file of the same cloud: fields in another order, an extra field, rgb as TYPE U, float64 x; and DATA ascii"""
+    from kinectpy_amd import pcd_io
+    hdr = (b"# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS rgb intensity x y z\nSIZE 4 4 8 4 4\nTYPE U F F F F\n"
+           b"COUNT 1 1 1 1 1\nWIDTH 2\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 2\nDATA binary\n")
+    rec = np.zeros(2, dtype=[("rgb", "<u4"), ("i", "<f4"), ("x", "<f8"), ("y", "<f4"), ("z", "<f4")])
+    rec["rgb"] = [(10 << 16) | (20 << 8) | 30, 0xFFFFFF]
+    rec["x"], rec["y"], rec["z"] = [1.25, -7.0], [2.0, 8.0], [3.0, 9.0]
+    p, n, c = pcd_io.decode_pcd(hdr + rec.tobytes())
+    assert np.array_equal(p, [[1.25, 2.0, 3.0], [-7.0, 8.0, 9.0]]) and n is None
+    assert np.array_equal(c, np.array([[10, 20, 30], [255, 255, 255]]) / 255.0)
+    txt = (b"VERSION .7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA ascii\n"
+           b"0.5 1.5 2.5 4.2108e+06\n-1 -2 -3 0\n")
+    p, n, c = pcd_io.decode_pcd(txt)
+    assert np.array_equal(p, [[0.5, 1.5, 2.5], [-1, -2, -3]]) and c.shape == (2, 3)
+    with pytest.raises(RuntimeError):
+        pcd_io.decode_pcd(hdr.replace(b"DATA binary", b"DATA binary_compressed"))
+
+
+def test_sort_filenames_by_timestamp_kat():
+    """SURVEY 8c KAT6 (captured from the reference): the key is the integer of all digits in the name"""
+    from kinectpy_amd.utils.processing import sort_filenames_by_timestamp
+    assert list(sort_filenames_by_timestamp(["10_rgb.png", "9_rgb.png", "0100_rgb.png"])) == ["9_rgb.png", "10_rgb.png", "0100_rgb.png"]

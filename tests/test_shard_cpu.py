@@ -75,3 +75,5 @@ def test_sensor_partition_equals_single_process_oracle_cpu(world, n_sensors, mod
                 continue
             assert np.array_equal(p, ref_p) and np.array_equal(c, ref_c)
         assert last["n_fused"] == len(aux["fused"]) and sum(last["counts"]) == last["n_fused"]
+        if not (mode == "rank0" and rank != 0):
+            assert last["n_voxel"] == len(aux["voxel"])
