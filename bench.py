@@ -3,21 +3,35 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one synchronised frame set of the sensors a GPU owns
-(BASELINE.json configs[3]: a 4-sensor frame, 640x576 u16 depth + person-mask colour per sensor, already
-resident in HBM):  depth -> masked/gated compacted clouds (a1-a4)  ->  every sub sensor registered
-onto the group master exactly as execute_point_to_plane_registration does (voxel 35 -> normals ->
-point-to-plane ICP, threshold 100, <= 30 iterations; a11-a14)  ->  transform, fuse, filter_outliers
-(voxel 10 mm + SOR k=20, ratio 2.0; a17, a6-a8).  With N GPUs every rank owns its own 4-sensor group
-(weak scaling: per-GPU work is fixed) and the frame ends with the fuse exchange over RCCL
-(transforms + filtered clouds, kinectpy_amd/parallel.py).
+A "step" is one pass of the hot path over one synchronised frame set of S sensors (BASELINE.json configs[3]: 4 Kinect views,
+640x576 u16 depth + person-mask colour each; S = 8 at 8 GPUs = configs[4]):
 
-One JSON line is printed by rank 0.  `roofline` is the dominant kernel (the ICP iteration kernel: row prep +
-culled fp64-MFMA nearest-neighbour sweep + pair sums; KPX_NN_ENGINE=dense selects the all-pairs sweeps instead)
-timed with HIP events on its own stream inside the timed region (kpx_prof_*); `achieved` is SURVEY 8(d)'s
-algorithmic work (8 flop per source-target pair) over the launch duration, `issued_*` the flops of the 16x16x4 tiles
-the kernel really multiplied (counted on the device);
-`cpu_baseline` is the CPU oracle (oracle/, OpenMP over the host cores) running the same step.
+    depth -> full cloud -> voxel 35 -> (master: normals)                       a1-a4, a7, a11
+    every sub sensor registered onto the master exactly as execute_point_to_plane_registration does
+        (point-to-plane ICP, threshold 100, <= 30 iterations)                   a12-a14
+    depth + person mask -> masked, gated clouds; pcd.transform(T_i) + vstack + voxel 10 mm in one fp64 pass; SOR(20, 2.0)
+                                                                                a3-a4, a17, a6-a8
+
+--partition sensor (default) is the north-star partition (kinectpy_amd.pipeline.SensorShardPipeline): sensor g on GPU g
+(fewer GPUs than sensors: contiguous blocks), rank 0 broadcasts the master's down-sampled cloud + normals, every rank
+registers its own sensors, ONE all-gather of the masked clouds + transforms, filter on the FUSED cloud (sharded SOR with
+one all-gather of the slabs' mean distances, or on rank 0 alone).  The sensor count is fixed as GPUs are added up to 4
+("scaling": "strong"; 8 GPUs run the 8-sensor configuration).  --partition group is round 1's layout (every rank owns an
+independent 4-sensor group, weak scaling).
+
+`value` counts input depth pixels per second with the frames already resident in HBM when the timed region starts
+(the contract of this bench); `from_pinned_host` is the same loop fed from pinned host memory (H2D inside the step).
+
+One JSON line is printed by rank 0:
+  roofline          the kernel with the largest share of device time (the ICP correspondence kernel), timed ALONE on a quiet
+                    device with HIP events on its launch stream: `achieved` = flops of the 16x16x4 fp64-MFMA tiles it
+                    really multiplied (counted on the device) / duration; it is latency-bound, so `frac` is small by
+                    construction and both roofs are reported (issued flops vs the fp64 MFMA peak, PMC bytes vs HBM);
+                    SURVEY 8(d)'s all-pairs pricing is kept under its own name (`algorithmic_TFLOPs`), not as `achieved`;
+  roofline_targets  the north-star kernels measured in this process at BASELINE sizes: the dense all-pairs fp64-MFMA
+                    correspondence sweep at 100k x 100k, the 33-D feature GEMM, and the HBM-bound operators on >= 0.75 GB;
+  cpu_baseline      the same step through the CPU oracle (oracle/, C + OpenMP on the host cores), a bounded sample;
+  spread            median / min / max over repeated blocks of steps.
 """
 import argparse
 import json
@@ -31,29 +45,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_PX = 576 * 640
-PROF_STRIDE = 8                       # every 8th launch of a tagged kernel is timed (kpx_prof_stride)
 FP64_MFMA_PEAK_TFLOPS = 78.6          # MI355X dense fp64 matrix peak (vendor figure)
 FP32_MFMA_PEAK_TFLOPS = 157.3         # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E (MI355X_MICROARCH.md; ~6.3 TB/s is what a copy kernel reaches)
+KERNEL_OF = {"nn_local": "icp_iter_kernel", "nn_screen": "nn_screen_kernel", "nn_mfma": "nn_mfma_kernel"}
 
 
 def perturb(T, deg=3.0, mm=50.0, seed=0):
-    """initial guess = ground-truth extrinsic perturbed by 3 deg / 50 mm"""
-    rng = np.random.default_rng(seed)
-    ax = rng.normal(size=3)
-    ax /= np.linalg.norm(ax)
-    a = np.deg2rad(deg)
-    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
-    R = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
-    t = rng.normal(size=3)
-    t *= mm / np.linalg.norm(t)
-    P = np.eye(4)
-    P[:3, :3] = R
-    P[:3, 3] = t
-    return P @ T
+    from kinectpy_amd.utils import synth
+    return synth.perturb(T, deg, mm, seed)
 
 
 def make_group(rank, world, spg, n_frames):
-    """depth (F, spg, N_PX) u16, rgb (F, spg, N_PX, 3) u8, initial transforms, group->global transform"""
+    """--partition group: depth (F, spg, N_PX) u16, rgb (F, spg, N_PX, 3) u8, initial transforms, group->global transform"""
     from kinectpy_amd.utils import synth
     total = spg * world
     xy = synth.xy_table()
@@ -75,183 +79,356 @@ def make_group(rank, world, spg, n_frames):
 
 def cpu_step(O, xy, depth, rgb, inits, P):
     """the same step through the CPU oracle (baseline only)"""
-    S = depth.shape[0]
-    full, masked = [], []
-    for i in range(S):
-        xyz = O.unproject_u16(depth[i], xy)
-        full.append(O.rgbd_compact(xyz)[0])
-        p, c, _ = O.rgbd_compact(xyz, rgb[i], True, True, O.median_z(xyz) + P.gate)
-        masked.append((p, c))
-    downs = [O.voxel_downsample(f, P.reg_voxel)[0] for f in full]
-    tn = O.estimate_normals(downs[0], 2 * P.reg_voxel, P.normals_nn)[0].astype(np.float32)
-    Ts = [np.eye(4)]
-    for i in range(1, S):
-        T, _, _, _ = O.registration_icp(downs[i], downs[0], P.icp_max_dist, inits[i - 1], P.icp_mode, tn,
-                                        P.icp_max_iteration, grid=True)
-        Ts.append(T)
-    pts = np.concatenate([masked[0][0]] + [O.transform(masked[i][0], Ts[i]) for i in range(1, S)])
-    col = np.concatenate([m[1] for m in masked])
-    vp, vc, _ = O.voxel_downsample(pts, P.filt_voxel, col)
-    keep, _, _ = O.sor(vp, P.filt_k, P.filt_ratio)
-    return vp[keep], vc[keep], Ts
+    p, c, Ts, _ = O.pipeline_step(xy, depth, rgb, inits, P)
+    return p, c, Ts
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed counter pass (profiles/rNN/pmc_summary.csv: separate
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench, see profiles/README.md).  A counter pass cannot
-    run inside the timed bench, so this is the recorded figure, not a live one; FETCH_SIZE is the raw value (the gfx950
-    correction of MI355X_MICROARCH.md, x2 for 16 B/lane reads, does not apply to this kernel's 8 B/lane tile loads)."""
+def pmc_recorded(kernel):
+    """HBM bytes per launch and matrix-pipe busy fraction of `kernel` from the newest committed counter passes
+    (profiles/rNN/pmc_summary.csv, pmc_mfma.csv: separate `rocprofv3 --pmc` runs of this bench, see profiles/README.md).  A
+    counter pass cannot run inside the timed bench, so these are the recorded figures, not live ones."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_summary.csv")))
-    if not files:
-        return {"traffic": None}
-    kb = {}
-    with open(files[-1]) as f:
-        for row in csv.DictReader(f):
-            if row["kernel"].split("::")[-1].strip() == kernel:
-                kb[row["counter"]] = float(row["avg_KB_per_dispatch_raw"])
-    if "FETCH_SIZE" not in kb or "WRITE_SIZE" not in kb:
-        return {"traffic": None}
-    return {"traffic": round((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), "traffic_unit": "B/launch",
-            "traffic_source": os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__))) +
-                              " (FETCH_SIZE + WRITE_SIZE, recorded counter pass)"}
+    out = {"traffic": None}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.csv")))
+    if files:
+        kb = {}
+        with open(files[-1]) as f:
+            for row in csv.DictReader(f):
+                if row["kernel"].split("::")[-1].strip() == kernel:
+                    kb[row["counter"]] = float(row["avg_KB_per_dispatch_raw"])
+        if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
+            out = {"traffic": round((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), "traffic_unit": "B/launch",
+                   "traffic_source": os.path.relpath(files[-1], ROOT) + " (FETCH_SIZE + WRITE_SIZE, recorded counter pass)"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_mfma.csv")))
+    if files:
+        with open(files[-1]) as f:
+            for row in csv.DictReader(f):
+                if row.get("kernel", "").split("::")[-1].strip() == kernel and row.get("mfma_busy_frac"):
+                    out["mfma_busy"] = float(row["mfma_busy_frac"])
+                    out["mfma_busy_source"] = os.path.relpath(files[-1], ROOT)
+    return out
+
+
+def ev_timed(torch, fn, reps=5, warm=2):
+    """median device time (ms) of fn() on the current stream, HIP events"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts, out = [], None
+    for _ in range(reps):
+        e0.record()
+        out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts)), out
+
+
+def quiet_kernel_roofline(torch, ops, xy, pair_depth, init, P):
+    """The dominant kernel alone on the device: ONE registration (one lane, nothing else queued) of the step's own clouds,
+    every launch bracketed by an event pair on its stream (kpx_prof_*, stride 1)."""
+    S = pair_depth.shape[0]
+    fp, _, _, fcnt = ops.depth_to_cloud(pair_depth, xy, None, S, False, False, sync=False)
+    fk = ops._count(fcnt)
+    downs = [d[0] for d in ops.voxel_downsample_batch([fp[i, :fk[i]] for i in range(S)], P.reg_voxel)]
+    tn = ops.estimate_normals(downs[0], 2.0 * P.reg_voxel, P.normals_nn) if P.icp_mode == "p2plane" else None
+    for _ in range(3):
+        ops.icp_batch([downs[1]], downs[0], P.icp_max_dist, [init], P.icp_mode, tn, P.icp_max_iteration)
+    torch.cuda.synchronize()
+    ops.prof_stride(1)
+    ops.prof_begin(1 << 14)
+    reps = 10
+    for _ in range(reps):
+        ops.icp_batch([downs[1]], downs[0], P.icp_max_dist, [init], P.icp_mode, tn, P.icp_max_iteration)
+    torch.cuda.synchronize()
+    prof = ops.prof_end()
+    kname = max(KERNEL_OF, key=lambda k: prof[k][0])
+    ms, launches, flops = prof[kname]
+    if not launches:
+        return None
+    n, m = int(downs[1].shape[0]), int(downs[0].shape[0])
+    peak = FP32_MFMA_PEAK_TFLOPS if kname == "nn_screen" else FP64_MFMA_PEAK_TFLOPS
+    dur = ms / launches * 1e-3
+    issued = flops / launches
+    dense = 8.0 * n * m
+    roof = {"kernel": KERNEL_OF[kname], "bound": "latency", "achieved": round(issued / dur / 1e12, 4), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(issued / dur / 1e12 / peak, 5), "mfma_dtype": "f32" if kname == "nn_screen" else "f64",
+            "avg_launch_us": round(dur * 1e6, 2), "launches_timed": launches, "launches_per_registration": round(launches / reps, 1),
+            "issued_flop_per_launch": round(issued), "source_points": n, "target_points": m,
+            "algorithmic_flop_per_launch": round(dense), "algorithmic_TFLOPs": round(dense / dur / 1e12, 2),
+            "culled_to": round(issued / dense, 6), "algorithmic_bytes": 12 * (n + m),
+            "timing": "one registration alone on the device, HIP event pair around every launch on its launch stream"}
+    rec = pmc_recorded(KERNEL_OF[kname])
+    roof.update(rec)
+    if rec.get("traffic"):
+        roof["hbm_GBps"] = round(rec["traffic"] / dur / 1e9, 1)
+        roof["hbm_frac"] = round(rec["traffic"] / dur / 1e9 / HBM_PEAK_GBS, 5)
+        roof["traffic_over_algorithmic"] = round(rec["traffic"] / (12 * (n + m)), 2)
+    roof["note"] = ("latency-bound: a launch is one round of waves whose duration is a wave's dependent-load chain; `achieved`/`frac` "
+                    "= flops of the MFMA tiles really multiplied vs the fp64 matrix peak, `hbm_frac` = recorded PMC bytes vs 8 TB/s; "
+                    "`algorithmic_TFLOPs` prices the search as SURVEY 8(d)'s all-pairs GEMM (8 flop per pair), which the kernel "
+                    "answers while multiplying `culled_to` of the tiles -- it is not a roofline fraction")
+    return roof
+
+
+def roofline_targets(torch, ops, quick=False):
+    """The north-star kernels at BASELINE sizes, measured here: MFMA distance GEMMs against the fp64 matrix peak,
+    HBM-bound operators on batches beyond the 256 MiB Infinity Cache against 8 TB/s (algorithmic bytes of SURVEY 8d)."""
+    from kinectpy_amd.utils import synth
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rows = []
+
+    def hbm(op, kernel, ms, nbytes, **extra):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        rows.append(dict({"op": op, "kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(gbs / HBM_PEAK_GBS, 4), "ms": round(ms, 4), "algorithmic_bytes": int(nbytes)}, **extra))
+
+    def mfma(op, kernel, ms, flops, **extra):
+        tf = flops / (ms * 1e-3) / 1e12
+        rows.append(dict({"op": op, "kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "ms": round(ms, 4), "flops": int(flops)}, **extra))
+
+    # ---- MFMA: the all-pairs correspondence sweep of the north star (dense engine), config 2: 100k x 100k
+    src, tgt, _ = synth.icp_pair(100_000)
+    s, t = torch.as_tensor(src).to(dev), torch.as_tensor(tgt).to(dev)
+    prev = ops.nn_engine("dense")
+    try:
+        ops.nn_search(s, t, np.eye(4))
+        torch.cuda.synchronize()
+        ops.prof_stride(1)
+        ops.prof_begin(256)
+        for _ in range(3):
+            ops.nn_search(s, t, np.eye(4))
+        torch.cuda.synchronize()
+        pr = ops.prof_end()
+    finally:
+        ops.nn_engine(prev)
+    for k in ("nn_mfma", "nn_screen"):
+        ms_k, cnt, work = pr[k]
+        if cnt:
+            mfma(f"all-pairs NN distance GEMM {len(src)} x {len(tgt)} (KPX_NN_ENGINE=dense, a14/a16)", KERNEL_OF[k], ms_k / cnt, work / cnt,
+                 launches=cnt, **({"peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(work / ms_k / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)} if k == "nn_screen" else {}))
+    del s, t
+    # ---- MFMA: 33-D feature matching GEMM (a13)
+    xy = synth.xy_table()
+    ex = synth.clutter()
+    feats = []
+    for i, seed in ((0, 100), (1, 101)):
+        dep = synth.render_depth(synth.camera_pose(i, 16), seed=seed, xy=xy, extra=ex)
+        pcl = ops.depth_to_cloud(dep, xy, None, 1, False, False)[0][0]
+        v = ops.voxel_downsample(pcl, 35.0)[0]
+        feats.append(ops.fpfh(v, ops.estimate_normals(v, 70.0, 40), 175.0, 40))
+    ms, _ = ev_timed(torch, lambda: ops.feature_nn(feats[1], feats[0]), reps=3, warm=1)
+    mfma(f"33-D feature NN GEMM {feats[1].shape[0]} x {feats[0].shape[0]} (a13, K = 36 augmented)", "feature_nn_kernel", ms,
+         2.0 * 36 * feats[1].shape[0] * feats[0].shape[0])
+    del feats
+    # ---- HBM: extract on 256 frames (0.19 GB of depth in, 0.57 - 2.3 GB out)
+    F = 64 if quick else 256
+    base_d, person = synth.render_depth(xy=xy, return_person=True)
+    depth = torch.as_tensor(np.tile(base_d, (F, 1))).to(dev)
+    rgb = torch.as_tensor(np.tile(synth.mask_rgb(person), (F, 1, 1))).to(dev)
+    xyd = torch.as_tensor(xy).to(dev)
+    ms, xyz = ev_timed(torch, lambda: ops.unproject_u16(depth, xyd, F))
+    hbm("unproject_u16 (a1)", "unproject_vec8_lds", ms, F * N_PX * 8, frames=F)
+    ms, res = ev_timed(torch, lambda: ops.depth_to_cloud(depth, xyd, None, F, False, False, sync=False))
+    kept = int(res[3].sum().item())
+    hbm("depth_to_cloud, no colour (a1+a3)", "depth_*", ms, F * N_PX * 2 + kept * 12, frames=F, kept=kept)
+    ms, res = ev_timed(torch, lambda: ops.depth_to_cloud(depth, xyd, rgb, F, True, True, sync=False))
+    kept = int(res[3].sum().item())
+    hbm("depth_to_cloud, mask + gate + colour (a1+a3+a4)", "depth_* + median_*", ms, F * N_PX * 5 + kept * 24, frames=F, kept=kept)
+    ms, res = ev_timed(torch, lambda: ops.rgbd_compact(xyz, rgb, F, True, True, want_idx=False), reps=3, warm=1)
+    kept = sum(int(r[0].shape[0]) for r in res)
+    hbm("rgbd_compact from int16 XYZ (a3+a4)", "compact_*", ms, F * N_PX * 9 + kept * 24, frames=F, kept=kept)
+    del depth, rgb, xyz, res
+    # ---- HBM: container operators on 64M points (0.77 GB)
+    n_big = 16_000_000 if quick else 64_000_000
+    big = torch.rand((n_big, 3), device=dev) * 3000
+    ms, _ = ev_timed(torch, lambda: ops.transform(big, synth.t_star(), out=big))
+    hbm("transform (a17)", "transform_lds_kernel", ms, n_big * 24, points=n_big)
+    idx = torch.randperm(n_big, device=dev)[: n_big // 2].to(torch.int32).sort().values
+    ms, _ = ev_timed(torch, lambda: ops.select_by_index([big], idx, trusted=True))
+    hbm("select_by_index (a22)", "gather3_kernel", ms, n_big // 2 * (12 + 12 + 4), points=n_big // 2)
+    ms, hs = ev_timed(torch, lambda: ops.halfspace_select(big, [0.1, -0.9, 0.2, 300.0]))
+    hbm("halfspace_select (a19)", "compact_pts_*", ms, n_big * 12 + int(hs.shape[0]) * 4, points=n_big)
+    ms, (lo_, up_) = ev_timed(torch, lambda: ops.slab_split(big, 200.0))
+    hbm("slab_split (a20)", "bbox + compact_pts_*", ms, n_big * 12 + n_big * 4, points=n_big)
+    del big, idx, hs, lo_, up_
+    # ---- HBM: voxel_down_sample of 64 clouds of 1M points (1.5 GB with colours)
+    nc = 16 if quick else 64
+    c3 = torch.as_tensor(synth.filter_cloud(1_000_000)).to(dev)
+    clouds = [(c3 + float(k)).contiguous() for k in range(nc)]
+    cols = [torch.rand_like(c3) for _ in range(nc)]
+    ms, outs = ev_timed(torch, lambda: ops.voxel_downsample_batch(clouds, 10.0, cols), reps=2, warm=1)
+    m_tot = sum(int(o[0].shape[0]) for o in outs)
+    hbm(f"voxel_down_sample, {nc} x 1M points, 10 mm, colours (a7)", "voxel_*", ms, 24 * nc * c3.shape[0] + 24 * m_tot, clouds=nc, voxels=m_tot)
+    return rows
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--sensors-per-gpu", type=int, default=4)
-    ap.add_argument("--frames", type=int, default=2, help="distinct synthetic time frames cycled through")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--partition", choices=["sensor", "group"], default="sensor")
+    ap.add_argument("--sensors", type=int, default=0, help="sensors of the rig (--partition sensor); 0 = 4, or 8 at 8 GPUs")
+    ap.add_argument("--fused-filter", choices=["sharded", "rank0"], default="sharded")
+    ap.add_argument("--sensors-per-gpu", type=int, default=4, help="--partition group only")
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic time frames cycled through")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--check", action="store_true", help="compare one GPU step against the oracle step")
     ap.add_argument("--overlap", type=int, default=2, help="frames in flight per GPU (pipeline.FrameStream); 1 = one after the other")
+    ap.add_argument("--spread-blocks", type=int, default=5, help="extra blocks of 20 steps for the run-to-run spread (0 = off)")
+    ap.add_argument("--no-targets", action="store_true", help="skip the roofline_targets leg")
+    ap.add_argument("--quick-targets", action="store_true", help="quarter-size batches for the roofline_targets leg")
     args = ap.parse_args()
 
     import torch
     from kinectpy_amd import ops, parallel
-    from kinectpy_amd.pipeline import FrameStream, PipelineParams, SensorGroupPipeline
+    from kinectpy_amd.pipeline import FrameStream, PipelineParams, SensorGroupPipeline, SensorShardPipeline
+    from kinectpy_amd.utils import synth
 
     rank, world, local = parallel.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
-    spg, F = args.sensors_per_gpu, args.frames
-    P = PipelineParams()
-    xy, depth_h, rgb_h, inits, truth, to_global = make_group(rank, world, spg, F)
-    depth = torch.as_tensor(depth_h).to(dev)
-    rgb = torch.as_tensor(rgb_h).to(dev)
-    pipe = SensorGroupPipeline(xy, inits, P, cloud_capacity=spg * 48 * 1024)
+    F, P = args.frames, PipelineParams()
+    overlap = max(1, args.overlap)
+    sensor_mode = args.partition == "sensor"
+    if sensor_mode:
+        S = args.sensors or (8 if world >= 8 else 4)
+        mine = parallel.shard_sensors(S, rank, world)
+        xy, depth_h, rgb_h, inits, truth = synth.sensor_ring(S, F, sensors=mine)
+        groups = [parallel.new_group() for _ in range(overlap)] if world > 1 else [None] * overlap
+        for g in groups:
+            parallel.warm(g, dev)
+        pipes = [SensorShardPipeline(xy, S, inits, P, group=g, fused_filter=args.fused_filter) for g in groups]
+        pipe = pipes[0]
+        px_per_step = S * N_PX                      # whole rig, all ranks together
+        local_inits = inits
+    else:
+        spg = args.sensors_per_gpu
+        xy, depth_h, rgb_h, local_inits, truth, to_global = make_group(rank, world, spg, F)
+        pipe = SensorGroupPipeline(xy, local_inits, P, cloud_capacity=spg * 48 * 1024)
+        pipes = None
+        px_per_step = world * spg * N_PX
+    depth_pin, rgb_pin = torch.as_tensor(depth_h).pin_memory(), torch.as_tensor(rgb_h).pin_memory()
+    depth, rgb = depth_pin.to(dev), rgb_pin.to(dev)
 
     def fuse(out):
-        out_p, out_c, Ts = out
-        if world > 1:                # the exchange stays on this thread, in frame order (one collective per frame)
+        if not sensor_mode and world > 1:           # group mode: the exchange stays on this thread, in frame order
+            out_p, out_c, Ts = out
             out_p, out_c, _, _ = pipe.exchange(out_p, out_c, Ts, to_global)
-        return out_p, out_c, Ts
+            return out_p, out_c, Ts
+        return out
 
-    def step(k):
-        f = k % F
-        return fuse(pipe.step(depth[f], rgb[f]))
+    frames = FrameStream(pipes if pipes is not None else pipe, overlap) if overlap > 1 else None
 
-    frames = FrameStream(pipe, args.overlap) if args.overlap > 1 else None
-
-    def run_steps(first, count):
+    def run_steps(first, count, d=None, c=None):
         """`count` steps, all finished on return; with --overlap > 1 up to that many frames are in flight"""
+        d, c = (depth, rgb) if d is None else (d, c)
         if frames is None:
             for k in range(first, first + count):
-                step(k)
+                dk, ck = d[k % F], c[k % F]
+                if not dk.is_cuda:
+                    dk, ck = dk.to(dev, non_blocking=True), ck.to(dev, non_blocking=True)
+                fuse(pipe.step(dk, ck))
             return
         for k in range(first, first + count):
             if frames.full():
                 fuse(frames.pop())
-            frames.submit(depth[k % F], rgb[k % F])
+            frames.submit(d[k % F], c[k % F])
         while frames.pending:
             fuse(frames.pop())
 
+    def timed(first, count, d=None, c=None):
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(first, count, d, c)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        return parallel.allreduce_max(time.perf_counter() - t0, dev)
+
     run_steps(0, args.warmup)
-    parallel.barrier()
-    torch.cuda.synchronize()
-    ops.prof_stride(PROF_STRIDE)    # an event pair around EVERY launch of the 16 us iteration kernel costs ~10 % end to end
-    ops.prof_begin(1 << 16)
-    t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    dt = time.perf_counter() - t0
-    prof = ops.prof_end()
-    dt = parallel.allreduce_max(dt, dev)
+    dt = timed(args.warmup, args.steps)                                  # THE timed region: exactly --steps steps
+    k0 = args.warmup + args.steps
+    blocks = []
+    for b in range(args.spread_blocks):
+        blocks.append(px_per_step * 20 / timed(k0, 20) / 1e6)
+        k0 += 20
+    dt_pin = timed(k0, args.steps, depth_pin, rgb_pin) if args.steps else None   # the same loop fed from pinned host memory
+    last = dict(pipe.last)
 
     if rank != 0:
         if frames is not None:
             frames.close()
         return
     ms_step = dt / args.steps * 1e3
-    value = world * spg * N_PX * args.steps / dt / 1e6
-    # dominant kernel = the correspondence sweep that took most device time: the fused ICP iteration kernel of the
-    # culled engine, or (KPX_NN_ENGINE=dense) the float32 screening sweep / the fp64 all-pairs sweep
-    kname = max(("nn_local", "nn_screen", "nn_mfma"), key=lambda k: prof[k][0])
-    ms, launches, flops = prof[kname]
-    peak = FP32_MFMA_PEAK_TFLOPS if kname == "nn_screen" else FP64_MFMA_PEAK_TFLOPS
-    kernel = {"nn_local": "icp_iter_kernel", "nn_screen": "nn_screen_kernel", "nn_mfma": "nn_mfma_kernel"}[kname]
-    roof = None
-    if launches:
-        achieved = flops / (ms * 1e-3) / 1e12
-        roof = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                "launches_timed": launches, "avg_launch_us": round(ms / launches * 1e3, 2),
-                "flop_per_launch": round(flops / launches), "timed_every": PROF_STRIDE,
-                "share_of_step": round(ms * PROF_STRIDE / (dt * 1e3), 3),
-                "mfma_dtype": "f32" if kname == "nn_screen" else "f64"}
-        if kname == "nn_local":
-            # SURVEY 8(d) prices the correspondence search at 8 flop per (source, target) pair per iteration; `achieved`
-            # follows that definition (algorithmic work / launch duration).  The culled kernel answers the same search
-            # while multiplying ~0.1 % of the pairs, so `frac` exceeds 1; the flops it really issues are reported beside it.
-            nd = pipe.last.get("n_down") if isinstance(pipe.last, dict) else None
-            if nd and len(nd) > 1:
-                dense = 8.0 * float(np.mean(nd[1:])) * float(nd[0])
-                algo = dense / (ms / launches * 1e-3) / 1e12
-                roof.update(achieved=round(algo, 2), frac=round(algo / peak, 3), flop_per_launch=round(dense),
-                            issued_flop_per_launch=round(flops / launches), issued_TFLOPs=round(achieved, 3),
-                            issued_frac=round(achieved / peak, 5), culled_to=round(flops / launches / dense, 5))
-            roof["note"] = ("achieved = SURVEY 8(d) algorithmic flops (8 per source-target pair) / launch duration; the kernel culls "
-                            "the pair matrix by bounding boxes and issues only issued_flop_per_launch: it is latency-bound "
-                            "(DESIGN.md 5); dense engine for comparison: KPX_NN_ENGINE=dense")
-    if roof is not None:
-        roof.update(pmc_traffic(kernel))
-    other = {k: {"launches": v[1], "avg_us": round(v[0] / max(v[1], 1) * 1e3, 2)} for k, v in prof.items() if k != kname}
+    value = px_per_step * args.steps / dt / 1e6
+
+    # ---- roofline of the dominant kernel, alone on the device
+    if sensor_mode and 1 in mine and 0 in mine:
+        pair = depth[0][[mine.index(0), mine.index(1)]].contiguous()
+        init01 = inits[0]
+    elif sensor_mode:
+        _, d01, _, i01, _ = synth.sensor_ring(S, 1, sensors=[0, 1])
+        pair, init01 = torch.as_tensor(d01[0]).to(dev), i01[0]
+    else:
+        pair, init01 = depth[0][:2].contiguous(), local_inits[0]
+    roof = quiet_kernel_roofline(torch, ops, pipe.xy, pair, init01, P)
+    if roof is not None and last.get("icp"):
+        its = [s[0] for s in last["icp"]]
+        roof["registrations_per_step_on_rank0"] = len(its)
+        roof["iterations_last_step"] = its
+    targets = None
+    if world == 1 and not args.no_targets:
+        targets = roofline_targets(torch, ops, quick=args.quick_targets)
 
     cpu = None
     if world == 1 and args.cpu_budget_s > 0:
         from oracle import oracle as O
         O.build()
         t_cpu, n_cpu, ref = 0.0, 0, None
-        while t_cpu < args.cpu_budget_s and n_cpu < max(1, F):
+        n_s = depth_h.shape[1]
+        while t_cpu < args.cpu_budget_s and n_cpu < max(1, min(F, 2)):
             t1 = time.perf_counter()
-            out = cpu_step(O, xy, depth_h[n_cpu % F], rgb_h[n_cpu % F], inits, P)
+            out = cpu_step(O, xy, depth_h[n_cpu % F], rgb_h[n_cpu % F], local_inits, P)
             ref = out if ref is None else ref          # frame 0, used by --check
             t_cpu += time.perf_counter() - t1
             n_cpu += 1
-        cpu = {"value": round(spg * N_PX * n_cpu / t_cpu / 1e6, 4), "unit": "Mpoints/s", "cores": O.num_threads(),
-               "kind": "port", "sample": f"{n_cpu} step(s) of the same {spg}-sensor frame workload through the CPU oracle "
+        cpu = {"value": round(n_s * N_PX * n_cpu / t_cpu / 1e6, 4), "unit": "Mpoints/s", "cores": O.num_threads(),
+               "kind": "port", "sample": f"{n_cpu} step(s) of the same {n_s}-sensor frame workload through the CPU oracle "
                f"(C/OpenMP restatement, grid-accelerated exact NN), {t_cpu:.1f} s"}
         if args.check:
-            gp, gc, gT = step(0)
+            gp, gc, gT = fuse(pipe.step(depth[0], rgb[0]))
             terr = np.abs(gT - np.stack(ref[2])).reshape(len(gT), -1).max(1)
             same = gp.shape[0] == ref[0].shape[0] and np.array_equal(gp.cpu().numpy(), ref[0])
-            close = gp.shape[0] == ref[0].shape[0] and np.abs(gp.cpu().numpy() - ref[0]).max() < 1e-3
-            print(f"# check vs oracle: transform errors {terr}, cloud sizes {gp.shape[0]}/{ref[0].shape[0]}, "
-                  f"identical={same}, within 1e-3 mm={close}", file=sys.stderr)
+            print(f"# check vs oracle: transform errors {terr}, cloud sizes {gp.shape[0]}/{ref[0].shape[0]}, identical={same}", file=sys.stderr)
+    if sensor_mode:
+        scaling = "strong"
+        workload = (f"BASELINE configs[{4 if S == 8 else 3}]: {S} synthetic Kinect views (640x576 u16 depth + person mask) per step, sensor g on "
+                    f"GPU g ({world} GPU{'s' if world > 1 else ''}: {len(mine)} sensor(s) per GPU): extract -> master-cloud broadcast -> per-GPU "
+                    f"point-to-plane ICP onto the master -> all-gather -> fused fp64 transform + voxel -> SOR on the fused cloud ({args.fused_filter})")
+        cfg = {"workload": workload, "partition": "sensor", "sensors": S, "sensors_on_rank0": mine, "fused_filter": args.fused_filter}
+    else:
+        scaling = "weak"
+        cfg = {"workload": "BASELINE configs[3], one independent 4-sensor group per GPU (round-1 layout): extract -> pairwise point-to-plane "
+                           "ICP onto the group master -> fuse -> voxel + SOR, then all-gather of the filtered clouds",
+               "partition": "group", "sensors_per_gpu": args.sensors_per_gpu}
+    cfg.update(pixels_per_step=px_per_step, icp=f"{P.icp_mode}, voxel {P.reg_voxel}, max_dist {P.icp_max_dist}, <= {P.icp_max_iteration} it",
+               filter=f"voxel {P.filt_voxel} + SOR({P.filt_k}, {P.filt_ratio})", frames_in_flight=overlap, distinct_frames=F, last_step=last)
     line = {
         "metric": "Mpoints/sec end-to-end (unproject+filter+ICP), 4-sensor frame", "value": round(value, 3), "unit": "Mpoints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3]: 4 synthetic Kinect views (640x576 u16 depth + person mask) per GPU per "
-                               "step: extract -> pairwise point-to-plane ICP onto the group master -> fuse -> voxel+SOR",
-                   "sensors_per_gpu": spg, "pixels_per_step_per_gpu": spg * N_PX, "icp": f"{P.icp_mode}, voxel {P.reg_voxel}, "
-                   f"max_dist {P.icp_max_dist}, <= {P.icp_max_iteration} it", "filter": f"voxel {P.filt_voxel} + SOR({P.filt_k}, {P.filt_ratio})",
-                   "frames_in_flight": args.overlap, "last_step": pipe.last},
-        "roofline": roof, "cpu_baseline": cpu, "kernels": other,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64 decisions / f32 storage", "data": "synthetic",
+        "config": cfg, "roofline": roof, "cpu_baseline": cpu,
+        "from_pinned_host": None if dt_pin is None else {"value": round(px_per_step * args.steps / dt_pin / 1e6, 3), "unit": "Mpoints/s",
+                                                         "ms_per_step": round(dt_pin / args.steps * 1e3, 3),
+                                                         "note": "same loop, every frame copied from pinned host memory inside its step"},
+        "spread": None if not blocks else {"blocks": len(blocks), "steps_per_block": 20, "median": round(float(np.median(blocks)), 1),
+                                          "min": round(min(blocks), 1), "max": round(max(blocks), 1), "unit": "Mpoints/s"},
+        "roofline_targets": targets,
     }
     if frames is not None:
         frames.close()

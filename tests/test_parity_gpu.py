@@ -1156,7 +1156,7 @@ def test_sharded_sor_bit_identical_to_one_call(ops, oracle, base_cloud, k, ratio
     assert torch.equal(keep, keep2) and torch.equal(stats, stats2) and torch.equal(avg, avg2)
     assert sorted(npy(order).tolist()) == list(range(n))
     ok, ostats, oavg = oracle.sor(npy(pts), k, ratio)
-    assert np.array_equal(npy(keep2), ok) and np.array_equal(npy(avg2), oavg)
+    assert np.array_equal(npy(keep2), ok) and np.allclose(npy(avg2), oavg, rtol=1e-12, atol=0)     # wave-order sums of sqrt: tolerance
     empty, _ = ops.sor_partial(pts, k, 5, 5)
     assert empty.numel() == 0
 

@@ -1,0 +1,66 @@
+"""Where does an ICP iteration's time go?  The bench's own registrations (31k x 31k down-sampled views, point to plane), run
+  alone (one registration, nothing else on the device), as the step runs them (3 side by side on the lanes), and 2 frames x 3.
+Prints per-launch kernel durations (HIP event pairs, stride 1) and host wall times.
+
+    python tools/icp_probe.py [reps]
+"""
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kinectpy_amd import ops  # noqa: E402
+from kinectpy_amd.pipeline import PipelineParams  # noqa: E402
+from kinectpy_amd.utils import synth  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+P = PipelineParams()
+xy, depth_h, rgb_h, inits, _ = synth.sensor_ring(4, 1)
+depth = torch.as_tensor(depth_h[0]).cuda()
+fp, _, _, fcnt = ops.depth_to_cloud(depth, xy, None, 4, False, False, sync=False)
+fk = ops._count(fcnt)
+downs = [d[0] for d in ops.voxel_downsample_batch([fp[i, :fk[i]] for i in range(4)], P.reg_voxel)]
+tn = ops.estimate_normals(downs[0], 2.0 * P.reg_voxel, P.normals_nn)
+print("clouds", [int(d.shape[0]) for d in downs])
+
+
+def run(count):
+    return ops.icp_batch(downs[1:1 + count], downs[0], P.icp_max_dist, inits[:count], P.icp_mode, tn, P.icp_max_iteration)
+
+
+def measure(label, fn, n_threads=1):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ops.prof_stride(1)
+    ops.prof_begin(1 << 16)
+    t0 = time.perf_counter()
+    if n_threads == 1:
+        for _ in range(reps):
+            r = fn()
+    else:
+        def worker():
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(reps):
+                    fn()
+                torch.cuda.current_stream().synchronize()
+        ths = [threading.Thread(target=worker) for _ in range(n_threads)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        r = None
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    pr = ops.prof_end()
+    ms, cnt, work = pr["nn_local"]
+    its = [x["iterations"] for x in r] if r else None
+    print(f"{label:46s} wall {wall:7.3f} ms/call  icp_iter launches/call {cnt / reps / n_threads:6.1f}  avg {ms / max(cnt, 1) * 1e3:6.2f} us  "
+          f"flop/launch {work / max(cnt, 1):.3g}  iterations {its}")
+
+
+measure("1 registration alone", lambda: run(1))
+measure("3 registrations side by side (one frame)", lambda: run(3))
+measure("2 frames in flight x 3 registrations", lambda: run(3), n_threads=2)
