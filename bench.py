@@ -369,7 +369,7 @@ def main():
 
     # ---- roofline of the dominant kernel, alone on the device
     if sensor_mode and 1 in mine and 0 in mine:
-        pair = depth[0][[mine.index(0), mine.index(1)]].contiguous()
+        pair = torch.stack([depth[0][mine.index(0)], depth[0][mine.index(1)]])
         init01 = inits[0]
     elif sensor_mode:
         _, d01, _, i01, _ = synth.sensor_ring(S, 1, sensors=[0, 1])

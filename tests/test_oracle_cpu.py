@@ -262,3 +262,43 @@ def test_coloured_icp_recovers_transform(oracle):
     tn = oracle.estimate_normals(tgt, 70.0, 30)[0].astype(np.float32)
     Tr, fit, rmse, it = oracle.registration_colored_icp(src, sc, tgt, tc, tn, 80.0, None, 0.968, 40)
     assert fit > 0.9 and np.abs(Tr[:3, :3] - T[:3, :3]).max() < 5e-3 and np.abs(Tr[:3, 3] - T[:3, 3]).max() < 6.0
+
+
+# ---- float32 storage (the product's contract) against float64 storage (the reference's) ---------------------------------
+def test_storage_modes_deviation(oracle):
+    """oracle.storage("f64") keeps clouds float64 between stages as the reference does (utils/io.py:29-41,
+    preprocessing/data.py:55-56).  Reduced-size configs 2, 3 and a config-4 step in both modes: coordinates agree to the
+    float32 spacing, registrations take the same iterations with the same correspondences, and the only index decisions that
+    move are voxel memberships of points lying within 2^-24 |x| of a voxel face WHEN the input of the voxel grid is itself a
+    float32 rounding of moved points (config 3; ~1e-5 of the points) -- which is why the frame loop's fuse runs
+    transform + stack + voxel in one fp64 pass (fuse_voxel_downsample, config-4 step: no disagreement at all).
+    Full-size numbers: profiles/r02/storage_deviation.json (python -m oracle.storage_deviation --full)."""
+    from oracle import storage_deviation as SD
+    rep = SD.report(full=False)
+    print(rep)
+    for mode in ("p2p", "p2plane"):
+        c2 = rep["config2"][mode]
+        assert c2["iterations"][0] == c2["iterations"][1] and c2["fitness_abs_diff"] == 0.0
+        assert c2["correspondences_differing_total"] <= 3 and c2["T_max_abs_diff"] < 1e-4
+    c3 = rep["config3"]
+    assert abs(c3["voxels"][0] - c3["voxels"][1]) <= 1e-4 * c3["n"] and max(c3["voxel_means_without_partner_within_1e-3mm"]) <= 1e-4 * c3["n"]
+    assert c3["voxel_mean_max_abs_diff_mm_of_matched"] < 5e-4 and c3["sor1_threshold_rel_diff"] < 1e-4
+    c4 = rep["config4_step"]
+    assert c4["icp_iterations"][0] == c4["icp_iterations"][1] and c4["T_max_abs_diff"] < 1e-3
+    assert c4["voxels"][0] == c4["voxels"][1] and c4["sor_keep_differing"] == 0 and c4["out_points"][0] == c4["out_points"][1]
+    assert c4["voxel_mean_max_abs_diff_mm"] < 1e-3
+
+
+def test_fused_voxel_grid_decides_on_fp64_values(oracle):
+    """fuse_voxel_downsample in float32 storage has the voxel membership of the float64 path (counts per voxel identical),
+    whereas voxel_down_sample of the float32-rounded moved points does not always"""
+    from kinectpy_amd.utils import synth
+    base = synth.frame_cloud()
+    a, b = base[0::2][:60000], base[1::2][:60000]
+    T = synth.perturb(np.eye(4), deg=17.0, mm=400.0, seed=3)
+    v32, _, c32 = oracle.fuse_voxel_downsample([a, b], None, [np.eye(4), T], 10.0, return_counts=True)
+    with oracle.storage("f64"):
+        v64, _, c64 = oracle.fuse_voxel_downsample([a, b], None, [np.eye(4), T], 10.0, return_counts=True)
+        w64, _, _, d64 = oracle.voxel_downsample(np.concatenate([a.astype(np.float64), oracle.transform(b, T)]), 10.0, return_counts=True)
+    assert np.array_equal(c32, c64) and np.array_equal(c64, d64) and np.array_equal(v64, w64)
+    assert np.abs(v32.astype(np.float64) - v64).max() < 3e-4
