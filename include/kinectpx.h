@@ -341,6 +341,11 @@ int kpx_prof_begin(int32_t capacity);
  * every launch of a 16 us kernel that is measurable in the end-to-end number (bench.py uses 8). */
 int kpx_prof_stride(int32_t stride);
 int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work);
+/* Device-side phase clock of the ICP iteration kernel (stamps while the profiler is armed), LAST launch: h_out8 = average
+ * microseconds a block spends in [0] the update prologue, [1] row preparation, [2] the culled sweep, [3] the pair epilogue,
+ * [4] the block sums; [5] blocks; [6] latest - earliest block start (dispatch ramp); [7] earliest start -> latest end;
+ * [8..12] the slowest block of each phase; [13] the longest block lifetime.  h_out8 holds 16 doubles. */
+int kpx_prof_icp_phases(double *h_out8);
 
 #ifdef __cplusplus
 }

@@ -661,6 +661,107 @@ __device__ void icp_finish(const double *acc, int64_t n, int mode, int k, int ma
     }
 }
 
+// The same step done by ONE WAVE (all 64 lanes call it; acc, st and fs in LDS or global memory visible to the wave).  The
+// serial version above keeps its 6x6 factors in scratch memory (dynamically indexed arrays): ~5 us of dependent memory
+// round trips in front of every block's sweep when the update runs in the iteration kernel's prologue.  Here the 6x6 system
+// is solved by Gauss-Jordan elimination on the augmented matrix [J^T J | -J^T r] held in LDS, lane (i, c) owning entry (i, c):
+// six rank-1 steps (no pivoting: the matrix is symmetric positive definite, as for Open3D's ldlt), then the three sine /
+// cosine pairs on three lanes and the 4x4 product U T on sixteen.  Point-to-point keeps the serial Jacobi/Kabsch on lane 0.
+// Mathematically the same update; rounding differs from the LDL^T order at the 1e-16 level (T is tolerance-checked).
+struct FinishScratch {
+    double M[6][8];
+    double trig[6];
+    double U[16];
+    double Tn[16];
+    int flag;
+};
+__device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, int mode, int k, int max_iter, double rel_fit, double rel_rmse,
+                                                IcpState *st, double *__restrict__ result, FinishScratch &fs, int lane)
+{
+    if (lane == 0) {
+        const double cnt = acc[0];
+        const double fit = (n > 0 && cnt > 0) ? cnt / (double)n : 0.0;
+        const double rmse = cnt > 0 ? sqrt(acc[1] / cnt) : 0.0;
+        bool done = false;
+        if (k >= 1 && fabs(st->fitness - fit) < rel_fit && fabs(st->rmse - rmse) < rel_rmse) done = true;
+        st->fitness = fit; st->rmse = rmse; st->count = cnt; st->iter = k;
+        if (k >= max_iter) done = true;
+        if (done) st->done = 1;
+        fs.flag = done ? 1 : (cnt < 1.0 ? 2 : 0);              // 2: no correspondence -> identity update
+    }
+    wave_lds_fence();
+    const int flag = fs.flag;
+    if (flag == 0) {
+        if (lane < 16) fs.U[lane] = (lane % 5 == 0) ? 1.0 : 0.0;
+        if (mode == 1) {
+            const int i = lane / 7, c = lane % 7;
+            if (lane < 42) {
+                double v;
+                if (c < 6) {
+                    const int a = i < c ? i : c, b = i < c ? c : i;           // upper-triangle slot of (a, b): 17 + a(13 - a)/2 + (b - a)
+                    v = acc[17 + (a * (13 - a)) / 2 + (b - a)];
+                } else {
+                    v = -acc[38 + i];
+                }
+                fs.M[i][c] = v;
+            }
+            wave_lds_fence();
+            bool ok = true;
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) {
+                const double d = fs.M[jj][jj];
+                ok = ok && (fabs(d) > 1e-300);
+                double v = 0.0;
+                const bool mine = lane < 42 && i != jj;
+                if (mine) {
+                    const double f = fs.M[i][jj] / d;
+                    v = c == jj ? 0.0 : fs.M[i][c] - f * fs.M[jj][c];
+                }
+                wave_lds_fence();
+                if (mine && ok) fs.M[i][c] = v;
+                wave_lds_fence();
+            }
+            if (ok) {
+                if (lane < 3) {
+                    const double a = fs.M[lane][6] / fs.M[lane][lane];
+                    fs.trig[2 * lane] = cos(a);
+                    fs.trig[2 * lane + 1] = sin(a);
+                } else if (lane < 6) {
+                    fs.U[4 * (lane - 3) + 3] = fs.M[lane][6] / fs.M[lane][lane];
+                }
+                wave_lds_fence();
+                if (lane == 0) {
+                    const double ca = fs.trig[0], sa = fs.trig[1], cb = fs.trig[2], sb = fs.trig[3], cg = fs.trig[4], sg = fs.trig[5];
+                    // Rz(g) Ry(b) Rx(a)
+                    fs.U[0] = cg * cb; fs.U[1] = cg * sb * sa - sg * ca; fs.U[2] = cg * sb * ca + sg * sa;
+                    fs.U[4] = sg * cb; fs.U[5] = sg * sb * sa + cg * ca; fs.U[6] = sg * sb * ca - cg * sa;
+                    fs.U[8] = -sb;     fs.U[9] = cb * sa;                fs.U[10] = cb * ca;
+                }
+            }
+        } else if (lane == 0) {
+            double U[16];
+            update_p2p(acc, U);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) fs.U[e] = U[e];
+        }
+        wave_lds_fence();
+        if (lane < 16) {
+            const int r = lane >> 2, c = lane & 3;
+            double v = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v += fs.U[4 * r + e] * st->T[4 * e + c];
+            fs.Tn[lane] = v;
+        }
+        wave_lds_fence();
+        if (lane < 16) st->T[lane] = fs.Tn[lane];
+    }
+    wave_lds_fence();
+    if (result) {
+        if (lane < 16) result[lane] = st->T[lane];
+        if (lane == 0) { result[16] = st->fitness; result[17] = st->rmse; result[18] = (double)k; result[19] = st->count; }
+    }
+}
+
 // 1024 threads: thread (slot q = t & 63, slice = t >> 6) sums its slice of the per-block partials with eight
 // interleaved accumulators (lanes of a wave read consecutive slots of one partial row: coalesced; a row-per-thread
 // variant was 3x slower, the single CU's address path saturates), the sixteen slices are then added in order (a
@@ -787,8 +888,10 @@ __global__ __launch_bounds__(256) void icp_solve_fixed_kernel(unsigned long long
     if (threadIdx.x < kAcc) sums[threadIdx.x] = (int)threadIdx.x < nacc ? fixed_total(acc, threadIdx.x) : 0.0;
     __syncthreads();
     for (int e = threadIdx.x; e < kAccCopies * kAcc * 2; e += 256) acc[e] = 0ull;
+    __shared__ FinishScratch fs;
+    if (threadIdx.x >= 64) return;
+    icp_finish_wave(sums, n, mode, k, max_iter, rel_fit, rel_rmse, st, result, fs, (int)threadIdx.x);
     if (threadIdx.x) return;
-    icp_finish(sums, n, mode, k, max_iter, rel_fit, rel_rmse, st, result);
     if (progress)
         __hip_atomic_store(progress, tag | ((unsigned long long)(st->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
@@ -830,34 +933,73 @@ struct IcpFuse {
     unsigned long long *progress, tag;
 };
 constexpr int kAccSet = kAccCopies * kAcc * 2;
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+// Phase clock of the iteration kernel (while the profiler is armed): thread 0 of every block stores 100 MHz wall-clock stamps in
+// its own row of g_icp_stamp -- [0] block start, [1] after the update prologue, [2] after row preparation, [3] after the culled
+// sweep, [4] after the pair epilogue, [5] block end.  Plain stores to private slots: the clock does not disturb what it times.
+// The rows of the LAST launch are read by kpx_prof_icp_phases.
+constexpr int kStampBlocks = 4096;
+__device__ unsigned long long g_icp_stamp[kStampBlocks][8];
+__device__ __forceinline__ void phase_tick(unsigned long long *__restrict__ armed, int slot, unsigned bid)
+{
+    if (!armed || threadIdx.x || bid >= kStampBlocks) return;
+    __builtin_nontemporal_store(wall_clock64(), &g_icp_stamp[bid][slot]);
+}
+// bid / nblocks: this block's index among the blocks of ITS registration (one launch may carry several, see icp_iter_batch_kernel)
+__device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned nblocks, const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
                                                        const double *__restrict__ tbbox, const int32_t *__restrict__ row_of,
                                                        const float *__restrict__ src_sorted, int32_t *__restrict__ idx_sorted,
+                                                       float *__restrict__ ptgt_sorted,
                                                        int32_t *__restrict__ idx_cur, double *__restrict__ d2_cur, double max_d2, int mode,
                                                        int k, const IcpState *__restrict__ st, unsigned long long *acc,
                                                        unsigned long long *__restrict__ tile_visits, IcpFuse fuse)
 {
     __shared__ IcpState s_state;
     __shared__ double s_sums[kAcc];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const int64_t row_base = ((int64_t)bid * kIWaves + wave) * kLRows;
+    const int64_t last = n - 1;
+    const unsigned long long t_block_start = (tile_visits && threadIdx.x == 0) ? wall_clock64() : 0ull;
+    // An iteration is a chain of dependent memory round trips, so everything that does not depend on this iteration's
+    // transform is requested FIRST -- the wave's rows, their previous partners (index AND coordinates, kept in sorted-row
+    // order by the previous launch: no gather through the index), the first 128 group boxes -- and arrives while the update
+    // algebra of the previous iteration runs below.
+    float my_src[3] = { 0.0f, 0.0f, 0.0f }, my_pt[3] = { 0.0f, 0.0f, 0.0f };
+    int32_t my_row = 0, my_prev = -1;
+    if (lane < 16) {
+        const int64_t r = row_base + lane < last ? row_base + lane : last;
+        my_row = row_of[r];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) my_src[a] = src_sorted[3 * r + a];
+        if (k > 0) {
+            my_prev = idx_sorted[r];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) my_pt[a] = ptgt_sorted[3 * r + a];
+        }
+    }
+    GroupPre gpre;
+    group_pre_load(gpre, group_box, n_groups, lane);
     const double *Tk = st->T;
     if (fuse.pair) {
         const IcpState *in = fuse.pair + ((k + 1) & 1);
         IcpState *out = fuse.pair + (k & 1);
-        if (in->done) {                                   // converged earlier: hand the state on, nothing else to do
-            if (blockIdx.x == 0 && threadIdx.x == 0) *out = *in;
-            return;
-        }
+        // state and accumulators are read in ONE round trip (the sums of a converged chain are simply not used)
         const unsigned long long *prev = fuse.ring + (int64_t)((k + 2) % 3) * kAccSet;
         if (k > 0 && threadIdx.x < kAcc) s_sums[threadIdx.x] = (int)threadIdx.x < (mode == 1 ? kAcc : 17) ? fixed_total(prev, threadIdx.x) : 0.0;
         if (threadIdx.x == 0) s_state = *in;
         __syncthreads();
-        if (k > 0 && threadIdx.x == 0)
-            icp_finish(s_sums, n, mode, k - 1, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, &s_state, blockIdx.x == 0 ? fuse.result : (double *)nullptr);
+        if (s_state.done) {                               // converged earlier: hand the state on, nothing else to do
+            if (bid == 0 && threadIdx.x == 0) *out = s_state;
+            return;
+        }
+        __shared__ FinishScratch s_fs;
+        if (k > 0 && wave == 0)
+            icp_finish_wave(s_sums, n, mode, k - 1, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, &s_state, bid == 0 ? fuse.result : (double *)nullptr,
+                            s_fs, lane);
         __syncthreads();
-        if (blockIdx.x == 0) {
+        if (bid == 0) {
             unsigned long long *next = fuse.ring + (int64_t)((k + 1) % 3) * kAccSet;
             for (int e = threadIdx.x; e < kAccSet; e += 256) next[e] = 0ull;
             if (threadIdx.x == 0) {
@@ -875,26 +1017,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ double rowd[kIWaves][16][5];          // s_x, s_y, s_z, K, bound / result value
     __shared__ int32_t rowi[kIWaves][16][2];         // partner (bound / result), original row
     __shared__ double sh[kAcc][kIRows + 1];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
-    const int64_t row_base = ((int64_t)blockIdx.x * kIWaves + wave) * kLRows;
-    const int64_t last = n - 1;
     const int nacc = mode == 1 ? kAcc : 17;
+    if (tile_visits && threadIdx.x == 0 && bid < kStampBlocks) {     // only launches that sweep stamp (not the converged / closing ones)
+        g_icp_stamp[bid][0] = t_block_start;
+        g_icp_stamp[bid][6] = (unsigned long long)nblocks;
+    }
+    phase_tick(tile_visits, 1, bid);
 
     if (lane < 16) {
-        // (source rows and last iteration's partners are kept in sorted-row order too: no dependent gather in front
-        // of the partner lookup)
-        const int64_t r = row_base + lane < last ? row_base + lane : last;
-        const int64_t i = row_of[r];
+        const int64_t i = my_row;
         double s[3];
-        xform_row(Tk, src_sorted + 3 * r, s);
+        xform_row(Tk, my_src, s);
         const double seed = row_seed(s);
         double bv = INFINITY;
         int32_t bj = INT_MAX;
         if (k > 0) {
-            const int32_t p = idx_sorted[r];
+            const int32_t p = my_prev;
             if (p >= 0) {
-                const float *tp = tgt + 3 * (int64_t)p;
-                const double tx = tp[0], ty = tp[1], tz = tp[2];
+                const double tx = my_pt[0], ty = my_pt[1], tz = my_pt[2];
                 const double t2 = fma(tx, tx, fma(ty, ty, tz * tz));
                 double d = fma(s[0], -2.0 * tx, seed);
                 d = fma(s[1], -2.0 * ty, d);
@@ -923,8 +1063,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         w.best[r] = rowd[wave][rr][4];
         w.bcol[r] = rowi[wave][rr][0];
     }
-    const unsigned visited = sweep_wave(w, Bs, orig, tile_box, group_box, n_groups, tbbox, lists[wave]);
-    if (tile_visits && lane == 0) atomicAdd(tile_visits + ((blockIdx.x * kIWaves + wave) & (kVisitSlots - 1)), (unsigned long long)visited);
+    phase_tick(tile_visits, 2, bid);
+    const unsigned visited = sweep_wave<true>(w, Bs, orig, tile_box, group_box, n_groups, tbbox, lists[wave], &gpre);
+    phase_tick(tile_visits, 3, bid);
+    if (tile_visits && lane == 0) atomicAdd(tile_visits + ((bid * kIWaves + wave) & (kVisitSlots - 1)), (unsigned long long)visited);
     wave_lds_fence();
     if (j == 0) {
 #pragma unroll
@@ -947,7 +1089,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             } else {
                 const double s[3] = { rowd[wave][lane][0], rowd[wave][lane][1], rowd[wave][lane][2] };
                 const float *tp = tgt + 3 * (int64_t)bj;
-                const double t[3] = { (double)tp[0], (double)tp[1], (double)tp[2] };
+                const float tf[3] = { tp[0], tp[1], tp[2] };
+                const double t[3] = { (double)tf[0], (double)tf[1], (double)tf[2] };
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ptgt_sorted[3 * (row_base + lane) + c] = tf[c];     // the next launch bounds this row with it
                 const double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
                 const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
                 d2_cur[i] = d2;
@@ -977,10 +1122,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     }
     __syncthreads();
+    phase_tick(tile_visits, 4, bid);
     if ((int)threadIdx.x < nacc) {
         double v = 0.0;
         for (int l = 0; l < kIRows; ++l) v += sh[threadIdx.x][l];
-        fixed_add(acc + (((int64_t)(blockIdx.x & (kAccCopies - 1)) * kAcc + threadIdx.x) * 2), v);
+        fixed_add(acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + threadIdx.x) * 2), v);
+    }
+    phase_tick(tile_visits, 5, bid);
+}
+
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+                                                       const float *__restrict__ tn, const double *__restrict__ Bs,
+                                                       const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
+                                                       const float *__restrict__ group_box, int32_t n_groups,
+                                                       const double *__restrict__ tbbox, const int32_t *__restrict__ row_of,
+                                                       const float *__restrict__ src_sorted, int32_t *__restrict__ idx_sorted,
+                                                       float *__restrict__ ptgt_sorted,
+                                                       int32_t *__restrict__ idx_cur, double *__restrict__ d2_cur, double max_d2, int mode,
+                                                       int k, const IcpState *__restrict__ st, unsigned long long *acc,
+                                                       unsigned long long *__restrict__ tile_visits, IcpFuse fuse)
+{
+    icp_iter_body(blockIdx.x, gridDim.x, src, n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, row_of, src_sorted, idx_sorted, ptgt_sorted,
+                  idx_cur, d2_cur, max_d2, mode, k, st, acc, tile_visits, fuse);
+}
+
+// Several registrations onto ONE shared target in one launch per iteration (kpx_icp_batch): block b belongs to the problem
+// whose block range holds it.  A frame's three or seven registrations then cost one chain of launches instead of three or
+// seven -- every kernel boundary writes back / invalidates the XCDs' L2s for everything else running on the device, so the
+// number of launches per frame, not their size, is what the frame rate of the pipeline follows.  A problem that has
+// converged keeps its blocks in the later launches: they read its state and return.
+constexpr int kIcpBatchMax = 8;
+struct IcpProblem {
+    const float *src;
+    const int32_t *row_of;
+    float *src_sorted;
+    int32_t *idx_sorted;
+    float *ptgt_sorted;
+    int32_t *idx_cur;
+    double *d2_cur;
+    IcpState *pair;
+    unsigned long long *ring;
+    double *result;
+    unsigned long long *progress;
+    int64_t n;
+    uint32_t block0, blocks;
+};
+struct IcpBatchArgs {
+    IcpProblem p[kIcpBatchMax];
+    int32_t count;
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void icp_iter_batch_kernel(IcpBatchArgs args, const float *__restrict__ tgt,
+                                                       const float *__restrict__ tn, const double *__restrict__ Bs,
+                                                       const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
+                                                       const float *__restrict__ group_box, int32_t n_groups,
+                                                       const double *__restrict__ tbbox, double max_d2, int mode, int k, int max_iter, double rel_fit,
+                                                       double rel_rmse, unsigned long long tag, unsigned long long *__restrict__ tile_visits)
+{
+    int pi = 0;
+#pragma unroll
+    for (int c = 1; c < kIcpBatchMax; ++c) pi += (c < args.count && blockIdx.x >= args.p[c].block0) ? 1 : 0;
+    const IcpProblem &P = args.p[pi];
+    const unsigned bid = blockIdx.x - P.block0;
+    if (k > max_iter && bid != 0) return;                   // the closing launch only performs the last update (one block per problem)
+    const IcpFuse fuse{ P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag };
+    icp_iter_body(bid, P.blocks, P.src, P.n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, P.row_of, P.src_sorted, P.idx_sorted, P.ptgt_sorted,
+                  P.idx_cur, P.d2_cur, max_d2, mode, k, P.pair, P.ring, tile_visits, fuse);
+}
+
+// Start of a batch chain in ONE launch: per problem both state slots <- the initial transform, the accumulator ring cleared,
+// the rows gathered into Morton order (what icp_init_kernel + a memset + gather_rows_kernel did per problem)
+struct Mat16x8 {
+    double m[kIcpBatchMax][16];
+};
+__global__ __launch_bounds__(256) void icp_batch_init_kernel(IcpBatchArgs args, Mat16x8 T0)
+{
+    int pi = 0;
+#pragma unroll
+    for (int c = 1; c < kIcpBatchMax; ++c) pi += (c < args.count && blockIdx.x >= args.p[c].block0) ? 1 : 0;
+    const IcpProblem &P = args.p[pi];
+    const unsigned bid = blockIdx.x - P.block0;
+    const int64_t r = (int64_t)bid * kIRows + (threadIdx.x >> 2);
+    const int c = threadIdx.x & 3;
+    if (r < P.n && c < 3) P.src_sorted[3 * r + c] = P.src[3 * (int64_t)P.row_of[r] + c];
+    if (bid == 0) {
+        for (int e = threadIdx.x; e < 3 * kAccSet; e += 256) P.ring[e] = 0ull;
+        if (threadIdx.x < 32) {
+            IcpState *st = P.pair + (threadIdx.x >> 4);
+            st->T[threadIdx.x & 15] = T0.m[pi][threadIdx.x & 15];
+            if ((threadIdx.x & 15) == 0) { st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0; }
+        }
     }
 }
 
@@ -992,6 +1223,41 @@ static unsigned long long *nn_visits_ptr()
     static unsigned long long *p = nullptr;
     if (!p && hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_nn_visits)) != hipSuccess) p = nullptr;
     return p;
+}
+// -> h_out8 (16 doubles): average us per block in the five phases of the LAST sweep launch, [5] blocks of that launch, [6] dispatch
+// ramp (latest block start - earliest block start), [7] span (earliest start -> latest end), [8..12] slowest block per phase,
+// [13] longest block lifetime
+int icp_phase_take(double *h_out8)
+{
+    static unsigned long long v[kStampBlocks][8];
+    unsigned long long *p = nullptr;
+    if (hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_icp_stamp)) != hipSuccess) return KPX_ERR_HIP;
+    if (hipMemcpy(v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return KPX_ERR_HIP;
+    for (int q = 0; q < 16; ++q) h_out8[q] = 0.0;
+    int blocks = (int)v[0][6];
+    if (blocks < 1) return KPX_OK;
+    if (blocks > kStampBlocks) blocks = kStampBlocks;
+    unsigned long long s_min = ~0ull, s_max = 0ull, e_max = 0ull;
+    int counted = 0;
+    for (int b = 0; b < blocks; ++b) {
+        if (!(v[b][5] >= v[b][0]) || v[b][1] < v[b][0]) continue;          // a block of an "already converged" launch stamps nothing new
+        for (int q = 0; q < 5; ++q) {
+            const double d = (double)(v[b][q + 1] - v[b][q]) * 0.01;
+            h_out8[q] += d;
+            if (d > h_out8[8 + q]) h_out8[8 + q] = d;                      // [8..12]: the slowest block of each phase
+        }
+        if ((double)(v[b][5] - v[b][0]) * 0.01 > h_out8[13]) h_out8[13] = (double)(v[b][5] - v[b][0]) * 0.01;   // longest block lifetime
+        s_min = v[b][0] < s_min ? v[b][0] : s_min;
+        s_max = v[b][0] > s_max ? v[b][0] : s_max;
+        e_max = v[b][5] > e_max ? v[b][5] : e_max;
+        ++counted;
+    }
+    if (!counted) return KPX_OK;
+    for (int q = 0; q < 5; ++q) h_out8[q] /= (double)counted;
+    h_out8[5] = (double)counted;
+    h_out8[6] = (double)(s_max - s_min) * 0.01;
+    h_out8[7] = (double)(e_max - s_min) * 0.01;
+    return KPX_OK;
 }
 double nn_local_take_visits()
 {
@@ -1074,7 +1340,7 @@ struct NnBuffers {
     // culled sweep
     double *Bs;
     int32_t *orig_t, *row_of, *idx_sorted;
-    float *src_sorted;
+    float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates of each row's last partner, same order
     unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
     float *tile_box, *group_box;
     SortScratch sort_t, sort_s;
@@ -1114,6 +1380,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->row_of = a.get<int32_t>(nn);
     b->idx_sorted = a.get<int32_t>(nn);
     b->src_sorted = a.get<float>(nn * 3);
+    b->ptgt_sorted = a.get<float>(nn * 3);
     b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * 2);      // ring of three sets (icp_iter_kernel, IcpFuse)
     sort_carve(a, n, &b->sort_s);
 }
@@ -1156,7 +1423,7 @@ static void icp_iter_launch(const float *src, const float *tgt, const float *tn,
     {
         ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
         hipLaunchKernelGGL(icp_iter_kernel, dim3((unsigned)cdiv(p.n_src, kIRows)), dim3(256), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t,
-                           b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.idx_cur, b.d2_cur,
+                           b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.ptgt_sorted, b.idx_cur, b.d2_cur,
                            max_d2, mode, k, b.state,
                            b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, IcpFuse{});
     }
@@ -1173,7 +1440,7 @@ static void icp_fused_launch(const float *src, const float *tgt, const float *tn
     const unsigned blocks = k > max_iter ? 1u : (unsigned)cdiv(p.n_src, kIRows);
     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
     hipLaunchKernelGGL(icp_iter_kernel, dim3(blocks), dim3(256), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t, b.tile_box, b.group_box,
-                       p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.idx_cur, b.d2_cur, max_d2, mode, k, b.state,
+                       p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.ptgt_sorted, b.idx_cur, b.d2_cur, max_d2, mode, k, b.state,
                        b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, fuse);
 }
 // ordered: b.orig_t / b.sort_t.bbox already hold the target's Morton order and bounding box (morton_order_batch)
@@ -1267,6 +1534,11 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
 
 using namespace kpx;
 
+KPX_EXPORT int kpx_prof_icp_phases(double *h_out8)
+{
+    KPX_REQUIRE(h_out8, "kpx_prof_icp_phases: null pointer");
+    return icp_phase_take(h_out8);
+}
 KPX_EXPORT int kpx_nn_engine(int32_t engine)
 {
     const int cur = local_engine() ? KPX_NN_ENGINE_CULLED : KPX_NN_ENGINE_DENSE;
@@ -1565,9 +1837,90 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         ++enq[i];
         return KPX_OK;
     };
-    const int used_lanes = count < kBatchLanes ? count : kBatchLanes;
-    rc = lanes_fork(ln, st, used_lanes);
-    if (local_engine()) {
+    // One chain of launches for up to kIcpBatchMax problems (icp_iter_batch_kernel) when the clouds were ordered by the batch sort;
+    // a single group runs on the caller's stream itself (no fork / join events).  KPX_ICP_BATCH_LAUNCH=0: one chain per problem.
+    static const bool batch_launch = [] { const char *e = getenv("KPX_ICP_BATCH_LAUNCH"); return !(e && e[0] == '0'); }();
+    static const bool fused_env = [] { const char *e = getenv("KPX_ICP_FUSE"); return !(e && e[0] == '0'); }();
+    const bool grouped = local_engine() && ordered && batch_launch && fused_env;
+    const int n_chain = grouped ? (int)cdiv(count, kIcpBatchMax) : count;
+    const bool on_caller = grouped && n_chain == 1;
+    const int used_lanes = on_caller ? 0 : (n_chain < kBatchLanes ? n_chain : kBatchLanes);
+    if (used_lanes) rc = lanes_fork(ln, st, used_lanes);
+    if (grouped) {
+        static thread_local unsigned long long *h_progress = nullptr;
+        static thread_local unsigned long long generation = 0;
+        if (!h_progress) KPX_HIP(hipHostMalloc((void **)&h_progress, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+        generation = (generation + 1) & 0xFFFFFFull;
+        const unsigned long long tag = generation << 40;
+        constexpr int window = 6;
+        IcpBatchArgs A[8], Ac[8];                              // count <= 64: at most 8 groups
+        int gk[8];
+        bool gfin[8];
+        unsigned gblocks[8];
+        for (int g = 0; g < n_chain && !rc; ++g) {
+            hipStream_t ls = on_caller ? st : lanes[g % kBatchLanes];
+            const int i0 = g * kIcpBatchMax, i1 = i0 + kIcpBatchMax < count ? i0 + kIcpBatchMax : count;
+            Mat16x8 T0;
+            unsigned b0 = 0;
+            for (int c = 0; c < kIcpBatchMax; ++c) {
+                const int i = i0 + c < i1 ? i0 + c : i1 - 1;      // unused slots repeat the last problem (never addressed: count bounds the search)
+                IcpProblem &P = A[g].p[c];
+                P.src = h_src[i]; P.row_of = bufs[i].row_of; P.src_sorted = bufs[i].src_sorted; P.idx_sorted = bufs[i].idx_sorted;
+                P.ptgt_sorted = bufs[i].ptgt_sorted; P.idx_cur = bufs[i].idx_cur; P.d2_cur = bufs[i].d2_cur; P.pair = bufs[i].state;
+                P.ring = bufs[i].acc_fixed; P.result = d_results + 20 * i; P.progress = &h_progress[i]; P.n = h_n_src[i];
+                P.block0 = b0; P.blocks = (unsigned)cdiv(h_n_src[i], kIRows);
+                Ac[g].p[c] = P;
+                Ac[g].p[c].block0 = (unsigned)c; Ac[g].p[c].blocks = 1u;
+                for (int e = 0; e < 16; ++e) T0.m[c][e] = h_init[16 * i + e];
+                if (i0 + c < i1) { b0 += P.blocks; __atomic_store_n(&h_progress[i], 0ull, __ATOMIC_RELAXED); }
+            }
+            A[g].count = Ac[g].count = i1 - i0;
+            gblocks[g] = b0;
+            gk[g] = 0; gfin[g] = false;
+            hipLaunchKernelGGL(icp_batch_init_kernel, dim3(b0), dim3(256), 0, ls, A[g], T0);
+        }
+        static const double stall_limit = [] { const char *e = getenv("KPX_ICP_STALL_SECONDS"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 60.0; }();
+        auto t_last = std::chrono::steady_clock::now();
+        const int last_k = max_iteration + 1;                  // the chain ends with an update-only launch
+        for (bool pending = true; pending && !rc;) {
+            pending = false;
+            bool advanced = false;
+            for (int g = 0; g < n_chain; ++g) {
+                if (gfin[g]) continue;
+                int seen = INT_MAX;
+                bool all_done = true;
+                for (int c = 0; c < A[g].count; ++c) {
+                    const unsigned long long w = __atomic_load_n(&h_progress[g * kIcpBatchMax + c], __ATOMIC_ACQUIRE);
+                    const bool mine = (w >> 40) == generation;
+                    if (mine && ((w >> 32) & 1ull)) continue;                          // this problem has converged
+                    all_done = false;
+                    const int sc = mine ? (int)(w & 0xFFFFFFFFull) : 0;
+                    seen = sc < seen ? sc : seen;
+                }
+                if (all_done) { gfin[g] = true; continue; }
+                hipStream_t ls = on_caller ? st : lanes[g % kBatchLanes];
+                while (gk[g] <= last_k && gk[g] - seen < window) {
+                    advanced = true;
+                    const bool closing = gk[g] > max_iteration;
+                    ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, ls);
+                    hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)A[g].count : gblocks[g]), dim3(256), 0, ls, closing ? Ac[g] : A[g], tgt,
+                                       tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box, bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2,
+                                       mode, gk[g], max_iteration, relative_fitness, relative_rmse, tag,
+                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr);
+                    ++gk[g];
+                }
+                if (gk[g] > last_k) { gfin[g] = true; continue; }
+                pending = true;
+            }
+            if (advanced) t_last = std::chrono::steady_clock::now();
+            else if (pending) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > stall_limit)
+                    rc = fail(KPX_ERR_HIP, "kpx_icp_batch: no progress for %.0f s (KPX_ICP_STALL_SECONDS)", stall_limit);
+                __builtin_ia32_pause();
+            }
+        }
+        if (hipGetLastError() != hipSuccess && !rc) rc = fail(KPX_ERR_HIP, "kpx_icp_batch: launch failed");
+    } else if (local_engine()) {
         // Culled engine: every update kernel publishes "iterations finished | converged" in a pinned word of its problem.
         // The driver keeps a window of iterations queued per problem and tops it up as the words advance: no copies, no
         // events, and at most `window` launches wasted after a problem converges (they return at once on its flag).
@@ -1646,7 +1999,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         }
     }
     }
-    {
+    if (used_lanes) {
         const int jrc = lanes_join(ln, st, used_lanes);
         rc = rc ? rc : jrc;
     }

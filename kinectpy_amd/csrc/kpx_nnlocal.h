@@ -139,9 +139,39 @@ struct WaveRows {
 
 // The culled sweep of one wave: on return best/bcol hold, in every lane, the row minimum (lexicographic (value,
 // original column)).  list: kLList ints of LDS owned by this wave.  Returns the number of tiles multiplied.
+// Group boxes the caller loaded ahead of time: box of group 64 t + lane in pre[t] (t < kGroupPre; an empty box beyond n_groups).
+// The loads do not depend on the transform, so the ICP kernel issues them before its update algebra and the first
+// level of the culling finds them in registers instead of waiting a memory round trip.
+constexpr int kGroupPre = 2;
+struct GroupPre {
+    float b[kGroupPre][6];
+};
+__device__ __forceinline__ void group_pre_load(GroupPre &g, const float *__restrict__ group_box, int32_t n_groups, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < kGroupPre; ++t) {
+        const int gi = 64 * t + lane;
+        const bool on = gi < n_groups;
+        const float *bx = group_box + (int64_t)(on ? gi : 0) * 6;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { g.b[t][a] = on ? bx[a] : kBoxBig; g.b[t][3 + a] = on ? bx[3 + a] : -kBoxBig; }
+    }
+}
+__device__ __forceinline__ double box_gap2v(const double slo[3], const double shi[3], const float bx[6])
+{
+    double g2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double g = fmax(0.0, fmax((double)bx[a] - shi[a], slo[a] - (double)bx[3 + a]));
+        g2 = fma(g, g, g2);
+    }
+    return g2;
+}
+
+template <bool PRE>
 __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
                                                const float *__restrict__ tile_box, const float *__restrict__ group_box,
-                                               int32_t n_groups, const double *__restrict__ tbbox, int32_t *list)
+                                               int32_t n_groups, const double *__restrict__ tbbox, int32_t *list, const GroupPre *pre)
 {
     const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
     constexpr double kRel = 1.0 + 9.31322574615478515625e-10;      // 1 + 2^-30
@@ -196,22 +226,24 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
         wave_lds_fence();                                  // the list writes before the reads
         bool updated = false;
         double b[4];
-        int32_t t[4];
-#pragma unroll
+        int32_t t[4], on[4];                               // the original column indices travel with the B operand: a tile
+#pragma unroll                                             // that reaches the list nearly always updates some row
         for (int h = 0; h < 4; ++h) {
             t[h] = h < nlist ? list[h] : -1;
             b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
+            on[h] = t[h] >= 0 ? orig[(int64_t)t[h] * 16 + j] : INT_MAX;
         }
         for (int e = 0; e < nlist; e += 4) {
             const d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[0], w.seed, 0, 0, 0);
             const d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[1], w.seed, 0, 0, 0);
             const d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[2], w.seed, 0, 0, 0);
             const d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[3], w.seed, 0, 0, 0);
-            const int32_t tc[4] = { t[0], t[1], t[2], t[3] };
+            const int32_t oc[4] = { on[0], on[1], on[2], on[3] };
 #pragma unroll
             for (int h = 0; h < 4; ++h) {                  // operands of the next trip
                 t[h] = e + 4 + h < nlist ? list[e + 4 + h] : -1;
                 b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
+                on[h] = t[h] >= 0 ? orig[(int64_t)t[h] * 16 + j] : INT_MAX;
             }
             bool pass = false;
 #pragma unroll
@@ -221,9 +253,6 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
             }
             if (__builtin_amdgcn_ballot_w64(pass) != 0) {
                 updated = true;
-                int32_t oc[4];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) oc[h] = tc[h] >= 0 ? orig[(int64_t)tc[h] * 16 + j] : INT_MAX;
 #define KPX_NNL_EXACT(ACC, COL)                                                                     \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
                     const bool tk = (int)(ACC[r] < w.best[r]) | ((int)(ACC[r] == w.best[r]) & (int)((COL) < w.bcol[r])); \
@@ -249,20 +278,24 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
         }
         wave_lds_fence();
     };
-    auto any_row_within = [&](const float *__restrict__ bx) {
-        double lo[3], hi[3];
-        load_box(bx, lo, hi);
+    auto any_row_within_v = [&](const float bx[6]) {
+        const double lo[3] = { (double)bx[0], (double)bx[1], (double)bx[2] }, hi[3] = { (double)bx[3], (double)bx[4], (double)bx[5] };
         bool t = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t |= pt_gap2(w.px[r], w.py[r], w.pz[r], lo, hi) <= rb[r];
         return t;
     };
-
-    for (int g0 = 0; g0 < n_groups; g0 += 64) {
-        const int g = g0 + lane;
-        const bool gp = g < n_groups && box_gap2(slo, shi, group_box + (int64_t)g * 6) <= R2;
-        const unsigned long long gmask = __builtin_amdgcn_ballot_w64(gp);
-        if (!gmask) continue;
+    auto any_row_within = [&](const float *__restrict__ bx) {
+        const float v[6] = { bx[0], bx[1], bx[2], bx[3], bx[4], bx[5] };
+        return any_row_within_v(v);
+    };
+    auto append_tiles = [&](int grp, bool hit) {
+        const unsigned tm16 = fold16(__builtin_amdgcn_ballot_w64(hit));
+        if (q == 0 && ((tm16 >> j) & 1u)) list[nlist + __builtin_popcount(tm16 & ((1u << j) - 1u))] = grp * kLGroupTiles + j;
+        nlist += __builtin_popcount(tm16);
+    };
+    // one 64-group trip: gmask = groups whose box the wave's box can reach
+    auto trip = [&](int g0, unsigned long long gmask) {
         for (int c = 0; c < 4; ++c) {
             const unsigned chunk = (unsigned)(gmask >> (16 * c)) & 0xFFFFu;
             if (!chunk) continue;
@@ -271,15 +304,36 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
             const bool gt = ((chunk >> j) & 1u) && any_row_within(group_box + (int64_t)gj * 6);
             unsigned gm16 = fold16(__builtin_amdgcn_ballot_w64(gt));
             while (gm16) {
-                const int grp = g0 + 16 * c + __builtin_ctz(gm16);
+                // the tile boxes of TWO surviving groups are fetched per round trip (a wave usually keeps one or two groups)
+                const int grp0 = g0 + 16 * c + __builtin_ctz(gm16);
                 gm16 &= gm16 - 1;
-                const int32_t tile = grp * kLGroupTiles + j;
-                const unsigned tm16 = fold16(__builtin_amdgcn_ballot_w64(any_row_within(tile_box + (int64_t)tile * 6)));
-                if (q == 0 && ((tm16 >> j) & 1u)) list[nlist + __builtin_popcount(tm16 & ((1u << j) - 1u))] = tile;
-                nlist += __builtin_popcount(tm16);
-                if (nlist > kLList - 16) process();
+                const bool two = gm16 != 0;
+                const int grp1 = two ? g0 + 16 * c + __builtin_ctz(gm16) : grp0;
+                gm16 &= gm16 - 1;
+                const float *p0 = tile_box + (int64_t)(grp0 * kLGroupTiles + j) * 6, *p1 = tile_box + (int64_t)(grp1 * kLGroupTiles + j) * 6;
+                const float v0[6] = { p0[0], p0[1], p0[2], p0[3], p0[4], p0[5] }, v1[6] = { p1[0], p1[1], p1[2], p1[3], p1[4], p1[5] };
+                append_tiles(grp0, any_row_within_v(v0));
+                if (two) append_tiles(grp1, any_row_within_v(v1));
+                if (nlist > kLList - 32) process();
             }
         }
+    };
+    int g_first = 0;
+    if (PRE) {
+#pragma unroll
+        for (int t = 0; t < kGroupPre; ++t) {
+            if (64 * t < n_groups) {
+                const unsigned long long gmask = __builtin_amdgcn_ballot_w64(box_gap2v(slo, shi, pre->b[t]) <= R2);   // empty boxes: gap = inf
+                if (gmask) trip(64 * t, gmask);
+            }
+        }
+        g_first = 64 * kGroupPre;
+    }
+    for (int g0 = g_first; g0 < n_groups; g0 += 64) {
+        const int g = g0 + lane;
+        const bool gp = g < n_groups && box_gap2(slo, shi, group_box + (int64_t)g * 6) <= R2;
+        const unsigned long long gmask = __builtin_amdgcn_ballot_w64(gp);
+        if (gmask) trip(g0, gmask);
     }
     if (nlist) process();
 
@@ -329,7 +383,7 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
         w.best[r] = init_val[row];
         w.bcol[r] = init_idx[row];
     }
-    const unsigned visited = sweep_wave(w, Bs, orig, tile_box, group_box, n_groups, tbbox, list);
+    const unsigned visited = sweep_wave<false>(w, Bs, orig, tile_box, group_box, n_groups, tbbox, list, nullptr);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = row_base + q + 4 * r;

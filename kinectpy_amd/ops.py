@@ -494,6 +494,18 @@ def prof_end():
     return {k: (float(ms[i]), int(cnt[i]), float(work[i])) for i, k in enumerate(PROF_KERNELS)}
 
 
+def prof_icp_phases():
+    """-> average microseconds per block and phase of the LAST launch of the ICP iteration kernel (profiler armed), the time
+    between the first and the last block start (dispatch ramp) and first start -> last end (span)"""
+    out = np.zeros(16)
+    L.check(L.load().kpx_prof_icp_phases(L.hptr(out)))
+    names = ("update_prologue", "row_prep", "sweep", "pair_epilogue", "block_sums")
+    d = {k: float(out[i]) for i, k in enumerate(names)}
+    d.update(blocks=int(out[5]), dispatch_ramp_us=float(out[6]), span_us=float(out[7]), slowest={k: float(out[8 + i]) for i, k in enumerate(names)},
+             longest_block_us=float(out[13]))
+    return d
+
+
 # ---- sampler / normaliser (SURVEY 8f rank 3) ---------------------------------------------------------
 NORM_OBB, NORM_OBB_ROT_TRANS, NORM_TRANSLATE, NORM_OBB_ROT = 0, 1, 2, 3
 _OBB_ERRORS = {-1: "fewer than 3 distinct points, or all points on one line", -2: "the convex hull did not close",

@@ -17,7 +17,8 @@ from kinectpy_amd import ops  # noqa: E402
 from kinectpy_amd.pipeline import PipelineParams  # noqa: E402
 from kinectpy_amd.utils import synth  # noqa: E402
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
+USE_PROF = "--noprof" not in sys.argv          # --noprof: no event pairs around the launches (for rocprofv3 traces: the pairs widen the gaps)
 P = PipelineParams()
 xy, depth_h, rgb_h, inits, _ = synth.sensor_ring(4, 1)
 depth = torch.as_tensor(depth_h[0]).cuda()
@@ -32,16 +33,14 @@ def run(count):
     return ops.icp_batch(downs[1:1 + count], downs[0], P.icp_max_dist, inits[:count], P.icp_mode, tn, P.icp_max_iteration)
 
 
-def measure(label, fn, n_threads=1):
-    for _ in range(3):
-        fn()
+def loop(fn, n_threads):
+    """reps calls of fn per thread, each thread on its own stream -> wall ms per call"""
     torch.cuda.synchronize()
-    ops.prof_stride(1)
-    ops.prof_begin(1 << 16)
     t0 = time.perf_counter()
+    last = [None]
     if n_threads == 1:
         for _ in range(reps):
-            r = fn()
+            last[0] = fn()
     else:
         def worker():
             with torch.cuda.stream(torch.cuda.Stream()):
@@ -51,14 +50,28 @@ def measure(label, fn, n_threads=1):
         ths = [threading.Thread(target=worker) for _ in range(n_threads)]
         [t.start() for t in ths]
         [t.join() for t in ths]
-        r = None
     torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / reps * 1e3
+    return (time.perf_counter() - t0) / reps * 1e3, last[0]
+
+
+def measure(label, fn, n_threads=1):
+    for _ in range(3):
+        fn()
+    wall_free, r = loop(fn, n_threads)                     # no event pairs around the launches
+    if not USE_PROF:
+        print(f"{label:46s} wall {wall_free:7.3f} ms/call")
+        return
+    ops.prof_stride(1)
+    ops.prof_begin(1 << 16)
+    ops.prof_icp_phases()
+    wall, r = loop(fn, n_threads)
     pr = ops.prof_end()
+    ph = ops.prof_icp_phases()
+    print("   last sweep launch, per-block phases (us):", {k: (round(v, 2) if not isinstance(v, dict) else {a: round(b, 2) for a, b in v.items()}) for k, v in ph.items()})
     ms, cnt, work = pr["nn_local"]
     its = [x["iterations"] for x in r] if r else None
-    print(f"{label:46s} wall {wall:7.3f} ms/call  icp_iter launches/call {cnt / reps / n_threads:6.1f}  avg {ms / max(cnt, 1) * 1e3:6.2f} us  "
-          f"flop/launch {work / max(cnt, 1):.3g}  iterations {its}")
+    print(f"{label:46s} wall {wall_free:7.3f} ms/call free, {wall:7.3f} with event pairs;  icp_iter launches/call {cnt / reps / n_threads:6.1f}  "
+          f"avg {ms / max(cnt, 1) * 1e3:6.2f} us  flop/launch {work / max(cnt, 1):.3g}  iterations {its}")
 
 
 measure("1 registration alone", lambda: run(1))

@@ -3,10 +3,10 @@ import cProfile, pstats, io, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
-from kinectpy_amd.pipeline import PipelineParams, SensorGroupPipeline
+from kinectpy_amd.pipeline import PipelineParams, SensorShardPipeline
 xy, depth_h, rgb_h, inits, truth, _ = bench.make_group(0, 1, 4, 2)
 depth = torch.as_tensor(depth_h).cuda(); rgb = torch.as_tensor(rgb_h).cuda()
-pipe = SensorGroupPipeline(xy, inits, PipelineParams())
+pipe = SensorShardPipeline(xy, 4, inits, PipelineParams())
 for k in range(5): pipe.step(depth[k % 2], rgb[k % 2])
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()

@@ -19,8 +19,7 @@ downs = T("voxel 35 x4, batch (what the pipeline calls)", lambda: [d[0] for d in
 tn = T("normals", lambda: ops.estimate_normals(downs[0], 70.0, 40))
 rs = T("icp_batch x3", lambda: ops.icp_batch(downs[1:], downs[0], 100.0, inits, "p2plane", tn, 30), reps=3)
 Ts = [np.eye(4)] + [r["transformation"] for r in rs]
-pts = T("transform x3 + cat", lambda: (torch.cat([masked[0][0]] + [ops.transform(masked[i][0], Ts[i]) for i in range(1, S)], 0), torch.cat([m[1] for m in masked], 0)))
-vp = T("voxel 10 fused", lambda: ops.voxel_downsample(pts[0], 10.0, pts[1]))
+vp = T("fused transform + stack + voxel 10", lambda: ops.fuse_voxel_downsample([m[0] for m in masked], [m[1] for m in masked], Ts, 10.0))
 keep = T("sor k=20", lambda: ops.sor(vp[0], 20, 2.0))
 out = T("select", lambda: ops.select_by_index([vp[0], vp[1]], keep[0], trusted=True))
 # one registration alone vs. the batch of three: how much of icp_batch is the latency chain of a single problem
