@@ -24,6 +24,7 @@ struct Grid {
     float *sorted_pts;       // device [n*3] points in cell order
     int32_t *sorted_idx;     // device [n] original index of each sorted point
     uint32_t *sorted_keys;   // device [n] cell id of each sorted point
+    int32_t *spare;          // device [16] words cleared by the build, for the caller's counters
 };
 // Carves a Grid out of the arena (dry arenas only count bytes) and, when real, builds it on `st`.
 // target_per_cell: desired mean occupancy of non-empty cells.

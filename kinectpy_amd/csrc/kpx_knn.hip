@@ -9,23 +9,18 @@
 #include <hipcub/hipcub.hpp>
 
 #include "kpx_gridknn.h"
+#include "kpx_morton.h"
 #include "kpx_linalg.h"
 
 namespace kpx {
 
 // ---- grid construction ------------------------------------------------------------------------------
-__global__ void grid_params_kernel(const double *__restrict__ bbox, int64_t n, double target, int32_t cell_cap, GridParams *gp)
+// Cell size of the grid: from the bounding box (volume and area heuristics), then -- refine -- corrected once by the occupancy an
+// average POINT saw in the first binning (sum c^2 / n: isolated outliers each own a cell and would drag a per-cell mean down);
+// occupancy ~ h^2.3 for surfaces with some thickness.  Pure function of (bbox, n, target, cell_cap, sumsq): every block of the
+// binning kernel evaluates it for itself (no parameter kernel in front of it), block 0 stores the result for the later kernels.
+__device__ __forceinline__ void grid_dims(const double ext[3], double &h, int32_t cell_cap, int dim[3])
 {
-    if (threadIdx.x || blockIdx.x) return;
-    double ext[3], vol = 1.0;
-    for (int a = 0; a < 3; ++a) { ext[a] = bbox[3 + a] - bbox[a]; if (!(ext[a] > 1e-9)) ext[a] = 1e-9; vol *= ext[a]; }
-    double nn = (double)(n > 0 ? n : 1);
-    double h3 = cbrt(vol * target / nn);
-    double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
-    double h2 = sqrt(area * target / nn) * 0.5;           // clouds are surfaces: size cells by area too
-    double h = h3 > h2 ? h3 : h2;
-    if (!(h > 0.0)) h = 1.0;
-    int dim[3];
     for (;;) {
         double tot = 1.0;
         for (int a = 0; a < 3; ++a) {
@@ -36,14 +31,33 @@ __global__ void grid_params_kernel(const double *__restrict__ bbox, int64_t n, d
         if (tot <= (double)cell_cap) break;
         h *= 1.26;
     }
-    gp->h = h;
-    for (int a = 0; a < 3; ++a) { gp->org[a] = bbox[a]; gp->dim[a] = dim[a]; }
-    gp->ncell = dim[0] * dim[1] * dim[2];
 }
-
-// occupancy feedback: the bounding-box heuristic above is far off for surfaces inside a mostly empty box, so the
-// cell size is corrected once from the measured occupancy.  The statistic is the occupancy seen by an average
-// POINT (sum c^2 / sum c): isolated outliers each own a cell and would drag a per-cell mean down.
+__device__ __forceinline__ GridParams grid_params_of(const double *__restrict__ bbox, int64_t n, double target, int32_t cell_cap,
+                                                     const unsigned long long *__restrict__ sumsq)
+{
+    GridParams gp;
+    double ext[3], vol = 1.0;
+    for (int a = 0; a < 3; ++a) { ext[a] = bbox[3 + a] - bbox[a]; if (!(ext[a] > 1e-9)) ext[a] = 1e-9; vol *= ext[a]; }
+    const double nn = (double)(n > 0 ? n : 1);
+    const double h3 = cbrt(vol * target / nn);
+    const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
+    const double h2 = sqrt(area * target / nn) * 0.5;           // clouds are surfaces: size cells by area too
+    double h = h3 > h2 ? h3 : h2;
+    if (!(h > 0.0)) h = 1.0;
+    int dim[3];
+    grid_dims(ext, h, cell_cap, dim);
+    if (sumsq) {
+        const double occ = (double)*sumsq / nn;
+        double f = pow(target / (occ > 1.0 ? occ : 1.0), 1.0 / 2.3);
+        f = f < 0.125 ? 0.125 : (f > 8.0 ? 8.0 : f);
+        h *= f;
+        grid_dims(ext, h, cell_cap, dim);
+    }
+    gp.h = h;
+    for (int a = 0; a < 3; ++a) { gp.org[a] = bbox[a]; gp.dim[a] = dim[a]; }
+    gp.ncell = dim[0] * dim[1] * dim[2];
+    return gp;
+}
 __global__ __launch_bounds__(256) void grid_occupancy_kernel(const uint32_t *__restrict__ cell_count, const GridParams *__restrict__ gp,
                                                              unsigned long long *__restrict__ sumsq)
 {
@@ -57,37 +71,17 @@ __global__ __launch_bounds__(256) void grid_occupancy_kernel(const uint32_t *__r
     c = block_sum(c, sh);
     if (threadIdx.x == 0 && c) atomicAdd(sumsq, c);
 }
-__global__ void grid_refine_kernel(const double *__restrict__ bbox, int64_t n, double target, const unsigned long long *__restrict__ sumsq,
-                                   int32_t cell_cap, GridParams *gp)
+__global__ __launch_bounds__(256) void grid_cell_kernel(const float *__restrict__ pts, int64_t n, const double *__restrict__ bbox, double target,
+                                                        int32_t cell_cap, const unsigned long long *__restrict__ sumsq, GridParams *gp,
+                                                        uint32_t *__restrict__ keys, int32_t *__restrict__ vals, uint32_t *__restrict__ cell_count)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    const double occ = (double)*sumsq / (double)(n > 0 ? n : 1);
-    double f = pow(target / (occ > 1.0 ? occ : 1.0), 1.0 / 2.3);       // occupancy ~ h^2.3 (surfaces with some thickness)
-    f = f < 0.125 ? 0.125 : (f > 8.0 ? 8.0 : f);
-    double h = gp->h * f;
-    double ext[3];
-    for (int a = 0; a < 3; ++a) { ext[a] = bbox[3 + a] - bbox[a]; if (!(ext[a] > 1e-9)) ext[a] = 1e-9; }
-    int dim[3];
-    for (;;) {
-        double tot = 1.0;
-        for (int a = 0; a < 3; ++a) {
-            double d = floor(ext[a] / h) + 1.0;
-            if (d > 1000000.0) d = 1000000.0;
-            dim[a] = (int)d; tot *= d;
-        }
-        if (tot <= (double)cell_cap) break;
-        h *= 1.26;
+    __shared__ GridParams sg;
+    if (threadIdx.x == 0) {
+        sg = grid_params_of(bbox, n, target, cell_cap, sumsq);
+        if (blockIdx.x == 0) *gp = sg;
     }
-    gp->h = h;
-    for (int a = 0; a < 3; ++a) gp->dim[a] = dim[a];
-    gp->ncell = dim[0] * dim[1] * dim[2];
-}
-
-__global__ __launch_bounds__(256) void grid_cell_kernel(const float *__restrict__ pts, int64_t n, const GridParams *__restrict__ gp,
-                                                        uint32_t *__restrict__ keys, int32_t *__restrict__ vals,
-                                                        uint32_t *__restrict__ cell_count)
-{
-    const GridParams g = *gp;
+    __syncthreads();
+    const GridParams g = sg;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int cx = cell_coord(pts[3 * i], g.org[0], g.h, g.dim[0]);
         int cy = cell_coord(pts[3 * i + 1], g.org[1], g.h, g.dim[1]);
@@ -111,7 +105,9 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
 {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     g->params = a.get<GridParams>(1);
-    uint32_t *count = a.get<uint32_t>((size_t)kGridMaxCells + 1);
+    // ONE cleared region per build: [16 spare words for the caller's counters | sum of squares | counts of the first binning |
+    // counts of the definitive binning] (each binning has its own counters so that nothing is cleared in between)
+    uint32_t *zero = a.get<uint32_t>(2 * ((size_t)kGridMaxCells + 1) + 32);
     g->cell_start = a.get<uint32_t>((size_t)kGridMaxCells + 1);
     g->sorted_pts = a.get<float>(nn * 3);
     g->sorted_idx = a.get<int32_t>(nn);
@@ -120,8 +116,8 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     int32_t *vals_in = a.get<int32_t>(nn);
     double *part = a.get<double>((size_t)kBboxBlocks * 6 + 8);
     size_t sort_bytes = 0, scan_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, (int)nn, 0, 22, st);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, count, g->cell_start, kGridMaxCells + 1, st);
+    (void)sort_pairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, (int64_t)nn, 22, st);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, zero, g->cell_start, kGridMaxCells + 1, st);
     char *tmp = a.get<char>(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
@@ -133,20 +129,19 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     // the neighbour search of a 30k-point cloud; a grid that would need more cells just gets coarser (results do not depend on h).
     int32_t cell_cap = 65536;
     while (cell_cap < kGridMaxCells && (int64_t)cell_cap < 16 * n) cell_cap <<= 1;
-    hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(1), 0, st, bbox, n, target_per_cell, cell_cap, g->params);
-    KPX_HIP(hipMemsetAsync(count, 0, ((size_t)cell_cap + 1) * sizeof(uint32_t), st));
+    g->spare = reinterpret_cast<int32_t *>(zero);
+    unsigned long long *sumsq = reinterpret_cast<unsigned long long *>(zero + 16);
+    uint32_t *count1 = zero + 32, *count2 = count1 + (size_t)cell_cap + 1;
+    KPX_HIP(hipMemsetAsync(zero, 0, (32 + 2 * ((size_t)cell_cap + 1)) * sizeof(uint32_t), st));
     int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
-    hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->params, keys_in, vals_in, count);
-    {   // one round of occupancy feedback, then the definitive binning
-        unsigned long long *sumsq = reinterpret_cast<unsigned long long *>(part);   // scratch word (bbox partials are consumed)
-        KPX_HIP(hipMemsetAsync(sumsq, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(grid_occupancy_kernel, dim3(1024), dim3(256), 0, st, count, g->params, sumsq);
-        hipLaunchKernelGGL(grid_refine_kernel, dim3(1), dim3(1), 0, st, bbox, n, target_per_cell, sumsq, cell_cap, g->params);
-        KPX_HIP(hipMemsetAsync(count, 0, ((size_t)cell_cap + 1) * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->params, keys_in, vals_in, count);
-    }
-    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, (int)n, 0, 22, st));
-    KPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, count, g->cell_start, cell_cap + 1, st));
+    // first binning from the bounding-box heuristic, one round of occupancy feedback, then the definitive binning
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, bbox, target_per_cell, cell_cap, (const unsigned long long *)nullptr, g->params,
+                       keys_in, vals_in, count1);
+    hipLaunchKernelGGL(grid_occupancy_kernel, dim3(1024), dim3(256), 0, st, count1, g->params, sumsq);
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, bbox, target_per_cell, cell_cap, (const unsigned long long *)sumsq, g->params,
+                       keys_in, vals_in, count2);
+    KPX_HIP(sort_pairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, n, 22, st));
+    KPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, count2, g->cell_start, cell_cap + 1, st));
     hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->sorted_idx, g->sorted_pts);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
@@ -294,7 +289,7 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     if (d_avg) avg = d_avg;
     const int32_t *out_idx = full ? g.sorted_idx : nullptr;
     const int64_t nq = q1 - q0;
-    int32_t *fb_count = fb_list + (n > 0 ? n : 1), *fb_count2 = fb_list2 + (n > 0 ? n : 1);
+    int32_t *fb_count = g.spare, *fb_count2 = g.spare + 1;       // cleared by the grid build
     const int threads = sor_block_threads(kk);
     const size_t lds = (size_t)kk * threads * sizeof(double);
     static bool attr_set = false;
@@ -304,8 +299,6 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
         KPX_HIP(hipFuncSetAttribute((const void *)sor_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
-    KPX_HIP(hipMemsetAsync(fb_count, 0, sizeof(int32_t), st));
-    KPX_HIP(hipMemsetAsync(fb_count2, 0, sizeof(int32_t), st));
     {
         ProfScope prof(KPX_PROF_SOR_KNN, 12.0 * (double)n + 8.0 * (double)n, st);     // read points, write mean distances
         const int32_t *none = nullptr;
@@ -452,7 +445,7 @@ static int normals_impl(const float *pts, int64_t n, double radius, int max_nn, 
     double *covbuf = a.get<double>((size_t)(n > 0 ? n : 1) * 10);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
-    int32_t *fb_count = fb_list + (n > 0 ? n : 1);
+    int32_t *fb_count = g.spare;                                  // cleared by the grid build
     const int threads = kk <= 48 ? 128 : 64;
     const size_t lds = (size_t)kk * threads * (sizeof(double) + sizeof(int32_t));
     static bool attr_set = false;
@@ -461,7 +454,6 @@ static int normals_impl(const float *pts, int64_t n, double radius, int max_nn, 
         KPX_HIP(hipFuncSetAttribute((const void *)normals_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
-    KPX_HIP(hipMemsetAsync(fb_count, 0, sizeof(int32_t), st));
     // pass 1: one wave per query, 512- or 1024-candidate buffer; pass 2: the few queries that did not fit, thread-per-query heap walk
     const int cap = kk <= 48 ? 512 : 1024;
     hipLaunchKernelGGL(normals_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256),

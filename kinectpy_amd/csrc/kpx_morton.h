@@ -10,6 +10,21 @@ namespace kpx {
 
 constexpr float kBoxBig = 3.0e38f;
 
+// Stable LSD radix sort of (key, int32 value) pairs on bits [0, end_bit).  Below 1M keys rocPRIM's default is a merge sort:
+// one block sort plus two launches per doubling (13 launches for 30k keys).  In this library's dependent chains the NUMBER of
+// launches is what costs (every boundary also writes back / invalidates the L2s under everything else on the device), so
+// keys of at most 32 significant bits go through Onesweep instead: histogram + scan + one pass per 8 bits (5 launches for
+// the 22-bit cell ids of a grid build).  Same result (both are stable).
+using NarrowSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+template <class Key>
+static inline hipError_t sort_pairs(void *tmp, size_t &bytes, const Key *keys_in, Key *keys_out, const int32_t *vals_in, int32_t *vals_out,
+                                    int64_t n, int end_bit, hipStream_t st)
+{
+    if (end_bit <= 32)
+        return rocprim::radix_sort_pairs<NarrowSortConfig>(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)end_bit, st);
+    return rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)end_bit, st);
+}
+
 // butterfly reductions: the result is valid in EVERY lane (kpx_common.h's wave_min / wave_max leave it in lane 0)
 __device__ __forceinline__ double wave_all_max(double v)
 {
@@ -85,8 +100,7 @@ static void sort_carve(Arena &a, int64_t n, SortScratch *s)
     s->keys_out = a.get<uint32_t>(nn);
     s->vals_in = a.get<int32_t>(nn);
     s->tmp_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->tmp_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_in, (int)nn, 0, 30,
-                                             (hipStream_t) nullptr);
+    (void)sort_pairs(nullptr, s->tmp_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_in, (int64_t)nn, 30, (hipStream_t) nullptr);
     s->tmp = a.get<char>(s->tmp_bytes);
     s->bbox_part = a.get<double>((size_t)kBboxBlocks * 6);
     s->bbox = a.get<double>(8);
@@ -97,7 +111,7 @@ static int morton_order(const float *pts, int64_t n, const SortScratch &s, int32
     if (rc) return rc;
     hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, pts, n, s.bbox, s.keys_in, s.vals_in);
     size_t bytes = s.tmp_bytes;
-    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.tmp, bytes, s.keys_in, s.keys_out, s.vals_in, d_perm, (int)n, 0, 30, st));
+    KPX_HIP(sort_pairs(s.tmp, bytes, s.keys_in, s.keys_out, s.vals_in, d_perm, n, 30, st));
     return KPX_OK;
 }
 

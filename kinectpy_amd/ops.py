@@ -153,7 +153,7 @@ def select_by_index(attrs, idx, invert=False, trusted=False):
     mode = 1 if invert else (0 if trusted else 2)
     m = n if mode else k
     outs = [torch.empty((m, 3), dtype=torch.float32, device=ref.device) if a is not None else None for a in attrs]
-    cnt = torch.zeros(1, dtype=torch.int32, device=ref.device) if mode else None
+    cnt = torch.empty(1, dtype=torch.int32, device=ref.device) if mode else None        # written by the compaction's scan
     ws, wsz = L.workspace(lib.kpx_select_workspace_bytes(n))
     L.check(lib.kpx_select_by_index(L.ptr(attrs[0]), L.ptr(attrs[1]), L.ptr(attrs[2]), n, L.ptr(idx), k, mode,
                                     L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(cnt), ws, wsz,
@@ -201,7 +201,7 @@ def voxel_downsample(pts, voxel, col=None, nrm=None):
     op = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
     oc = torch.empty_like(op) if col is not None else None
     on = torch.empty_like(op) if nrm is not None else None
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)                                  # written by the library (0 for an empty cloud)
     ws, wsz = L.workspace(lib.kpx_voxel_workspace_bytes(n))
     L.check(lib.kpx_voxel_downsample(L.ptr(pts), L.ptr(col), L.ptr(nrm), n, float(voxel), L.ptr(op), L.ptr(oc),
                                      L.ptr(on), L.ptr(cnt), ws, wsz, L.stream_ptr()))
@@ -223,7 +223,7 @@ def voxel_downsample_batch(clouds, voxel, cols=None):
     ocols = [torch.empty_like(o) for o in outs] if cols is not None else None
     n_arr = np.array([p.shape[0] for p in clouds], dtype=np.int64)
     arr = lambda ts: C.cast((C.c_void_p * cnt)(*[t.data_ptr() for t in ts]), C.c_void_p) if ts is not None else None
-    counts = torch.zeros(cnt, dtype=torch.int32, device=dev)
+    counts = torch.empty(cnt, dtype=torch.int32, device=dev)
     ws, wsz = L.workspace(lib.kpx_voxel_batch_workspace_bytes(cnt, n_arr.ctypes.data_as(C.c_void_p)))
     L.check(lib.kpx_voxel_downsample_batch(cnt, arr(clouds), arr(cols), n_arr.ctypes.data_as(C.c_void_p), float(voxel), arr(outs),
                                            arr(ocols), L.ptr(counts), ws, wsz, L.stream_ptr()))
@@ -246,7 +246,7 @@ def fuse_voxel_downsample(clouds, cols, Ts, voxel):
     arr = lambda ts: C.cast((C.c_void_p * cnt)(*[t.data_ptr() for t in ts]), C.c_void_p) if ts is not None else None
     op = torch.empty((max(total, 1), 3), dtype=torch.float32, device=dev)
     oc = torch.empty_like(op) if cols is not None else None
-    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_cnt = torch.empty(1, dtype=torch.int32, device=dev)
     ws, wsz = L.workspace(lib.kpx_fuse_voxel_workspace_bytes(total))
     L.check(lib.kpx_fuse_voxel_downsample(cnt, arr(clouds), arr(cols), n_arr.ctypes.data_as(C.c_void_p), L.hptr(T), float(voxel), L.ptr(op),
                                           L.ptr(oc), L.ptr(d_cnt), ws, wsz, L.stream_ptr()))
@@ -261,8 +261,8 @@ def sor(pts, nb_neighbors, std_ratio, want_avg=False):
     n = pts.shape[0]
     dev = pts.device
     idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    stats = torch.empty(3, dtype=torch.float64, device=dev) if n else torch.zeros(3, dtype=torch.float64, device=dev)   # written by the statistics kernels
     avg = torch.empty(max(n, 1), dtype=torch.float64, device=dev) if want_avg else None
     ws, wsz = L.workspace(lib.kpx_sor_workspace_bytes(n, int(nb_neighbors)))
     L.check(lib.kpx_sor(L.ptr(pts), n, int(nb_neighbors), float(std_ratio), L.ptr(idx), L.ptr(cnt), L.ptr(stats),
@@ -294,8 +294,8 @@ def sor_finish(avg_sorted, order, std_ratio, want_avg=False):
     assert avg_sorted.numel() == n
     dev = order.device
     idx = torch.empty(n, dtype=torch.int32, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    stats = torch.empty(3, dtype=torch.float64, device=dev)
     avg = torch.empty(n, dtype=torch.float64, device=dev) if want_avg else None
     ws, wsz = L.workspace(lib.kpx_sor_finish_workspace_bytes(n))
     L.check(lib.kpx_sor_finish(L.ptr(avg_sorted), L.ptr(order), n, float(std_ratio), L.ptr(idx), L.ptr(cnt), L.ptr(stats), L.ptr(avg),
@@ -450,7 +450,7 @@ def icp_batch(srcs, tgt, max_dist, inits, mode="p2p", tgt_normals=None, max_iter
     n_arr = np.array([s.shape[0] for s in srcs], dtype=np.int64)
     p_arr = (C.c_void_p * cnt)(*[s.data_ptr() for s in srcs])
     init = np.ascontiguousarray(np.stack([_T(np.eye(4) if T is None else T) for T in inits]))
-    res = torch.zeros((cnt, 20), dtype=torch.float64, device=dev)
+    res = torch.empty((cnt, 20), dtype=torch.float64, device=dev)
     ws, wsz = L.workspace(lib.kpx_icp_batch_workspace_bytes(cnt, n_arr.ctypes.data_as(C.c_void_p), m))
     L.check(lib.kpx_icp_batch(cnt, C.cast(p_arr, C.c_void_p), n_arr.ctypes.data_as(C.c_void_p), L.ptr(tgt), L.ptr(tn), m,
                               float(max_dist), L.hptr(init), md, int(max_iteration), float(relative_fitness),
