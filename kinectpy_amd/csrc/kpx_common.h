@@ -1,5 +1,6 @@
 // kpx_common.h -- shared host/device helpers of libkinectpx.so (gfx950 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -138,7 +139,51 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total)
     return base + incl - v;
 }
 
-// ---- order-preserving stream compaction (three launches; every phase is a plain grid) ----------
+// ---- decoupled look-back (Merrill & Garland): a tile's exclusive prefix without a scan pass ----------------------------
+// One 64-bit word per tile, cleared before the launch: bits 63:62 = 0 nothing yet, 1 the tile's own total, 2 its inclusive
+// prefix; bits 31:0 = the value.  Flag and value travel in ONE word, so a relaxed device-scope load / store pair is all the
+// ordering there is (no fences, no L2 write-backs).  A tile publishes its total, then its first wave walks back over the
+// preceding tiles 64 at a time -- lane l reads tile (pos - l) -- until it meets an inclusive prefix.  Tiles are taken in
+// blockIdx order (workgroups are dispatched in linear-id order and a resident block never yields), so every predecessor of
+// a running tile is running or finished: the spin terminates.
+// All threads of the block call it; sh: one int of LDS.  Returns the exclusive prefix of `tile` within its row of states.
+constexpr unsigned long long kTileTotal = 1ull << 62, kTilePrefix = 2ull << 62;
+__device__ __forceinline__ int lookback_exclusive(unsigned long long *__restrict__ state, int tile, int tot, int *sh)
+{
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(&state[tile], (tile == 0 ? kTilePrefix : kTileTotal) | (unsigned long long)(unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int excl = 0;
+        if (tile > 0) {
+            int pos = tile - 1;
+            for (;;) {
+                const int idx = pos - lane;
+                unsigned long long st;
+                for (;;) {
+                    st = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kTilePrefix;
+                    if (__ballot((st >> 62) == 0ull) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const unsigned long long pm = __ballot((st >> 62) == 2ull);
+                const int first = pm ? __builtin_ctzll(pm) : 64;
+                int v = lane <= first ? (int)(unsigned)(st & 0xFFFFFFFFull) : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                excl += v;
+                if (pm) break;
+                pos -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&state[tile], kTilePrefix | (unsigned long long)(unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) *sh = excl;
+    }
+    __syncthreads();
+    return *sh;
+}
+
+// ---- order-preserving stream compaction -------------------------------------------------------------------------------
 // A Pred is a device functor  bool operator()(int64_t item, int frame) const
 // An Emit is a device functor void operator()(int64_t item, int frame, int32_t dst) const
 constexpr int kCompactThreads = 256;
@@ -286,17 +331,61 @@ static __global__ __launch_bounds__(kCompactThreads) void compact_flags_scatter_
     for (int e = threadIdx.x; e < tot; e += kCompactThreads) idx[o + e] = si[e];
 }
 
-// Host driver.  ws_counts: int32 [frames * tiles(n)].
+// ONE pass: predicate evaluated once, the tile's offset by decoupled look-back, items emitted in place (the count -> scan ->
+// scatter kernels above read the input twice and cost three launches).  tile_state: 64-bit word per (frame, tile), cleared.
+template <class Pred, class Emit>
+__global__ __launch_bounds__(kCompactThreads) void compact_onepass_kernel(Pred pred, Emit emit, int64_t n, unsigned long long *__restrict__ tile_state,
+                                                                            int32_t *__restrict__ d_count)
+{
+    __shared__ int sh[kCompactThreads / 64 + 2];
+    const int frame = blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
+    unsigned flags = 0;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactItems; ++k) {
+        int64_t i = base + k;
+        if (i < n && pred(i, frame)) { flags |= 1u << k; ++c; }
+    }
+    int tot;
+    const int ex = block_excl_scan(c, sh, &tot);
+    __syncthreads();
+    const int before = lookback_exclusive(tile_state + (int64_t)frame * gridDim.x, blockIdx.x, tot, sh + kCompactThreads / 64 + 1);
+    int32_t dst = before + ex;
+#pragma unroll
+    for (int k = 0; k < kCompactItems; ++k)
+        if (flags & (1u << k)) emit(base + k, frame, dst++);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && d_count) d_count[frame] = before + tot;
+}
+
+// Host driver.  ws_counts: int32 [frames * compact_ws_ints(n)] (8-byte aligned: it holds the 64-bit tile states).
 static inline int64_t compact_tiles(int64_t n) { return cdiv(n > 0 ? n : 1, kCompactTile); }
+static inline int64_t compact_ws_ints(int64_t n) { return 2 * compact_tiles(n) + 2; }
+// One pass or three launches?  Measured on MI355X: on batches that stream hundreds of MB the look-back costs bandwidth (every
+// tile holds its registers and LDS through a device-scope round trip: 256 frames of depth -> cloud ran at 2.2 TB/s against 3.0
+// with count -> scan -> scatter), while a frame-sized problem is a chain of launches whose NUMBER is what matters.  So the one-pass
+// kernels serve problems of at most kOnePassTiles tiles; KPX_ONEPASS=0 / 1 forces either path (A/B runs).
+constexpr int64_t kOnePassTiles = 2048;
+static inline bool use_onepass(int64_t tiles_total)
+{
+    static const int mode = [] { const char *e = getenv("KPX_ONEPASS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return mode < 0 ? tiles_total <= kOnePassTiles : mode != 0;
+}
 template <class Pred, class Emit>
 int compact(Pred pred, Emit emit, int64_t n, int32_t frames, int32_t *ws_counts, int32_t *d_count, hipStream_t st)
 {
     const int32_t tiles = (int32_t)compact_tiles(n);
     dim3 grid(tiles, frames);
+    if (use_onepass((int64_t)tiles * frames)) {
+        unsigned long long *state = reinterpret_cast<unsigned long long *>(ws_counts);
+        KPX_HIP(hipMemsetAsync(state, 0, (size_t)tiles * frames * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL((compact_onepass_kernel<Pred, Emit>), grid, dim3(kCompactThreads), 0, st, pred, emit, n, state, d_count);
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
     hipLaunchKernelGGL(compact_count_kernel<Pred>, grid, dim3(kCompactThreads), 0, st, pred, n, ws_counts);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(compact_scan_threads(tiles)), 0, st, ws_counts, tiles, d_count);
-    hipLaunchKernelGGL((compact_scatter_kernel<Pred, Emit>), grid, dim3(kCompactThreads), 0, st, pred, emit, n,
-                       ws_counts);
+    hipLaunchKernelGGL((compact_scatter_kernel<Pred, Emit>), grid, dim3(kCompactThreads), 0, st, pred, emit, n, ws_counts);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
@@ -313,6 +402,63 @@ static inline void compact_pts_carve(Arena &a, int64_t n, CompactPtsScratch *s)
         s->counts[l] = a.get<int32_t>(tiles);
     }
 }
+// ONE pass for one list: the wave-staged predicate evaluation of compact_pts_flag_kernel, then the tile's offset by look-back and
+// the kept indices written from LDS as consecutive dwords -- the points are read once, nothing else is read or written but the
+// index list (12 n + 4 K bytes, the algorithmic minimum) and one launch replaces three.
+template <class PredXYZ>
+__global__ __launch_bounds__(kCompactThreads) void compact_pts_onepass_kernel(const float *__restrict__ pts, int64_t n, PredXYZ pred, bool aligned,
+                                                                              unsigned long long *__restrict__ tile_state, int32_t *__restrict__ idx,
+                                                                              int32_t *__restrict__ d_count)
+{
+    __shared__ __align__(16) float stage[kCompactThreads / 64][1536];
+    __shared__ int sh[kCompactThreads / 64 + 2];
+    __shared__ int wave_base[kCompactThreads / 64 + 1];
+    const int wave = wave_id(), lane = lane_id();
+    const int64_t wbase = (int64_t)blockIdx.x * kCompactTile + (int64_t)wave * 512;
+    const bool full = aligned && wbase + 512 <= n;
+    if (full) {
+        const float4 *src = reinterpret_cast<const float4 *>(pts + 3 * wbase);
+        float4 *dst = reinterpret_cast<float4 *>(stage[wave]);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) dst[64 * r + lane] = src[64 * r + lane];
+        wave_lds_fence();
+    }
+    unsigned long long m[8];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int p = 64 * k + lane;
+        unsigned r = 0;
+        if (full) r = pred(stage[wave][3 * p], stage[wave][3 * p + 1], stage[wave][3 * p + 2]);
+        else if (wbase + p < n) r = pred(pts[3 * (wbase + p)], pts[3 * (wbase + p) + 1], pts[3 * (wbase + p) + 2]);
+        m[k] = __ballot((r & 1u) != 0);
+        cnt += __builtin_popcountll(m[k]);
+    }
+    if (lane == 0) sh[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < kCompactThreads / 64; ++w) { wave_base[w] = run; run += sh[w]; }
+        wave_base[kCompactThreads / 64] = run;
+    }
+    __syncthreads();
+    const int tot = wave_base[kCompactThreads / 64];
+    const int before = lookback_exclusive(tile_state, blockIdx.x, tot, sh + kCompactThreads / 64 + 1);
+    // kept indices of the wave's 512 points in ascending order: row k (points 64 k + l) after the rows before it
+    int32_t *si = reinterpret_cast<int32_t *>(stage[wave]);          // the staged points are consumed: reuse the wave's LDS
+    wave_lds_fence();
+    int off = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if ((m[k] >> lane) & 1ull) si[off + __builtin_popcountll(m[k] & ((1ull << lane) - 1ull))] = (int32_t)(wbase + 64 * k + lane);
+        off += __builtin_popcountll(m[k]);
+    }
+    wave_lds_fence();
+    const int64_t o = (int64_t)before + wave_base[wave];
+    for (int e = lane; e < cnt; e += 64) idx[o + e] = si[e];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *d_count = before + tot;
+}
+
 // idx_b / d_count_b == nullptr: one list (the predicate's bit 0).
 template <class PredXYZ>
 int compact_points(const float *pts, int64_t n, PredXYZ pred, int32_t *idx_a, int32_t *d_count_a, int32_t *idx_b, int32_t *d_count_b,
@@ -320,6 +466,13 @@ int compact_points(const float *pts, int64_t n, PredXYZ pred, int32_t *idx_a, in
 {
     const int32_t tiles = (int32_t)compact_tiles(n);
     const bool aligned = ((uintptr_t)pts % 16) == 0;
+    if (!idx_b && use_onepass(tiles)) {                 // one list, frame-sized: one pass
+        unsigned long long *state = reinterpret_cast<unsigned long long *>(s.flags[0]);     // tiles * 256 bytes >= tiles * 8
+        KPX_HIP(hipMemsetAsync(state, 0, (size_t)tiles * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL((compact_pts_onepass_kernel<PredXYZ>), dim3(tiles), dim3(kCompactThreads), 0, st, pts, n, pred, aligned, state, idx_a, d_count_a);
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
     if (idx_b)
         hipLaunchKernelGGL((compact_pts_flag_kernel<PredXYZ, true>), dim3(tiles), dim3(kCompactThreads), 0, st, pts, n, pred, aligned, s.flags[0],
                            s.counts[0], s.flags[1], s.counts[1]);

@@ -494,7 +494,7 @@ KPX_EXPORT int kpx_median_i16(const int16_t *v, int64_t n, int64_t stride, int32
 KPX_EXPORT size_t kpx_compact_workspace_bytes(int64_t n, int32_t frames)
 {
     Arena a(nullptr, 0);
-    a.get<int32_t>((size_t)(frames < 1 ? 1 : frames) * compact_tiles(n));
+    a.get<int32_t>((size_t)(frames < 1 ? 1 : frames) * compact_ws_ints(n));
     return a.off;
 }
 // ---- vectorised fused depth -> cloud (n_px % 8 == 0, 16-byte aligned frames) ---------------------------------------
@@ -596,17 +596,68 @@ __global__ __launch_bounds__(kCompactThreads) void depth_scatter_vec_kernel(cons
         for (int e = threadIdx.x; e < tot; e += kCompactThreads) idx[o + e] = si[e];
 }
 
-// count -> scan -> scatter with the 8-pixel kernels (xy == NULL: int16 XYZ image input)
+// ONE pass over the frame: the tile's pixels are unprojected and tested once, its offset inside the frame's cloud comes from the
+// decoupled look-back (kpx_common.h), the kept points leave through LDS as consecutive dwords.  Against count -> scan ->
+// scatter: depth / table / colour are read once instead of twice and three launches become one (+ the clear of the tile words).
+template <bool COL, bool IDX>
+__global__ __launch_bounds__(kCompactThreads) void depth_onepass_vec_kernel(const uint16_t *__restrict__ depth, const float *__restrict__ xy,
+                                                                            const uint8_t *__restrict__ rgb, const double *__restrict__ median,
+                                                                            int64_t n, int flags, double gate, unsigned long long *__restrict__ tile_state,
+                                                                            float *__restrict__ pts, float *__restrict__ col, int32_t *__restrict__ idx,
+                                                                            int32_t *__restrict__ d_count)
+{
+    __shared__ int sh[kCompactThreads / 64 + 2];
+    __shared__ int16_t sp[kCompactTile * 3];
+    __shared__ uint8_t sc[COL ? kCompactTile * 3 : 1];
+    __shared__ int32_t si[IDX ? kCompactTile : 1];
+    const int f = blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
+    Px8 p;
+    p.keep = 0;
+    if (base < n) load_px8(depth, xy, rgb, median, n, f, base, flags, gate, p);
+    int tot;
+    int pos = block_excl_scan(__builtin_popcount(p.keep), sh, &tot);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (p.keep & (1u << k)) {
+            sp[3 * pos] = p.x[k]; sp[3 * pos + 1] = p.y[k]; sp[3 * pos + 2] = p.z[k];
+            if (COL) { sc[3 * pos] = p.c[3 * k]; sc[3 * pos + 1] = p.c[3 * k + 1]; sc[3 * pos + 2] = p.c[3 * k + 2]; }
+            if (IDX) si[pos] = (int32_t)(base + k);
+            ++pos;
+        }
+    __syncthreads();
+    const int before = lookback_exclusive(tile_state + (int64_t)f * gridDim.x, blockIdx.x, tot, sh + kCompactThreads / 64 + 1);
+    const int64_t o = (int64_t)f * n + before;
+    for (int e = threadIdx.x; e < tot * 3; e += kCompactThreads) {
+        pts[o * 3 + e] = (float)sp[e];
+        if (COL) col[o * 3 + e] = (float)((double)sc[e] / 255.0);
+    }
+    if (IDX)
+        for (int e = threadIdx.x; e < tot; e += kCompactThreads) idx[o + e] = si[e];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) d_count[f] = before + tot;
+}
+
+// the 8-pixel kernels (xy == NULL: int16 XYZ image input).  counts: frames * compact_ws_ints(n) ints (the 64-bit tile words)
 static int px8_compact(const uint16_t *depth, const float *xy, const uint8_t *rgb, const double *med, int64_t n, int32_t frames, int32_t flags,
                        double gate, int32_t *counts, float *pts, float *col, int32_t *idx, int32_t *d_count, hipStream_t st)
 {
     const int32_t tiles = (int32_t)compact_tiles(n);
     const dim3 grid(tiles, frames), thr(kCompactThreads);
-    hipLaunchKernelGGL(depth_count_vec_kernel, grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(compact_scan_threads(tiles)), 0, st, counts, tiles, d_count);
     const bool wc = col && rgb;
-#define KPX_D2C(COL, IDX)                                                                                           \
-    hipLaunchKernelGGL((depth_scatter_vec_kernel<COL, IDX>), grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts, pts, col, idx)
+    const bool onepass = use_onepass((int64_t)tiles * frames);
+    unsigned long long *state = reinterpret_cast<unsigned long long *>(counts);
+    if (onepass) KPX_HIP(hipMemsetAsync(state, 0, (size_t)tiles * frames * sizeof(unsigned long long), st));
+    else {
+        hipLaunchKernelGGL(depth_count_vec_kernel, grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts);
+        hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(compact_scan_threads(tiles)), 0, st, counts, tiles, d_count);
+    }
+#define KPX_D2C(COL, IDX)                                                                                                       \
+    do {                                                                                                                        \
+        if (onepass)                                                                                                            \
+            hipLaunchKernelGGL((depth_onepass_vec_kernel<COL, IDX>), grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, state, pts, col, idx, d_count); \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((depth_scatter_vec_kernel<COL, IDX>), grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts, pts, col, idx);        \
+    } while (0)
     if (wc && idx) KPX_D2C(true, true);
     else if (wc) KPX_D2C(true, false);
     else if (idx) KPX_D2C(false, true);
@@ -620,7 +671,7 @@ static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uin
                                int32_t flags, double gate, float *pts, float *col, int32_t *idx, int32_t *d_count,
                                Arena &a, hipStream_t st)
 {
-    int32_t *counts = a.get<int32_t>((size_t)frames * compact_tiles(n));
+    int32_t *counts = a.get<int32_t>((size_t)frames * compact_ws_ints(n));
     double *med = a.get<double>((size_t)frames);
     int rc = KPX_OK;
     if (flags & KPX_COMPACT_DEPTH_GATE || a.dry)
@@ -644,7 +695,7 @@ KPX_EXPORT int kpx_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t 
     KPX_REQUIRE(!(flags & KPX_COMPACT_DEPTH_GATE) || d_median, "kpx_rgbd_compact: depth gate needs d_median");
     KPX_REQUIRE(n < ((int64_t)1 << 31), "kpx_rgbd_compact: frame too large");
     Arena a(ws, ws_bytes);
-    int32_t *counts = a.get<int32_t>((size_t)frames * compact_tiles(n));
+    int32_t *counts = a.get<int32_t>((size_t)frames * compact_ws_ints(n));
     KPX_ARENA_CHECK(a);
     XyzPred pred{ xyz, rgb, d_median, n, flags, gate };
     XyzEmit emit{ xyz, rgb, n, pts, col, idx };

@@ -599,7 +599,7 @@ static int ransac_carve(const float *tgt, int64_t n_src, int64_t n_tgt, int max_
     b->pass = a.get<uint8_t>(kRansacBatch);
     b->Ts = a.get<double>((size_t)kRansacBatch * 16);
     b->list = a.get<int32_t>(kRansacBatch);
-    b->counts = a.get<int32_t>((size_t)compact_tiles(kRansacBatch));
+    b->counts = a.get<int32_t>((size_t)compact_ws_ints(kRansacBatch));
     b->n_pass = a.get<int32_t>(1);
     b->part_cnt = a.get<int64_t>((size_t)max_validate * b->vblocks);
     b->part_err = a.get<double>((size_t)max_validate * b->vblocks);

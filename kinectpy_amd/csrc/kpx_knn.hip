@@ -281,7 +281,7 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     if (rc) return rc;
     double *avg = a.get<double>((size_t)(n > 0 ? n : 1));
     double *part = a.get<double>(1024);
-    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    int32_t *counts = a.get<int32_t>((size_t)compact_ws_ints(n));
     int32_t *fb_list = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
     int32_t *fb_list2 = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
     if (a.dry) return KPX_OK;
@@ -507,7 +507,7 @@ KPX_EXPORT size_t kpx_sor_finish_workspace_bytes(int64_t n)
     Arena a(nullptr, 0);
     a.get<double>((size_t)(n > 0 ? n : 1));
     a.get<double>(1024);
-    a.get<int32_t>((size_t)compact_tiles(n));
+    a.get<int32_t>((size_t)compact_ws_ints(n));
     return a.off;
 }
 KPX_EXPORT int kpx_sor_finish(const double *d_avg_sorted, const int32_t *d_order, int64_t n, double std_ratio, int32_t *keep_idx,
@@ -520,7 +520,7 @@ KPX_EXPORT int kpx_sor_finish(const double *d_avg_sorted, const int32_t *d_order
     Arena a(ws, ws_bytes);
     double *avg = a.get<double>((size_t)n);
     double *part = a.get<double>(1024);
-    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    int32_t *counts = a.get<int32_t>((size_t)compact_ws_ints(n));
     KPX_ARENA_CHECK(a);
     if (d_avg) avg = d_avg;
     hipLaunchKernelGGL(sor_unsort_kernel, dim3((unsigned)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256))), dim3(256), 0, st, d_avg_sorted, d_order, n, avg);

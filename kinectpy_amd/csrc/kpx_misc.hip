@@ -404,7 +404,7 @@ KPX_EXPORT size_t kpx_select_workspace_bytes(int64_t n)
 {
     Arena a(nullptr, 0);
     a.get<uint8_t>((size_t)(n > 0 ? n : 1));
-    a.get<int32_t>((size_t)compact_tiles(n));
+    a.get<int32_t>((size_t)compact_ws_ints(n));
     a.get<double>((size_t)kBboxBlocks * 6 + 8);
     CompactPtsScratch cs;
     compact_pts_carve(a, n, &cs);
@@ -427,7 +427,7 @@ KPX_EXPORT int kpx_select_by_index(const float *a0, const float *a1, const float
     KPX_REQUIRE(ws && d_count, "kpx_select_by_index: the mask modes need workspace and d_count");
     Arena a(ws, ws_bytes);
     uint8_t *flag = a.get<uint8_t>((size_t)(n > 0 ? n : 1));
-    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    int32_t *counts = a.get<int32_t>((size_t)compact_ws_ints(n));
     KPX_ARENA_CHECK(a);
     KPX_HIP(hipMemsetAsync(flag, 0, (size_t)(n > 0 ? n : 1), st));
     if (n_idx) hipLaunchKernelGGL(mark_kernel, dim3(grid_for(n_idx, 256)), dim3(256), 0, st, idx, n_idx, n, flag);
@@ -441,7 +441,7 @@ KPX_EXPORT int kpx_halfspace_select(const float *pts, int64_t n, const double *h
     KPX_REQUIRE(n >= 0 && h_plane && idx && d_count && ws, "kpx_halfspace_select: bad arguments");
     Arena a(ws, ws_bytes);
     a.get<uint8_t>((size_t)(n > 0 ? n : 1));
-    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    int32_t *counts = a.get<int32_t>((size_t)compact_ws_ints(n));
     a.get<double>((size_t)kBboxBlocks * 6 + 8);
     CompactPtsScratch cs;
     compact_pts_carve(a, n, &cs);
@@ -459,7 +459,7 @@ KPX_EXPORT int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t 
     hipStream_t st = (hipStream_t)stream;
     Arena a(ws, ws_bytes);
     a.get<uint8_t>((size_t)n);
-    a.get<int32_t>((size_t)compact_tiles(n));
+    a.get<int32_t>((size_t)compact_ws_ints(n));
     double *part = a.get<double>((size_t)kBboxBlocks * 6 + 8);
     CompactPtsScratch cs;
     compact_pts_carve(a, n, &cs);

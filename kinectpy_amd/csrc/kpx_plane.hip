@@ -225,7 +225,7 @@ static int plane_impl(const float *pts, int64_t n, double thr, int ransac_n, int
     double *err = a.get<double>(HH);
     double *best = a.get<double>(8);
     double *rpart = a.get<double>(1024 * 6);
-    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    int32_t *counts = a.get<int32_t>((size_t)compact_ws_ints(n));
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     if (H > 0) {

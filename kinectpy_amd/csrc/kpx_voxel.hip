@@ -98,7 +98,7 @@ static int voxel_impl(const float *pts, const float *col, const float *nrm, int6
     uint64_t *keys_in = a.get<uint64_t>(nn), *keys_out = a.get<uint64_t>(nn);
     int32_t *vals_in = a.get<int32_t>(nn), *vals_out = a.get<int32_t>(nn);
     int32_t *seg_start = a.get<int32_t>(nn);
-    int32_t *counts = a.get<int32_t>((size_t)compact_tiles(n));
+    int32_t *counts = a.get<int32_t>((size_t)compact_ws_ints(n));
     double *part = a.get<double>((size_t)kBboxBlocks * 6 + 8);
     int32_t *err = a.get<int32_t>(1);
     size_t sort_bytes = 0;
@@ -320,7 +320,7 @@ static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
     s->keys_in = a.get<uint64_t>(nn); s->keys_out = a.get<uint64_t>(nn);
     s->vals_in = a.get<int32_t>(nn); s->vals_out = a.get<int32_t>(nn);
     s->seg_start = a.get<int32_t>(nn);
-    s->counts = a.get<int32_t>((size_t)compact_tiles(total));
+    s->counts = a.get<int32_t>((size_t)compact_ws_ints(total));
     s->err = a.get<int32_t>(kVoxelBatchMax);
     s->head = a.get<int32_t>(kVoxelBatchMax + 1);
     s->d_total = a.get<int32_t>(1);
@@ -506,7 +506,7 @@ static void fuse_carve(Arena &a, int64_t total, FuseScratch *s)
     s->keys_in = a.get<uint64_t>(nn); s->keys_out = a.get<uint64_t>(nn);
     s->vals_in = a.get<int32_t>(nn); s->vals_out = a.get<int32_t>(nn);
     s->seg_start = a.get<int32_t>(nn);
-    s->counts = a.get<int32_t>((size_t)compact_tiles(total));
+    s->counts = a.get<int32_t>((size_t)compact_ws_ints(total));
     s->err = a.get<int32_t>(1);
     s->part = a.get<double>((size_t)kFuseMax * kFuseBboxBlocks * 6);
     s->bbox = a.get<double>(8);
