@@ -1055,10 +1055,10 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     wave_lds_fence();
     WaveRows w;
     w.a = q < 3 ? rowd[wave][j][q] : 1.0;
+    w.rows = &rowd[wave][0][0];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int rr = q + 4 * r;
-        w.px[r] = rowd[wave][rr][0]; w.py[r] = rowd[wave][rr][1]; w.pz[r] = rowd[wave][rr][2];
         w.seed[r] = rowd[wave][rr][3];
         w.best[r] = rowd[wave][rr][4];
         w.bcol[r] = rowi[wave][rr][0];
@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
 }
 
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
@@ -1172,7 +1172,7 @@ struct IcpBatchArgs {
     IcpProblem p[kIcpBatchMax];
     int32_t count;
 };
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void icp_iter_batch_kernel(IcpBatchArgs args, const float *__restrict__ tgt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_iter_batch_kernel(IcpBatchArgs args, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,

@@ -132,17 +132,20 @@ __device__ __forceinline__ unsigned fold16(unsigned long long m) { return (unsig
 struct WaveRows {
     double a;                  // A operand: component q of row j
     d4 seed;                   // C operand: K of the lane's rows
-    double px[4], py[4], pz[4];
+    const double *rows;        // LDS: the wave's 16 transformed rows, row r at rows[5 r .. 5 r + 2] (x, y, z).  The culling tests
+                               // read the lane's four rows (q, q+4, q+8, q+12) from here instead of holding 24 registers for them:
+                               // the kernel then fits 128 VGPRs = 4 waves per SIMD, and a latency-bound sweep lives on resident waves
     double best[4];            // running minimum (per lane: over the columns j of the tiles seen)
     int32_t bcol[4];           // its ORIGINAL target index
 };
+constexpr int kRowStride = 5;
 
 // The culled sweep of one wave: on return best/bcol hold, in every lane, the row minimum (lexicographic (value,
 // original column)).  list: kLList ints of LDS owned by this wave.  Returns the number of tiles multiplied.
 // Group boxes the caller loaded ahead of time: box of group 64 t + lane in pre[t] (t < kGroupPre; an empty box beyond n_groups).
 // The loads do not depend on the transform, so the ICP kernel issues them before its update algebra and the first
 // level of the culling finds them in registers instead of waiting a memory round trip.
-constexpr int kGroupPre = 2;
+constexpr int kGroupPre = 1;
 struct GroupPre {
     float b[kGroupPre][6];
 };
@@ -206,7 +209,10 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
                 double lo[3], hi[3];
                 load_box(group_box + (int64_t)g * 6, lo, hi);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) u[r] = fmin(u[r], pt_far2(w.px[r], w.py[r], w.pz[r], lo, hi));
+                for (int r = 0; r < 4; ++r) {
+                    const double *pr = w.rows + kRowStride * (q + 4 * r);
+                    u[r] = fmin(u[r], pt_far2(pr[0], pr[1], pr[2], lo, hi));
+                }
             }
         }
 #pragma unroll
@@ -226,24 +232,22 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
         wave_lds_fence();                                  // the list writes before the reads
         bool updated = false;
         double b[4];
-        int32_t t[4], on[4];                               // the original column indices travel with the B operand: a tile
-#pragma unroll                                             // that reaches the list nearly always updates some row
+        int32_t t[4];
+#pragma unroll
         for (int h = 0; h < 4; ++h) {
             t[h] = h < nlist ? list[h] : -1;
             b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
-            on[h] = t[h] >= 0 ? orig[(int64_t)t[h] * 16 + j] : INT_MAX;
         }
         for (int e = 0; e < nlist; e += 4) {
             const d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[0], w.seed, 0, 0, 0);
             const d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[1], w.seed, 0, 0, 0);
             const d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[2], w.seed, 0, 0, 0);
             const d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[3], w.seed, 0, 0, 0);
-            const int32_t oc[4] = { on[0], on[1], on[2], on[3] };
+            const int32_t tc[4] = { t[0], t[1], t[2], t[3] };
 #pragma unroll
             for (int h = 0; h < 4; ++h) {                  // operands of the next trip
                 t[h] = e + 4 + h < nlist ? list[e + 4 + h] : -1;
                 b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
-                on[h] = t[h] >= 0 ? orig[(int64_t)t[h] * 16 + j] : INT_MAX;
             }
             bool pass = false;
 #pragma unroll
@@ -253,6 +257,9 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
             }
             if (__builtin_amdgcn_ballot_w64(pass) != 0) {
                 updated = true;
+                int32_t oc[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) oc[h] = tc[h] >= 0 ? orig[(int64_t)tc[h] * 16 + j] : INT_MAX;
 #define KPX_NNL_EXACT(ACC, COL)                                                                     \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
                     const bool tk = (int)(ACC[r] < w.best[r]) | ((int)(ACC[r] == w.best[r]) & (int)((COL) < w.bcol[r])); \
@@ -282,7 +289,10 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
         const double lo[3] = { (double)bx[0], (double)bx[1], (double)bx[2] }, hi[3] = { (double)bx[3], (double)bx[4], (double)bx[5] };
         bool t = false;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t |= pt_gap2(w.px[r], w.py[r], w.pz[r], lo, hi) <= rb[r];
+        for (int r = 0; r < 4; ++r) {
+            const double *pr = w.rows + kRowStride * (q + 4 * r);
+            t |= pt_gap2(pr[0], pr[1], pr[2], lo, hi) <= rb[r];
+        }
         return t;
     };
     auto any_row_within = [&](const float *__restrict__ bx) {
@@ -367,6 +377,7 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
 {
     if (done && *done) return;
     __shared__ int32_t list[kLList];
+    __shared__ double rows[kLRows * kRowStride];
     const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
     const int64_t row_base = (int64_t)blockIdx.x * kLRows;
     const int64_t last = n - 1;
@@ -374,11 +385,12 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
     // rows past the end repeat the last row: same points, never written
     const int64_t arow = row_base + j < last ? row_base + j : last;
     w.a = A64[arow * 4 + q];
+    if (q < 3) rows[kRowStride * j + q] = w.a;
+    wave_lds_fence();
+    w.rows = rows;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = row_base + q + 4 * r < last ? row_base + q + 4 * r : last;
-        const double2 xy = reinterpret_cast<const double2 *>(A64)[2 * row];
-        w.px[r] = xy.x; w.py[r] = xy.y; w.pz[r] = A64[4 * row + 2];
         w.seed[r] = K64[row];
         w.best[r] = init_val[row];
         w.bcol[r] = init_idx[row];
