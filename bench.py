@@ -48,7 +48,7 @@ N_PX = 576 * 640
 FP64_MFMA_PEAK_TFLOPS = 78.6          # MI355X dense fp64 matrix peak (vendor figure)
 FP32_MFMA_PEAK_TFLOPS = 157.3         # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E (MI355X_MICROARCH.md; ~6.3 TB/s is what a copy kernel reaches)
-KERNEL_OF = {"nn_local": "icp_iter_kernel", "nn_screen": "nn_screen_kernel", "nn_mfma": "nn_mfma_kernel"}
+KERNEL_OF = {"nn_local": "icp_iter_batch_kernel", "nn_screen": "nn_screen_kernel", "nn_mfma": "nn_mfma_kernel"}
 
 
 def perturb(T, deg=3.0, mm=50.0, seed=0):

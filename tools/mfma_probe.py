@@ -23,4 +23,8 @@ for eng in ("dense", "culled"):
     ops.nn_engine(eng)
     ops.icp(s, t, 100.0, None, "p2p", None, 6)
 ops.nn_engine("culled")
+# the batch form of the culled sweep (one launch per iteration for all registrations: what the frame pipeline runs)
+subs = [s[: 30000 + 500 * i].contiguous() for i in range(3)]
+tn = ops.estimate_normals(t[:31000].contiguous(), 70.0, 40)
+ops.icp_batch(subs, t[:31000].contiguous(), 100.0, [np.eye(4)] * 3, "p2plane", tn, 6)
 torch.cuda.synchronize()

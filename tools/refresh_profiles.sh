@@ -1,18 +1,21 @@
 #!/bin/bash
-# Re-creates the files kept under profiles/rNN on a 1-GPU MI355X box:  bash tools/refresh_profiles.sh gpurun_out/r01
+# Re-creates the files kept under profiles/rNN on a 1-GPU MI355X box:  bash tools/refresh_profiles.sh gpurun_out/r02
 # (run from the repository root; copy the results into profiles/rNN afterwards)
 set -e -o pipefail
 OUT=$(realpath -m "${1:-gpurun_out/prof}")
 ROOT=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout -k 10 300 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-KPX_NN_ENGINE=dense timeout -k 10 300 python3 bench.py --cpu-budget-s 0 > "$OUT/bench_n1_dense_engine.json" 2>> "$OUT/bench_n1.err"
+Q="--no-targets --cpu-budget-s 0 --spread-blocks 0"
+timeout -k 10 400 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+KPX_NN_ENGINE=dense timeout -k 10 300 python3 bench.py $Q > "$OUT/bench_n1_dense_engine.json" 2>> "$OUT/bench_n1.err"
+timeout -k 10 300 python3 bench.py $Q --overlap 1 > "$OUT/bench_n1_overlap1.json" 2>> "$OUT/bench_n1.err"
 timeout -k 10 300 python3 tools/bench_kernels.py > "$OUT/kernels.json" 2>> "$OUT/bench_n1.err"
+timeout -k 10 120 python3 tools/icp_probe.py 20 > "$OUT/icp_probe.txt" 2>> "$OUT/bench_n1.err"
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$ROOT/bench.py" --steps 20 --warmup 3 --cpu-budget-s 0 > "$OUT/bench_n1_under_rocprof.json" 2>> "$OUT/bench_n1.err"
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o b -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --cpu-budget-s 0 > /dev/null 2>> "$OUT/bench_n1.err"
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o b -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --cpu-budget-s 0 > /dev/null 2>> "$OUT/bench_n1.err"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$ROOT/bench.py" --steps 40 --warmup 5 $Q > "$OUT/bench_n1_under_rocprof.json" 2>> "$OUT/bench_n1.err"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o b -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 $Q --overlap 1 > /dev/null 2>> "$OUT/bench_n1.err"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o b -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 $Q --overlap 1 > /dev/null 2>> "$OUT/bench_n1.err"
 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o m -- python3 "$ROOT/tools/mfma_probe.py" > /dev/null 2>> "$OUT/bench_n1.err"
 cd "$ROOT"
 python3 tools/pmc_mfma.py "$OUT/pmc_mfma.csv" "$OUT/pmc_mfma"
