@@ -224,6 +224,19 @@ def roofline_targets(torch, ops, quick=False):
     mfma(f"33-D feature NN GEMM {feats[1].shape[0]} x {feats[0].shape[0]} (a13, K = 36 augmented)", "feature_nn_kernel", ms,
          2.0 * 36 * feats[1].shape[0] * feats[0].shape[0])
     del feats
+    # ---- HBM reference ceilings of this device, same process (what the runtime's own copy / fill / reduction kernels reach on 1 GiB)
+    ref = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    dst = torch.empty_like(ref)
+    ms, _ = ev_timed(torch, lambda: dst.copy_(ref))
+    rows.append({"op": "reference: device copy, 1 GiB (read + write)", "kernel": "runtime copy", "bound": "hbm", "achieved": round(2 * ref.numel() * 4 / ms / 1e6, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(2 * ref.numel() * 4 / ms / 1e6 / HBM_PEAK_GBS, 4), "ms": round(ms, 4)})
+    ms, _ = ev_timed(torch, lambda: dst.fill_(1.0))
+    rows.append({"op": "reference: device fill, 1 GiB (write only)", "kernel": "runtime fill", "bound": "hbm", "achieved": round(ref.numel() * 4 / ms / 1e6, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ref.numel() * 4 / ms / 1e6 / HBM_PEAK_GBS, 4), "ms": round(ms, 4)})
+    ms, _ = ev_timed(torch, lambda: dst.sum())
+    rows.append({"op": "reference: device reduction, 1 GiB (read only)", "kernel": "runtime sum", "bound": "hbm", "achieved": round(ref.numel() * 4 / ms / 1e6, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ref.numel() * 4 / ms / 1e6 / HBM_PEAK_GBS, 4), "ms": round(ms, 4)})
+    del ref, dst
     # ---- HBM: extract on 256 frames (0.19 GB of depth in, 0.57 - 2.3 GB out)
     F = 64 if quick else 256
     base_d, person = synth.render_depth(xy=xy, return_person=True)
@@ -278,10 +291,12 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic time frames cycled through")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--check", action="store_true", help="compare one GPU step against the oracle step")
-    ap.add_argument("--overlap", type=int, default=2, help="frames in flight per GPU (pipeline.FrameStream); 1 = one after the other")
+    ap.add_argument("--overlap", type=int, default=3, help="frames in flight per GPU (pipeline.FrameStream); 1 = one after the other")
     ap.add_argument("--spread-blocks", type=int, default=5, help="extra blocks of 20 steps for the run-to-run spread (0 = off)")
     ap.add_argument("--no-targets", action="store_true", help="skip the roofline_targets leg")
     ap.add_argument("--quick-targets", action="store_true", help="quarter-size batches for the roofline_targets leg")
+    ap.add_argument("--python-step", action="store_true", help="one GPU: run the frame loop through the Python pipeline instead of the native "
+                    "kpx_frame_step (several GPUs always use the Python pipeline: the collectives are torch.distributed's)")
     ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval for the frame threads (0 = leave the default 5 ms)")
     args = ap.parse_args()
 
@@ -289,7 +304,7 @@ def main():
         sys.setswitchinterval(args.switch_interval)
     import torch
     from kinectpy_amd import ops, parallel
-    from kinectpy_amd.pipeline import FrameStream, PipelineParams, SensorGroupPipeline, SensorShardPipeline
+    from kinectpy_amd.pipeline import FrameStream, NativeFramePipeline, PipelineParams, SensorGroupPipeline, SensorShardPipeline
     from kinectpy_amd.utils import synth
 
     rank, world, local = parallel.init_distributed()
@@ -305,7 +320,11 @@ def main():
         groups = [parallel.new_group() for _ in range(overlap)] if world > 1 else [None] * overlap
         for g in groups:
             parallel.warm(g, dev)
-        pipes = [SensorShardPipeline(xy, S, inits, P, group=g, fused_filter=args.fused_filter) for g in groups]
+        native = world == 1 and not args.python_step
+        if native:                                  # one GPU: the whole frame loop is ONE native call per frame (kpx_frame_step)
+            pipes = [NativeFramePipeline(xy, S, inits, P) for _ in groups]
+        else:
+            pipes = [SensorShardPipeline(xy, S, inits, P, group=g, fused_filter=args.fused_filter) for g in groups]
         pipe = pipes[0]
         px_per_step = S * N_PX                      # whole rig, all ranks together
         local_inits = inits
@@ -355,15 +374,16 @@ def main():
 
     # Priming (setup, untimed, before the --warmup steps): the first ~100 steps of a process run at a fraction of the steady
     # rate -- the caching allocator and the library's workspaces are still growing, the clocks ramping -- and the driver's
-    # default warm-up (5 steps) is far inside that ramp.  Steps are run in blocks of 25 until a block is no faster than the one
-    # before it (at most 12 blocks); every rank runs the same number (the stop test is all-reduced).
-    prev_t, k_prime = None, 0
-    for _ in range(12):
+    # default warm-up (5 steps) is far inside that ramp.  Steps are run in blocks of 25 (at least four) until two blocks in a row
+    # are no faster than the best so far (at most 16 blocks); every rank runs the same number (the stop test is all-reduced).
+    best_t, k_prime, flat = None, 0, 0
+    for blk in range(16):
         t_blk = timed(k_prime, 25)
         k_prime += 25
-        if prev_t is not None and t_blk > 0.97 * prev_t:
+        flat = flat + 1 if (best_t is not None and t_blk > 0.97 * best_t) else 0
+        best_t = t_blk if best_t is None else min(best_t, t_blk)
+        if blk >= 3 and flat >= 2:                  # at least 100 steps; two blocks in a row without a 3 % gain on the best so far
             break
-        prev_t = t_blk
     run_steps(k_prime, args.warmup)
     dt = timed(k_prime + args.warmup, args.steps)                        # THE timed region: exactly --steps steps
     k0 = k_prime + args.warmup + args.steps
@@ -424,7 +444,8 @@ def main():
         workload = (f"BASELINE configs[{4 if S == 8 else 3}]: {S} synthetic Kinect views (640x576 u16 depth + person mask) per step, sensor g on "
                     f"GPU g ({world} GPU{'s' if world > 1 else ''}: {len(mine)} sensor(s) per GPU): extract -> master-cloud broadcast -> per-GPU "
                     f"point-to-plane ICP onto the master -> all-gather -> fused fp64 transform + voxel -> SOR on the fused cloud ({args.fused_filter})")
-        cfg = {"workload": workload, "partition": "sensor", "sensors": S, "sensors_on_rank0": mine, "fused_filter": args.fused_filter}
+        cfg = {"workload": workload, "partition": "sensor", "sensors": S, "sensors_on_rank0": mine, "fused_filter": args.fused_filter,
+               "host_loop": "native (kpx_frame_step)" if native else "python (SensorShardPipeline)"}
     else:
         scaling = "weak"
         cfg = {"workload": "BASELINE configs[3], one independent 4-sensor group per GPU (round-1 layout): extract -> pairwise point-to-plane "

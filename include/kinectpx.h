@@ -323,6 +323,35 @@ int kpx_colored_icp(const float *src, const float *src_colors, int64_t n_src, co
 int kpx_fuse_skeletons(const double *skeletons, int32_t cams, int64_t frames, int32_t joints, double alpha, double beta,
                        int32_t initial_frame, double *out, void *stream);
 
+/* ---- the frame loop as one native call ------------------------------------------------------------------------------- */
+/* One synchronised frame set of `sensors` devices held by this GPU: the body of DataProcessor's frame loop
+ * (preprocessing/data.py:35-61) with the registration of data.py:127-161 on the same depth images folded in --
+ *   depth -> full cloud -> voxel_down_sample(reg_voxel) per sensor; normals of the master's (sensor 0);
+ *   execute_point_to_plane_registration of every sub sensor onto the master (h_init: the sensors - 1 initial 4x4, host);
+ *   depth + person mask (rgb with the background zeroed, data.py:169) + depth gate -> the person clouds;
+ *   pcd.transform(T_i) + np.vstack + voxel_down_sample(filt_voxel) in one fp64 pass; remove_statistical_outlier(filt_k, filt_ratio).
+ * Host orchestration in C++ over the entry points above (the Python mirror of this loop is kinectpy_amd/pipeline.py): one
+ * call per frame, synchronous (the data-dependent counts are read back on `stream` inside); when it returns the selection
+ * kernel that writes out_pts / out_col is queued on `stream`.  depth u16 [sensors][n_px], rgb u8 [sensors][n_px][3], xy_table
+ * f32 [n_px][2] on the device; out_pts / out_col f32 [sensors * n_px][3] worst case; h_count: points written; h_T f64
+ * [sensors][16] (identity for the master); h_info (optional, 64 ints): [0..15] down-sampled points per sensor, [16..31] masked
+ * points per sensor, [32..47] ICP iterations per sensor, [48] voxels of the fused cloud. */
+typedef struct {
+    double reg_voxel;          /* 35   preprocessing/registration.py:35,69 */
+    double icp_max_dist;       /* 100  registration.py:75 */
+    double filt_voxel;         /* filter_outliers voxel_size (filtering.py:16) */
+    double filt_ratio;         /* filter_outliers std_ratio */
+    double gate;               /* 750  data.py:170-171 */
+    int32_t normals_nn;        /* 40   registration.py:24 */
+    int32_t icp_mode;          /* KPX_ICP_POINT_TO_PLANE (registration.py:83) */
+    int32_t icp_max_iteration; /* 30   Open3D's default criteria */
+    int32_t filt_k;            /* filter_outliers nb_neighbors */
+} kpx_frame_params;
+size_t kpx_frame_step_workspace_bytes(int32_t sensors, int64_t n_px);
+int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const float *xy_table, int64_t n_px, int32_t sensors,
+                   const double *h_init, const kpx_frame_params *params, float *out_pts, float *out_col, int32_t *h_count,
+                   double *h_T, int32_t *h_info, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it
  * (capacity = max launches recorded); every launch of a tagged kernel is bracketed by an event pair;

@@ -75,6 +75,8 @@ SIGNATURES = {
     "kpx_icp_batch": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _i32, _i32, _f64, _f64, _vp, _vp, _sz, _vp]),
     "kpx_prof_begin": (C.c_int, [_i32]),
     "kpx_prof_stride": (C.c_int, [_i32]),
+    "kpx_frame_step_workspace_bytes": (_sz, [_i32, _i64]),
+    "kpx_frame_step": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_prof_icp_phases": (C.c_int, [_vp]),
     "kpx_prof_end": (C.c_int, [_vp, _vp, _vp]),
 }

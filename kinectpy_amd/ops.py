@@ -460,6 +460,38 @@ def icp_batch(srcs, tgt, max_dist, inits, mode="p2p", tgt_normals=None, max_iter
              "iterations": int(r[i, 18]), "count": int(r[i, 19])} for i in range(cnt)]
 
 
+# ---- the frame loop as one native call ---------------------------------------------------------------------
+class FrameParams(C.Structure):
+    _fields_ = [("reg_voxel", C.c_double), ("icp_max_dist", C.c_double), ("filt_voxel", C.c_double), ("filt_ratio", C.c_double),
+                ("gate", C.c_double), ("normals_nn", C.c_int32), ("icp_mode", C.c_int32), ("icp_max_iteration", C.c_int32),
+                ("filt_k", C.c_int32)]
+
+
+def frame_step(depth, rgb, xy_table, inits, params: FrameParams, out=None):
+    """kpx_frame_step: depth (S, n_px) u16, rgb (S, n_px, 3) u8, xy (n_px*2) f32 on the device; inits: (S-1) 4x4.
+    -> points f32 (K,3), colours f32 (K,3), transforms f64 (S,4,4) numpy, info int32 (64) numpy.
+    out: optional (points, colours) buffers of S*n_px rows to write into (otherwise allocated)."""
+    lib = L.load()
+    depth = _dev(depth, torch.uint16)
+    S = int(depth.shape[0])
+    depth = depth.reshape(S, -1)
+    n_px = int(depth.shape[1])
+    rgb = _dev(rgb, torch.uint8).reshape(S, n_px, 3)
+    xy = _dev(xy_table, torch.float32).reshape(-1)
+    dev = depth.device
+    init = np.ascontiguousarray(np.stack([_T(T) for T in inits])) if S > 1 else np.zeros((1, 4, 4))
+    if out is None:
+        out = (torch.empty((S * n_px, 3), dtype=torch.float32, device=dev), torch.empty((S * n_px, 3), dtype=torch.float32, device=dev))
+    h_count = np.zeros(1, dtype=np.int32)
+    h_T = np.zeros((S, 4, 4))
+    h_info = np.zeros(64, dtype=np.int32)
+    ws, wsz = L.workspace(lib.kpx_frame_step_workspace_bytes(S, n_px))
+    L.check(lib.kpx_frame_step(L.ptr(depth), L.ptr(rgb), L.ptr(xy), n_px, S, L.hptr(init), C.byref(params), L.ptr(out[0]), L.ptr(out[1]),
+                               h_count.ctypes.data_as(C.c_void_p), L.hptr(h_T), h_info.ctypes.data_as(C.c_void_p), ws, wsz, L.stream_ptr()))
+    k = int(h_count[0])
+    return out[0][:k], out[1][:k], h_T, h_info
+
+
 # ---- measurement hooks --------------------------------------------------------------------------------
 NN_ENGINES = ("culled", "dense")
 

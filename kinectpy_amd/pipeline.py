@@ -203,6 +203,32 @@ class SensorShardPipeline:
         return self.fuse(depth, rgb, masked)
 
 
+class NativeFramePipeline:
+    """The same step as SensorShardPipeline.step on ONE GPU, as a single native call (kpx_frame_step): the host side of the
+    frame loop runs in C++ inside the library, the interpreter only hands the frame over -- so several frames in flight on
+    host threads (FrameStream) do not queue up behind the GIL."""
+
+    def __init__(self, xy_table, n_sensors: int, init_transforms: List[np.ndarray], params: Optional[PipelineParams] = None):
+        self.p = params or PipelineParams()
+        self.n_sensors = int(n_sensors)
+        if len(init_transforms) != self.n_sensors - 1:
+            raise ValueError("init_transforms: one 4x4 per sub sensor (sensors 1 .. n-1)")
+        self.init = [np.asarray(T, dtype=np.float64) for T in init_transforms]
+        self.xy = ops._dev(xy_table, torch.float32).reshape(-1)
+        p = self.p
+        self._c = ops.FrameParams(p.reg_voxel, p.icp_max_dist, p.filt_voxel, p.filt_ratio, p.gate, p.normals_nn,
+                                  {"p2p": 0, "p2plane": 1}[p.icp_mode], p.icp_max_iteration, p.filt_k)
+        self.last = {}
+
+    def step(self, depth: torch.Tensor, rgb: torch.Tensor):
+        S = self.n_sensors
+        out_p, out_c, Ts, info = ops.frame_step(depth, rgb, self.xy, self.init, self._c)
+        self.last = {"icp": [(int(info[32 + i]), None, None) for i in range(1, S)], "n_down": [int(v) for v in info[:S]],
+                     "n_masked": [int(v) for v in info[16:16 + S]], "n_fused": int(info[16:16 + S].sum()), "n_voxel": int(info[48]),
+                     "n_out": int(out_p.shape[0])}
+        return out_p, out_c, Ts
+
+
 class FrameStream:
     """Several frames of a stream in flight.  A frame is a chain of short, mostly latency-bound kernels (the ICP loop alone
     is ~75 dependent launches that keep a fraction of the CUs busy), and consecutive frames are independent, so `depth`

@@ -1334,3 +1334,34 @@ def test_manual_registration_from_picked_points(ops, oracle, base_cloud):
     assert np.abs(got[:3, 3] - T[:3, 3]).max() < 5.0
     with pytest.raises(NotImplementedError):
         manual_registration(PointCloud(tgt), PointCloud(src))
+
+
+def test_native_frame_step_equals_python_pipeline_and_oracle(four_sensor_oracle):
+    """kpx_frame_step (the frame loop in C++ inside the library) against the Python pipeline (bit-identical: same entry points
+    in the same order) and against the oracle step, serially and with three frames in flight"""
+    from kinectpy_amd.pipeline import FrameStream, NativeFramePipeline, PipelineParams, SensorShardPipeline
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    d, c = torch.as_tensor(depth).cuda(), torch.as_tensor(rgb).cuda()
+    nat, py = NativeFramePipeline(xy, 4, inits, PipelineParams()), SensorShardPipeline(xy, 4, inits, PipelineParams())
+    for f in range(2):
+        gp, gc, gT = nat.step(d[f], c[f])
+        pp, pc, pT = py.step(d[f], c[f])
+        assert torch.equal(gp, pp) and torch.equal(gc, pc) and np.array_equal(gT, pT)
+        assert nat.last["n_down"] == py.last["n_down"] and nat.last["n_voxel"] == py.last["n_voxel"]
+        assert [s[0] for s in nat.last["icp"]] == [s[0] for s in py.last["icp"]]
+        rp, rc, rT, _ = ref[f]
+        assert np.array_equal(npy(gp), rp) and np.array_equal(npy(gc), rc) and np.abs(gT - np.stack(rT)).max() < TOL_T
+    fs = FrameStream(nat, 3)
+    got = []
+    for k in range(7):
+        if fs.full():
+            got.append(fs.pop())
+        fs.submit(d[k % 2], c[k % 2])
+    while fs.pending:
+        got.append(fs.pop())
+    fs.close()
+    for k, (gp, gc, gT) in enumerate(got):
+        assert np.array_equal(npy(gp), ref[k % 2][0]) and np.array_equal(npy(gc), ref[k % 2][1])
+    one = NativeFramePipeline(xy, 1, [], PipelineParams())
+    gp, gc, gT = one.step(d[0][:1], c[0][:1])
+    assert gT.shape == (1, 4, 4) and np.array_equal(gT[0], np.eye(4)) and gp.shape[0] > 1000
