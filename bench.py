@@ -291,7 +291,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic time frames cycled through")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--check", action="store_true", help="compare one GPU step against the oracle step")
-    ap.add_argument("--overlap", type=int, default=3, help="frames in flight per GPU (pipeline.FrameStream); 1 = one after the other")
+    ap.add_argument("--overlap", type=int, default=0, help="frames in flight per GPU (pipeline.FrameStream); 1 = one after the other; 0 = 3 with "
+                    "the native frame loop, 2 with the Python pipeline (measured best of 1..4 for each)")
     ap.add_argument("--spread-blocks", type=int, default=5, help="extra blocks of 20 steps for the run-to-run spread (0 = off)")
     ap.add_argument("--no-targets", action="store_true", help="skip the roofline_targets leg")
     ap.add_argument("--quick-targets", action="store_true", help="quarter-size batches for the roofline_targets leg")
@@ -311,7 +312,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     F, P = args.frames, PipelineParams()
-    overlap = max(1, args.overlap)
+    overlap = args.overlap if args.overlap > 0 else (3 if (world == 1 and not args.python_step and args.partition == "sensor") else 2)
     sensor_mode = args.partition == "sensor"
     if sensor_mode:
         S = args.sensors or (8 if world >= 8 else 4)

@@ -100,6 +100,55 @@ __global__ __launch_bounds__(256) void grid_gather_kernel(const float *__restric
         sorted_pts[3 * s] = pts[3 * i]; sorted_pts[3 * s + 1] = pts[3 * i + 1]; sorted_pts[3 * s + 2] = pts[3 * i + 2];
     }
 }
+// Cell order without a radix sort (a sort of 30k keys is 9-13 launches; this is 2): every point takes the next free slot of its
+// cell's range (atomic cursor: the order inside a cell is whatever the hardware made it) ...
+__global__ __launch_bounds__(256) void grid_place_kernel(const uint32_t *__restrict__ cell_of, int64_t n, const uint32_t *__restrict__ cell_start,
+                                                         uint32_t *__restrict__ cursor, int32_t *__restrict__ slot_idx)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = cell_of[i];
+        slot_idx[cell_start[c] + atomicAdd(&cursor[c], 1u)] = (int32_t)i;
+    }
+}
+// ... and one thread per cell then puts its range into ascending point index -- the order a stable sort by cell gives, so the
+// result is deterministic and identical to the sorted build -- and gathers the points.  Cells hold a handful of points (the
+// grid is sized for 6-96 per cell); insertion sort in place, a heap sort for the rare crowded cell (duplicates).
+__global__ __launch_bounds__(256) void grid_order_kernel(const float *__restrict__ pts, const uint32_t *__restrict__ cell_start, int32_t ncell_cap,
+                                                         int32_t *__restrict__ sorted_idx, float *__restrict__ sorted_pts)
+{
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell_cap; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s0 = cell_start[c], s1 = cell_start[c + 1];
+        const int64_t len = s1 - s0;
+        if (len <= 0) continue;
+        int32_t *v = sorted_idx + s0;
+        if (len <= 48) {
+            for (int64_t a = 1; a < len; ++a) {
+                const int32_t x = v[a];
+                int64_t b = a - 1;
+                while (b >= 0 && v[b] > x) { v[b + 1] = v[b]; --b; }
+                v[b + 1] = x;
+            }
+        } else {                                         // heap sort, in place
+            auto sift = [&](int64_t root, int64_t end) {
+                for (;;) {
+                    int64_t ch = 2 * root + 1;
+                    if (ch >= end) break;
+                    if (ch + 1 < end && v[ch + 1] > v[ch]) ++ch;
+                    if (v[root] >= v[ch]) break;
+                    const int32_t t = v[root]; v[root] = v[ch]; v[ch] = t;
+                    root = ch;
+                }
+            };
+            for (int64_t r = len / 2 - 1; r >= 0; --r) sift(r, len);
+            for (int64_t e = len - 1; e > 0; --e) { const int32_t t = v[0]; v[0] = v[e]; v[e] = t; sift(0, e); }
+        }
+        for (int64_t a = 0; a < len; ++a) {
+            const int64_t i = v[a];
+            float *o = sorted_pts + 3 * (s0 + a);
+            o[0] = pts[3 * i]; o[1] = pts[3 * i + 1]; o[2] = pts[3 * i + 2];
+        }
+    }
+}
 
 int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Grid *g, hipStream_t st)
 {
@@ -107,7 +156,7 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     g->params = a.get<GridParams>(1);
     // ONE cleared region per build: [16 spare words for the caller's counters | sum of squares | counts of the first binning |
     // counts of the definitive binning] (each binning has its own counters so that nothing is cleared in between)
-    uint32_t *zero = a.get<uint32_t>(2 * ((size_t)kGridMaxCells + 1) + 32);
+    uint32_t *zero = a.get<uint32_t>(3 * ((size_t)kGridMaxCells + 1) + 32);
     g->cell_start = a.get<uint32_t>((size_t)kGridMaxCells + 1);
     g->sorted_pts = a.get<float>(nn * 3);
     g->sorted_idx = a.get<int32_t>(nn);
@@ -131,8 +180,8 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     while (cell_cap < kGridMaxCells && (int64_t)cell_cap < 16 * n) cell_cap <<= 1;
     g->spare = reinterpret_cast<int32_t *>(zero);
     unsigned long long *sumsq = reinterpret_cast<unsigned long long *>(zero + 16);
-    uint32_t *count1 = zero + 32, *count2 = count1 + (size_t)cell_cap + 1;
-    KPX_HIP(hipMemsetAsync(zero, 0, (32 + 2 * ((size_t)cell_cap + 1)) * sizeof(uint32_t), st));
+    uint32_t *count1 = zero + 32, *count2 = count1 + (size_t)cell_cap + 1, *cursor = count2 + (size_t)cell_cap + 1;
+    KPX_HIP(hipMemsetAsync(zero, 0, (32 + 3 * ((size_t)cell_cap + 1)) * sizeof(uint32_t), st));
     int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
     // first binning from the bounding-box heuristic, one round of occupancy feedback, then the definitive binning
     hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, bbox, target_per_cell, cell_cap, (const unsigned long long *)nullptr, g->params,
@@ -140,9 +189,16 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     hipLaunchKernelGGL(grid_occupancy_kernel, dim3(1024), dim3(256), 0, st, count1, g->params, sumsq);
     hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, bbox, target_per_cell, cell_cap, (const unsigned long long *)sumsq, g->params,
                        keys_in, vals_in, count2);
-    KPX_HIP(sort_pairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, n, 22, st));
     KPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, count2, g->cell_start, cell_cap + 1, st));
-    hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->sorted_idx, g->sorted_pts);
+    static const bool by_sort = [] { const char *e = getenv("KPX_GRID_SORT"); return e && e[0] == '1'; }();     // A/B: the radix-sort build
+    if (by_sort) {
+        KPX_HIP(sort_pairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, n, 22, st));
+        hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->sorted_idx, g->sorted_pts);
+    } else {
+        hipLaunchKernelGGL(grid_place_kernel, dim3(nb), dim3(256), 0, st, keys_in, n, g->cell_start, cursor, g->sorted_idx);
+        hipLaunchKernelGGL(grid_order_kernel, dim3((unsigned)(cdiv(cell_cap, 256) > 4096 ? 4096 : cdiv(cell_cap, 256))), dim3(256), 0, st, pts, g->cell_start,
+                           cell_cap, g->sorted_idx, g->sorted_pts);
+    }
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
