@@ -110,43 +110,22 @@ __global__ __launch_bounds__(256) void grid_place_kernel(const uint32_t *__restr
         slot_idx[cell_start[c] + atomicAdd(&cursor[c], 1u)] = (int32_t)i;
     }
 }
-// ... and one thread per cell then puts its range into ascending point index -- the order a stable sort by cell gives, so the
-// result is deterministic and identical to the sorted build -- and gathers the points.  Cells hold a handful of points (the
-// grid is sized for 6-96 per cell); insertion sort in place, a heap sort for the rare crowded cell (duplicates).
-__global__ __launch_bounds__(256) void grid_order_kernel(const float *__restrict__ pts, const uint32_t *__restrict__ cell_start, int32_t ncell_cap,
-                                                         int32_t *__restrict__ sorted_idx, float *__restrict__ sorted_pts)
+// ... and one thread per point then finds its rank among the points of its cell (how many of them have a lower index: the
+// cell's range is a handful of entries, read by neighbouring threads together) and moves itself there: ascending point index
+// inside every cell, i.e. exactly the order a stable sort by cell gives -- deterministic, identical to the sorted build.
+__global__ __launch_bounds__(256) void grid_rank_kernel(const float *__restrict__ pts, int64_t n, const uint32_t *__restrict__ cell_of,
+                                                        const uint32_t *__restrict__ cell_start, const int32_t *__restrict__ slot_idx,
+                                                        int32_t *__restrict__ sorted_idx, float *__restrict__ sorted_pts)
 {
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell_cap; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t i = slot_idx[s];
+        const uint32_t c = cell_of[i];
         const int64_t s0 = cell_start[c], s1 = cell_start[c + 1];
-        const int64_t len = s1 - s0;
-        if (len <= 0) continue;
-        int32_t *v = sorted_idx + s0;
-        if (len <= 48) {
-            for (int64_t a = 1; a < len; ++a) {
-                const int32_t x = v[a];
-                int64_t b = a - 1;
-                while (b >= 0 && v[b] > x) { v[b + 1] = v[b]; --b; }
-                v[b + 1] = x;
-            }
-        } else {                                         // heap sort, in place
-            auto sift = [&](int64_t root, int64_t end) {
-                for (;;) {
-                    int64_t ch = 2 * root + 1;
-                    if (ch >= end) break;
-                    if (ch + 1 < end && v[ch + 1] > v[ch]) ++ch;
-                    if (v[root] >= v[ch]) break;
-                    const int32_t t = v[root]; v[root] = v[ch]; v[ch] = t;
-                    root = ch;
-                }
-            };
-            for (int64_t r = len / 2 - 1; r >= 0; --r) sift(r, len);
-            for (int64_t e = len - 1; e > 0; --e) { const int32_t t = v[0]; v[0] = v[e]; v[e] = t; sift(0, e); }
-        }
-        for (int64_t a = 0; a < len; ++a) {
-            const int64_t i = v[a];
-            float *o = sorted_pts + 3 * (s0 + a);
-            o[0] = pts[3 * i]; o[1] = pts[3 * i + 1]; o[2] = pts[3 * i + 2];
-        }
+        int rank = 0;
+        for (int64_t t = s0; t < s1; ++t) rank += slot_idx[t] < i ? 1 : 0;
+        const int64_t d = s0 + rank;
+        sorted_idx[d] = i;
+        sorted_pts[3 * d] = pts[3 * (int64_t)i]; sorted_pts[3 * d + 1] = pts[3 * (int64_t)i + 1]; sorted_pts[3 * d + 2] = pts[3 * (int64_t)i + 2];
     }
 }
 
@@ -195,9 +174,8 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
         KPX_HIP(sort_pairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, n, 22, st));
         hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->sorted_idx, g->sorted_pts);
     } else {
-        hipLaunchKernelGGL(grid_place_kernel, dim3(nb), dim3(256), 0, st, keys_in, n, g->cell_start, cursor, g->sorted_idx);
-        hipLaunchKernelGGL(grid_order_kernel, dim3((unsigned)(cdiv(cell_cap, 256) > 4096 ? 4096 : cdiv(cell_cap, 256))), dim3(256), 0, st, pts, g->cell_start,
-                           cell_cap, g->sorted_idx, g->sorted_pts);
+        hipLaunchKernelGGL(grid_place_kernel, dim3(nb), dim3(256), 0, st, keys_in, n, g->cell_start, cursor, vals_in);
+        hipLaunchKernelGGL(grid_rank_kernel, dim3(nb), dim3(256), 0, st, pts, n, keys_in, g->cell_start, vals_in, g->sorted_idx, g->sorted_pts);
     }
     KPX_LAUNCH_CHECK();
     return KPX_OK;
