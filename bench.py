@@ -291,8 +291,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic time frames cycled through")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--check", action="store_true", help="compare one GPU step against the oracle step")
-    ap.add_argument("--overlap", type=int, default=0, help="frames in flight per GPU (pipeline.FrameStream); 1 = one after the other; 0 = 3 with "
-                    "the native frame loop, 2 with the Python pipeline (measured best of 1..4 for each)")
+    ap.add_argument("--overlap", type=int, default=0, help="frames in flight per GPU (pipeline.FrameStream); 1 = one after the other; 0 = 4 with "
+                    "the native frame loop, 2 with the Python pipeline (measured best of 1..6 for each)")
     ap.add_argument("--spread-blocks", type=int, default=5, help="extra blocks of 20 steps for the run-to-run spread (0 = off)")
     ap.add_argument("--no-targets", action="store_true", help="skip the roofline_targets leg")
     ap.add_argument("--quick-targets", action="store_true", help="quarter-size batches for the roofline_targets leg")
@@ -303,6 +303,10 @@ def main():
 
     if args.switch_interval > 0:
         sys.setswitchinterval(args.switch_interval)
+    # The ROCm runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); frames in flight that
+    # share a queue serialise.  Measured on MI355X (profiles/r02/exp_queues_overlap_native.txt): 8 queues with 4 frames in flight
+    # 1730-1770 Mpoints/s against 1570 with the default 4 queues and 3 frames.  Must be set before the runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     from kinectpy_amd import ops, parallel
     from kinectpy_amd.pipeline import FrameStream, NativeFramePipeline, PipelineParams, SensorGroupPipeline, SensorShardPipeline
@@ -312,7 +316,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     F, P = args.frames, PipelineParams()
-    overlap = args.overlap if args.overlap > 0 else (3 if (world == 1 and not args.python_step and args.partition == "sensor") else 2)
+    overlap = args.overlap if args.overlap > 0 else (4 if (world == 1 and not args.python_step and args.partition == "sensor") else 2)
     sensor_mode = args.partition == "sensor"
     if sensor_mode:
         S = args.sensors or (8 if world >= 8 else 4)
@@ -453,7 +457,8 @@ def main():
                            "ICP onto the group master -> fuse -> voxel + SOR, then all-gather of the filtered clouds",
                "partition": "group", "sensors_per_gpu": args.sensors_per_gpu}
     cfg.update(pixels_per_step=px_per_step, icp=f"{P.icp_mode}, voxel {P.reg_voxel}, max_dist {P.icp_max_dist}, <= {P.icp_max_iteration} it",
-               filter=f"voxel {P.filt_voxel} + SOR({P.filt_k}, {P.filt_ratio})", frames_in_flight=overlap, distinct_frames=F, priming_steps=k_prime,
+               filter=f"voxel {P.filt_voxel} + SOR({P.filt_k}, {P.filt_ratio})", frames_in_flight=overlap, hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
+               distinct_frames=F, priming_steps=k_prime,
                last_step=last)
     line = {
         "metric": "Mpoints/sec end-to-end (unproject+filter+ICP), 4-sensor frame", "value": round(value, 3), "unit": "Mpoints/s",
