@@ -90,7 +90,9 @@ def pmc_recorded(kernel):
     import csv
     import glob
     out = {"traffic": None}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.csv")))
+    # launches of ONE registration (tools/icp_probe.py --single under the counters) when recorded: the same launch shape as the quiet
+    # timing; otherwise the bench-wide pass (launches carrying up to three registrations)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_icp_single.csv"))) or sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.csv")))
     if files:
         kb = {}
         with open(files[-1]) as f:

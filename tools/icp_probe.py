@@ -75,5 +75,7 @@ def measure(label, fn, n_threads=1):
 
 
 measure("1 registration alone", lambda: run(1))
+if "--single" in sys.argv:                       # counter passes: launches of ONE registration only
+    sys.exit(0)
 measure("3 registrations side by side (one frame)", lambda: run(3))
 measure("2 frames in flight x 3 registrations", lambda: run(3), n_threads=2)

@@ -16,11 +16,15 @@ cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$ROOT/bench.py" --steps 40 --warmup 5 $Q > "$OUT/bench_n1_under_rocprof.json" 2>> "$OUT/bench_n1.err"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o b -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 $Q --overlap 1 > /dev/null 2>> "$OUT/bench_n1.err"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o b -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 $Q --overlap 1 > /dev/null 2>> "$OUT/bench_n1.err"
+# the dominant kernel with ONE registration per launch (what bench.py's quiet timing measures): traffic per launch
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch1" -o b -- python3 "$ROOT/tools/icp_probe.py" 3 --noprof --single > /dev/null 2>> "$OUT/bench_n1.err"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write1" -o b -- python3 "$ROOT/tools/icp_probe.py" 3 --noprof --single > /dev/null 2>> "$OUT/bench_n1.err"
 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o m -- python3 "$ROOT/tools/mfma_probe.py" > /dev/null 2>> "$OUT/bench_n1.err"
 cd "$ROOT"
 python3 tools/pmc_mfma.py "$OUT/pmc_mfma.csv" "$OUT/pmc_mfma"
 python3 tools/pmc_summary.py "$OUT/pmc_summary.csv" "$OUT/pmc_fetch" "$OUT/pmc_write"
+python3 tools/pmc_summary.py "$OUT/pmc_icp_single.csv" "$OUT/pmc_fetch1" "$OUT/pmc_write1"
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_n1_kernel_stats.csv" \;
 find "$OUT/stats" -name "*domain_stats.csv" -exec cp {} "$OUT/bench_n1_domain_stats.csv" \;
-rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_mfma"
+rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_mfma" "$OUT/pmc_fetch1" "$OUT/pmc_write1"
 ls -la "$OUT"
