@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
                                                        const double *__restrict__ tbbox, double max_d2, int mode, int k, int max_iter, double rel_fit,
-                                                       double rel_rmse, unsigned long long tag, unsigned long long *__restrict__ tile_visits)
+                                                       double rel_rmse, unsigned long long tag, unsigned long long *__restrict__ tile_visits, int split)
 {
     int pi = 0;
 #pragma unroll
@@ -1185,9 +1185,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const IcpProblem &P = args.p[pi];
     const unsigned bid = blockIdx.x - P.block0;
     if (k > max_iter && bid != 0) return;                   // the closing launch only performs the last update (one block per problem)
-    const IcpFuse fuse{ P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag };
+    // split: the update runs in icp_solve_batch_kernel between the sweeps (state slot 0, first accumulator set): the sweep's blocks
+    // then live 8 us instead of 12 -- under load (several frames in flight) the device's wave slots are what the sweeps compete for
+    const IcpFuse fuse{ split ? (IcpState *)nullptr : P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag };
     icp_iter_body(bid, P.blocks, P.src, P.n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, P.row_of, P.src_sorted, P.idx_sorted, P.ptgt_sorted,
                   P.idx_cur, P.d2_cur, max_d2, mode, k, P.pair, P.ring, tile_visits, fuse);
+}
+
+// The update step of every registration of a batch, one block each (split mode: see icp_iter_batch_kernel)
+__global__ __launch_bounds__(256) void icp_solve_batch_kernel(IcpBatchArgs args, int mode, int k, int max_iter, double rel_fit, double rel_rmse,
+                                                              unsigned long long tag)
+{
+    const IcpProblem &P = args.p[blockIdx.x];
+    IcpState *st = P.pair;
+    if (st->done) return;
+    __shared__ double sums[kAcc];
+    __shared__ FinishScratch fs;
+    unsigned long long *acc = P.ring;
+    const int nacc = mode == 1 ? kAcc : 17;
+    if (threadIdx.x < kAcc) sums[threadIdx.x] = (int)threadIdx.x < nacc ? fixed_total(acc, threadIdx.x) : 0.0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < kAccCopies * kAcc * 2; e += 256) acc[e] = 0ull;
+    if (threadIdx.x >= 64) return;
+    icp_finish_wave(sums, P.n, mode, k, max_iter, rel_fit, rel_rmse, st, P.result, fs, (int)threadIdx.x);
+    if (threadIdx.x == 0 && P.progress)
+        __hip_atomic_store(P.progress, tag | ((unsigned long long)(st->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Start of a batch chain in ONE launch: per problem both state slots <- the initial transform, the accumulator ring cleared,
@@ -1881,7 +1904,11 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         }
         static const double stall_limit = [] { const char *e = getenv("KPX_ICP_STALL_SECONDS"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 60.0; }();
         auto t_last = std::chrono::steady_clock::now();
-        const int last_k = max_iteration + 1;                  // the chain ends with an update-only launch
+        // split (default): the update of every registration runs in icp_solve_batch_kernel between the sweeps; KPX_ICP_SPLIT=0: in the
+        // prologue of the next sweep's blocks (one launch per iteration).  Same-run A/B with four frames in flight: 1830-1930 vs
+        // 1730-1830 Mpoints/s -- the redundant prologue holds every block's wave slots 4 us longer, and slots are what frames compete for.
+        static const bool split = [] { const char *e = getenv("KPX_ICP_SPLIT"); return !(e && e[0] == '0'); }();
+        const int last_k = split ? max_iteration : max_iteration + 1;     // the fused chain ends with an update-only launch
         for (bool pending = true; pending && !rc;) {
             pending = false;
             bool advanced = false;
@@ -1906,7 +1933,10 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                     hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)A[g].count : gblocks[g]), dim3(256), 0, ls, closing ? Ac[g] : A[g], tgt,
                                        tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box, bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2,
                                        mode, gk[g], max_iteration, relative_fitness, relative_rmse, tag,
-                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr);
+                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split ? 1 : 0);
+                    if (split)
+                        hipLaunchKernelGGL(icp_solve_batch_kernel, dim3((unsigned)A[g].count), dim3(256), 0, ls, A[g], mode, gk[g], max_iteration,
+                                           relative_fitness, relative_rmse, tag);
                     ++gk[g];
                 }
                 if (gk[g] > last_k) { gfin[g] = true; continue; }
