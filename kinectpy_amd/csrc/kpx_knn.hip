@@ -169,7 +169,12 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, bbox, target_per_cell, cell_cap, (const unsigned long long *)sumsq, g->params,
                        keys_in, vals_in, count2);
     KPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, count2, g->cell_start, cell_cap + 1, st));
-    static const bool by_sort = [] { const char *e = getenv("KPX_GRID_SORT"); return e && e[0] == '1'; }();     // A/B: the radix-sort build
+    // The rank pass reads a cell's whole range per point: quadratic in the cell's population.  Cells are sized for 6-96 points, but
+    // exact duplicates cannot be split by any grid, so the counting build is kept to frame-sized clouds (where the launch count is
+    // what matters and an all-duplicates input costs at most 65536^2 range reads, ~1 s); larger clouds take the radix sort, whose
+    // cost does not depend on the data.  KPX_GRID_SORT=1 forces the sort (A/B runs).
+    static const bool force_sort = [] { const char *e = getenv("KPX_GRID_SORT"); return e && e[0] == '1'; }();
+    const bool by_sort = force_sort || n > 65536;
     if (by_sort) {
         KPX_HIP(sort_pairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, n, 22, st));
         hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->sorted_idx, g->sorted_pts);
@@ -279,15 +284,55 @@ static int sor_block_threads(int k)
     return 64;
 }
 
+// The four launches below (partial sums, fold, partial squared deviations, fold) as ONE block for clouds it can walk in a few
+// microseconds: the same block partition (thread t of virtual block b adds items b*2048 + t, +256, ... in the same order, the
+// virtual blocks' sums are folded in the same order), so the statistics are bit-identical to the multi-launch form.
+__global__ __launch_bounds__(1024) void sor_stats_small_kernel(const double *__restrict__ avg, int64_t n, int nb, double std_ratio, double *__restrict__ stats)
+{
+    __shared__ double part[64];               // nb <= 64 virtual blocks of 256 threads x 8 items
+    __shared__ double sh[4][4];
+    __shared__ double s_mean;
+    const int vb = threadIdx.x >> 8, t = threadIdx.x & 255;          // 4 virtual blocks at a time
+    for (int pass = 0; pass < 2; ++pass) {
+        const double mean = pass ? s_mean : 0.0;
+        for (int b0 = 0; b0 < nb; b0 += 4) {
+            const int b = b0 + vb;
+            double acc = 0.0;
+            if (b < nb)
+                for (int64_t i = (int64_t)b * 256 + t; i < n; i += (int64_t)nb * 256) {
+                    const double v = avg[i];
+                    if (v > 0.0) acc += pass ? (v - mean) * (v - mean) : v;
+                }
+            // block_sum of a 256-thread block: wave sums, then the four waves in order
+            acc = wave_sum(acc);
+            if ((t & 63) == 0) sh[vb][t >> 6] = acc;
+            __syncthreads();
+            if (t == 0 && b < nb) part[b] = ((sh[vb][0] + sh[vb][1]) + sh[vb][2]) + sh[vb][3];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int b = 0; b < nb; ++b) s += part[b];
+            if (pass == 0) { stats[0] = s / (double)n; s_mean = stats[0]; }
+            else { stats[1] = sqrt(s / (double)(n - 1)); stats[2] = stats[0] + std_ratio * stats[1]; }
+        }
+        __syncthreads();
+    }
+}
+
 // statistics over avg (caller's point order) + ascending keep list -- shared by kpx_sor and kpx_sor_finish, so that the
 // sharded filter folds the very same reduction tree over the very same array as the one-GPU call
 static int sor_stats_compact(const double *avg, int64_t n, double std_ratio, double *part, int32_t *counts, int32_t *keep_idx,
                              int32_t *d_count, double *d_stats, hipStream_t st)
 {
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
-    for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(sor_sum_kernel, dim3(nb), dim3(256), 0, st, avg, n, d_stats, pass, part);
-        hipLaunchKernelGGL(sor_final_kernel, dim3(1), dim3(1), 0, st, part, nb, n, std_ratio, pass, d_stats);
+    if (nb <= 64) {
+        hipLaunchKernelGGL(sor_stats_small_kernel, dim3(1), dim3(1024), 0, st, avg, n, nb, std_ratio, d_stats);
+    } else {
+        for (int pass = 0; pass < 2; ++pass) {
+            hipLaunchKernelGGL(sor_sum_kernel, dim3(nb), dim3(256), 0, st, avg, n, d_stats, pass, part);
+            hipLaunchKernelGGL(sor_final_kernel, dim3(1), dim3(1), 0, st, part, nb, n, std_ratio, pass, d_stats);
+        }
     }
     KPX_LAUNCH_CHECK();
     return compact(SorPred{ avg, d_stats }, IdxEmit{ keep_idx }, n, 1, counts, d_count, st);
