@@ -1916,6 +1916,12 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                 if (gfin[g]) continue;
                 int seen = INT_MAX;
                 bool all_done = true;
+                // the launches still to be queued carry only the registrations that have not converged yet (as far as the host
+                // knows: the progress words lag by up to `window` launches); a converged problem's blocks in an already queued
+                // launch read its state and return
+                IcpBatchArgs act, actc;
+                act.count = actc.count = 0;
+                unsigned ab = 0;
                 for (int c = 0; c < A[g].count; ++c) {
                     const unsigned long long w = __atomic_load_n(&h_progress[g * kIcpBatchMax + c], __ATOMIC_ACQUIRE);
                     const bool mine = (w >> 40) == generation;
@@ -1923,19 +1929,26 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                     all_done = false;
                     const int sc = mine ? (int)(w & 0xFFFFFFFFull) : 0;
                     seen = sc < seen ? sc : seen;
+                    act.p[act.count] = A[g].p[c];
+                    act.p[act.count].block0 = ab;
+                    ab += A[g].p[c].blocks;
+                    actc.p[actc.count] = Ac[g].p[c];
+                    actc.p[actc.count].block0 = (unsigned)actc.count;
+                    ++act.count; ++actc.count;
                 }
                 if (all_done) { gfin[g] = true; continue; }
+                for (int c = act.count; c < kIcpBatchMax; ++c) { act.p[c] = act.p[act.count - 1]; actc.p[c] = actc.p[actc.count - 1]; }
                 hipStream_t ls = on_caller ? st : lanes[g % kBatchLanes];
                 while (gk[g] <= last_k && gk[g] - seen < window) {
                     advanced = true;
                     const bool closing = gk[g] > max_iteration;
                     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, ls);
-                    hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)A[g].count : gblocks[g]), dim3(256), 0, ls, closing ? Ac[g] : A[g], tgt,
+                    hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)act.count : ab), dim3(256), 0, ls, closing ? actc : act, tgt,
                                        tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box, bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2,
                                        mode, gk[g], max_iteration, relative_fitness, relative_rmse, tag,
                                        prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split ? 1 : 0);
                     if (split)
-                        hipLaunchKernelGGL(icp_solve_batch_kernel, dim3((unsigned)A[g].count), dim3(256), 0, ls, A[g], mode, gk[g], max_iteration,
+                        hipLaunchKernelGGL(icp_solve_batch_kernel, dim3((unsigned)act.count), dim3(256), 0, ls, act, mode, gk[g], max_iteration,
                                            relative_fitness, relative_rmse, tag);
                     ++gk[g];
                 }

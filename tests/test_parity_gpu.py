@@ -1365,3 +1365,19 @@ def test_native_frame_step_equals_python_pipeline_and_oracle(four_sensor_oracle)
     one = NativeFramePipeline(xy, 1, [], PipelineParams())
     gp, gc, gT = one.step(d[0][:1], c[0][:1])
     assert gT.shape == (1, 4, 4) and np.array_equal(gT[0], np.eye(4)) and gp.shape[0] > 1000
+
+
+def test_sor_and_normals_with_thousands_of_duplicates(ops, oracle, base_cloud):
+    """exact duplicates all land in one grid cell whatever its size (the counting grid build ranks a point against its whole
+    cell): 6000 copies of one point + 3000 of another inside an ordinary cloud -- keep list equal to the oracle's, normals finite"""
+    pts = base_cloud[::12][:20000].copy()
+    pts[:6000] = pts[0]
+    pts[6000:9000] = pts[7000]
+    rng = np.random.default_rng(3)
+    pts = pts[rng.permutation(len(pts))]
+    keep, stats, _ = ops.sor(pts, 20, 2.0)
+    ok, ostats, _ = oracle.sor(pts, 20, 2.0)
+    assert np.array_equal(npy(keep), ok)
+    assert np.allclose(npy(stats), np.array(ostats), rtol=TOL_STATS)
+    nrm = npy(ops.estimate_normals(pts, 70.0, 40))
+    assert np.isfinite(nrm).all() and np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-5)
