@@ -2,7 +2,6 @@
 transform from picked point pairs (Umeyama / Kabsch without scale) and the point-to-point ICP refinement.  The interactive
 point picking (Open3D's VisualizerWithEditing, :60-67) and the before / after viewers are GUI and out of scope: the picked
 indices are passed in."""
-import copy
 import os
 
 import numpy as np
@@ -32,19 +31,18 @@ def pick_points(pcd):
 
 
 def manual_registration(pcd_master, pcd_sub, picked_id_source=None, picked_id_target=None, threshold: float = 0.03) -> np.ndarray:
-    """manual_pointcloud_registration.py:70-101.  source = the sub device's cloud, target = the master's (:75-76);
-    picked_id_source[i] <-> picked_id_target[i] are the user's correspondences (:80-87); returns the 4x4 sub -> master.
-    threshold 0.03 is the reference's literal (:95)."""
-    source, target = copy.deepcopy(pcd_sub), copy.deepcopy(pcd_master)
+    """manual_pointcloud_registration.py:70-101: rough sub -> master transform from the user's picked point pairs (Umeyama /
+    Kabsch without scale, :90-91), refined by point-to-point ICP on the full clouds (:96-98); returns the 4x4.  The sub device's
+    cloud is the source, the master's the target.  picked_id_source[i] <-> picked_id_target[i] are indices into the two clouds
+    (the reference obtains them from two GUI sessions, :80-81); threshold 0.03 is the reference's literal (:95)."""
     if picked_id_source is None or picked_id_target is None:
-        picked_id_source, picked_id_target = pick_points(source), pick_points(target)
-    assert len(picked_id_source) >= 3 and len(picked_id_target) >= 3
-    assert len(picked_id_source) == len(picked_id_target)
-    corr = np.zeros((len(picked_id_source), 2))
-    corr[:, 0] = picked_id_source
-    corr[:, 1] = picked_id_target
-    p2p = o3d.pipelines.registration.TransformationEstimationPointToPoint()
-    trans_init = p2p.compute_transformation(source, target, o3d.utility.Vector2iVector(corr))
-    reg_p2p = o3d.pipelines.registration.registration_icp(source, target, threshold, trans_init,
-                                                           o3d.pipelines.registration.TransformationEstimationPointToPoint())
-    return reg_p2p.transformation
+        picked_id_source, picked_id_target = pick_points(pcd_sub), pick_points(pcd_master)
+    src_ids = np.asarray(picked_id_source, dtype=np.int64).reshape(-1)
+    tgt_ids = np.asarray(picked_id_target, dtype=np.int64).reshape(-1)
+    if min(len(src_ids), len(tgt_ids)) < 3 or len(src_ids) != len(tgt_ids):
+        raise AssertionError("pick at least three points in each cloud, the same number in both")        # the reference asserts (:82-83)
+    reg = o3d.pipelines.registration
+    point_to_point = reg.TransformationEstimationPointToPoint()
+    rough = point_to_point.compute_transformation(pcd_sub, pcd_master, o3d.utility.Vector2iVector(np.stack([src_ids, tgt_ids], 1)))
+    refined = reg.registration_icp(pcd_sub, pcd_master, threshold, rough, point_to_point)              # inputs are not modified
+    return refined.transformation
