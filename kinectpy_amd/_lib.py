@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libkinectpx.so")
+# KPX_LIBRARY: another build of the same library (A/B runs of compile-time variants, e.g. -DKPX_ICP_WAVES=2)
+SO_PATH = os.environ.get("KPX_LIBRARY") or os.path.join(_HERE, "libkinectpx.so")
 
 _i64, _i32, _f64, _u64, _vp, _sz = C.c_int64, C.c_int32, C.c_double, C.c_uint64, C.c_void_p, C.c_size_t
 

@@ -916,7 +916,11 @@ namespace kpx {
 // device-scope stores, a drained vmcnt and a relaxed ticket it still adds ~13 us at 485 blocks -- the same-address
 // ticket atomics serialise at ~12 ns each and the last block reads 170 KB through sc1 loads -- against ~11 us for
 // the boundary + the 1024-thread solve kernel.)
-constexpr int kIWaves = 4;
+#ifndef KPX_ICP_WAVES
+#define KPX_ICP_WAVES 4
+#endif
+constexpr int kIWaves = KPX_ICP_WAVES;       // waves (16-row tiles) per block: a block lives as long as its slowest wave
+constexpr int kIThreads = kIWaves * 64;
 constexpr int kIRows = kIWaves * kLRows;
 // One launch per iteration (used by kpx_icp_batch, whose chains are bound by the host's launch rate once several
 // registrations and two frames run side by side): launch k first performs the update of iteration k-1 -- every block
@@ -1001,7 +1005,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         __syncthreads();
         if (bid == 0) {
             unsigned long long *next = fuse.ring + (int64_t)((k + 1) % 3) * kAccSet;
-            for (int e = threadIdx.x; e < kAccSet; e += 256) next[e] = 0ull;
+            for (int e = threadIdx.x; e < kAccSet; e += kIThreads) next[e] = 0ull;
             if (threadIdx.x == 0) {
                 *out = s_state;
                 if (k > 0 && fuse.progress)
@@ -1132,7 +1136,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
 }
 
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+__global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
@@ -1172,7 +1176,7 @@ struct IcpBatchArgs {
     IcpProblem p[kIcpBatchMax];
     int32_t count;
 };
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_iter_batch_kernel(IcpBatchArgs args, const float *__restrict__ tgt,
+__global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_iter_batch_kernel(IcpBatchArgs args, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
@@ -1225,9 +1229,11 @@ __global__ __launch_bounds__(256) void icp_batch_init_kernel(IcpBatchArgs args, 
     for (int c = 1; c < kIcpBatchMax; ++c) pi += (c < args.count && blockIdx.x >= args.p[c].block0) ? 1 : 0;
     const IcpProblem &P = args.p[pi];
     const unsigned bid = blockIdx.x - P.block0;
-    const int64_t r = (int64_t)bid * kIRows + (threadIdx.x >> 2);
     const int c = threadIdx.x & 3;
-    if (r < P.n && c < 3) P.src_sorted[3 * r + c] = P.src[3 * (int64_t)P.row_of[r] + c];
+    for (int rr = threadIdx.x >> 2; rr < kIRows; rr += 64) {
+        const int64_t r = (int64_t)bid * kIRows + rr;
+        if (r < P.n && c < 3) P.src_sorted[3 * r + c] = P.src[3 * (int64_t)P.row_of[r] + c];
+    }
     if (bid == 0) {
         for (int e = threadIdx.x; e < 3 * kAccSet; e += 256) P.ring[e] = 0ull;
         if (threadIdx.x < 32) {
@@ -1445,7 +1451,7 @@ static void icp_iter_launch(const float *src, const float *tgt, const float *tn,
 {
     {
         ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
-        hipLaunchKernelGGL(icp_iter_kernel, dim3((unsigned)cdiv(p.n_src, kIRows)), dim3(256), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t,
+        hipLaunchKernelGGL(icp_iter_kernel, dim3((unsigned)cdiv(p.n_src, kIRows)), dim3(kIThreads), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t,
                            b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.ptgt_sorted, b.idx_cur, b.d2_cur,
                            max_d2, mode, k, b.state,
                            b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, IcpFuse{});
@@ -1462,7 +1468,7 @@ static void icp_fused_launch(const float *src, const float *tgt, const float *tn
     const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag };
     const unsigned blocks = k > max_iter ? 1u : (unsigned)cdiv(p.n_src, kIRows);
     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
-    hipLaunchKernelGGL(icp_iter_kernel, dim3(blocks), dim3(256), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t, b.tile_box, b.group_box,
+    hipLaunchKernelGGL(icp_iter_kernel, dim3(blocks), dim3(kIThreads), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t, b.tile_box, b.group_box,
                        p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.ptgt_sorted, b.idx_cur, b.d2_cur, max_d2, mode, k, b.state,
                        b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, fuse);
 }
@@ -1943,7 +1949,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                     advanced = true;
                     const bool closing = gk[g] > max_iteration;
                     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, ls);
-                    hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)act.count : ab), dim3(256), 0, ls, closing ? actc : act, tgt,
+                    hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)act.count : ab), dim3(kIThreads), 0, ls, closing ? actc : act, tgt,
                                        tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box, bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2,
                                        mode, gk[g], max_iteration, relative_fitness, relative_rmse, tag,
                                        prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split ? 1 : 0);

@@ -26,10 +26,11 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const float *__restrict_
     }
 }
 
-struct HeadPred {
-    const uint64_t *keys;
+template <class Key> struct HeadPredT {
+    const Key *keys;
     __device__ bool operator()(int64_t s, int) const { return s == 0 || keys[s] != keys[s - 1]; }
 };
+using HeadPred = HeadPredT<uint64_t>;
 struct HeadEmit {
     int32_t *seg_start;
     __device__ void operator()(int64_t s, int, int32_t dst) const { seg_start[dst] = (int32_t)s; }
@@ -211,8 +212,9 @@ __global__ void voxel_batch_bits_kernel(VoxelBatch b, const double *__restrict__
     }
     *bits = n;
 }
+template <class Key>
 __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, const double *__restrict__ bbox, double voxel,
-                                                              uint64_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ err)
+                                                              Key *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ err)
 {
     __shared__ double dims[3];
     __shared__ int overflow;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, cons
         double fz = floor(((double)pts[3 * j + 2] - oz) / voxel);
         const bool bad = overflow || !(fx >= 0.0) || !(fy >= 0.0) || !(fz >= 0.0) || fx >= 2097152.0 || fy >= 2097152.0 || fz >= 2097152.0;
         if (bad) { err[c] = 1; fx = fy = fz = 0.0; }
-        keys[i] = (((uint64_t)c * DX + (uint64_t)fx) * DY + (uint64_t)fy) * DZ + (uint64_t)fz;
+        keys[i] = (Key)((((uint64_t)c * DX + (uint64_t)fx) * DY + (uint64_t)fy) * DZ + (uint64_t)fz);
         vals[i] = (int32_t)i;
     }
 }
@@ -340,11 +342,11 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
     hipLaunchKernelGGL(voxel_batch_bbox_partial_kernel, dim3(kVoxelBatchBboxBlocks, b.count), dim3(256), 0, st, b, s.part);
     hipLaunchKernelGGL(voxel_batch_bbox_final_kernel, dim3(b.count), dim3(64), 0, st, s.part, s.bbox, s.err);
     const int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
-    hipLaunchKernelGGL(voxel_batch_key_kernel, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err);
     int end_bit = 64;
     if (total > (int64_t)1024 * 1024) {
         // above rocPRIM's merge-sort limit the sort is an Onesweep with one pass per 8 key bits: reading the width back (one
-        // small round trip; the caller waits for the counts anyway) saves four or five of the eight ~27 us passes
+        // small round trip; the caller waits for the counts anyway) saves four or five of the eight ~27 us passes -- and keys of at
+        // most 32 bits (a 4-sensor frame needs ~25) are written, sorted and compared as 32-bit words: half the key traffic
         static thread_local int32_t *h_bits = nullptr;
         if (!h_bits) KPX_HIP(hipHostMalloc((void **)&h_bits, sizeof(int32_t), hipHostMallocDefault));
         hipLaunchKernelGGL(voxel_batch_bits_kernel, dim3(1), dim3(1), 0, st, b, s.bbox, voxel, s.head);
@@ -353,8 +355,17 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
         end_bit = *h_bits < 1 ? 1 : (*h_bits > 64 ? 64 : *h_bits);
     }
     size_t bytes = s.sort_bytes;
-    KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, end_bit, st));
-    int rc = compact(HeadPred{ s.keys_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st);
+    int rc;
+    if (end_bit <= 32) {
+        uint32_t *k_in = reinterpret_cast<uint32_t *>(s.keys_in), *k_out = reinterpret_cast<uint32_t *>(s.keys_out);
+        hipLaunchKernelGGL(voxel_batch_key_kernel<uint32_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, k_in, s.vals_in, s.err);
+        KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, k_in, k_out, s.vals_in, s.vals_out, (int)total, 0, end_bit, st));
+        rc = compact(HeadPredT<uint32_t>{ k_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st);
+    } else {
+        hipLaunchKernelGGL(voxel_batch_key_kernel<uint64_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err);
+        KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, end_bit, st));
+        rc = compact(HeadPred{ s.keys_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(voxel_batch_locate_kernel, dim3(1), dim3(64), 0, st, b, s.seg_start, s.d_total, s.err, s.head, d_counts);
     hipLaunchKernelGGL(voxel_batch_mean_kernel, dim3(nb), dim3(256), 0, st, b, s.vals_out, s.seg_start, s.d_total, s.head);
