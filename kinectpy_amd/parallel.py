@@ -12,6 +12,15 @@ import torch
 import torch.distributed as dist
 
 
+# Test hook: run the collectives on a ONE-rank group too (a single-GPU box can then push the north-star partition through RCCL
+# itself -- broadcast, all_gather_into_tensor on device tensors, one communicator per frame slot -- instead of short-cutting them)
+FORCE_COLLECTIVES = False
+
+
+def collectives_on(group=None) -> bool:
+    return dist.is_initialized() and (world_size(group) > 1 or FORCE_COLLECTIVES)
+
+
 def init_distributed(backend: str = None) -> Tuple[int, int, int]:
     """-> (rank, world, local_rank).  Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -46,7 +55,7 @@ def world_size(group=None) -> int:
 def new_group():
     """another communicator over all ranks (one per frame slot of pipeline.FrameStream: collectives of different frames in
     flight must not share a communicator, their issue order differs between ranks); None on a single rank"""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         return None
     return dist.new_group(ranks=list(range(dist.get_world_size())), backend=dist.get_backend())
 
@@ -124,7 +133,7 @@ def allgather_clouds(padded: torch.Tensor, count: int, transforms: torch.Tensor,
     tail[:words] = hdr.view(torch.float32)
     msg[cap:] = tail.reshape(hrows, C).to(padded.device, non_blocking=True)
     allm = _all_gather_flat(msg, group)                         # (world, cap + hrows, C)
-    hdrs = allm[:, cap:].reshape(W, -1)[:, :words].contiguous().cpu().view(torch.float64)   # one read-back
+    hdrs = allm[:, cap:].reshape(W, -1)[:, :words].cpu().reshape(-1).clone().view(torch.float64).reshape(W, -1)   # one read-back
     counts = [int(c) for c in hdrs[:, 0].tolist()]
     all_T = hdrs[:, 1:].reshape(-1, 4, 4).to(padded.device)
     cloud = torch.cat([allm[r, :min(c, cap)] for r, c in enumerate(counts)], 0)
@@ -185,7 +194,7 @@ class SensorExchange:
         Tl = np.tile(np.eye(4), (K, 1, 1))
         Tl[:len(ns)] = np.asarray(transforms, dtype=np.float64).reshape(-1, 4, 4)
         hdr[K:] = Tl.reshape(-1)
-        if W == 1:
+        if not collectives_on(self.group):
             return [list(clouds)], Tl[None], np.array([ns + [0] * (K - len(ns))], dtype=np.int64)
         dev = clouds[0][0].device
         words = hdr.size * 2
@@ -203,7 +212,7 @@ class SensorExchange:
                 off += k
             msg[2 * cap:] = tail.reshape(hrows, 3).to(dev, non_blocking=True)
             allm = _all_gather_flat(msg, self.group)                                  # (world, 2 cap + hrows, 3)
-            h = allm[:, 2 * cap:].reshape(W, -1)[:, :words].contiguous().cpu().view(torch.float64).numpy()   # one read-back
+            h = np.ascontiguousarray(allm[:, 2 * cap:].reshape(W, -1)[:, :words].cpu().numpy()).copy().view(np.float64)   # one read-back
             counts = h[:, :K].astype(np.int64)
             need = int(counts.sum(1).max())
             self.cap = max(4096, -(-int(need * 1.25) // 4096) * 4096)
@@ -232,7 +241,7 @@ class MasterBroadcast:
 
     def __call__(self, pts, nrm, device=None):
         """rank src: pts (n,3), nrm (n,3) | None; other ranks: None, None (+ device) -> (pts, nrm | None) on every rank"""
-        if world_size(self.group) == 1:
+        if not collectives_on(self.group):
             return pts, nrm
         me = dist.get_rank()
         if me == self.src:
@@ -263,7 +272,7 @@ def allgather_slabs(part: torch.Tensor, rows: int, group=None) -> torch.Tensor:
     (the tail of a short slab is padding).  Used by the sharded fused filter for the per-slab mean kNN distances."""
     buf = torch.zeros(rows, dtype=part.dtype, device=part.device)
     buf[: part.numel()] = part
-    if world_size(group) == 1:
+    if not collectives_on(group):
         return buf[None]
     return _all_gather_flat(buf, group)
 
@@ -271,7 +280,7 @@ def allgather_slabs(part: torch.Tensor, rows: int, group=None) -> torch.Tensor:
 def warm(group, device):
     """create the communicator of `group` now, from the calling thread (a tiny all-reduce): the frame slots use their
     groups from worker threads, and every rank has to build its communicators in the same order"""
-    if dist.is_initialized() and world_size(group) > 1:
+    if collectives_on(group):
         t = torch.zeros(1, dtype=torch.float32, device="cpu" if dist.get_backend(group) == "gloo" else device)
         dist.all_reduce(t, group=group)
         if t.is_cuda:

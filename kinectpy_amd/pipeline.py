@@ -113,7 +113,7 @@ class SensorShardPipeline:
         self.p = params or PipelineParams()
         self.group = group
         self.world = parallel.world_size(group) if world is None else world
-        self.rank = (torch.distributed.get_rank() if self.world > 1 else 0) if rank is None else rank
+        self.rank = (torch.distributed.get_rank() if torch.distributed.is_initialized() else 0) if rank is None else rank
         self.n_sensors = int(n_sensors)
         if self.world > self.n_sensors:
             raise ValueError(f"{self.world} ranks for {self.n_sensors} sensors: a rank needs at least one sensor")
@@ -177,12 +177,13 @@ class SensorShardPipeline:
         Ts = np.concatenate([all_T[r, :owned[r]] for r in range(self.world)])             # sensor order
         clouds = [seg for r in range(self.world) for seg in segs[r][:owned[r]]]
         self.last.update(n_masked=[int(k) for k in mk], n_fused=int(counts.sum()), counts=[int(c) for c in counts.sum(1)])
-        if self.world > 1 and self.fused_filter == "rank0" and self.rank != 0:
+        dist_on = parallel.collectives_on(self.group)
+        if dist_on and self.fused_filter == "rank0" and self.rank != 0:
             return None, None, Ts
         # pcd.transform(T_i) + np.vstack + voxel_down_sample (data.py:44-61) in one pass, on the fp64 values of the moved points
         vp, vc = o.fuse_voxel_downsample([c[0] for c in clouds], [c[1] for c in clouds], Ts, p.filt_voxel)
         M = int(vp.shape[0])
-        if self.world > 1 and self.fused_filter == "sharded" and M > 0:
+        if dist_on and self.fused_filter == "sharded" and M > 0:
             rows = -(-M // self.world)                                                    # slab r = grid-order positions [r rows, (r+1) rows)
             q0, q1 = min(M, self.rank * rows), min(M, (self.rank + 1) * rows)
             part, order = o.sor_partial(vp, p.filt_k, q0, q1)

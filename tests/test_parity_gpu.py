@@ -850,6 +850,38 @@ cloud, all_T, counts = parallel.allgather_clouds(buf, 5000, T, always_collective
 assert counts == [5000] and cloud.shape[0] == 4096
 parallel.barrier()
 assert parallel.allreduce_max(2.5, buf.device) == 2.5
+# the north-star partition through RCCL on a one-rank group: broadcast, all_gather_into_tensor and the slab all-gather on device
+# tensors, serially and with two frames in flight (one communicator per slot) -- same result as without any collective
+import numpy as np
+from kinectpy_amd.pipeline import FrameStream, PipelineParams, SensorShardPipeline
+from kinectpy_amd.utils import synth
+xy, depth, rgb, inits, _ = synth.sensor_ring(2, 2, synth.small_xy(2))
+d, c = torch.as_tensor(depth).cuda(), torch.as_tensor(rgb).cuda()
+plain = SensorShardPipeline(xy, 2, inits, PipelineParams())
+want = [plain.step(d[f], c[f]) for f in range(2)]
+parallel.FORCE_COLLECTIVES = True
+for mode in ("sharded", "rank0"):
+    pipe = SensorShardPipeline(xy, 2, inits, PipelineParams(), fused_filter=mode, cloud_capacity=4096)
+    for rep in range(2):
+        for f in range(2):
+            p_, c_, T_ = pipe.step(d[f], c[f])
+            assert torch.equal(p_, want[f][0]) and torch.equal(c_, want[f][1]) and np.array_equal(T_, want[f][2]), (mode, rep, f)
+groups = [parallel.new_group() for _ in range(2)]
+assert all(g is not None for g in groups)
+for g in groups:
+    parallel.warm(g, d.device)
+fs = FrameStream([SensorShardPipeline(xy, 2, inits, PipelineParams(), group=g, cloud_capacity=4096) for g in groups])
+got = []
+for k in range(5):
+    if fs.full():
+        got.append(fs.pop())
+    fs.submit(d[k % 2], c[k % 2])
+while fs.pending:
+    got.append(fs.pop())
+fs.close()
+for k, (p_, c_, T_) in enumerate(got):
+    assert torch.equal(p_, want[k % 2][0]) and torch.equal(c_, want[k % 2][1])
+parallel.FORCE_COLLECTIVES = False
 dist.destroy_process_group()
 print("rccl-ok")
 """
