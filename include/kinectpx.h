@@ -375,6 +375,10 @@ int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work);
  * [4] the block sums; [5] blocks; [6] latest - earliest block start (dispatch ramp); [7] earliest start -> latest end;
  * [8..12] the slowest block of each phase; [13] the longest block lifetime.  h_out8 holds 16 doubles. */
 int kpx_prof_icp_phases(double *h_out8);
+/* Per-wave rows of the same launch (4 x uint64 per wave: sweep start, sweep end in 10 ns ticks; counters = tiles multiplied |
+ * tile-box fetches << 16 | operand fetches << 32 | groups kept << 48; sampled rows with a partner).  *h_count = the number of
+ * waves written (<= cap_waves). */
+int kpx_prof_icp_waves(uint64_t *h_out, int64_t cap_waves, int64_t *h_count);
 
 #ifdef __cplusplus
 }

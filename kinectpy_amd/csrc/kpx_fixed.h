@@ -24,6 +24,27 @@ __device__ __forceinline__ void fixed_add(unsigned long long *acc2, double v)
     const unsigned long long carry = (old + lo) < old ? 1ull : 0ull;
     if (hi + carry != 0ull) atomicAdd(acc2 + 1, hi + carry);
 }
+// The same add with both atomics RETURNING: when the call returns, the add has been performed at the device's point of
+// coherence (what a later ticket of the same block may be ordered behind without a release fence).
+__device__ __forceinline__ void fixed_add_performed(unsigned long long *acc2, double v)
+{
+    const bool neg = v < 0.0;
+    const double m = fabs(v);
+    const double ip = floor(m);
+    unsigned long long hi = (unsigned long long)ip;
+    unsigned long long lo = (unsigned long long)((m - ip) * 18446744073709551616.0);
+    if (neg) {
+        lo = ~lo + 1ull;
+        hi = ~hi + (lo == 0ull ? 1ull : 0ull);
+    }
+    if (hi == 0ull && lo == 0ull) return;
+    const unsigned long long old = __hip_atomic_fetch_add(acc2, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long carry = (old + lo) < old ? 1ull : 0ull;
+    if (hi + carry != 0ull) {
+        const unsigned long long back = __hip_atomic_fetch_add(acc2 + 1, hi + carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(back));                       // the value is waited for
+    }
+}
 // (lo, hi) two's complement -> double: (double)hi + (double)lo * 2^-64 on the magnitude
 __device__ __forceinline__ double fixed_value(unsigned long long lo, unsigned long long hi)
 {

@@ -34,6 +34,12 @@
 namespace kpx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+#ifndef KPX_ICP_SPLIT_DEFAULT
+#define KPX_ICP_SPLIT_DEFAULT 2
+#endif
+#ifndef KPX_ICP_WPE
+#define KPX_ICP_WPE 3                            // waves per SIMD the iteration kernels are register-budgeted for
+#endif
 
 constexpr int kRT = 2;                       // 16-row tiles per wave (the sweep below is written for 2)
 constexpr int kWaves = 4;
@@ -875,6 +881,23 @@ __device__ __forceinline__ double fixed_total(const unsigned long long *acc, int
     }
     return fixed_value(lo, hi);
 }
+// the same through device-coherent loads (for a reader inside the launch that did the adds: the XCDs' L2s are not coherent)
+__device__ __forceinline__ double fixed_total_coherent(unsigned long long *acc, int slot)
+{
+    unsigned long long l[kAccCopies], h[kAccCopies];
+#pragma unroll
+    for (int c = 0; c < kAccCopies; ++c) {
+        l[c] = __hip_atomic_load(acc + ((int64_t)c * kAcc + slot) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h[c] = __hip_atomic_load(acc + ((int64_t)c * kAcc + slot) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned long long lo = 0ull, hi = 0ull;
+#pragma unroll
+    for (int c = 0; c < kAccCopies; ++c) {
+        lo += l[c];
+        hi += h[c] + (lo < l[c] ? 1ull : 0ull);
+    }
+    return fixed_value(lo, hi);
+}
 // sums -> update step; clears the accumulators for the next iteration (single block: no race)
 // progress: optional word in pinned host memory, tag | done << 32 | iterations finished -- the batch driver reads it to keep
 // a window of iterations queued per problem without copies or events (system-scope release store by one thread)
@@ -935,6 +958,7 @@ struct IcpFuse {
     double rel_fit, rel_rmse;
     double *result;
     unsigned long long *progress, tag;
+    unsigned long long *ticket;        // non-null (with pair == nullptr): the LAST block of the launch to deliver its sums performs the update
 };
 constexpr int kAccSet = kAccCopies * kAcc * 2;
 // Phase clock of the iteration kernel (while the profiler is armed): thread 0 of every block stores 100 MHz wall-clock stamps in
@@ -943,6 +967,9 @@ constexpr int kAccSet = kAccCopies * kAcc * 2;
 // The rows of the LAST launch are read by kpx_prof_icp_phases.
 constexpr int kStampBlocks = 4096;
 __device__ unsigned long long g_icp_stamp[kStampBlocks][8];
+// per WAVE of the last sweep launch: [0] sweep start, [1] sweep end (100 MHz), [2] the packed counters sweep_wave returns, [3] rows
+// of the wave that ended with a partner
+__device__ unsigned long long g_icp_wave[kStampBlocks * 4][4];
 __device__ __forceinline__ void phase_tick(unsigned long long *__restrict__ armed, int slot, unsigned bid)
 {
     if (!armed || threadIdx.x || bid >= kStampBlocks) return;
@@ -966,6 +993,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     const int64_t row_base = ((int64_t)bid * kIWaves + wave) * kLRows;
     const int64_t last = n - 1;
     const unsigned long long t_block_start = (tile_visits && threadIdx.x == 0) ? wall_clock64() : 0ull;
+    const double t2max = target_t2max(tbbox);
     // An iteration is a chain of dependent memory round trips, so everything that does not depend on this iteration's
     // transform is requested FIRST -- the wave's rows, their previous partners (index AND coordinates, kept in sorted-row
     // order by the previous launch: no gather through the index), the first 128 group boxes -- and arrives while the update
@@ -1017,8 +1045,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         Tk = s_state.T;
         acc = fuse.ring + (int64_t)(k % 3) * kAccSet;
     } else if (st->done) return;
-    __shared__ int32_t lists[kIWaves][kLList];
-    __shared__ double rowd[kIWaves][16][5];          // s_x, s_y, s_z, K, bound / result value
+    __shared__ int32_t lists[kIWaves][kLScratch];
+    __shared__ double rowd[kIWaves][16][kRowStride]; // s_x, s_y, s_z, (the sweep's row bound), K, bound / result value
     __shared__ int32_t rowi[kIWaves][16][2];         // partner (bound / result), original row
     __shared__ double sh[kAcc][kIRows + 1];
     const int nacc = mode == 1 ? kAcc : 17;
@@ -1047,13 +1075,10 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                 bj = p;
             }
         }
-        double t2max = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) t2max += fmax(tbbox[a] * tbbox[a], tbbox[3 + a] * tbbox[3 + a]);
         const double clamp = (max_d2 + 1.0) * (1.0 + 9.31322574615478515625e-10) + ldexp(seed + t2max + 1.0, -38);
         if (!(bv <= clamp)) { bv = clamp; bj = INT_MAX; }
         rowd[wave][lane][0] = s[0]; rowd[wave][lane][1] = s[1]; rowd[wave][lane][2] = s[2];
-        rowd[wave][lane][3] = seed; rowd[wave][lane][4] = bv;
+        rowd[wave][lane][4] = seed; rowd[wave][lane][5] = bv;
         rowi[wave][lane][0] = bj; rowi[wave][lane][1] = (int32_t)i;
     }
     wave_lds_fence();
@@ -1063,12 +1088,21 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int rr = q + 4 * r;
-        w.seed[r] = rowd[wave][rr][3];
-        w.best[r] = rowd[wave][rr][4];
+        w.seed[r] = rowd[wave][rr][4];
+        w.best[r] = rowd[wave][rr][5];
         w.bcol[r] = rowi[wave][rr][0];
     }
     phase_tick(tile_visits, 2, bid);
-    const unsigned visited = sweep_wave<true>(w, Bs, orig, tile_box, group_box, n_groups, tbbox, lists[wave], &gpre);
+    const unsigned long long t_sweep = tile_visits ? wall_clock64() : 0ull;
+    const unsigned long long swept = sweep_wave<true>(w, Bs, orig, tile_box, group_box, n_groups, t2max, lists[wave], &gpre);
+    const unsigned visited = (unsigned)(swept & 0xFFFFu);
+    if (tile_visits && lane == 0 && bid < kStampBlocks && kIWaves <= 4) {
+        unsigned long long *o = g_icp_wave[bid * 4 + wave];
+        int with = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) with += (w.bcol[r] >= 0 && w.bcol[r] != INT_MAX) ? 1 : 0;      // lane 0: rows 0, 4, 8, 12 (a sample)
+        o[0] = t_sweep; o[1] = wall_clock64(); o[2] = swept; o[3] = (unsigned long long)with;
+    }
     phase_tick(tile_visits, 3, bid);
     if (tile_visits && lane == 0) atomicAdd(tile_visits + ((bid * kIWaves + wave) & (kVisitSlots - 1)), (unsigned long long)visited);
     wave_lds_fence();
@@ -1130,13 +1164,36 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     if ((int)threadIdx.x < nacc) {
         double v = 0.0;
         for (int l = 0; l < kIRows; ++l) v += sh[threadIdx.x][l];
-        fixed_add(acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + threadIdx.x) * 2), v);
+        unsigned long long *slot = acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + threadIdx.x) * 2);
+        if (fuse.ticket) fixed_add_performed(slot, v); else fixed_add(slot, v);
     }
     phase_tick(tile_visits, 5, bid);
+    if (!fuse.ticket) return;
+    // "The last block finishes the job": every add above has RETURNED (it has been performed at the device's point of coherence),
+    // the barrier orders the block's ticket behind them, and the block that draws the last ticket of its registration reads the
+    // totals -- 8 x 44 pairs of words -- with device-coherent loads, clears them for the next launch and performs the update.
+    // Only relaxed atomics: no release fence, which on this part writes back the XCD's L2 (measured 10x slower, once per block).
+    // The state is written with plain stores: its readers are the blocks of the NEXT launch, behind the kernel boundary.
+    __shared__ unsigned s_ticket;
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = (unsigned)__hip_atomic_fetch_add(fuse.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != nblocks - 1u) return;
+    if (threadIdx.x < kAcc) s_sums[threadIdx.x] = (int)threadIdx.x < nacc ? fixed_total_coherent(acc, threadIdx.x) : 0.0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < kAccSet; e += kIThreads) __hip_atomic_store(acc + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(fuse.ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave != 0) return;
+    __shared__ FinishScratch s_tail;
+    IcpState *stw = const_cast<IcpState *>(st);
+    icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, stw, fuse.result, s_tail, lane);
+    if (lane == 0 && fuse.progress)
+        __hip_atomic_store(fuse.progress, fuse.tag | ((unsigned long long)(stw->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 
-__global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
+__global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE, KPX_ICP_WPE))) void icp_iter_kernel(const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
@@ -1176,7 +1233,7 @@ struct IcpBatchArgs {
     IcpProblem p[kIcpBatchMax];
     int32_t count;
 };
-__global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_iter_batch_kernel(IcpBatchArgs args, const float *__restrict__ tgt,
+__global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE, KPX_ICP_WPE))) void icp_iter_batch_kernel(IcpBatchArgs args, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
@@ -1191,7 +1248,10 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     if (k > max_iter && bid != 0) return;                   // the closing launch only performs the last update (one block per problem)
     // split: the update runs in icp_solve_batch_kernel between the sweeps (state slot 0, first accumulator set): the sweep's blocks
     // then live 8 us instead of 12 -- under load (several frames in flight) the device's wave slots are what the sweeps compete for
-    const IcpFuse fuse{ split ? (IcpState *)nullptr : P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag };
+    // split == 2: no update kernel either -- the last block of every registration's sweep performs it (ticket: first word of the
+    // second accumulator set, which only the one-launch form uses)
+    const IcpFuse fuse{ split ? (IcpState *)nullptr : P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag,
+                        split == 2 ? P.ring + kAccSet : (unsigned long long *)nullptr };
     icp_iter_body(bid, P.blocks, P.src, P.n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, P.row_of, P.src_sorted, P.idx_sorted, P.ptgt_sorted,
                   P.idx_cur, P.d2_cur, max_d2, mode, k, P.pair, P.ring, tile_visits, fuse);
 }
@@ -1287,6 +1347,20 @@ int icp_phase_take(double *h_out8)
     h_out8[6] = (double)(s_max - s_min) * 0.01;
     h_out8[7] = (double)(e_max - s_min) * 0.01;
     return KPX_OK;
+}
+// raw rows of g_icp_wave for the blocks of the last sweep launch -> h_out (4 u64 per wave); returns the number of waves
+int64_t icp_wave_take(unsigned long long *h_out, int64_t cap_waves)
+{
+    unsigned long long *p = nullptr, *ps = nullptr;
+    if (hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_icp_wave)) != hipSuccess) return -1;
+    if (hipGetSymbolAddress((void **)&ps, HIP_SYMBOL(g_icp_stamp)) != hipSuccess) return -1;
+    unsigned long long first[8];
+    if (hipMemcpy(first, ps, sizeof(first), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int64_t waves = (int64_t)first[6] * kIWaves;
+    if (waves > kStampBlocks * 4) waves = kStampBlocks * 4;
+    if (waves > cap_waves) waves = cap_waves;
+    if (waves > 0 && hipMemcpy(h_out, p, (size_t)waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return waves;
 }
 double nn_local_take_visits()
 {
@@ -1465,7 +1539,7 @@ static void icp_fused_launch(const float *src, const float *tgt, const float *tn
                              int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st,
                              unsigned long long *progress, unsigned long long tag)
 {
-    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag };
+    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag, nullptr };
     const unsigned blocks = k > max_iter ? 1u : (unsigned)cdiv(p.n_src, kIRows);
     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
     hipLaunchKernelGGL(icp_iter_kernel, dim3(blocks), dim3(kIThreads), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t, b.tile_box, b.group_box,
@@ -1562,6 +1636,13 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
 }  // namespace kpx
 
 using namespace kpx;
+
+KPX_EXPORT int kpx_prof_icp_waves(uint64_t *h_out, int64_t cap_waves, int64_t *h_count)
+{
+    KPX_REQUIRE(h_out && h_count && cap_waves >= 0, "kpx_prof_icp_waves: null pointer or negative capacity");
+    *h_count = icp_wave_take((unsigned long long *)h_out, cap_waves);
+    return *h_count < 0 ? KPX_ERR_HIP : KPX_OK;
+}
 
 KPX_EXPORT int kpx_prof_icp_phases(double *h_out8)
 {
@@ -1913,7 +1994,8 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         // split (default): the update of every registration runs in icp_solve_batch_kernel between the sweeps; KPX_ICP_SPLIT=0: in the
         // prologue of the next sweep's blocks (one launch per iteration).  Same-run A/B with four frames in flight: 1830-1930 vs
         // 1730-1830 Mpoints/s -- the redundant prologue holds every block's wave slots 4 us longer, and slots are what frames compete for.
-        static const bool split = [] { const char *e = getenv("KPX_ICP_SPLIT"); return !(e && e[0] == '0'); }();
+        // KPX_ICP_SPLIT=2: in the LAST block of the sweep itself (no update kernel, no redundant prologue).
+        static const int split = [] { const char *e = getenv("KPX_ICP_SPLIT"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : KPX_ICP_SPLIT_DEFAULT; }();
         const int last_k = split ? max_iteration : max_iteration + 1;     // the fused chain ends with an update-only launch
         for (bool pending = true; pending && !rc;) {
             pending = false;
@@ -1952,8 +2034,8 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                     hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)act.count : ab), dim3(kIThreads), 0, ls, closing ? actc : act, tgt,
                                        tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box, bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2,
                                        mode, gk[g], max_iteration, relative_fitness, relative_rmse, tag,
-                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split ? 1 : 0);
-                    if (split)
+                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split);
+                    if (split == 1)
                         hipLaunchKernelGGL(icp_solve_batch_kernel, dim3((unsigned)act.count), dim3(256), 0, ls, act, mode, gk[g], max_iteration,
                                            relative_fitness, relative_rmse, tag);
                     ++gk[g];

@@ -24,7 +24,7 @@ namespace kpx {
 
 constexpr int kLGroupTiles = 16;                 // tiles per group (256 sorted columns)
 constexpr int kLRows = 16;                       // source rows per wave
-constexpr int kLList = 512;                      // tile list capacity (LDS, per wave)
+constexpr int kLList = 320;                      // tile list capacity (LDS, per wave): 64 carried over + 16 groups x 16 tiles
 constexpr int kVisitSlots = 1024;                // profiling counter slots
 
 // Sorted fp64 B operand (element (k, j) of tile t at Bs[t*64 + k*16 + j]), original index of every sorted column
@@ -114,51 +114,96 @@ __global__ __launch_bounds__(256) void nn_local_rowprep_kernel(const float *__re
     init_idx[r] = bj;
 }
 
-__device__ __forceinline__ double box_gap2(const double slo[3], const double shi[3], const float *__restrict__ bx)
-{
-    double g2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double g = fmax(0.0, fmax((double)bx[a] - shi[a], slo[a] - (double)bx[3 + a]));
-        g2 = fma(g, g, g2);
-    }
-    return g2;
-}
 // OR of the four 16-lane fields of a ballot
 __device__ __forceinline__ unsigned fold16(unsigned long long m) { return (unsigned)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xFFFFull); }
 
-// Per-lane state of one wave's 16 rows.  Lane (q = lane>>4, j = lane&15) owns rows q, q+4, q+8, q+12 (the MFMA D
-// layout) and, in the culling tests, box j of the 16 groups / tiles under test.
+// Cross-lane moves inside a 16-lane row on the DPP path of the VALU (row_ror:n): a few cycles, where __shfl_xor goes through
+// the LDS crossbar (ds_bpermute, ~100 cycles of latency per butterfly step).  Rotations by 1, 2, 4, 8 leave the reduction of the
+// whole row in EVERY lane of the row.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    i2 b = __builtin_bit_cast(i2, v);
+    b[0] = dpp_i32<CTRL>(b[0]);
+    b[1] = dpp_i32<CTRL>(b[1]);
+    return __builtin_bit_cast(double, b);
+}
+constexpr int kRor1 = 0x121, kRor2 = 0x122, kRor4 = 0x124, kRor8 = 0x128;
+__device__ __forceinline__ double row16_all_max(double v)
+{
+    v = fmax(v, dpp_f64<kRor1>(v)); v = fmax(v, dpp_f64<kRor2>(v)); v = fmax(v, dpp_f64<kRor4>(v)); v = fmax(v, dpp_f64<kRor8>(v));
+    return v;
+}
+__device__ __forceinline__ double row16_all_min(double v)
+{
+    v = fmin(v, dpp_f64<kRor1>(v)); v = fmin(v, dpp_f64<kRor2>(v)); v = fmin(v, dpp_f64<kRor4>(v)); v = fmin(v, dpp_f64<kRor8>(v));
+    return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    i2 b = __builtin_bit_cast(i2, v);
+    b[0] = __builtin_amdgcn_readlane(b[0], l);
+    b[1] = __builtin_amdgcn_readlane(b[1], l);
+    return __builtin_bit_cast(double, b);
+}
+// maximum over the wave, as a wave-uniform value
+__device__ __forceinline__ double wave_uniform_max(double v)
+{
+    v = row16_all_max(v);
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
+// Per-lane state of one wave's 16 rows.  Lane (q = lane>>4, j = lane&15) owns rows q, q+4, q+8, q+12 (the MFMA D layout).
 struct WaveRows {
     double a;                  // A operand: component q of row j
     d4 seed;                   // C operand: K of the lane's rows
-    const double *rows;        // LDS: the wave's 16 transformed rows, row r at rows[5 r .. 5 r + 2] (x, y, z).  The culling tests
-                               // read the lane's four rows (q, q+4, q+8, q+12) from here instead of holding 24 registers for them:
-                               // the kernel then fits 128 VGPRs = 4 waves per SIMD, and a latency-bound sweep lives on resident waves
+    double *rows;              // LDS: the wave's 16 transformed rows, record r at rows[kRowStride r ..]: x, y, z, then the row's current
+                               // bound on d^2 (kRowBound, written by the sweep).  The culling tests read rows from here instead of
+                               // holding them in registers: the kernel fits 128 VGPRs = 4 waves per SIMD, and a latency-bound sweep
+                               // lives on resident waves
     double best[4];            // running minimum (per lane: over the columns j of the tiles seen)
     int32_t bcol[4];           // its ORIGINAL target index
 };
-constexpr int kRowStride = 5;
+constexpr int kRowStride = 6, kRowBound = 3;
 
-// The culled sweep of one wave: on return best/bcol hold, in every lane, the row minimum (lexicographic (value,
-// original column)).  list: kLList ints of LDS owned by this wave.  Returns the number of tiles multiplied.
+// LDS scratch of one wave (ints): the tile list, 16 candidate groups (box + id), up to 16 surviving groups (id, row mask)
+constexpr int kLCand = 16, kLSurv = 16;
+constexpr int kLScratch = kLList + 7 * kLCand + 2 * kLSurv;
+#ifndef KPX_MUL_BATCH
+#define KPX_MUL_BATCH 8
+#endif
+constexpr int kMulBatch = KPX_MUL_BATCH;         // column tiles whose operands are requested together
+
 // Group boxes the caller loaded ahead of time: box of group 64 t + lane in pre[t] (t < kGroupPre; an empty box beyond n_groups).
-// The loads do not depend on the transform, so the ICP kernel issues them before its update algebra and the first
-// level of the culling finds them in registers instead of waiting a memory round trip.
-constexpr int kGroupPre = 1;
+// The loads do not depend on the transform, so the ICP kernel issues them first and the culling finds them in registers
+// instead of waiting a memory round trip.
+constexpr int kGroupPre = 2;
 struct GroupPre {
     float b[kGroupPre][6];
 };
+__device__ __forceinline__ void group_box_load(float b[6], const float *__restrict__ group_box, int32_t n_groups, int gi)
+{
+    const bool on = gi < n_groups;
+    const float *bx = group_box + (int64_t)(on ? gi : 0) * 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { b[a] = on ? bx[a] : kBoxBig; b[3 + a] = on ? bx[3 + a] : -kBoxBig; }
+}
 __device__ __forceinline__ void group_pre_load(GroupPre &g, const float *__restrict__ group_box, int32_t n_groups, int lane)
 {
 #pragma unroll
-    for (int t = 0; t < kGroupPre; ++t) {
-        const int gi = 64 * t + lane;
-        const bool on = gi < n_groups;
-        const float *bx = group_box + (int64_t)(on ? gi : 0) * 6;
+    for (int t = 0; t < kGroupPre; ++t) group_box_load(g.b[t], group_box, n_groups, 64 * t + lane);
+}
+// largest |t|^2 a target point can have (from the target's bounding box): scales the rounding margin of the expanded metric
+__device__ __forceinline__ double target_t2max(const double *__restrict__ tbbox)
+{
+    double t2max = 0.0;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { g.b[t][a] = on ? bx[a] : kBoxBig; g.b[t][3 + a] = on ? bx[3 + a] : -kBoxBig; }
-    }
+    for (int a = 0; a < 3; ++a) t2max += fmax(tbbox[a] * tbbox[a], tbbox[3 + a] * tbbox[3 + a]);
+    return t2max;
 }
 __device__ __forceinline__ double box_gap2v(const double slo[3], const double shi[3], const float bx[6])
 {
@@ -171,34 +216,43 @@ __device__ __forceinline__ double box_gap2v(const double slo[3], const double sh
     return g2;
 }
 
+// The culled sweep of one wave: on return best/bcol hold, in every lane, the row minimum (lexicographic (value, original
+// column)).  scr: kLScratch ints of LDS owned by this wave; t2max: target_t2max(tbbox), read by the caller at its very start so
+// that the load is in flight with everything else.  Returns the number of tiles multiplied in bits 0..15 and, for the
+// probes, the dependent memory round trips of the wave: tile-box fetches (bits 16..31), operand fetches of the multiply loop
+// (bits 32..47), groups that survived the per-row test (bits 48..63).
+//
+// A sweep is a chain of DEPENDENT memory round trips (~1 us each on a loaded device) with little arithmetic between them, so
+// it is organised to make few of them, each as wide as the registers allow:
+//   G  group level, no memory: the wave's box against 64 group boxes per lane-parallel test (boxes in registers, loaded ahead);
+//      the groups that pass are handed, 16 at a time through LDS, to the per-row test (lane (q, j): rows q+4r against candidate
+//      j), which also yields the mask of rows that reach each surviving group;
+//   T  ONE round trip for the tile boxes of up to 16 surviving groups (lane (k, j): tile j of group 4p + k, four passes whose
+//      loads are issued together); a tile is tested against the rows of its group's mask only;
+//   M  ONE round trip per kMulBatch listed tiles: B operands and original column ids requested together, then the fp64 MFMAs
+//      behind the 32-bit high-word prefilter; the row bounds tighten afterwards (registers and LDS).
 template <bool PRE>
-__device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
-                                               const float *__restrict__ tile_box, const float *__restrict__ group_box,
-                                               int32_t n_groups, const double *__restrict__ tbbox, int32_t *list, const GroupPre *pre)
+__device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
+                                                         const float *__restrict__ tile_box, const float *__restrict__ group_box,
+                                                         int32_t n_groups, const double t2max, int32_t *scr, const GroupPre *pre)
 {
     const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int32_t *list = scr, *cand = scr + kLList, *surv = scr + kLList + 7 * kLCand;
     constexpr double kRel = 1.0 + 9.31322574615478515625e-10;      // 1 + 2^-30
     double slo[3], shi[3];
     {
-        double mn = w.a, mx = w.a;
+        const double mn = row16_all_min(w.a), mx = row16_all_max(w.a);
 #pragma unroll
-        for (int msk = 1; msk < 16; msk <<= 1) {
-            mn = fmin(mn, __shfl_xor(mn, msk, 64));
-            mx = fmax(mx, __shfl_xor(mx, msk, 64));
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { slo[k] = __shfl(mn, 16 * k, 64); shi[k] = __shfl(mx, 16 * k, 64); }
+        for (int k = 0; k < 3; ++k) { slo[k] = readlane_f64(mn, 16 * k); shi[k] = readlane_f64(mx, 16 * k); }
     }
-    double kmax = wave_all_max(fmax(fmax(w.seed[0], w.seed[1]), fmax(w.seed[2], w.seed[3])));
-    double t2max = 0.0;
-#pragma unroll
-    for (int a3 = 0; a3 < 3; ++a3) t2max += fmax(tbbox[a3] * tbbox[a3], tbbox[3 + a3] * tbbox[3 + a3]);
+    const double kmax = wave_uniform_max(fmax(fmax(w.seed[0], w.seed[1]), fmax(w.seed[2], w.seed[3])));
     const double eps = ldexp(kmax + t2max + 1.0, -38);
     // rb[r]: the row's bound on d^2 (same value in the 16 lanes of a quad); R2: the largest of them
     double rb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) rb[r] = (w.best[r] - 1.0) * kRel + eps;             // +inf stays +inf
-    double R2 = wave_all_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
+    double R2 = wave_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     if (!(R2 < 1e290)) {
         // some row has no finite bound: every group holds a real point, so the distance to the farthest corner of
         // the nearest group box bounds that row's nearest-neighbour distance
@@ -216,58 +270,57 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int msk = 1; msk < 16; msk <<= 1) u[r] = fmin(u[r], __shfl_xor(u[r], msk, 64));
-            rb[r] = fmin(rb[r], u[r] * kRel + eps);
-        }
-        R2 = wave_all_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
+        for (int r = 0; r < 4; ++r) rb[r] = fmin(rb[r], row16_all_min(u[r]) * kRel + eps);
+        R2 = wave_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     }
+    auto publish_bounds = [&]() {
+        if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w.rows[kRowStride * (q + 4 * r) + kRowBound] = rb[r];
+        }
+    };
+    publish_bounds();
 
     const double bpad = q == 3 ? kSentinel : 0.0;
-    int nlist = 0;
-    unsigned visited = 0;
+    int nlist = 0, ns = 0;
+    unsigned visited = 0, box_trips = 0, mul_trips = 0, groups_kept = 0;
 
-    auto process = [&]() {
+    // M: multiply the listed tiles
+    auto multiply = [&]() {
         wave_lds_fence();                                  // the list writes before the reads
         bool updated = false;
-        double b[4];
-        int32_t t[4];
+        for (int e0 = 0; e0 < nlist; e0 += kMulBatch) {
+            double b[kMulBatch];
+            int32_t oc[kMulBatch];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            t[h] = h < nlist ? list[h] : -1;
-            b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
-        }
-        for (int e = 0; e < nlist; e += 4) {
-            const d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[0], w.seed, 0, 0, 0);
-            const d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[1], w.seed, 0, 0, 0);
-            const d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[2], w.seed, 0, 0, 0);
-            const d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[3], w.seed, 0, 0, 0);
-            const int32_t tc[4] = { t[0], t[1], t[2], t[3] };
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {                  // operands of the next trip
-                t[h] = e + 4 + h < nlist ? list[e + 4 + h] : -1;
-                b[h] = t[h] >= 0 ? Bs[(int64_t)t[h] * 64 + lane] : bpad;
+            for (int h = 0; h < kMulBatch; ++h) {
+                const int32_t t = e0 + h < nlist ? list[e0 + h] : -1;
+                b[h] = t >= 0 ? Bs[(int64_t)t * 64 + lane] : bpad;
+                oc[h] = t >= 0 ? orig[(int64_t)t * 16 + j] : INT_MAX;
             }
-            bool pass = false;
+            ++mul_trips;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned hb = hi32(w.best[r]);
-                pass |= (bool)((int)(hi32(c0[r]) <= hb) | (int)(hi32(c1[r]) <= hb) | (int)(hi32(c2[r]) <= hb) | (int)(hi32(c3[r]) <= hb));
-            }
-            if (__builtin_amdgcn_ballot_w64(pass) != 0) {
-                updated = true;
-                int32_t oc[4];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) oc[h] = tc[h] >= 0 ? orig[(int64_t)tc[h] * 16 + j] : INT_MAX;
-#define KPX_NNL_EXACT(ACC, COL)                                                                     \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
-                    const bool tk = (int)(ACC[r] < w.best[r]) | ((int)(ACC[r] == w.best[r]) & (int)((COL) < w.bcol[r])); \
-                    w.best[r] = tk ? ACC[r] : w.best[r];                                           \
-                    w.bcol[r] = tk ? (COL) : w.bcol[r];                                            \
+            for (int h0 = 0; h0 < kMulBatch; h0 += 4) {
+                if (e0 + h0 >= nlist) break;
+                const d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[h0], w.seed, 0, 0, 0);
+                const d4 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[h0 + 1], w.seed, 0, 0, 0);
+                const d4 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[h0 + 2], w.seed, 0, 0, 0);
+                const d4 c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.a, b[h0 + 3], w.seed, 0, 0, 0);
+#define KPX_NNL_TILE(ACC, COL)                                                                      \
+                {                                                                                   \
+                    bool pass = false;                                                              \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) pass |= hi32(ACC[r]) <= hi32(w.best[r]); \
+                    if (__builtin_amdgcn_ballot_w64(pass) != 0) {                                   \
+                        updated = true;                                                             \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                            \
+                            const bool tk = (int)(ACC[r] < w.best[r]) | ((int)(ACC[r] == w.best[r]) & (int)((COL) < w.bcol[r])); \
+                            w.best[r] = tk ? ACC[r] : w.best[r];                                   \
+                            w.bcol[r] = tk ? (COL) : w.bcol[r];                                    \
+                        }                                                                           \
+                    }                                                                               \
                 }
-                KPX_NNL_EXACT(c0, oc[0]) KPX_NNL_EXACT(c1, oc[1]) KPX_NNL_EXACT(c2, oc[2]) KPX_NNL_EXACT(c3, oc[3])
-#undef KPX_NNL_EXACT
+                KPX_NNL_TILE(c0, oc[h0]) KPX_NNL_TILE(c1, oc[h0 + 1]) KPX_NNL_TILE(c2, oc[h0 + 2]) KPX_NNL_TILE(c3, oc[h0 + 3])
+#undef KPX_NNL_TILE
             }
         }
         visited += (unsigned)nlist;
@@ -275,95 +328,147 @@ __device__ __forceinline__ unsigned sweep_wave(WaveRows &w, const double *__rest
         if (updated) {
             // tighten the row bounds with the best value any of the row's 16 lanes holds
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double v = w.best[r];
-#pragma unroll
-                for (int msk = 1; msk < 16; msk <<= 1) v = fmin(v, __shfl_xor(v, msk, 64));
-                rb[r] = fmin(rb[r], (v - 1.0) * kRel + eps);
-            }
-            R2 = wave_all_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
+            for (int r = 0; r < 4; ++r) rb[r] = fmin(rb[r], (row16_all_min(w.best[r]) - 1.0) * kRel + eps);
+            R2 = wave_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
+            publish_bounds();
         }
         wave_lds_fence();
     };
-    auto any_row_within_v = [&](const float bx[6]) {
-        const double lo[3] = { (double)bx[0], (double)bx[1], (double)bx[2] }, hi[3] = { (double)bx[3], (double)bx[4], (double)bx[5] };
-        bool t = false;
+
+    // T: the tile boxes of the surviving groups surv[0 .. ns) -> tile list
+    auto tiles_of_survivors = [&]() {
+        wave_lds_fence();
+        float bx[4][6];
+        int32_t grp[4];
+        unsigned rmask[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double *pr = w.rows + kRowStride * (q + 4 * r);
-            t |= pt_gap2(pr[0], pr[1], pr[2], lo, hi) <= rb[r];
-        }
-        return t;
-    };
-    auto any_row_within = [&](const float *__restrict__ bx) {
-        const float v[6] = { bx[0], bx[1], bx[2], bx[3], bx[4], bx[5] };
-        return any_row_within_v(v);
-    };
-    auto append_tiles = [&](int grp, bool hit) {
-        const unsigned tm16 = fold16(__builtin_amdgcn_ballot_w64(hit));
-        if (q == 0 && ((tm16 >> j) & 1u)) list[nlist + __builtin_popcount(tm16 & ((1u << j) - 1u))] = grp * kLGroupTiles + j;
-        nlist += __builtin_popcount(tm16);
-    };
-    // one 64-group trip: gmask = groups whose box the wave's box can reach
-    auto trip = [&](int g0, unsigned long long gmask) {
-        for (int c = 0; c < 4; ++c) {
-            const unsigned chunk = (unsigned)(gmask >> (16 * c)) & 0xFFFFu;
-            if (!chunk) continue;
-            // per-row test of the 16 groups of this chunk (lane: rows of quad q against group j)
-            const int gj = g0 + 16 * c + j;
-            const bool gt = ((chunk >> j) & 1u) && any_row_within(group_box + (int64_t)gj * 6);
-            unsigned gm16 = fold16(__builtin_amdgcn_ballot_w64(gt));
-            while (gm16) {
-                // the tile boxes of TWO surviving groups are fetched per round trip (a wave usually keeps one or two groups)
-                const int grp0 = g0 + 16 * c + __builtin_ctz(gm16);
-                gm16 &= gm16 - 1;
-                const bool two = gm16 != 0;
-                const int grp1 = two ? g0 + 16 * c + __builtin_ctz(gm16) : grp0;
-                gm16 &= gm16 - 1;
-                const float *p0 = tile_box + (int64_t)(grp0 * kLGroupTiles + j) * 6, *p1 = tile_box + (int64_t)(grp1 * kLGroupTiles + j) * 6;
-                const float v0[6] = { p0[0], p0[1], p0[2], p0[3], p0[4], p0[5] }, v1[6] = { p1[0], p1[1], p1[2], p1[3], p1[4], p1[5] };
-                append_tiles(grp0, any_row_within_v(v0));
-                if (two) append_tiles(grp1, any_row_within_v(v1));
-                if (nlist > kLList - 32) process();
+        for (int p = 0; p < 4; ++p) {
+            const int k = 4 * p + q;
+            const bool on = k < ns;
+            grp[p] = on ? surv[2 * k] : 0;
+            rmask[p] = on ? (unsigned)surv[2 * k + 1] : 0u;
+            if (4 * p < ns) {                                                    // wave-uniform
+                const float *tb = tile_box + ((int64_t)grp[p] * kLGroupTiles + j) * 6;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) bx[p][a] = tb[a];
             }
         }
-    };
-    int g_first = 0;
-    if (PRE) {
+        ++box_trips;
 #pragma unroll
-        for (int t = 0; t < kGroupPre; ++t) {
-            if (64 * t < n_groups) {
-                const unsigned long long gmask = __builtin_amdgcn_ballot_w64(box_gap2v(slo, shi, pre->b[t]) <= R2);   // empty boxes: gap = inf
-                if (gmask) trip(64 * t, gmask);
+        for (int p = 0; p < 4; ++p) {
+            if (4 * p >= ns) break;
+            const double lo[3] = { (double)bx[p][0], (double)bx[p][1], (double)bx[p][2] }, hi[3] = { (double)bx[p][3], (double)bx[p][4], (double)bx[p][5] };
+            // the rows any of the pass's four groups needs, two per trip (wave-uniform loop, broadcast LDS reads issued together)
+            unsigned um = (unsigned)(__builtin_amdgcn_readlane((int)rmask[p], 0) | __builtin_amdgcn_readlane((int)rmask[p], 16) |
+                                     __builtin_amdgcn_readlane((int)rmask[p], 32) | __builtin_amdgcn_readlane((int)rmask[p], 48));
+            bool hit = false;
+            while (um) {
+                const int r0 = __builtin_ctz(um);
+                um &= um - 1u;
+                const int r1 = um ? __builtin_ctz(um) : r0;
+                um &= um - 1u;
+                const double *p0 = w.rows + kRowStride * r0, *p1 = w.rows + kRowStride * r1;
+                const double x0 = p0[0], y0 = p0[1], z0 = p0[2], b0 = p0[kRowBound], x1 = p1[0], y1 = p1[1], z1 = p1[2], b1 = p1[kRowBound];
+                hit |= (bool)((int)((rmask[p] >> r0) & 1u) & (int)(pt_gap2(x0, y0, z0, lo, hi) <= b0));
+                hit |= (bool)((int)((rmask[p] >> r1) & 1u) & (int)(pt_gap2(x1, y1, z1, lo, hi) <= b1));
             }
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+            if (hit) list[nlist + __builtin_popcountll(hm & lt)] = grp[p] * kLGroupTiles + j;
+            nlist += __builtin_popcountll(hm);
         }
-        g_first = 64 * kGroupPre;
+        ns = 0;
+    };
+
+    // G: lane holds the box of group gbase + lane; gmask = groups the wave's box can reach
+    int g_next = 0, gbase = 0;
+    unsigned long long gmask = 0ull;
+    float box[6] = { kBoxBig, kBoxBig, kBoxBig, -kBoxBig, -kBoxBig, -kBoxBig };
+    for (;;) {
+        while (ns < kLSurv && (gmask != 0ull || g_next < n_groups)) {
+            if (gmask == 0ull) {
+                gbase = g_next;
+                g_next += 64;
+                if (PRE && gbase == 0) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) box[a] = pre->b[0][a];
+                } else if (PRE && kGroupPre > 1 && gbase == 64) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) box[a] = pre->b[kGroupPre > 1 ? 1 : 0][a];
+                } else {
+                    group_box_load(box, group_box, n_groups, gbase + lane);
+                }
+                gmask = __builtin_amdgcn_ballot_w64(box_gap2v(slo, shi, box) <= R2);          // empty boxes: gap = inf
+                continue;
+            }
+            // hand the next (at most kLSurv - ns) reachable groups to the per-row test through LDS
+            const int room = kLSurv - ns;
+            const int slot = __builtin_popcountll(gmask & lt);
+            const bool mine = ((gmask >> lane) & 1ull) != 0ull && slot < room;
+            if (mine) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) cand[7 * slot + a] = __float_as_int(box[a]);
+                cand[7 * slot + 6] = gbase + lane;
+            }
+            const unsigned long long taken = __builtin_amdgcn_ballot_w64(mine);
+            const int nc = __builtin_popcountll(taken);
+            gmask &= ~taken;
+            wave_lds_fence();
+            bool h[4] = { false, false, false, false };
+            int32_t gid = -1;
+            if (j < nc) {
+                const double lo[3] = { (double)__int_as_float(cand[7 * j]), (double)__int_as_float(cand[7 * j + 1]), (double)__int_as_float(cand[7 * j + 2]) };
+                const double hi[3] = { (double)__int_as_float(cand[7 * j + 3]), (double)__int_as_float(cand[7 * j + 4]), (double)__int_as_float(cand[7 * j + 5]) };
+                gid = cand[7 * j + 6];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double *pr = w.rows + kRowStride * (q + 4 * r);
+                    h[r] = pt_gap2(pr[0], pr[1], pr[2], lo, hi) <= rb[r];
+                }
+            }
+            // mask of the rows (bit q + 4 r) that reach candidate j, assembled from the four ballots
+            unsigned rm = 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long x = __builtin_amdgcn_ballot_w64(h[r]) >> j;
+                rm |= (unsigned)((x & 1ull) | ((x >> 15) & 2ull) | ((x >> 30) & 4ull) | ((x >> 45) & 8ull)) << (4 * r);
+            }
+            const bool sv = q == 0 && rm != 0u;
+            const unsigned long long sm = __builtin_amdgcn_ballot_w64(sv);
+            if (sv) {
+                const int k = ns + __builtin_popcountll(sm & lt);
+                surv[2 * k] = gid;
+                surv[2 * k + 1] = (int32_t)rm;
+            }
+            ns += __builtin_popcountll(sm);
+            groups_kept += (unsigned)__builtin_popcountll(sm);
+            wave_lds_fence();                              // the candidate slots are reused by the next pass
+        }
+        const bool last = gmask == 0ull && g_next >= n_groups;
+        if (ns) tiles_of_survivors();
+        if (nlist > kLList - 16 * kLSurv || (last && nlist)) multiply();
+        if (last) break;
     }
-    for (int g0 = g_first; g0 < n_groups; g0 += 64) {
-        const int g = g0 + lane;
-        const bool gp = g < n_groups && box_gap2(slo, shi, group_box + (int64_t)g * 6) <= R2;
-        const unsigned long long gmask = __builtin_amdgcn_ballot_w64(gp);
-        if (gmask) trip(g0, gmask);
-    }
-    if (nlist) process();
 
     // reduce over the 16 lanes that hold the same rows (lexicographic (value, original column) minimum)
+#define KPX_NNL_ROWMIN(CTRL)                                               \
+    {                                                                      \
+        const double ov = dpp_f64<CTRL>(v);                                \
+        const int32_t oc = dpp_i32<CTRL>(c);                               \
+        const bool take = ov < v || (ov == v && oc < c);                   \
+        v = take ? ov : v;                                                 \
+        c = take ? oc : c;                                                 \
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         double v = w.best[r];
         int32_t c = w.bcol[r];
-#pragma unroll
-        for (int msk = 1; msk < 16; msk <<= 1) {
-            const double ov = __shfl_xor(v, msk, 64);
-            const int32_t oc = __shfl_xor(c, msk, 64);
-            const bool take = ov < v || (ov == v && oc < c);
-            v = take ? ov : v;
-            c = take ? oc : c;
-        }
+        KPX_NNL_ROWMIN(kRor1) KPX_NNL_ROWMIN(kRor2) KPX_NNL_ROWMIN(kRor4) KPX_NNL_ROWMIN(kRor8)
         w.best[r] = v;
         w.bcol[r] = c;
     }
-    return visited;
+#undef KPX_NNL_ROWMIN
+    return (unsigned long long)(visited & 0xFFFFu) | ((unsigned long long)(box_trips & 0xFFFFu) << 16) | ((unsigned long long)(mul_trips & 0xFFFFu) << 32) |
+           ((unsigned long long)(groups_kept & 0xFFFFu) << 48);
 }
 
 // One wave (= one block) per 16 sorted rows.  out_val / out_idx are indexed by ORIGINAL row.
@@ -376,9 +481,10 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
                                                       int32_t *__restrict__ out_idx, unsigned long long *__restrict__ tile_visits)
 {
     if (done && *done) return;
-    __shared__ int32_t list[kLList];
+    __shared__ int32_t list[kLScratch];
     __shared__ double rows[kLRows * kRowStride];
     const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    const double t2max = target_t2max(tbbox);
     const int64_t row_base = (int64_t)blockIdx.x * kLRows;
     const int64_t last = n - 1;
     WaveRows w;
@@ -395,7 +501,7 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
         w.best[r] = init_val[row];
         w.bcol[r] = init_idx[row];
     }
-    const unsigned visited = sweep_wave<false>(w, Bs, orig, tile_box, group_box, n_groups, tbbox, list, nullptr);
+    const unsigned visited = (unsigned)(sweep_wave<false>(w, Bs, orig, tile_box, group_box, n_groups, t2max, list, nullptr) & 0xFFFFu);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = row_base + q + 4 * r;

@@ -538,6 +538,19 @@ def prof_icp_phases():
     return d
 
 
+def prof_icp_waves(cap=16384):
+    """-> per wave of the LAST sweep launch: dict of numpy arrays (sweep_us, tiles, box_trips, mul_trips, groups_kept, with_partner)"""
+    raw = np.zeros((cap, 4), dtype=np.uint64)
+    cnt = np.zeros(1, dtype=np.int64)
+    L.check(L.load().kpx_prof_icp_waves(raw.ctypes.data_as(C.c_void_p), cap, cnt.ctypes.data_as(C.c_void_p)))
+    raw = raw[:int(cnt[0])]
+    c = raw[:, 2]
+    return dict(start=raw[:, 0].astype(np.int64), sweep_us=(raw[:, 1].astype(np.int64) - raw[:, 0].astype(np.int64)) * 0.01,
+                tiles=(c & np.uint64(0xFFFF)).astype(np.int64), box_trips=((c >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64),
+                mul_trips=((c >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64), groups_kept=((c >> np.uint64(48)) & np.uint64(0xFFFF)).astype(np.int64),
+                with_partner=raw[:, 3].astype(np.int64))
+
+
 # ---- sampler / normaliser (SURVEY 8f rank 3) ---------------------------------------------------------
 NORM_OBB, NORM_OBB_ROT_TRANS, NORM_TRANSLATE, NORM_OBB_ROT = 0, 1, 2, 3
 _OBB_ERRORS = {-1: "fewer than 3 distinct points, or all points on one line", -2: "the convex hull did not close",

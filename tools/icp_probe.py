@@ -68,6 +68,22 @@ def measure(label, fn, n_threads=1):
     pr = ops.prof_end()
     ph = ops.prof_icp_phases()
     print("   last sweep launch, per-block phases (us):", {k: (round(v, 2) if not isinstance(v, dict) else {a: round(b, 2) for a, b in v.items()}) for k, v in ph.items()})
+    if "--waves" in sys.argv:
+        wv = ops.prof_icp_waves()
+        us = wv["sweep_us"]
+        if len(us):
+            order = np.argsort(us)
+            print(f"   waves {len(us)}: sweep us  p10 {np.percentile(us, 10):.2f}  p50 {np.percentile(us, 50):.2f}  p90 {np.percentile(us, 90):.2f}  p99 {np.percentile(us, 99):.2f}  max {us.max():.2f};"
+                  f"  start spread {(wv['start'].max() - wv['start'].min()) * 0.01:.2f} us")
+            for name in ("tiles", "box_trips", "mul_trips", "groups_kept"):
+                v = wv[name]
+                print(f"      {name:12s} mean {v.mean():6.2f}  p50 {np.percentile(v, 50):5.1f}  p90 {np.percentile(v, 90):5.1f}  p99 {np.percentile(v, 99):5.1f}  max {v.max():4d}   corr with sweep us {np.corrcoef(v, us)[0, 1]:+.2f}")
+            print("      slowest 12 waves (us, tiles, box_trips, mul_trips, groups_kept, sampled rows with partner):",
+                  [(round(float(us[i]), 1), int(wv["tiles"][i]), int(wv["box_trips"][i]), int(wv["mul_trips"][i]), int(wv["groups_kept"][i]), int(wv["with_partner"][i])) for i in order[-12:]])
+            # least-squares cost model: sweep us ~ a + b box_trips + c mul_trips
+            A = np.stack([np.ones_like(us), wv["box_trips"], wv["mul_trips"]], 1).astype(float)
+            coef = np.linalg.lstsq(A, us, rcond=None)[0]
+            print(f"      model: sweep us = {coef[0]:.2f} + {coef[1]:.2f} per tile-box fetch + {coef[2]:.2f} per operand fetch (4 tiles)")
     ms, cnt, work = pr["nn_local"]
     its = [x["iterations"] for x in r] if r else None
     print(f"{label:46s} wall {wall_free:7.3f} ms/call free, {wall:7.3f} with event pairs;  icp_iter launches/call {cnt / reps / n_threads:6.1f}  "
