@@ -373,7 +373,8 @@ int kpx_prof_end(double *h_ms, int64_t *h_launches, double *h_work);
 /* Device-side phase clock of the ICP iteration kernel (stamps while the profiler is armed), LAST launch: h_out8 = average
  * microseconds a block spends in [0] the update prologue, [1] row preparation, [2] the culled sweep, [3] the pair epilogue,
  * [4] the block sums; [5] blocks; [6] latest - earliest block start (dispatch ramp); [7] earliest start -> latest end;
- * [8..12] the slowest block of each phase; [13] the longest block lifetime.  h_out8 holds 16 doubles. */
+ * [8..12] the slowest block of each phase; [13] the longest block lifetime; [14] blocks the launch did not sweep because they
+ * provably had no partner within reach.  h_out8 holds 16 doubles. */
 int kpx_prof_icp_phases(double *h_out8);
 /* Per-wave rows of the same launch (4 x uint64 per wave: sweep start, sweep end in 10 ns ticks; counters = tiles multiplied |
  * tile-box fetches << 16 | operand fetches << 32 | groups kept << 48; sampled rows with a partner).  *h_count = the number of

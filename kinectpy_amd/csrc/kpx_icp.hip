@@ -60,6 +60,7 @@ struct IcpState {
     double fitness, rmse;
     double count;
     int32_t iter, done;
+    double motion, reach;      // see LightSkip: accumulated bound on how far any source point has moved; reach of a row's search
 };
 
 __device__ __forceinline__ void xform_row(const double *__restrict__ T, const float *__restrict__ p, double s[3])
@@ -674,6 +675,17 @@ __device__ void icp_finish(const double *acc, int64_t n, int mode, int k, int ma
 // six rank-1 steps (no pivoting: the matrix is symmetric positive definite, as for Open3D's ldlt), then the three sine /
 // cosine pairs on three lanes and the 4x4 product U T on sixteen.  Point-to-point keeps the serial Jacobi/Kabsch on lane 0.
 // Mathematically the same update; rounding differs from the LDL^T order at the 1e-16 level (T is tolerance-checked).
+// Blocks that provably cannot find a partner are not swept again (icp_iter_body).  A block whose four waves all found NO target
+// group within reach records key = motion + g, g = the smallest distance from a wave's box to any group box (> reach).  Every
+// later update moves a source point by at most  |U s - s| <= ||R_u - I||_F |s| + |t_u|,  |s| <= |p|max + |t_T|  (rigid T), which
+// the update step adds to `motion`; `reach` bounds the square root of any row's search bound under the current T (the clamp of
+// max_correspondence_distance plus the rounding margins of nn_local's metric).  While motion + reach < key no row of the block
+// can have a target point within its bound, so the sweep would report "no partner" for all of them -- exactly what the rows
+// already hold.  The bounds carry relative margins of 1e-9 .. 1e-6: they only delay skipping, never allow a wrong one.
+struct LightSkip {
+    const double *sbbox;       // bounding box of the ORIGINAL source points (lo xyz, hi xyz); nullptr: no bookkeeping
+    double max_d2, t2max;
+};
 struct FinishScratch {
     double M[6][8];
     double trig[6];
@@ -682,8 +694,14 @@ struct FinishScratch {
     int flag;
 };
 __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, int mode, int k, int max_iter, double rel_fit, double rel_rmse,
-                                                IcpState *st, double *__restrict__ result, FinishScratch &fs, int lane)
+                                                IcpState *st, double *__restrict__ result, FinishScratch &fs, int lane, const LightSkip ls = LightSkip{ nullptr, 0.0, 0.0 })
 {
+    double pmax = 0.0;
+    if (ls.sbbox && lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pmax += fmax(ls.sbbox[a] * ls.sbbox[a], ls.sbbox[3 + a] * ls.sbbox[3 + a]);
+        pmax = sqrt(pmax) * (1.0 + 1e-9);
+    }
     if (lane == 0) {
         const double cnt = acc[0];
         const double fit = (n > 0 && cnt > 0) ? cnt / (double)n : 0.0;
@@ -751,6 +769,16 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
             for (int e = 0; e < 16; ++e) fs.U[e] = U[e];
         }
         wave_lds_fence();
+        if (ls.sbbox && lane == 0) {                       // bound on the displacement this update gives any source point
+            double rot = 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const double d = fs.U[4 * r + c] - (r == c ? 1.0 : 0.0); rot += d * d; }
+            const double told = sqrt(st->T[3] * st->T[3] + st->T[7] * st->T[7] + st->T[11] * st->T[11]);
+            const double tu = sqrt(fs.U[3] * fs.U[3] + fs.U[7] * fs.U[7] + fs.U[11] * fs.U[11]);
+            st->motion += (sqrt(rot) * (pmax + told) + tu) * (1.0 + 1e-9) + 1e-9;
+        }
         if (lane < 16) {
             const int r = lane >> 2, c = lane & 3;
             double v = 0.0;
@@ -762,6 +790,13 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
         if (lane < 16) st->T[lane] = fs.Tn[lane];
     }
     wave_lds_fence();
+    if (ls.sbbox && lane == 0) {                           // reach of a row's search under the transform the next sweep uses
+        const double tn = sqrt(st->T[3] * st->T[3] + st->T[7] * st->T[7] + st->T[11] * st->T[11]);
+        const double smax = (pmax + tn) * (1.0 + 1e-9);
+        // upper bound of nn_local's row bound rb = (clamp - 1)(1 + 2^-30) + eps with clamp, eps as in icp_iter_body / sweep_wave
+        const double r2 = ls.max_d2 * (1.0 + 3.7252902984619140625e-9) + 3.7252902984619140625e-9 + 1.4551915228366851806640625e-11 * (smax * smax + ls.t2max + 2.0);
+        st->reach = sqrt(r2) * (1.0 + 1e-9);
+    }
     if (result) {
         if (lane < 16) result[lane] = st->T[lane];
         if (lane == 0) { result[16] = st->fitness; result[17] = st->rmse; result[18] = (double)k; result[19] = st->count; }
@@ -819,6 +854,7 @@ __global__ void icp_init_kernel(IcpState *st, Mat16 T0)
     for (int slot = 0; slot < 2; ++slot) {               // both slots (see IcpFuse)
         for (int q = 0; q < 16; ++q) st[slot].T[q] = T0.m[q];
         st[slot].fitness = 0.0; st[slot].rmse = 0.0; st[slot].count = 0.0; st[slot].iter = 0; st[slot].done = 0;
+        st[slot].motion = 0.0; st[slot].reach = INFINITY;
     }
 }
 static Mat16 mat16_from(const double *h)
@@ -959,6 +995,8 @@ struct IcpFuse {
     double *result;
     unsigned long long *progress, tag;
     unsigned long long *ticket;        // non-null (with pair == nullptr): the LAST block of the launch to deliver its sums performs the update
+    double *light_key;                 // with ticket: per block, LightSkip key (0 = sweep); nullptr: every block sweeps
+    const double *sbbox;               // with light_key: the source's bounding box
 };
 constexpr int kAccSet = kAccCopies * kAcc * 2;
 // Phase clock of the iteration kernel (while the profiler is armed): thread 0 of every block stores 100 MHz wall-clock stamps in
@@ -1045,11 +1083,21 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         Tk = s_state.T;
         acc = fuse.ring + (int64_t)(k % 3) * kAccSet;
     } else if (st->done) return;
+    // LightSkip: nothing of this block can have come within reach since it was last swept -> straight to the ticket
+    bool skip = false;
+    if (fuse.ticket && fuse.light_key) {
+        const double key = fuse.light_key[bid];
+        skip = key > 0.0 && (st->motion + st->reach) * (1.0 + 1e-6) + 1e-6 < key;
+    }
+    __shared__ double s_light[kIWaves];
+    const int nacc = mode == 1 ? kAcc : 17;
+    if (tile_visits && threadIdx.x == 0 && bid < kStampBlocks) { g_icp_stamp[bid][7] = skip ? 1ull : 0ull; g_icp_stamp[bid][6] = (unsigned long long)nblocks; }
+    do {
+    if (skip) break;
     __shared__ int32_t lists[kIWaves][kLScratch];
     __shared__ double rowd[kIWaves][16][kRowStride]; // s_x, s_y, s_z, (the sweep's row bound), K, bound / result value
     __shared__ int32_t rowi[kIWaves][16][2];         // partner (bound / result), original row
     __shared__ double sh[kAcc][kIRows + 1];
-    const int nacc = mode == 1 ? kAcc : 17;
     if (tile_visits && threadIdx.x == 0 && bid < kStampBlocks) {     // only launches that sweep stamp (not the converged / closing ones)
         g_icp_stamp[bid][0] = t_block_start;
         g_icp_stamp[bid][6] = (unsigned long long)nblocks;
@@ -1096,6 +1144,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     const unsigned long long t_sweep = tile_visits ? wall_clock64() : 0ull;
     const unsigned long long swept = sweep_wave<true>(w, Bs, orig, tile_box, group_box, n_groups, t2max, lists[wave], &gpre);
     const unsigned visited = (unsigned)(swept & 0xFFFFu);
+    if (lane == 0) s_light[wave] = w.light_gap2;
     if (tile_visits && lane == 0 && bid < kStampBlocks && kIWaves <= 4) {
         unsigned long long *o = g_icp_wave[bid * 4 + wave];
         int with = 0;
@@ -1167,7 +1216,15 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         unsigned long long *slot = acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + threadIdx.x) * 2);
         if (fuse.ticket) fixed_add_performed(slot, v); else fixed_add(slot, v);
     }
+    if (fuse.light_key && threadIdx.x == kIThreads - 1) {      // (after the barrier above: s_light is complete)
+        double g2 = INFINITY;
+        bool light = true;
+#pragma unroll
+        for (int wv = 0; wv < kIWaves; ++wv) { light = light && s_light[wv] >= 0.0; g2 = fmin(g2, s_light[wv]); }
+        fuse.light_key[bid] = light ? st->motion + sqrt(g2) * (1.0 - 1e-9) : 0.0;
+    }
     phase_tick(tile_visits, 5, bid);
+    } while (false);
     if (!fuse.ticket) return;
     // "The last block finishes the job": every add above has RETURNED (it has been performed at the device's point of coherence),
     // the barrier orders the block's ticket behind them, and the block that draws the last ticket of its registration reads the
@@ -1186,7 +1243,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     if (wave != 0) return;
     __shared__ FinishScratch s_tail;
     IcpState *stw = const_cast<IcpState *>(st);
-    icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, stw, fuse.result, s_tail, lane);
+    icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, stw, fuse.result, s_tail, lane,
+                    LightSkip{ fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max });
     if (lane == 0 && fuse.progress)
         __hip_atomic_store(fuse.progress, fuse.tag | ((unsigned long long)(stw->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1226,6 +1284,8 @@ struct IcpProblem {
     unsigned long long *ring;
     double *result;
     unsigned long long *progress;
+    double *light_key;
+    const double *sbbox;
     int64_t n;
     uint32_t block0, blocks;
 };
@@ -1238,7 +1298,7 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_I
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
                                                        const double *__restrict__ tbbox, double max_d2, int mode, int k, int max_iter, double rel_fit,
-                                                       double rel_rmse, unsigned long long tag, unsigned long long *__restrict__ tile_visits, int split)
+                                                       double rel_rmse, unsigned long long tag, unsigned long long *__restrict__ tile_visits, int split, int light)
 {
     int pi = 0;
 #pragma unroll
@@ -1251,7 +1311,7 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_I
     // split == 2: no update kernel either -- the last block of every registration's sweep performs it (ticket: first word of the
     // second accumulator set, which only the one-launch form uses)
     const IcpFuse fuse{ split ? (IcpState *)nullptr : P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag,
-                        split == 2 ? P.ring + kAccSet : (unsigned long long *)nullptr };
+                        split == 2 ? P.ring + kAccSet : (unsigned long long *)nullptr, light ? P.light_key : (double *)nullptr, P.sbbox };
     icp_iter_body(bid, P.blocks, P.src, P.n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, P.row_of, P.src_sorted, P.idx_sorted, P.ptgt_sorted,
                   P.idx_cur, P.d2_cur, max_d2, mode, k, P.pair, P.ring, tile_visits, fuse);
 }
@@ -1294,12 +1354,13 @@ __global__ __launch_bounds__(256) void icp_batch_init_kernel(IcpBatchArgs args, 
         const int64_t r = (int64_t)bid * kIRows + rr;
         if (r < P.n && c < 3) P.src_sorted[3 * r + c] = P.src[3 * (int64_t)P.row_of[r] + c];
     }
+    if (threadIdx.x == 0) P.light_key[bid] = 0.0;
     if (bid == 0) {
         for (int e = threadIdx.x; e < 3 * kAccSet; e += 256) P.ring[e] = 0ull;
         if (threadIdx.x < 32) {
             IcpState *st = P.pair + (threadIdx.x >> 4);
             st->T[threadIdx.x & 15] = T0.m[pi][threadIdx.x & 15];
-            if ((threadIdx.x & 15) == 0) { st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0; }
+            if ((threadIdx.x & 15) == 0) { st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0; st->motion = 0.0; st->reach = INFINITY; }
         }
     }
 }
@@ -1326,10 +1387,11 @@ int icp_phase_take(double *h_out8)
     int blocks = (int)v[0][6];
     if (blocks < 1) return KPX_OK;
     if (blocks > kStampBlocks) blocks = kStampBlocks;
+    for (int b = 0; b < blocks; ++b) h_out8[14] += v[b][7] ? 1.0 : 0.0;        // blocks LightSkip left out of the last launch
     unsigned long long s_min = ~0ull, s_max = 0ull, e_max = 0ull;
     int counted = 0;
     for (int b = 0; b < blocks; ++b) {
-        if (!(v[b][5] >= v[b][0]) || v[b][1] < v[b][0]) continue;          // a block of an "already converged" launch stamps nothing new
+        if (v[b][7] || !(v[b][5] >= v[b][0]) || v[b][1] < v[b][0]) continue;          // a block of an "already converged" launch stamps nothing new
         for (int q = 0; q < 5; ++q) {
             const double d = (double)(v[b][q + 1] - v[b][q]) * 0.01;
             h_out8[q] += d;
@@ -1445,6 +1507,7 @@ struct NnBuffers {
     int32_t *orig_t, *row_of, *idx_sorted;
     float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates of each row's last partner, same order
     unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
+    double *light_key;                                  // per block of the iteration kernel (LightSkip)
     float *tile_box, *group_box;
     SortScratch sort_t, sort_s;
 };
@@ -1485,6 +1548,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->src_sorted = a.get<float>(nn * 3);
     b->ptgt_sorted = a.get<float>(nn * 3);
     b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * 2);      // ring of three sets (icp_iter_kernel, IcpFuse)
+    b->light_key = a.get<double>((size_t)cdiv((int64_t)nn, kIRows));
     sort_carve(a, n, &b->sort_s);
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
@@ -1539,7 +1603,7 @@ static void icp_fused_launch(const float *src, const float *tgt, const float *tn
                              int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st,
                              unsigned long long *progress, unsigned long long tag)
 {
-    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag, nullptr };
+    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag, nullptr, nullptr, nullptr };
     const unsigned blocks = k > max_iter ? 1u : (unsigned)cdiv(p.n_src, kIRows);
     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
     hipLaunchKernelGGL(icp_iter_kernel, dim3(blocks), dim3(kIThreads), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t, b.tile_box, b.group_box,
@@ -1978,6 +2042,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                 P.src = h_src[i]; P.row_of = bufs[i].row_of; P.src_sorted = bufs[i].src_sorted; P.idx_sorted = bufs[i].idx_sorted;
                 P.ptgt_sorted = bufs[i].ptgt_sorted; P.idx_cur = bufs[i].idx_cur; P.d2_cur = bufs[i].d2_cur; P.pair = bufs[i].state;
                 P.ring = bufs[i].acc_fixed; P.result = d_results + 20 * i; P.progress = &h_progress[i]; P.n = h_n_src[i];
+                P.light_key = bufs[i].light_key; P.sbbox = bufs[i].sort_s.bbox;
                 P.block0 = b0; P.blocks = (unsigned)cdiv(h_n_src[i], kIRows);
                 Ac[g].p[c] = P;
                 Ac[g].p[c].block0 = (unsigned)c; Ac[g].p[c].blocks = 1u;
@@ -1997,6 +2062,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
         // KPX_ICP_SPLIT=2: in the LAST block of the sweep itself (no update kernel, no redundant prologue).
         static const int split = [] { const char *e = getenv("KPX_ICP_SPLIT"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : KPX_ICP_SPLIT_DEFAULT; }();
         const int last_k = split ? max_iteration : max_iteration + 1;     // the fused chain ends with an update-only launch
+        static const int light = [] { const char *e = getenv("KPX_ICP_LIGHT_SKIP"); return (e && e[0] == '0') ? 0 : 1; }();   // A/B switch (LightSkip)
         for (bool pending = true; pending && !rc;) {
             pending = false;
             bool advanced = false;
@@ -2034,7 +2100,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                     hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)act.count : ab), dim3(kIThreads), 0, ls, closing ? actc : act, tgt,
                                        tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box, bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2,
                                        mode, gk[g], max_iteration, relative_fitness, relative_rmse, tag,
-                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split);
+                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split, split == 2 ? light : 0);
                     if (split == 1)
                         hipLaunchKernelGGL(icp_solve_batch_kernel, dim3((unsigned)act.count), dim3(256), 0, ls, act, mode, gk[g], max_iteration,
                                            relative_fitness, relative_rmse, tag);

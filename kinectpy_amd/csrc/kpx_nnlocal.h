@@ -167,6 +167,7 @@ struct WaveRows {
                                // lives on resident waves
     double best[4];            // running minimum (per lane: over the columns j of the tiles seen)
     int32_t bcol[4];           // its ORIGINAL target index
+    double light_gap2;         // out: no group box was within reach of the wave's box -> the smallest squared box-to-box gap; else -1
 };
 constexpr int kRowStride = 6, kRowBound = 3;
 
@@ -214,6 +215,12 @@ __device__ __forceinline__ double box_gap2v(const double slo[3], const double sh
         g2 = fma(g, g, g2);
     }
     return g2;
+}
+
+__device__ __forceinline__ double wave_uniform_min(double v)
+{
+    v = row16_all_min(v);
+    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 // The culled sweep of one wave: on return best/bcol hold, in every lane, the row minimum (lexicographic (value, original
@@ -382,6 +389,8 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
     // G: lane holds the box of group gbase + lane; gmask = groups the wave's box can reach
     int g_next = 0, gbase = 0;
     unsigned long long gmask = 0ull;
+    double gap_min = INFINITY;
+    bool reached = false;
     float box[6] = { kBoxBig, kBoxBig, kBoxBig, -kBoxBig, -kBoxBig, -kBoxBig };
     for (;;) {
         while (ns < kLSurv && (gmask != 0ull || g_next < n_groups)) {
@@ -397,7 +406,10 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
                 } else {
                     group_box_load(box, group_box, n_groups, gbase + lane);
                 }
-                gmask = __builtin_amdgcn_ballot_w64(box_gap2v(slo, shi, box) <= R2);          // empty boxes: gap = inf
+                const double gp = box_gap2v(slo, shi, box);                                   // empty boxes: a huge gap
+                gap_min = fmin(gap_min, gp);
+                gmask = __builtin_amdgcn_ballot_w64(gp <= R2);
+                reached = reached || gmask != 0ull;
                 continue;
             }
             // hand the next (at most kLSurv - ns) reachable groups to the per-row test through LDS
@@ -449,6 +461,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         if (last) break;
     }
 
+    w.light_gap2 = reached ? -1.0 : wave_uniform_min(gap_min);
     // reduce over the 16 lanes that hold the same rows (lexicographic (value, original column) minimum)
 #define KPX_NNL_ROWMIN(CTRL)                                               \
     {                                                                      \

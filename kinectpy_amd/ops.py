@@ -534,7 +534,7 @@ def prof_icp_phases():
     names = ("update_prologue", "row_prep", "sweep", "pair_epilogue", "block_sums")
     d = {k: float(out[i]) for i, k in enumerate(names)}
     d.update(blocks=int(out[5]), dispatch_ramp_us=float(out[6]), span_us=float(out[7]), slowest={k: float(out[8 + i]) for i, k in enumerate(names)},
-             longest_block_us=float(out[13]))
+             longest_block_us=float(out[13]), blocks_skipped=int(out[14]))
     return d
 
 

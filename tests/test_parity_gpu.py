@@ -1413,3 +1413,46 @@ def test_sor_and_normals_with_thousands_of_duplicates(ops, oracle, base_cloud):
     assert np.allclose(npy(stats), np.array(ostats), rtol=TOL_STATS)
     nrm = npy(ops.estimate_normals(pts, 70.0, 40))
     assert np.isfinite(nrm).all() and np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-5)
+
+
+_ICP_UPDATE_MODES = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from kinectpy_amd import ops
+from kinectpy_amd.pipeline import PipelineParams
+from kinectpy_amd.utils import synth
+P = PipelineParams()
+xy, depth, rgb, inits, _ = synth.sensor_ring(4, 1)
+d = torch.as_tensor(depth[0]).cuda()
+fp, _, _, cnt = ops.depth_to_cloud(d, xy, None, 4, False, False, sync=False)
+k = ops._count(cnt)
+downs = [x[0] for x in ops.voxel_downsample_batch([fp[i, :k[i]] for i in range(4)], P.reg_voxel)]
+tn = ops.estimate_normals(downs[0], 2.0 * P.reg_voxel, P.normals_nn)
+out = {}
+for mode in ("p2plane", "p2p"):
+    r = ops.icp_batch(downs[1:], downs[0], P.icp_max_dist, inits, mode, tn, P.icp_max_iteration)
+    out[mode + "_T"] = np.stack([x["transformation"] for x in r])
+    out[mode + "_s"] = np.array([[x["fitness"], x["inlier_rmse"], x["iterations"], x["count"]] for x in r])
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
+    """The update step in its own kernel (KPX_ICP_SPLIT=1), in the last block of the sweep (2, the default) and with the blocks
+    that provably cannot find a partner left out of the sweeps (KPX_ICP_LIGHT_SKIP, default on): the exact fixed-point sums do
+    not depend on which blocks add to them or when, so transforms, fitness, rmse, iterations and counts agree to the last bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, env in (("tail+skip", {}), ("tail", {"KPX_ICP_LIGHT_SKIP": "0"}), ("kernel", {"KPX_ICP_SPLIT": "1"})):
+        f = str(tmp_path / (name.replace("+", "_") + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _ICP_UPDATE_MODES, f], cwd=root, capture_output=True, text=True, timeout=300,
+                           env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[name] = dict(np.load(f))
+    for name in ("tail", "kernel"):
+        for key, v in got["tail+skip"].items():
+            assert np.array_equal(v, got[name][key]), (name, key)
+    its = got["tail+skip"]["p2plane_s"][:, 2]
+    assert its.max() >= 10, its                                        # a chain long enough for blocks to be skipped

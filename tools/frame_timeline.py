@@ -44,6 +44,17 @@ fr = frames[spans[len(spans) // 2]]
 t0 = fr[0][0]
 period = sorted(b[0][0] - a[0][0] for a, b in zip(frames[:-1], frames[1:]))[len(frames) // 2] / 1e3
 print(f"{len(frames)} frames; median frame: {len(fr)} dispatches, first start -> last end {(fr[-1][1] - t0) / 1e3:.1f} us, frame period {period:.1f} us")
+# averages over ALL frames (the frames of a run differ in their iteration counts)
+tot_busy = sum((e - s_) for fr_ in frames for s_, e, _ in fr_) / len(frames) / 1e3
+icp = [(e - s_) / 1e3 for fr_ in frames for s_, e, n in fr_ if "icp_iter" in n]
+span_icp = []
+for fr_ in frames:
+    ii = [(s_, e) for s_, e, n in fr_ if "icp_iter" in n]
+    if ii:
+        span_icp.append((ii[-1][1] - ii[0][0]) / 1e3)
+print(f"all frames: period {(frames[-1][0][0] - frames[0][0][0]) / (len(frames) - 1) / 1e3:.1f} us, busy {tot_busy:.1f} us, ICP launches {len(icp) / len(frames):.1f} per frame, "
+      f"ICP busy {sum(icp) / len(frames):.1f} us, ICP chain first start -> last end {sum(span_icp) / max(len(span_icp), 1):.1f} us, sweeps >= 10 us: {sum(1 for v in icp if v >= 10) / len(frames):.1f} per frame "
+      f"(avg {sum(v for v in icp if v >= 10) / max(1, sum(1 for v in icp if v >= 10)):.1f} us)")
 busy = defaultdict(float)
 gap = defaultdict(float)
 cnt = defaultdict(int)
