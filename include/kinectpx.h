@@ -107,6 +107,13 @@ int kpx_select_by_index(const float *a0, const float *a1, const float *a2, int64
                         int64_t n_idx, int32_t invert, float *o0, float *o1, float *o2, int32_t *d_count,
                         void *ws, size_t ws_bytes, void *stream);
 
+/* Stable sort of (key, value) pairs by the low end_bit (1..32) bits of the key -- the ordering step behind a7 / a8 / a11 (voxel keys,
+ * grid cells, Morton codes; the reference gets it from Open3D's hash maps and np.argsort).  Inputs are not modified and may not
+ * alias the outputs. */
+size_t kpx_sort_pairs_u32_workspace_bytes(int64_t n);
+int kpx_sort_pairs_u32(const uint32_t *keys_in, const int32_t *vals_in, int64_t n, int32_t end_bit, uint32_t *keys_out,
+                       int32_t *vals_out, void *ws, size_t ws_bytes, void *stream);
+
 /* a19: pcd_above_plane (floor_removal.py:39-51): indices of points with a x + b y + c z + d < 0
  * (evaluated left to right in fp64, as the reference's Python loop). */
 int kpx_halfspace_select(const float *pts, int64_t n, const double *h_plane, int32_t *idx, int32_t *d_count,

@@ -10,6 +10,7 @@
 
 #include "kpx_gridknn.h"
 #include "kpx_morton.h"
+#include "kpx_radix.h"
 #include "kpx_linalg.h"
 
 namespace kpx {
@@ -147,6 +148,9 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     (void)sort_pairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, (int64_t)nn, 22, st);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, zero, g->cell_start, kGridMaxCells + 1, st);
     char *tmp = a.get<char>(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
+    RadixScratch rx{};
+    const bool own_sort = (int64_t)nn > 65536 && (int64_t)nn <= kRadixMaxPairs;     // the sort build's sizes that kpx_radix.h serves
+    if (own_sort) radix_carve(a, (int64_t)nn, &rx);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     double *bbox = part + (size_t)kBboxBlocks * 6;
@@ -176,7 +180,12 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     static const bool force_sort = [] { const char *e = getenv("KPX_GRID_SORT"); return e && e[0] == '1'; }();
     const bool by_sort = force_sort || n > 65536;
     if (by_sort) {
-        KPX_HIP(sort_pairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, n, 22, st));
+        if (own_sort) {
+            rc = radix_sort_pairs_u32(rx, keys_in, keys_out, vals_in, g->sorted_idx, n, 22, st);
+            if (rc) return rc;
+        } else {
+            KPX_HIP(sort_pairs(tmp, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, n, 22, st));
+        }
         hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, pts, n, g->sorted_idx, g->sorted_pts);
     } else {
         hipLaunchKernelGGL(grid_place_kernel, dim3(nb), dim3(256), 0, st, keys_in, n, g->cell_start, cursor, vals_in);

@@ -1,6 +1,8 @@
 // kpx_misc.hip -- container operations of the Open3D surface the path touches:
 // transform, select_by_index, half-space select, slab split, bounding box.  HBM-streaming.
 #include "kpx_internal.h"
+#include "kpx_morton.h"
+#include "kpx_radix.h"
 
 namespace kpx {
 
@@ -397,6 +399,42 @@ KPX_EXPORT int kpx_fuse_skeletons(const double *skeletons, int32_t cams, int64_t
     hipLaunchKernelGGL(fuse_skeletons_kernel, dim3((unsigned)cdiv(joints, 64)), dim3(64), 0, (hipStream_t)stream, skeletons, cams, frames, joints,
                        alpha, beta, initial_frame, out);
     KPX_LAUNCH_CHECK();
+    return KPX_OK;
+}
+
+// ---- stable sort of (uint32 key, int32 value) pairs on the low end_bit key bits: the library's own radix sort up to
+// kRadixMaxPairs pairs, rocPRIM above (exported for tests and for callers that order their own index lists)
+static void sort_u32_carve(Arena &a, int64_t n, RadixScratch *rx, char **tmp, size_t *tmp_bytes)
+{
+    if (n <= kRadixMaxPairs) { radix_carve(a, n, rx); return; }
+    *tmp_bytes = 0;
+    (void)sort_pairs<uint32_t>(nullptr, *tmp_bytes, nullptr, nullptr, nullptr, nullptr, n, 32, (hipStream_t) nullptr);
+    *tmp = a.get<char>(*tmp_bytes);
+}
+KPX_EXPORT size_t kpx_sort_pairs_u32_workspace_bytes(int64_t n)
+{
+    Arena a(nullptr, 0);
+    RadixScratch rx;
+    char *tmp = nullptr;
+    size_t tb = 0;
+    sort_u32_carve(a, n, &rx, &tmp, &tb);
+    return a.off;
+}
+KPX_EXPORT int kpx_sort_pairs_u32(const uint32_t *keys_in, const int32_t *vals_in, int64_t n, int32_t end_bit, uint32_t *keys_out,
+                                  int32_t *vals_out, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && end_bit >= 1 && end_bit <= 32, "kpx_sort_pairs_u32: bad size or bit count");
+    if (n == 0) return KPX_OK;
+    KPX_REQUIRE(keys_in && vals_in && keys_out && vals_out && ws, "kpx_sort_pairs_u32: null pointer");
+    KPX_REQUIRE(keys_in != keys_out && vals_in != vals_out, "kpx_sort_pairs_u32: outputs may not alias the inputs");
+    Arena a(ws, ws_bytes);
+    RadixScratch rx;
+    char *tmp = nullptr;
+    size_t tb = 0;
+    sort_u32_carve(a, n, &rx, &tmp, &tb);
+    KPX_ARENA_CHECK(a);
+    if (n <= kRadixMaxPairs) return radix_sort_pairs_u32(rx, keys_in, keys_out, vals_in, vals_out, n, end_bit, (hipStream_t)stream);
+    KPX_HIP(sort_pairs<uint32_t>(tmp, tb, keys_in, keys_out, vals_in, vals_out, n, end_bit, (hipStream_t)stream));
     return KPX_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "kpx_internal.h"
+#include "kpx_radix.h"
 
 namespace kpx {
 
@@ -315,6 +316,7 @@ struct VoxelBatchScratch {
     double *part, *bbox;
     char *sort_tmp;
     size_t sort_bytes;
+    RadixScratch rx;            // the hand-written sort (keys of at most 32 bits, total <= kRadixMaxPairs)
 };
 static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
 {
@@ -332,6 +334,7 @@ static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->sort_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 64,
                                              (hipStream_t) nullptr);
     s->sort_tmp = a.get<char>(s->sort_bytes);
+    if (total <= kRadixMaxPairs) radix_carve(a, total, &s->rx);
 }
 static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts, Arena &a, hipStream_t st)
 {
@@ -359,7 +362,13 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
     if (end_bit <= 32) {
         uint32_t *k_in = reinterpret_cast<uint32_t *>(s.keys_in), *k_out = reinterpret_cast<uint32_t *>(s.keys_out);
         hipLaunchKernelGGL(voxel_batch_key_kernel<uint32_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, k_in, s.vals_in, s.err);
-        KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, k_in, k_out, s.vals_in, s.vals_out, (int)total, 0, end_bit, st));
+        static const bool vendor_sort = [] { const char *e = getenv("KPX_RADIX"); return e && e[0] == '0'; }();       // A/B switch
+        if (total <= kRadixMaxPairs && !vendor_sort) {
+            rc = radix_sort_pairs_u32(s.rx, k_in, k_out, s.vals_in, s.vals_out, total, end_bit, st);
+            if (rc) return rc;
+        } else {
+            KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, k_in, k_out, s.vals_in, s.vals_out, (int)total, 0, end_bit, st));
+        }
         rc = compact(HeadPredT<uint32_t>{ k_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st);
     } else {
         hipLaunchKernelGGL(voxel_batch_key_kernel<uint64_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err);

@@ -538,6 +538,18 @@ def prof_icp_phases():
     return d
 
 
+def sort_pairs_u32(keys, vals, end_bit=32):
+    """stable sort of (uint32 key, int32 value) pairs by the low end_bit key bits -> (keys, vals)"""
+    lib = L.load()
+    keys = _dev(keys, torch.uint32).reshape(-1)
+    vals = _dev(vals, torch.int32).reshape(-1)
+    n = keys.shape[0]
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    ws, wsz = L.workspace(lib.kpx_sort_pairs_u32_workspace_bytes(n))
+    L.check(lib.kpx_sort_pairs_u32(L.ptr(keys), L.ptr(vals), n, int(end_bit), L.ptr(ko), L.ptr(vo), ws, wsz, L.stream_ptr()))
+    return ko, vo
+
+
 def prof_icp_waves(cap=16384):
     """-> per wave of the LAST sweep launch: dict of numpy arrays (sweep_us, tiles, box_trips, mul_trips, groups_kept, with_partner)"""
     raw = np.zeros((cap, 4), dtype=np.uint64)

@@ -1456,3 +1456,25 @@ def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
             assert np.array_equal(v, got[name][key]), (name, key)
     its = got["tail+skip"]["p2plane_s"][:, 2]
     assert its.max() >= 10, its                                        # a chain long enough for blocks to be skipped
+
+
+@pytest.mark.parametrize("n,end_bit", [(1, 32), (63, 8), (2048, 9), (2049, 24), (100_003, 27), (1_130_000, 24), (1_130_000, 32), (300_000, 1),
+                                       (4_194_304, 17), (4_200_000, 22)])
+def test_radix_sort_pairs_is_the_stable_sort(ops, n, end_bit):
+    """kpx_sort_pairs_u32 (the library's own LSD radix sort up to 4M pairs, rocPRIM above) against numpy's stable argsort of the
+    masked keys: keys AND values identical, i.e. equal keys keep their input order; few distinct keys, full-range keys, a
+    partial last tile, all keys equal."""
+    rng = np.random.default_rng(n + end_bit)
+    mask = np.uint32((1 << end_bit) - 1) if end_bit < 32 else np.uint32(0xFFFFFFFF)
+    for kind in ("random", "few", "equal"):
+        if kind == "random":
+            keys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        elif kind == "few":
+            keys = (rng.integers(0, 37, n, dtype=np.uint64) * np.uint64(2654435761) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        else:
+            keys = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+        vals = np.arange(n, dtype=np.int32)[::-1].copy()
+        ko, vo = ops.sort_pairs_u32(torch.from_numpy(keys.view(np.int32)).cuda().view(torch.uint32), torch.from_numpy(vals).cuda(), end_bit)
+        order = np.argsort(keys & mask, kind="stable")
+        assert np.array_equal(npy(ko.view(torch.int32)).view(np.uint32), keys[order]), (kind, "keys")
+        assert np.array_equal(npy(vo), vals[order]), (kind, "values")
