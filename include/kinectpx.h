@@ -163,6 +163,12 @@ size_t kpx_sor_workspace_bytes(int64_t n, int32_t nb_neighbors);
 int kpx_sor(const float *pts, int64_t n, int32_t nb_neighbors, double std_ratio, int32_t *keep_idx,
             int32_t *d_count, double *d_stats, double *d_avg, void *ws, size_t ws_bytes, void *stream);
 
+/* `cl, ind = pcd.remove_statistical_outlier(nb_neighbors, std_ratio)` (preprocessing/filtering.py:33, data.py:61) with BOTH results:
+ * the keep list as kpx_sor and, in the same pass, the kept rows of pts (and of one more (n,3) attribute array, e.g. colours; NULL for
+ * none) -- kpx_sor + kpx_select_by_index without the count read-back in between.  Workspace: kpx_sor_workspace_bytes. */
+int kpx_sor_select(const float *pts, const float *attr, int64_t n, int32_t nb_neighbors, double std_ratio, float *out_pts,
+                   float *out_attr, int32_t *keep_idx, int32_t *d_count, double *d_stats, void *ws, size_t ws_bytes, void *stream);
+
 /* The same filter sharded over GPUs (the fused-cloud filter_outliers of preprocessing/data.py:61 when every GPU holds the
  * fused cloud): the grid order of the cloud is the same on every GPU, each searches only the queries at
  * cell-sorted positions [q_begin, q_end) -- a spatial slab -- and writes their mean distances, in that order, to

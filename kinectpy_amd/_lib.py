@@ -78,6 +78,7 @@ SIGNATURES = {
     "kpx_prof_stride": (C.c_int, [_i32]),
     "kpx_frame_step_workspace_bytes": (_sz, [_i32, _i64]),
     "kpx_frame_step": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_sor_select": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "kpx_sort_pairs_u32_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "kpx_sort_pairs_u32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "kpx_prof_icp_phases": (C.c_int, [_vp]),

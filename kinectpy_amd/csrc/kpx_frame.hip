@@ -139,11 +139,10 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     if (h_info) h_info[48] = (int32_t)M;
     *h_count = 0;
     if (M == 0) return KPX_OK;
-    KPX_SUB(kpx_sor(L.vox_pts, M, prm->filt_k, prm->filt_ratio, L.keep_idx, L.keep_cnt, L.sor_stats, nullptr, L.op_ws, L.op_bytes, st));
+    // filter + selection in one pass (no count read-back between them)
+    KPX_SUB(kpx_sor_select(L.vox_pts, L.vox_col, M, prm->filt_k, prm->filt_ratio, out_pts, out_col, L.keep_idx, L.keep_cnt, L.sor_stats, L.op_ws, L.op_bytes, st));
     KPX_HIP(hipMemcpyAsync(h_i + 49, L.keep_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     KPX_HIP(hipStreamSynchronize(st));
-    const int64_t K = h_i[49];
-    KPX_SUB(kpx_select_by_index(L.vox_pts, L.vox_col, nullptr, M, L.keep_idx, K, KPX_SELECT_GATHER, out_pts, out_col, nullptr, nullptr, L.op_ws, L.op_bytes, st));
-    *h_count = (int32_t)K;
+    *h_count = h_i[49];
     return KPX_OK;
 }

@@ -284,6 +284,21 @@ struct IdxEmit {
     int32_t *idx;
     __device__ void operator()(int64_t i, int, int32_t dst) const { idx[dst] = (int32_t)i; }
 };
+// keep list AND the kept rows of up to two (n,3) attribute arrays: `cl, ind = remove_statistical_outlier(...)` in one pass
+struct SorGather {
+    const float *a0, *a1;
+    float *o0, *o1;
+};
+struct IdxGatherEmit {
+    int32_t *idx;
+    SorGather g;
+    __device__ void operator()(int64_t i, int, int32_t dst) const
+    {
+        idx[dst] = (int32_t)i;
+        if (g.a0) { g.o0[3 * (int64_t)dst] = g.a0[3 * i]; g.o0[3 * (int64_t)dst + 1] = g.a0[3 * i + 1]; g.o0[3 * (int64_t)dst + 2] = g.a0[3 * i + 2]; }
+        if (g.a1) { g.o1[3 * (int64_t)dst] = g.a1[3 * i]; g.o1[3 * (int64_t)dst + 1] = g.a1[3 * i + 1]; g.o1[3 * (int64_t)dst + 2] = g.a1[3 * i + 2]; }
+    }
+};
 
 static int sor_block_threads(int k)
 {
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(1024) void sor_stats_small_kernel(const double *__r
 // statistics over avg (caller's point order) + ascending keep list -- shared by kpx_sor and kpx_sor_finish, so that the
 // sharded filter folds the very same reduction tree over the very same array as the one-GPU call
 static int sor_stats_compact(const double *avg, int64_t n, double std_ratio, double *part, int32_t *counts, int32_t *keep_idx,
-                             int32_t *d_count, double *d_stats, hipStream_t st)
+                             int32_t *d_count, double *d_stats, hipStream_t st, const SorGather *ga = nullptr)
 {
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
     if (nb <= 64) {
@@ -344,6 +359,7 @@ static int sor_stats_compact(const double *avg, int64_t n, double std_ratio, dou
         }
     }
     KPX_LAUNCH_CHECK();
+    if (ga) return compact(SorPred{ avg, d_stats }, IdxGatherEmit{ keep_idx, *ga }, n, 1, counts, d_count, st);
     return compact(SorPred{ avg, d_stats }, IdxEmit{ keep_idx }, n, 1, counts, d_count, st);
 }
 
@@ -356,7 +372,8 @@ __global__ __launch_bounds__(256) void sor_unsort_kernel(const double *__restric
 // q0 <= q1: only the queries at cell-sorted positions [q0, q1) are searched (kpx_sor_partial: avg_out is indexed by sorted
 // position - q0 and the statistics / keep list are skipped); full == true: the whole filter (kpx_sor)
 static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_t *keep_idx, int32_t *d_count, double *d_stats,
-                    double *d_avg, Arena &a, hipStream_t st, bool full = true, int64_t q0 = 0, int64_t q1 = 0, int32_t *d_order = nullptr)
+                    double *d_avg, Arena &a, hipStream_t st, bool full = true, int64_t q0 = 0, int64_t q1 = 0, int32_t *d_order = nullptr,
+                    const SorGather *ga = nullptr)
 {
     Grid g;
     if (full) { q0 = 0; q1 = n; }
@@ -407,7 +424,7 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
-    return sor_stats_compact(avg, n, std_ratio, part, counts, keep_idx, d_count, d_stats, st);
+    return sor_stats_compact(avg, n, std_ratio, part, counts, keep_idx, d_count, d_stats, st, ga);
 }
 
 // ---- estimate_normals ---------------------------------------------------------------------------------
@@ -577,6 +594,22 @@ KPX_EXPORT int kpx_sor(const float *pts, int64_t n, int32_t nb_neighbors, double
     KPX_REQUIRE(pts && keep_idx, "kpx_sor: null pointer");
     Arena a(ws, ws_bytes);
     return sor_impl(pts, n, nb_neighbors, std_ratio, keep_idx, d_count, d_stats, d_avg, a, st);
+}
+
+KPX_EXPORT int kpx_sor_select(const float *pts, const float *attr, int64_t n, int32_t nb_neighbors, double std_ratio, float *out_pts,
+                              float *out_attr, int32_t *keep_idx, int32_t *d_count, double *d_stats, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(nb_neighbors >= 1 && std_ratio > 0.0, "remove_statistical_outlier: nb_neighbors and std_ratio must be positive");
+    KPX_REQUIRE(nb_neighbors <= KPX_SOR_MAX_K, "remove_statistical_outlier: nb_neighbors > %d is not supported", KPX_SOR_MAX_K);
+    KPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "kpx_sor_select: bad size");
+    KPX_REQUIRE(d_count && d_stats && ws, "kpx_sor_select: null pointer");
+    KPX_REQUIRE(!attr || out_attr, "kpx_sor_select: attributes without an output array");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { KPX_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return KPX_OK; }
+    KPX_REQUIRE(pts && keep_idx && out_pts, "kpx_sor_select: null pointer");
+    Arena a(ws, ws_bytes);
+    const SorGather ga{ pts, attr, out_pts, out_attr };
+    return sor_impl(pts, n, nb_neighbors, std_ratio, keep_idx, d_count, d_stats, nullptr, a, st, true, 0, 0, nullptr, &ga);
 }
 
 KPX_EXPORT int kpx_sor_partial(const float *pts, int64_t n, int32_t nb_neighbors, int64_t q_begin, int64_t q_end, double *d_avg_sorted,

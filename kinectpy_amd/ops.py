@@ -271,6 +271,26 @@ def sor(pts, nb_neighbors, std_ratio, want_avg=False):
     return idx[:k], stats, (avg[:n] if avg is not None else None)
 
 
+def sor_select(pts, attr, nb_neighbors, std_ratio):
+    """a8 with both results of `cl, ind = remove_statistical_outlier(...)`: -> kept points f32 (K,3), kept rows of `attr` (K,3) | None,
+    keep_idx i32 (K), stats f64 (3) -- one pass, no count read-back between filter and selection (kpx_sor_select)."""
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    dev = pts.device
+    attr = _dev(attr, torch.float32).reshape(n, 3) if attr is not None else None
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    stats = torch.empty(3, dtype=torch.float64, device=dev) if n else torch.zeros(3, dtype=torch.float64, device=dev)
+    op = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
+    oa = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev) if attr is not None else None
+    ws, wsz = L.workspace(lib.kpx_sor_workspace_bytes(n, int(nb_neighbors)))
+    L.check(lib.kpx_sor_select(L.ptr(pts), L.ptr(attr), n, int(nb_neighbors), float(std_ratio), L.ptr(op), L.ptr(oa), L.ptr(idx), L.ptr(cnt),
+                               L.ptr(stats), ws, wsz, L.stream_ptr()))
+    k = _count(cnt)[0]
+    return op[:k], (oa[:k] if oa is not None else None), idx[:k], stats
+
+
 def sor_partial(pts, nb_neighbors, q_begin, q_end, want_order=True):
     """Sharded a8, first half: mean kNN distances of the queries at cell-sorted positions [q_begin, q_end) of the cloud's
     grid order -> (avg f64 (q_end - q_begin) in that order, order i32 (N) sorted position -> point index | None)."""

@@ -1478,3 +1478,18 @@ def test_radix_sort_pairs_is_the_stable_sort(ops, n, end_bit):
         order = np.argsort(keys & mask, kind="stable")
         assert np.array_equal(npy(ko.view(torch.int32)).view(np.uint32), keys[order]), (kind, "keys")
         assert np.array_equal(npy(vo), vals[order]), (kind, "values")
+
+
+def test_sor_select_equals_filter_then_selection(ops):
+    """kpx_sor_select = kpx_sor + kpx_select_by_index: the same keep list, statistics and rows (points and one attribute array),
+    also for an empty cloud and without attributes"""
+    pts = torch.as_tensor(synth.filter_cloud(60_000)).cuda()
+    col = torch.rand_like(pts)
+    idx, stats, _ = ops.sor(pts, 20, 2.0)
+    p, c, i2, st2 = ops.sor_select(pts, col, 20, 2.0)
+    assert torch.equal(idx, i2) and torch.equal(stats, st2)
+    assert torch.equal(p, pts[idx.long()]) and torch.equal(c, col[idx.long()])
+    p3, c3, i3, _ = ops.sor_select(pts, None, 20, 2.0)
+    assert c3 is None and torch.equal(p3, p) and torch.equal(i3, idx)
+    pe, ce, ie, _ = ops.sor_select(torch.zeros((0, 3)), None, 20, 2.0)
+    assert pe.shape[0] == 0 and ie.shape[0] == 0
