@@ -11,7 +11,7 @@ namespace kpx {
 
 struct FrameLayout {
     float *full_pts, *mask_pts, *mask_col, *down_pts, *normals, *vox_pts, *vox_col;
-    int32_t *full_cnt, *mask_cnt, *down_cnt, *vox_cnt, *keep_cnt, *keep_idx;
+    int32_t *full_cnt, *mask_cnt, *down_cnt, *vox_cnt, *keep_cnt, *keep_idx, *key_bits;
     double *icp_res, *sor_stats;
     void *op_ws;
     size_t op_bytes;
@@ -31,6 +31,7 @@ static void frame_carve(Arena &a, int32_t S, int64_t n_px, FrameLayout *L)
     L->mask_cnt = a.get<int32_t>((size_t)S);
     L->down_cnt = a.get<int32_t>((size_t)S);
     L->vox_cnt = a.get<int32_t>(1);
+    L->key_bits = a.get<int32_t>(1);
     L->keep_cnt = a.get<int32_t>(1);
     L->keep_idx = a.get<int32_t>(all);
     L->icp_res = a.get<double>((size_t)S * 20);
@@ -105,9 +106,23 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     KPX_HIP(hipStreamSynchronize(st));                     // read-back 1: both extractions' counts
     for (int i = 0; i < S; ++i) { fk[(size_t)i] = h_i[i]; mk[(size_t)i] = h_i[16 + i]; }
     if (negative(h_i, S) || negative(h_i + 16, S)) return fail(KPX_ERR_RANGE, "kpx_frame_step: extraction reported %d", negative(h_i, S) | negative(h_i + 16, S));
-    KPX_SUB(kpx_voxel_downsample_batch(S, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, L.down_cnt, L.op_ws, L.op_bytes, st));
-    KPX_HIP(hipMemcpyAsync(h_i + 32, L.down_cnt, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    KPX_HIP(hipStreamSynchronize(st));
+    // The sort-key width of the registration voxel grid is speculated from the last frame of this thread (the scene's extent in
+    // voxels barely changes from frame to frame): its read-back inside the call is one host round trip less; a frame that needs
+    // more bits is detected with the counts and done again the careful way.
+    static thread_local int spec_bits = 0;
+    static const bool speculate = [] { const char *e = getenv("KPX_FRAME_SPECULATE"); return !(e && e[0] == '0'); }();      // A/B switch
+    if (!speculate) spec_bits = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        KPX_SUB(voxel_downsample_batch_spec(S, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, L.down_cnt, L.op_ws, L.op_bytes, st,
+                                            attempt == 0 ? spec_bits : 0, L.key_bits));
+        KPX_HIP(hipMemcpyAsync(h_i + 32, L.down_cnt, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KPX_HIP(hipMemcpyAsync(h_i + 50, L.key_bits, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KPX_HIP(hipStreamSynchronize(st));
+        const int need = h_i[50];
+        const bool narrow = attempt == 0 && spec_bits > 0 && need > spec_bits;
+        spec_bits = need > 0 && need <= 32 ? (need + 7) / 8 * 8 : 0;      // whole 8-bit passes; wide keys are not speculated
+        if (!narrow) break;
+    }
     if (negative(h_i + 32, S)) return fail(KPX_ERR_RANGE, "voxel_size is too small");
     for (int i = 0; i < S; ++i) dk[(size_t)i] = h_i[32 + i];
     for (int q = 0; q < 16; ++q) h_T[q] = (q % 5 == 0) ? 1.0 : 0.0;

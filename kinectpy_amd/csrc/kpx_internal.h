@@ -44,6 +44,13 @@ int lanes_get(LaneSet **out);
 int lanes_fork(LaneSet *l, hipStream_t caller, int used);
 int lanes_join(LaneSet *l, hipStream_t caller, int used);
 
+// kpx_voxel_downsample_batch with a speculated sort-key width (kpx_frame_step): spec_bits > 0 skips the width's read-back (one host
+// round trip per call); *d_bits receives the width the batch needs (0 = the call did not speculate) and the caller repeats the call
+// with spec_bits = 0 when that is larger than spec_bits.  spec_bits = 0, d_bits = NULL: the exported behaviour.
+int voxel_downsample_batch_spec(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n, double voxel,
+                                float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws, size_t ws_bytes, void *stream,
+                                int spec_bits, int32_t *d_bits);
+
 // Column tiles (16 rows x 16 columns, 2048 flops each) the culled nearest-neighbour sweep has multiplied since the
 // last call; resets the device counter (kpx_icp.hip).
 double nn_local_take_visits();

@@ -336,7 +336,11 @@ static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
     s->sort_tmp = a.get<char>(s->sort_bytes);
     if (total <= kRadixMaxPairs) radix_carve(a, total, &s->rx);
 }
-static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts, Arena &a, hipStream_t st)
+// spec_bits > 0 (frame loop): the key width is NOT read back -- the sort covers spec_bits bits and *d_bits receives the width the
+// batch really needs; the caller compares the two after its own read-back of the counts and repeats the call with spec_bits = 0
+// when the speculation was too narrow (the outputs of that call are garbage).
+static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts, Arena &a, hipStream_t st, int spec_bits = 0,
+                            int32_t *d_bits = nullptr)
 {
     const int64_t total = b.off[b.count];
     VoxelBatchScratch s;
@@ -346,7 +350,10 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
     hipLaunchKernelGGL(voxel_batch_bbox_final_kernel, dim3(b.count), dim3(64), 0, st, s.part, s.bbox, s.err);
     const int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
     int end_bit = 64;
-    if (total > (int64_t)1024 * 1024) {
+    if (spec_bits > 0 && d_bits) {
+        hipLaunchKernelGGL(voxel_batch_bits_kernel, dim3(1), dim3(1), 0, st, b, s.bbox, voxel, d_bits);
+        end_bit = spec_bits > 64 ? 64 : spec_bits;
+    } else if (total > (int64_t)1024 * 1024) {
         // above rocPRIM's merge-sort limit the sort is an Onesweep with one pass per 8 key bits: reading the width back (one
         // small round trip; the caller waits for the counts anyway) saves four or five of the eight ~27 us passes -- and keys of at
         // most 32 bits (a 4-sensor frame needs ~25) are written, sorted and compared as 32-bit words: half the key traffic
@@ -354,8 +361,11 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
         if (!h_bits) KPX_HIP(hipHostMalloc((void **)&h_bits, sizeof(int32_t), hipHostMallocDefault));
         hipLaunchKernelGGL(voxel_batch_bits_kernel, dim3(1), dim3(1), 0, st, b, s.bbox, voxel, s.head);
         KPX_HIP(hipMemcpyAsync(h_bits, s.head, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (d_bits) KPX_HIP(hipMemcpyAsync(d_bits, s.head, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         KPX_HIP(hipStreamSynchronize(st));
         end_bit = *h_bits < 1 ? 1 : (*h_bits > 64 ? 64 : *h_bits);
+    } else if (d_bits) {
+        hipLaunchKernelGGL(voxel_batch_bits_kernel, dim3(1), dim3(1), 0, st, b, s.bbox, voxel, d_bits);      // for the caller's next speculation
     }
     size_t bytes = s.sort_bytes;
     int rc;
@@ -636,6 +646,12 @@ KPX_EXPORT int kpx_voxel_downsample_batch(int32_t count, const float *const *h_p
                                           double voxel, float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws,
                                           size_t ws_bytes, void *stream)
 {
+    return kpx::voxel_downsample_batch_spec(count, h_pts, h_col, h_n, voxel, h_opts, h_ocol, d_counts, ws, ws_bytes, stream, 0, nullptr);
+}
+int kpx::voxel_downsample_batch_spec(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n, double voxel,
+                                     float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws, size_t ws_bytes, void *stream,
+                                     int spec_bits, int32_t *d_bits)
+{
     KPX_REQUIRE(voxel > 0.0, "voxel_size <= 0");
     KPX_REQUIRE(count >= 1 && count <= 64 && h_pts && h_n && h_opts && d_counts && ws, "kpx_voxel_downsample_batch: bad arguments");
     for (int i = 0; i < count; ++i)
@@ -657,8 +673,9 @@ KPX_EXPORT int kpx_voxel_downsample_batch(int32_t count, const float *const *h_p
             b.off[i + 1] = b.off[i] + (on ? h_n[i] : 0);
         }
         Arena one(ws, ws_bytes);
-        return voxel_batch_impl(b, voxel, d_counts, one, st);
+        return voxel_batch_impl(b, voxel, d_counts, one, st, spec_bits, d_bits);
     }
+    if (d_bits) KPX_HIP(hipMemsetAsync(d_bits, 0, sizeof(int32_t), st));         // the other forms do not speculate: width 0 = "fine"
     if (count > kVoxelBatchMax && total > 0) {
         // more clouds than one pass takes: groups of kVoxelBatchMax, one concatenated pass each, one after the other on `stream`
         // (64 clouds of 1M points: 11 ms cloud by cloud on the lanes -- every cloud its own 8-pass sort -- against eight 8M-key sorts)

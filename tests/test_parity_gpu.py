@@ -1397,6 +1397,13 @@ def test_native_frame_step_equals_python_pipeline_and_oracle(four_sensor_oracle)
     one = NativeFramePipeline(xy, 1, [], PipelineParams())
     gp, gc, gT = one.step(d[0][:1], c[0][:1])
     assert gT.shape == (1, 4, 4) and np.array_equal(gT[0], np.eye(4)) and gp.shape[0] > 1000
+    # the frame loop speculates the voxel sort's key width from the thread's previous frame: a frame that suddenly needs MORE bits
+    # (a 7x finer registration grid here: 24 -> 33 bits) must be caught and redone, one that needs fewer just sorts zero bits
+    for voxel in (5.0, 35.0, 70.0, 35.0):
+        prm = PipelineParams(reg_voxel=voxel)
+        gp, gc, gT = NativeFramePipeline(xy, 4, inits, prm).step(d[0], c[0])
+        pp, pc, pT = SensorShardPipeline(xy, 4, inits, prm).step(d[0], c[0])
+        assert torch.equal(gp, pp) and torch.equal(gc, pc) and np.array_equal(gT, pT), voxel
 
 
 def test_sor_and_normals_with_thousands_of_duplicates(ops, oracle, base_cloud):
