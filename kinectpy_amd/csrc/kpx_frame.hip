@@ -137,18 +137,23 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
         }
         KPX_SUB(kpx_icp_batch(S - 1, subs.data(), dk.data() + 1, L.down_pts, plane ? L.normals : nullptr, dk[0], prm->icp_max_dist, h_init, prm->icp_mode,
                               prm->icp_max_iteration, 1e-6, 1e-6, L.icp_res, L.op_ws, L.op_bytes, st));
+        // the results reach the host with the NEXT read-back: the fuse below takes the transforms from device memory, in stream order
         KPX_HIP(hipMemcpyAsync(h_d, L.icp_res, (size_t)(S - 1) * 20 * sizeof(double), hipMemcpyDeviceToHost, st));
-        KPX_HIP(hipStreamSynchronize(st));
-        for (int i = 1; i < S; ++i) {
-            for (int q = 0; q < 16; ++q) h_T[16 * i + q] = h_d[20 * (i - 1) + q];
-            if (h_info) h_info[32 + i] = (int32_t)h_d[20 * (i - 1) + 18];
-        }
     }
     // fuse: pcd.transform(T_i) + np.vstack + voxel_down_sample in one fp64 pass, remove_statistical_outlier, selection
-    for (int i = 0; i < S; ++i) { p_in[(size_t)i] = L.mask_pts + (size_t)i * n_px * 3; c_in[(size_t)i] = L.mask_col + (size_t)i * n_px * 3; }
-    KPX_SUB(kpx_fuse_voxel_downsample(S, p_in.data(), c_in.data(), mk.data(), h_T, prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws, L.op_bytes, st));
+    std::vector<const double *> dT((size_t)S, nullptr);
+    for (int i = 0; i < S; ++i) {
+        p_in[(size_t)i] = L.mask_pts + (size_t)i * n_px * 3; c_in[(size_t)i] = L.mask_col + (size_t)i * n_px * 3;
+        if (i > 0) dT[(size_t)i] = L.icp_res + 20 * (size_t)(i - 1);
+    }
+    KPX_SUB(fuse_voxel_downsample_dev(S, p_in.data(), c_in.data(), mk.data(), h_T, dT.data(), prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws,
+                                      L.op_bytes, st));
     KPX_HIP(hipMemcpyAsync(h_i + 48, L.vox_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     KPX_HIP(hipStreamSynchronize(st));
+    for (int i = 1; i < S; ++i) {
+        for (int q = 0; q < 16; ++q) h_T[16 * i + q] = h_d[20 * (i - 1) + q];
+        if (h_info) h_info[32 + i] = (int32_t)h_d[20 * (i - 1) + 18];
+    }
     if (h_i[48] < 0) return fail(KPX_ERR_RANGE, "voxel_size is too small");
     const int64_t M = h_i[48];
     if (h_info) h_info[48] = (int32_t)M;

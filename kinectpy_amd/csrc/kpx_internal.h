@@ -51,6 +51,12 @@ int voxel_downsample_batch_spec(int32_t count, const float *const *h_pts, const 
                                 float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws, size_t ws_bytes, void *stream,
                                 int spec_bits, int32_t *d_bits);
 
+// kpx_fuse_voxel_downsample whose transforms may live in device memory: h_dT[i] non-null = cloud i's row-major 4x4 is read there
+// (h_T[16 i ..] is then ignored); h_dT == NULL: the exported behaviour.
+int fuse_voxel_downsample_dev(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n, const double *h_T,
+                              const double *const *h_dT, double voxel, float *opts, float *ocol, int32_t *d_count, void *ws, size_t ws_bytes,
+                              void *stream);
+
 // Column tiles (16 rows x 16 columns, 2048 flops each) the culled nearest-neighbour sweep has multiplied since the
 // last call; resets the device counter (kpx_icp.hip).
 double nn_local_take_visits();

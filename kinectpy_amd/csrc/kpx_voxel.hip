@@ -406,6 +406,8 @@ struct FuseBatch {
     const float *col[kFuseMax];
     int64_t off[kFuseMax + 1];
     double T[kFuseMax][12];               // rows of [R | t]
+    const double *dT[kFuseMax];           // non-null: the cloud's 4x4 (row-major, first 12 entries used) is read from device memory instead --
+                                          // the frame loop hands over the registrations' results without a host round trip
     int32_t count;
 };
 __device__ __forceinline__ int fuse_cloud(const FuseBatch &b, int64_t i)
@@ -419,7 +421,7 @@ __device__ __forceinline__ void fuse_point(const FuseBatch &b, int c, int64_t j,
 {
     const float *p = b.pts[c] + 3 * j;
     const double x = p[0], y = p[1], z = p[2];
-    const double *T = b.T[c];
+    const double *T = b.dT[c] ? b.dT[c] : b.T[c];
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[k] = fma(T[4 * k], x, fma(T[4 * k + 1], y, fma(T[4 * k + 2], z, T[4 * k + 3])));
 }
@@ -579,6 +581,12 @@ KPX_EXPORT int kpx_fuse_voxel_downsample(int32_t count, const float *const *h_pt
                                          const double *h_T, double voxel, float *opts, float *ocol, int32_t *d_count, void *ws,
                                          size_t ws_bytes, void *stream)
 {
+    return kpx::fuse_voxel_downsample_dev(count, h_pts, h_col, h_n, h_T, nullptr, voxel, opts, ocol, d_count, ws, ws_bytes, stream);
+}
+int kpx::fuse_voxel_downsample_dev(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n, const double *h_T,
+                                   const double *const *h_dT, double voxel, float *opts, float *ocol, int32_t *d_count, void *ws, size_t ws_bytes,
+                                   void *stream)
+{
     KPX_REQUIRE(voxel > 0.0, "voxel_size <= 0");
     KPX_REQUIRE(count >= 1 && count <= kFuseMax, "kpx_fuse_voxel_downsample: 1 .. %d clouds", kFuseMax);
     KPX_REQUIRE(h_pts && h_n && h_T && d_count && ws, "kpx_fuse_voxel_downsample: null pointer");
@@ -597,6 +605,7 @@ KPX_EXPORT int kpx_fuse_voxel_downsample(int32_t count, const float *const *h_pt
         b.col[i] = (on && h_col) ? h_col[i] : nullptr;
         b.off[i + 1] = b.off[i] + (on ? h_n[i] : 0);
         for (int k = 0; k < 12; ++k) b.T[i][k] = on ? h_T[16 * i + k] : 0.0;
+        b.dT[i] = (on && h_dT) ? h_dT[i] : nullptr;
     }
     const int64_t total = b.off[count];
     KPX_REQUIRE(total < ((int64_t)1 << 31), "kpx_fuse_voxel_downsample: bad size");
