@@ -11,7 +11,7 @@ namespace kpx {
 
 struct FrameLayout {
     float *full_pts, *mask_pts, *mask_col, *down_pts, *normals, *vox_pts, *vox_col;
-    int32_t *full_cnt, *mask_cnt, *down_cnt, *vox_cnt, *keep_cnt, *keep_idx, *key_bits;
+    int32_t *vox_cnt, *keep_idx;
     double *icp_res, *sor_stats;
     void *op_ws;
     size_t op_bytes;
@@ -27,14 +27,9 @@ static void frame_carve(Arena &a, int32_t S, int64_t n_px, FrameLayout *L)
     L->normals = a.get<float>(px * 3);
     L->vox_pts = a.get<float>(all * 3);
     L->vox_col = a.get<float>(all * 3);
-    L->full_cnt = a.get<int32_t>((size_t)S);
-    L->mask_cnt = a.get<int32_t>((size_t)S);
-    L->down_cnt = a.get<int32_t>((size_t)S);
-    L->vox_cnt = a.get<int32_t>(1);
-    L->key_bits = a.get<int32_t>(1);
-    L->keep_cnt = a.get<int32_t>(1);
     L->keep_idx = a.get<int32_t>(all);
-    L->icp_res = a.get<double>((size_t)S * 20);
+    L->icp_res = a.get<double>((size_t)S * 20 + 1);              // + one slot for the fused cloud's count: both go home in ONE copy
+    L->vox_cnt = reinterpret_cast<int32_t *>(L->icp_res + (size_t)S * 20);
     L->sor_stats = a.get<double>(4);
     // one scratch region for whichever operator runs (they run one after the other), sized for the worst case of each
     std::vector<int64_t> worst((size_t)S, n_px);
@@ -86,18 +81,19 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     static thread_local double *h_d = nullptr;
     if (!h_i) {
         KPX_HIP(hipHostMalloc((void **)&h_i, 256 * sizeof(int32_t), hipHostMallocDefault));
-        KPX_HIP(hipHostMalloc((void **)&h_d, 16 * 20 * sizeof(double), hipHostMallocDefault));
+        KPX_HIP(hipHostMalloc((void **)&h_d, (16 * 20 + 1) * sizeof(double), hipHostMallocDefault));
     }
     auto negative = [&](const int32_t *c, int n) { for (int i = 0; i < n; ++i) if (c[i] < 0) return c[i]; return 0; };
 
     // extract: the registration input (every valid pixel) and the person clouds (mask + depth gate + colours); both are queued
     // before the first count is read
-    KPX_SUB(kpx_depth_to_cloud(depth, xy_table, nullptr, n_px, S, 0, prm->gate, L.full_pts, nullptr, nullptr, L.full_cnt, L.op_ws, L.op_bytes, st));
-    KPX_HIP(hipMemcpyAsync(h_i, L.full_cnt, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // Counts that only the HOST reads next are written by the kernels straight into the thread's pinned area (device-visible host
+    // memory): every D2H copy of a few bytes is a dispatch of its own (~5 us) in front of the read-back it serves.  Counts that
+    // later kernels read (the fused cloud's, the registrations' results) stay in device memory and are copied.
+    KPX_SUB(kpx_depth_to_cloud(depth, xy_table, nullptr, n_px, S, 0, prm->gate, L.full_pts, nullptr, nullptr, h_i, L.op_ws, L.op_bytes, st));
     // (every operator runs on `st`: stream order alone makes the shared scratch region safe)
     KPX_SUB(kpx_depth_to_cloud(depth, xy_table, rgb, n_px, S, KPX_COMPACT_COLOR_MASK | KPX_COMPACT_DEPTH_GATE, prm->gate, L.mask_pts, L.mask_col, nullptr,
-                               L.mask_cnt, L.op_ws, L.op_bytes, st));
-    KPX_HIP(hipMemcpyAsync(h_i + 16, L.mask_cnt, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                               h_i + 16, L.op_ws, L.op_bytes, st));
     std::vector<int64_t> fk((size_t)S), mk((size_t)S), dk((size_t)S);
     // registration: voxel_down_sample(reg_voxel) of every sensor's cloud, normals of the master's, point-to-plane ICP of every sub
     std::vector<const float *> p_in((size_t)S), c_in((size_t)S);
@@ -113,10 +109,8 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     static const bool speculate = [] { const char *e = getenv("KPX_FRAME_SPECULATE"); return !(e && e[0] == '0'); }();      // A/B switch
     if (!speculate) spec_bits = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        KPX_SUB(voxel_downsample_batch_spec(S, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, L.down_cnt, L.op_ws, L.op_bytes, st,
-                                            attempt == 0 ? spec_bits : 0, L.key_bits));
-        KPX_HIP(hipMemcpyAsync(h_i + 32, L.down_cnt, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        KPX_HIP(hipMemcpyAsync(h_i + 50, L.key_bits, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KPX_SUB(voxel_downsample_batch_spec(S, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, h_i + 32, L.op_ws, L.op_bytes, st,
+                                            attempt == 0 ? spec_bits : 0, h_i + 50));
         KPX_HIP(hipStreamSynchronize(st));
         const int need = h_i[50];
         const bool narrow = attempt == 0 && spec_bits > 0 && need > spec_bits;
@@ -138,7 +132,6 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
         KPX_SUB(kpx_icp_batch(S - 1, subs.data(), dk.data() + 1, L.down_pts, plane ? L.normals : nullptr, dk[0], prm->icp_max_dist, h_init, prm->icp_mode,
                               prm->icp_max_iteration, 1e-6, 1e-6, L.icp_res, L.op_ws, L.op_bytes, st));
         // the results reach the host with the NEXT read-back: the fuse below takes the transforms from device memory, in stream order
-        KPX_HIP(hipMemcpyAsync(h_d, L.icp_res, (size_t)(S - 1) * 20 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     // fuse: pcd.transform(T_i) + np.vstack + voxel_down_sample in one fp64 pass, remove_statistical_outlier, selection
     std::vector<const double *> dT((size_t)S, nullptr);
@@ -148,8 +141,9 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     }
     KPX_SUB(fuse_voxel_downsample_dev(S, p_in.data(), c_in.data(), mk.data(), h_T, dT.data(), prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws,
                                       L.op_bytes, st));
-    KPX_HIP(hipMemcpyAsync(h_i + 48, L.vox_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    KPX_HIP(hipMemcpyAsync(h_d, L.icp_res, ((size_t)S * 20 + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
     KPX_HIP(hipStreamSynchronize(st));
+    h_i[48] = *reinterpret_cast<const int32_t *>(h_d + (size_t)S * 20);
     for (int i = 1; i < S; ++i) {
         for (int q = 0; q < 16; ++q) h_T[16 * i + q] = h_d[20 * (i - 1) + q];
         if (h_info) h_info[32 + i] = (int32_t)h_d[20 * (i - 1) + 18];
@@ -160,8 +154,7 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     *h_count = 0;
     if (M == 0) return KPX_OK;
     // filter + selection in one pass (no count read-back between them)
-    KPX_SUB(kpx_sor_select(L.vox_pts, L.vox_col, M, prm->filt_k, prm->filt_ratio, out_pts, out_col, L.keep_idx, L.keep_cnt, L.sor_stats, L.op_ws, L.op_bytes, st));
-    KPX_HIP(hipMemcpyAsync(h_i + 49, L.keep_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    KPX_SUB(kpx_sor_select(L.vox_pts, L.vox_col, M, prm->filt_k, prm->filt_ratio, out_pts, out_col, L.keep_idx, h_i + 49, L.sor_stats, L.op_ws, L.op_bytes, st));
     KPX_HIP(hipStreamSynchronize(st));
     *h_count = h_i[49];
     return KPX_OK;
