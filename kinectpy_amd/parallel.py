@@ -21,6 +21,85 @@ def collectives_on(group=None) -> bool:
     return dist.is_initialized() and (world_size(group) > 1 or FORCE_COLLECTIVES)
 
 
+class CollectiveOrder:
+    """One global order for the collectives of the frames in flight on a rank (pipeline.FrameStream with SensorShardPipeline).
+
+    Frames in flight run on host threads; which thread reaches its next collective first depends on timing, so two ranks would
+    enqueue the collectives of frames f and f + 1 in different orders.  A collective kernel spins on the device until its peers
+    arrive, and two of them -- even on different communicators -- are only safe when the device can run both at once, which
+    nothing guarantees (streams share hardware queues).  So every rank issues them in ONE fixed, software-pipelined order,
+    independent of timing: stage s (0 master broadcast, 1 cloud exchange, 2 slab all-gather) of frame f has the key
+        3 f                      for s = 0,
+        3 (f + depth - 1) + s    for s = 1, 2,
+    i.e. frame f + 1's broadcast goes before frame f's exchange (it is ready earlier: the registration lies in between), and a
+    thread may issue a collective only when every smaller key of the frames submitted so far is done.  If the next frame has not
+    been submitted yet and its broadcast key is smaller, the thread waits until the main thread either submits it or waits in
+    FrameStream.pop() for THIS frame (then the next frame cannot come before this collective on any rank: the main thread's
+    submit / pop sequence is the same program everywhere, and it cannot go on before this frame is done).  Stages a frame does
+    not use are passed with skip()."""
+
+    STAGES = 3
+
+    def __init__(self, depth: int):
+        import threading
+        self.depth = max(1, int(depth))
+        self.cv = threading.Condition()
+        self.pending = set()           # keys of submitted frames not yet done
+        self.submitted = 0
+        self.waiting_for = None        # frame the main thread waits for in pop(), else None
+        self.log = []                  # keys in the order they were issued (tests)
+
+    def key(self, frame: int, stage: int) -> int:
+        return 3 * frame if stage == 0 else 3 * (frame + self.depth - 1) + stage
+
+    def submit(self) -> int:
+        """main thread: a new frame enters; -> its frame number"""
+        with self.cv:
+            f = self.submitted
+            self.submitted += 1
+            for s_ in range(self.STAGES):
+                self.pending.add(self.key(f, s_))
+            self.cv.notify_all()
+            return f
+
+    def block(self, frame):
+        """main thread: waits for `frame` (None: the wait is over)"""
+        with self.cv:
+            self.waiting_for = frame
+            self.cv.notify_all()
+
+    def _may_go(self, k: int, frame: int) -> bool:
+        return k == min(self.pending) and (k < 3 * self.submitted or self.waiting_for == frame)
+
+    def turn(self, frame: int, stage: int):
+        order, k = self, self.key(frame, stage)
+
+        class _Turn:
+            def __enter__(self_inner):
+                with order.cv:
+                    order.cv.wait_for(lambda: order._may_go(k, frame))
+                    order.log.append(k)
+
+            def __exit__(self_inner, *exc):
+                with order.cv:
+                    order.pending.discard(k)
+                    order.cv.notify_all()
+                return False
+        return _Turn()
+
+    def skip(self, frame: int, stage: int):
+        with self.cv:
+            self.pending.discard(self.key(frame, stage))
+            self.cv.notify_all()
+
+    def finish(self, frame: int):
+        """the frame is over (also after an exception): whatever stages it did not reach are passed"""
+        with self.cv:
+            for s_ in range(self.STAGES):
+                self.pending.discard(self.key(frame, s_))
+            self.cv.notify_all()
+
+
 def init_distributed(backend: str = None) -> Tuple[int, int, int]:
     """-> (rank, world, local_rank).  Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -10,6 +10,7 @@ and, across GPUs, the exchange of parallel.py.  Everything on the device goes th
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
+import contextlib
 from typing import List, Optional
 
 import numpy as np
@@ -130,6 +131,13 @@ class SensorShardPipeline:
         self._xchg = parallel.SensorExchange(max(4096, cloud_capacity * self.k_max), self.k_max, group)     # the same on every rank
         self.transforms = None            # (len(self.sensors), 4, 4) sub -> master of the sensors this rank owns
         self.last = {}
+        self.order = None                 # (parallel.CollectiveOrder, frame number) while a FrameStream runs this step
+
+    def _turn(self, stage):
+        """the collective of `stage` in the rank's global order (FrameStream with several frames in flight), else a no-op"""
+        if self.order is None:
+            return contextlib.nullcontext()
+        return self.order[0].turn(self.order[1], stage)
 
     # -- calibration ------------------------------------------------------------------------------------------------
     def calibrate(self, depth: torch.Tensor):
@@ -147,7 +155,8 @@ class SensorShardPipeline:
         owns_master = self.sensors[0] == 0
         master = downs[0] if owns_master else None
         tn = o.estimate_normals(master, 2.0 * p.reg_voxel, p.normals_nn) if (owns_master and p.icp_mode == "p2plane") else None
-        master, tn = self._bcast(master, tn, device=fp.device)                          # collective 1 (world > 1)
+        with self._turn(0):
+            master, tn = self._bcast(master, tn, device=fp.device)                      # collective 1 (world > 1)
         subs = downs[1:] if owns_master else downs
         ids = [g for g in self.sensors if g != 0]
         Ts = [np.eye(4)] if owns_master else []
@@ -172,7 +181,8 @@ class SensorShardPipeline:
         mp, mc, _, mcnt = extracted if extracted is not None else o.depth_to_cloud(depth, self.xy, rgb, S, True, True, gate=p.gate, sync=False)
         mk = o._count(mcnt)
         local = [(mp[i, :mk[i]], mc[i, :mk[i]]) for i in range(S)]
-        segs, all_T, counts = self._xchg(local, self.transforms)                          # collective 2 (world > 1)
+        with self._turn(1):
+            segs, all_T, counts = self._xchg(local, self.transforms)                      # collective 2 (world > 1)
         owned = [len(parallel.shard_sensors(self.n_sensors, r, self.world)) for r in range(self.world)]
         Ts = np.concatenate([all_T[r, :owned[r]] for r in range(self.world)])             # sensor order
         clouds = [seg for r in range(self.world) for seg in segs[r][:owned[r]]]
@@ -187,9 +197,12 @@ class SensorShardPipeline:
             rows = -(-M // self.world)                                                    # slab r = grid-order positions [r rows, (r+1) rows)
             q0, q1 = min(M, self.rank * rows), min(M, (self.rank + 1) * rows)
             part, order = o.sor_partial(vp, p.filt_k, q0, q1)
-            slabs = parallel.allgather_slabs(part, rows, self.group)                       # collective 3
+            with self._turn(2):
+                slabs = parallel.allgather_slabs(part, rows, self.group)                   # collective 3
             keep, _, _ = o.sor_finish(slabs.reshape(-1)[:M], order, p.filt_ratio)
         else:
+            if self.order is not None:
+                self.order[0].skip(self.order[1], 2)                                       # this frame has no third collective
             keep, _, _ = o.sor(vp, p.filt_k, p.filt_ratio)
         out_p, out_c, _ = o.select_by_index([vp, vc], keep, trusted=True)
         self.last.update(n_voxel=M, n_out=int(out_p.shape[0]))
@@ -248,16 +261,28 @@ class FrameStream:
         self.pool = ThreadPoolExecutor(max_workers=self.depth)
         self.pending = deque()
         self.submitted = 0
+        # several ranks: the frames' collectives are issued in one global order on every rank (parallel.CollectiveOrder)
+        ordered = self.pipes is not None and self.depth > 1 and all(hasattr(p_, "order") for p_ in self.pipes) and \
+            parallel.collectives_on(getattr(self.pipes[0], "group", None))
+        self.order = parallel.CollectiveOrder(self.depth) if ordered else None
 
-    def _run(self, slot, depth, rgb):
+    def _run(self, slot, depth, rgb, frame=None):
         torch.cuda.set_device(self.device)
         stream = self.streams[slot]
-        with torch.cuda.stream(stream):
-            if not depth.is_cuda:                # frames handed over in pinned host memory: the copy is part of the frame
-                depth = depth.to(self.device, non_blocking=True)
-                rgb = rgb.to(self.device, non_blocking=True)
-            out = (self.pipes[slot] if self.pipes else self.pipe).step(depth, rgb)
-            stream.synchronize()                 # the outputs are consumed on the caller's stream
+        pipe = self.pipes[slot] if self.pipes else self.pipe
+        try:
+            with torch.cuda.stream(stream):
+                if not depth.is_cuda:            # frames handed over in pinned host memory: the copy is part of the frame
+                    depth = depth.to(self.device, non_blocking=True)
+                    rgb = rgb.to(self.device, non_blocking=True)
+                if frame is not None:
+                    pipe.order = (self.order, frame)
+                out = pipe.step(depth, rgb)
+                stream.synchronize()             # the outputs are consumed on the caller's stream
+        finally:
+            if frame is not None:
+                pipe.order = None
+                self.order.finish(frame)         # stages the frame did not use (or did not reach) are passed
         return out
 
     def full(self) -> bool:
@@ -268,14 +293,24 @@ class FrameStream:
         assert not self.full()
         slot = self.submitted % self.depth
         self.submitted += 1
-        self.pending.append(self.pool.submit(self._run, slot, depth, rgb))
+        frame = self.order.submit() if self.order is not None else None
+        fut = self.pool.submit(self._run, slot, depth, rgb, frame)
+        fut.frame = frame
+        self.pending.append(fut)
 
     def pop(self):
         """-> (points, colours, transforms) of the oldest frame in flight.  The tensors were allocated on the frame's side
         stream: they are handed to the caller's current stream with record_stream(), so that the caching allocator does not
         give their blocks back to the side stream (whose next frame would overwrite them) while kernels the caller queued
         asynchronously are still reading them."""
-        out = self.pending.popleft().result()
+        fut = self.pending.popleft()
+        if self.order is not None:
+            self.order.block(fut.frame)          # no frame can be submitted before this one is done: see CollectiveOrder
+        try:
+            out = fut.result()
+        finally:
+            if self.order is not None:
+                self.order.block(None)
         cur = torch.cuda.current_stream(self.device)
         for t in out:
             if isinstance(t, torch.Tensor) and t.is_cuda:

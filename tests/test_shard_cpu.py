@@ -77,3 +77,61 @@ def test_sensor_partition_equals_single_process_oracle_cpu(world, n_sensors, mod
         assert last["n_fused"] == len(aux["fused"]) and sum(last["counts"]) == last["n_fused"]
         if not (mode == "rank0" and rank != 0):
             assert last["n_voxel"] == len(aux["voxel"])
+
+
+def test_collective_order_is_the_same_on_every_rank_whatever_the_timing():
+    """parallel.CollectiveOrder: frames in flight on host threads with random delays in front of every collective, a main thread
+    that submits / pops like bench.py -- every simulated rank issues its collectives in ONE order (the software-pipelined key
+    order), including the drain at the end and a frame that skips its third collective"""
+    import random
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from kinectpy_amd.parallel import CollectiveOrder
+
+    def rank_run(seed, depth, n_frames, skip3):
+        rnd = random.Random(seed)
+        order = CollectiveOrder(depth)
+        pool = ThreadPoolExecutor(max_workers=depth)
+
+        def frame(f):
+            try:
+                for stage in range(3):
+                    time.sleep(rnd.random() * 0.004)
+                    if stage == 2 and f in skip3:
+                        order.skip(f, 2)
+                        continue
+                    with order.turn(f, stage):
+                        time.sleep(rnd.random() * 0.001)
+            finally:
+                order.finish(f)
+
+        pending = []
+        for k in range(n_frames):
+            if len(pending) >= depth:
+                f0, fut = pending.pop(0)
+                order.block(f0)
+                fut.result()
+                order.block(None)
+            time.sleep(rnd.random() * 0.003)
+            f = order.submit()
+            pending.append((f, pool.submit(frame, f)))
+        while pending:
+            f0, fut = pending.pop(0)
+            order.block(f0)
+            fut.result()
+            order.block(None)
+        pool.shutdown()
+        return order.log
+
+    import time
+    for depth in (1, 2, 3):
+        logs = []
+        ths = [threading.Thread(target=lambda s_=s_: logs.append(rank_run(s_, depth, 9, {4}))) for s_ in range(4)]
+        [t.start() for t in ths]
+        [t.join(timeout=60) for t in ths]
+        assert len(logs) == 4 and all(lg == logs[0] for lg in logs), (depth, logs)
+        o = CollectiveOrder(depth)
+        want = sorted(o.key(f, s_) for f in range(9) for s_ in range(3) if not (s_ == 2 and f == 4))
+        assert sorted(logs[0]) == want
+        if depth == 2:                       # steady state: the next frame's broadcast goes before this frame's exchange
+            assert logs[0][:6] == [o.key(0, 0), o.key(1, 0), o.key(0, 1), o.key(0, 2), o.key(2, 0), o.key(1, 1)]
