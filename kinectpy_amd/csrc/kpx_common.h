@@ -371,14 +371,16 @@ static inline bool use_onepass(int64_t tiles_total)
     static const int mode = [] { const char *e = getenv("KPX_ONEPASS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     return mode < 0 ? tiles_total <= kOnePassTiles : mode != 0;
 }
+// state_is_clear: the caller cleared ws_counts together with a neighbouring region it had to clear anyway (one memset dispatch
+// less per call; a frame is a chain of ~5 us dispatches)
 template <class Pred, class Emit>
-int compact(Pred pred, Emit emit, int64_t n, int32_t frames, int32_t *ws_counts, int32_t *d_count, hipStream_t st)
+int compact(Pred pred, Emit emit, int64_t n, int32_t frames, int32_t *ws_counts, int32_t *d_count, hipStream_t st, bool state_is_clear = false)
 {
     const int32_t tiles = (int32_t)compact_tiles(n);
     dim3 grid(tiles, frames);
     if (use_onepass((int64_t)tiles * frames)) {
         unsigned long long *state = reinterpret_cast<unsigned long long *>(ws_counts);
-        KPX_HIP(hipMemsetAsync(state, 0, (size_t)tiles * frames * sizeof(unsigned long long), st));
+        if (!state_is_clear) KPX_HIP(hipMemsetAsync(state, 0, (size_t)tiles * frames * sizeof(unsigned long long), st));
         hipLaunchKernelGGL((compact_onepass_kernel<Pred, Emit>), grid, dim3(kCompactThreads), 0, st, pred, emit, n, state, d_count);
         KPX_LAUNCH_CHECK();
         return KPX_OK;

@@ -312,8 +312,10 @@ __global__ __launch_bounds__(64) void median_select_kernel(uint32_t *__restrict_
     }
 }
 
+// clear_from: start of a region in FRONT of the histogram (carved just before this call) that the one memset of the histogram
+// shall cover too -- the fused depth path's tile states
 static int median_impl(const int16_t *v, int64_t n, int64_t stride, int64_t frame_stride, int32_t frames,
-                       double *d_median, Arena &a, hipStream_t st, const float *xy = nullptr)
+                       double *d_median, Arena &a, hipStream_t st, const float *xy = nullptr, void *clear_from = nullptr)
 {
     uint32_t *hist = a.get<uint32_t>((size_t)frames * 512);
     MedianSel *sel = a.get<MedianSel>((size_t)frames);
@@ -321,7 +323,10 @@ static int median_impl(const int16_t *v, int64_t n, int64_t stride, int64_t fram
     uint8_t *nanmask = (xy || (a.dry && n > 0)) ? a.get<uint8_t>((size_t)(n / 8 + 1)) : nullptr;
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
-    KPX_HIP(hipMemsetAsync(hist, 0, (size_t)frames * 512 * sizeof(uint32_t), st));
+    {
+        char *c0 = clear_from ? reinterpret_cast<char *>(clear_from) : reinterpret_cast<char *>(hist);
+        KPX_HIP(hipMemsetAsync(c0, 0, (size_t)(reinterpret_cast<char *>(hist + (size_t)frames * 512) - c0), st));
+    }
     const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)xy % 16 == 0);
     if (xy && vec)
         hipLaunchKernelGGL(xy_nanmask_kernel, dim3((unsigned)(cdiv(n / 8, 256) > 1024 ? 1024 : cdiv(n / 8, 256))), dim3(256), 0, st, xy, n / 8, nanmask);
@@ -639,14 +644,14 @@ __global__ __launch_bounds__(kCompactThreads) void depth_onepass_vec_kernel(cons
 
 // the 8-pixel kernels (xy == NULL: int16 XYZ image input).  counts: frames * compact_ws_ints(n) ints (the 64-bit tile words)
 static int px8_compact(const uint16_t *depth, const float *xy, const uint8_t *rgb, const double *med, int64_t n, int32_t frames, int32_t flags,
-                       double gate, int32_t *counts, float *pts, float *col, int32_t *idx, int32_t *d_count, hipStream_t st)
+                       double gate, int32_t *counts, float *pts, float *col, int32_t *idx, int32_t *d_count, hipStream_t st, bool state_is_clear = false)
 {
     const int32_t tiles = (int32_t)compact_tiles(n);
     const dim3 grid(tiles, frames), thr(kCompactThreads);
     const bool wc = col && rgb;
     const bool onepass = use_onepass((int64_t)tiles * frames);
     unsigned long long *state = reinterpret_cast<unsigned long long *>(counts);
-    if (onepass) KPX_HIP(hipMemsetAsync(state, 0, (size_t)tiles * frames * sizeof(unsigned long long), st));
+    if (onepass) { if (!state_is_clear) KPX_HIP(hipMemsetAsync(state, 0, (size_t)tiles * frames * sizeof(unsigned long long), st)); }
     else {
         hipLaunchKernelGGL(depth_count_vec_kernel, grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts);
         hipLaunchKernelGGL(compact_scan_kernel, dim3(frames), dim3(compact_scan_threads(tiles)), 0, st, counts, tiles, d_count);
@@ -674,8 +679,9 @@ static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uin
     int32_t *counts = a.get<int32_t>((size_t)frames * compact_ws_ints(n));
     double *med = a.get<double>((size_t)frames);
     int rc = KPX_OK;
-    if (flags & KPX_COMPACT_DEPTH_GATE || a.dry)
-        rc = median_impl(reinterpret_cast<const int16_t *>(depth), n, 1, n, frames, med, a, st, xy);
+    const bool gated = (flags & KPX_COMPACT_DEPTH_GATE) != 0;
+    if (gated || a.dry)          // the median's histogram clear also covers the tile states carved in front of it (counts, med)
+        rc = median_impl(reinterpret_cast<const int16_t *>(depth), n, 1, n, frames, med, a, st, xy, counts);
     if (a.dry || rc) return rc;
     KPX_ARENA_CHECK(a);
     DepthPred pred{ depth, xy, rgb, med, n, flags, gate };
@@ -683,8 +689,8 @@ static int depth_to_cloud_impl(const uint16_t *depth, const float *xy, const uin
     // algorithmic input bytes (u16 depth + rgb); outputs depend on the kept count and are added by the caller
     ProfScope prof(KPX_PROF_COMPACT, (double)frames * (double)n * (2.0 + (rgb ? 3.0 : 0.0)), st);
     const bool vec = (n % 8 == 0) && (((uintptr_t)depth | (uintptr_t)xy) % 16 == 0) && ((uintptr_t)rgb % 8 == 0);
-    if (!vec) return compact(pred, emit, n, frames, counts, d_count, st);
-    return px8_compact(depth, xy, rgb, med, n, frames, flags, gate, counts, pts, col, idx, d_count, st);
+    if (!vec) return compact(pred, emit, n, frames, counts, d_count, st, gated);
+    return px8_compact(depth, xy, rgb, med, n, frames, flags, gate, counts, pts, col, idx, d_count, st, gated);
 }
 KPX_EXPORT int kpx_rgbd_compact(const int16_t *xyz, const uint8_t *rgb, int64_t n, int32_t frames, int32_t flags,
                                 const double *d_median, double gate, float *pts, float *col, int32_t *idx,

@@ -25,7 +25,9 @@ struct Grid {
     int32_t *sorted_idx;     // device [n] original index of each sorted point
     uint32_t *sorted_keys;   // device [n] cell id of each sorted point
     int32_t *spare;          // device [16] words cleared by the build, for the caller's counters
+    int32_t *extra;          // device [kGridExtraWords] more cleared words (the tile states of a compaction that follows the search)
 };
+constexpr int kGridExtraWords = 4104;
 // Carves a Grid out of the arena (dry arenas only count bytes) and, when real, builds it on `st`.
 // target_per_cell: desired mean occupancy of non-empty cells.
 int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Grid *g, hipStream_t st);

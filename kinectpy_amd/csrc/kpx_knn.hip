@@ -136,7 +136,7 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     g->params = a.get<GridParams>(1);
     // ONE cleared region per build: [16 spare words for the caller's counters | sum of squares | counts of the first binning |
     // counts of the definitive binning] (each binning has its own counters so that nothing is cleared in between)
-    uint32_t *zero = a.get<uint32_t>(3 * ((size_t)kGridMaxCells + 1) + 32);
+    uint32_t *zero = a.get<uint32_t>(3 * ((size_t)kGridMaxCells + 1) + 32 + kGridExtraWords);
     g->cell_start = a.get<uint32_t>((size_t)kGridMaxCells + 1);
     g->sorted_pts = a.get<float>(nn * 3);
     g->sorted_idx = a.get<int32_t>(nn);
@@ -163,8 +163,9 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     while (cell_cap < kGridMaxCells && (int64_t)cell_cap < 16 * n) cell_cap <<= 1;
     g->spare = reinterpret_cast<int32_t *>(zero);
     unsigned long long *sumsq = reinterpret_cast<unsigned long long *>(zero + 16);
-    uint32_t *count1 = zero + 32, *count2 = count1 + (size_t)cell_cap + 1, *cursor = count2 + (size_t)cell_cap + 1;
-    KPX_HIP(hipMemsetAsync(zero, 0, (32 + 3 * ((size_t)cell_cap + 1)) * sizeof(uint32_t), st));
+    g->extra = reinterpret_cast<int32_t *>(zero + 32);
+    uint32_t *count1 = zero + 32 + kGridExtraWords, *count2 = count1 + (size_t)cell_cap + 1, *cursor = count2 + (size_t)cell_cap + 1;
+    KPX_HIP(hipMemsetAsync(zero, 0, (32 + kGridExtraWords + 3 * ((size_t)cell_cap + 1)) * sizeof(uint32_t), st));
     int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
     // first binning from the bounding-box heuristic, one round of occupancy feedback, then the definitive binning
     hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, bbox, target_per_cell, cell_cap, (const unsigned long long *)nullptr, g->params,
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(1024) void sor_stats_small_kernel(const double *__r
 // statistics over avg (caller's point order) + ascending keep list -- shared by kpx_sor and kpx_sor_finish, so that the
 // sharded filter folds the very same reduction tree over the very same array as the one-GPU call
 static int sor_stats_compact(const double *avg, int64_t n, double std_ratio, double *part, int32_t *counts, int32_t *keep_idx,
-                             int32_t *d_count, double *d_stats, hipStream_t st, const SorGather *ga = nullptr)
+                             int32_t *d_count, double *d_stats, hipStream_t st, const SorGather *ga = nullptr, bool state_is_clear = false)
 {
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
     if (nb <= 64) {
@@ -359,8 +360,8 @@ static int sor_stats_compact(const double *avg, int64_t n, double std_ratio, dou
         }
     }
     KPX_LAUNCH_CHECK();
-    if (ga) return compact(SorPred{ avg, d_stats }, IdxGatherEmit{ keep_idx, *ga }, n, 1, counts, d_count, st);
-    return compact(SorPred{ avg, d_stats }, IdxEmit{ keep_idx }, n, 1, counts, d_count, st);
+    if (ga) return compact(SorPred{ avg, d_stats }, IdxGatherEmit{ keep_idx, *ga }, n, 1, counts, d_count, st, state_is_clear);
+    return compact(SorPred{ avg, d_stats }, IdxEmit{ keep_idx }, n, 1, counts, d_count, st, state_is_clear);
 }
 
 __global__ __launch_bounds__(256) void sor_unsort_kernel(const double *__restrict__ avg_sorted, const int32_t *__restrict__ order, int64_t n,
@@ -424,7 +425,9 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
-    return sor_stats_compact(avg, n, std_ratio, part, counts, keep_idx, d_count, d_stats, st, ga);
+    // the grid build cleared g.extra together with its counters: the compaction's tile states live there when they fit
+    const bool fits = compact_ws_ints(n) <= kGridExtraWords;
+    return sor_stats_compact(avg, n, std_ratio, part, fits ? g.extra : counts, keep_idx, d_count, d_stats, st, ga, fits);
 }
 
 // ---- estimate_normals ---------------------------------------------------------------------------------

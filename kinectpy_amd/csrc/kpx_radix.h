@@ -162,13 +162,18 @@ static __global__ __launch_bounds__(kRxThreads) void radix_scatter_kernel(const 
 
 // keys_out / vals_out receive the pairs sorted by bits [0, end_bit) of the key (stable).  keys_in / vals_in are not modified and
 // may not alias the outputs.  n <= kRadixMaxPairs.
+// clear_end: end of a region carved right BEHIND the scratch that the sort's one memset shall clear too (the caller's tile states).
 static inline int radix_sort_pairs_u32(const RadixScratch &s, const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in, int32_t *vals_out,
-                                       int64_t n, int end_bit, hipStream_t st)
+                                       int64_t n, int end_bit, hipStream_t st, const void *clear_end = nullptr)
 {
     if (n <= 0) return KPX_OK;
     const int passes = radix_passes(end_bit);
     const int tiles = (int)radix_tiles(n), groups = (int)radix_groups(n);
-    KPX_HIP(hipMemsetAsync(s.group_hist, 0, (size_t)passes * groups * 256 * sizeof(uint32_t), st));
+    {
+        char *c0 = reinterpret_cast<char *>(s.group_hist);
+        const char *c1 = clear_end ? reinterpret_cast<const char *>(clear_end) : c0 + (size_t)passes * groups * 256 * sizeof(uint32_t);
+        KPX_HIP(hipMemsetAsync(c0, 0, (size_t)(c1 - c0), st));
+    }
     const uint32_t *k_src = keys_in;
     const int32_t *v_src = vals_in;
     for (int p = 0; p < passes; ++p) {

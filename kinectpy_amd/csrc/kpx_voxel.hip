@@ -317,6 +317,7 @@ struct VoxelBatchScratch {
     char *sort_tmp;
     size_t sort_bytes;
     RadixScratch rx;            // the hand-written sort (keys of at most 32 bits, total <= kRadixMaxPairs)
+    char *counts_end;
 };
 static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
 {
@@ -324,7 +325,6 @@ static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
     s->keys_in = a.get<uint64_t>(nn); s->keys_out = a.get<uint64_t>(nn);
     s->vals_in = a.get<int32_t>(nn); s->vals_out = a.get<int32_t>(nn);
     s->seg_start = a.get<int32_t>(nn);
-    s->counts = a.get<int32_t>((size_t)compact_ws_ints(total));
     s->err = a.get<int32_t>(kVoxelBatchMax);
     s->head = a.get<int32_t>(kVoxelBatchMax + 1);
     s->d_total = a.get<int32_t>(1);
@@ -335,6 +335,8 @@ static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
                                              (hipStream_t) nullptr);
     s->sort_tmp = a.get<char>(s->sort_bytes);
     if (total <= kRadixMaxPairs) radix_carve(a, total, &s->rx);
+    s->counts = a.get<int32_t>((size_t)compact_ws_ints(total));          // right behind the sort's cleared histograms: one memset for both
+    s->counts_end = reinterpret_cast<char *>(s->counts + (size_t)compact_ws_ints(total));
 }
 // spec_bits > 0 (frame loop): the key width is NOT read back -- the sort covers spec_bits bits and *d_bits receives the width the
 // batch really needs; the caller compares the two after its own read-back of the counts and repeats the call with spec_bits = 0
@@ -373,13 +375,15 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
         uint32_t *k_in = reinterpret_cast<uint32_t *>(s.keys_in), *k_out = reinterpret_cast<uint32_t *>(s.keys_out);
         hipLaunchKernelGGL(voxel_batch_key_kernel<uint32_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, k_in, s.vals_in, s.err);
         static const bool vendor_sort = [] { const char *e = getenv("KPX_RADIX"); return e && e[0] == '0'; }();       // A/B switch
+        bool cleared = false;
         if (total <= kRadixMaxPairs && !vendor_sort) {
-            rc = radix_sort_pairs_u32(s.rx, k_in, k_out, s.vals_in, s.vals_out, total, end_bit, st);
+            rc = radix_sort_pairs_u32(s.rx, k_in, k_out, s.vals_in, s.vals_out, total, end_bit, st, s.counts_end);
             if (rc) return rc;
+            cleared = true;
         } else {
             KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, k_in, k_out, s.vals_in, s.vals_out, (int)total, 0, end_bit, st));
         }
-        rc = compact(HeadPredT<uint32_t>{ k_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st);
+        rc = compact(HeadPredT<uint32_t>{ k_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st, cleared);
     } else {
         hipLaunchKernelGGL(voxel_batch_key_kernel<uint64_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err);
         KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, end_bit, st));
