@@ -253,8 +253,8 @@ def roofline_targets(torch, ops, quick=False):
     ms, res = ev_timed(torch, lambda: ops.depth_to_cloud(depth, xyd, rgb, F, True, True, sync=False))
     kept = int(res[3].sum().item())
     hbm("depth_to_cloud, mask + gate + colour (a1+a3+a4)", "depth_* + median_*", ms, F * N_PX * 5 + kept * 24, frames=F, kept=kept)
-    ms, res = ev_timed(torch, lambda: ops.rgbd_compact(xyz, rgb, F, True, True, want_idx=False), reps=3, warm=1)
-    kept = sum(int(r[0].shape[0]) for r in res)
+    ms, res = ev_timed(torch, lambda: ops.rgbd_compact(xyz, rgb, F, True, True, want_idx=False, sync=False), reps=3, warm=1)
+    kept = int(res[3].sum().item())
     hbm("rgbd_compact from int16 XYZ (a3+a4)", "compact_*", ms, F * N_PX * 9 + kept * 24, frames=F, kept=kept)
     del depth, rgb, xyz, res
     # ---- HBM: container operators on 64M points (0.77 GB)

@@ -56,9 +56,10 @@ def median_i16(v, n, stride, frames=1):
     return out
 
 
-def rgbd_compact(xyz, rgb=None, frames=1, color_mask=False, depth_gate=False, gate=GATE_MM, want_idx=True):
+def rgbd_compact(xyz, rgb=None, frames=1, color_mask=False, depth_gate=False, gate=GATE_MM, want_idx=True, sync=True):
     """a3 (+a4).  xyz int16 [frames, n, 3]; rgb u8 [frames, n, 3] or None.
-    Returns per-frame lists (points f32 (K,3), colours f32 (K,3)|None, idx i32 (K)|None)."""
+    Returns per-frame lists (points f32 (K,3), colours f32 (K,3)|None, idx i32 (K)|None) or, with sync=False, the padded buffers
+    and the device count tensor (no host round trip)."""
     lib = L.load()
     xyz = _dev(xyz, torch.int16).reshape(frames, -1, 3)
     n = xyz.shape[1]
@@ -73,6 +74,8 @@ def rgbd_compact(xyz, rgb=None, frames=1, color_mask=False, depth_gate=False, ga
     ws, wsz = L.workspace(lib.kpx_compact_workspace_bytes(n, frames))
     L.check(lib.kpx_rgbd_compact(L.ptr(xyz), L.ptr(rgb_t), n, frames, flags, L.ptr(med), float(gate), L.ptr(pts),
                                  L.ptr(col), L.ptr(idx), L.ptr(cnt), ws, wsz, L.stream_ptr()))
+    if not sync:
+        return pts, col, idx, cnt
     ks = _count(cnt)
     return [(pts[f, :k], col[f, :k] if col is not None else None, idx[f, :k] if idx is not None else None)
             for f, k in enumerate(ks)]

@@ -70,8 +70,8 @@ def main():
     ms, res = timed(lambda: ops.depth_to_cloud(depth, xyd, rgb, F, True, True, sync=False))
     kept = int(res[3].sum().item())
     report("depth_to_cloud mask+gate+colour (a1+a3+a4)", ms, F * N_PX * 5 + kept * 24, frames=F, kept=kept)
-    ms, res = timed(lambda: ops.rgbd_compact(xyz, rgb, F, True, True, want_idx=False))
-    kept = sum(int(r[0].shape[0]) for r in res)
+    ms, res = timed(lambda: ops.rgbd_compact(xyz, rgb, F, True, True, want_idx=False, sync=False))
+    kept = int(res[3].sum().item())
     report("rgbd_compact from int16 XYZ (a3+a4)", ms, F * N_PX * 9 + kept * 24, frames=F, kept=kept)
     del depth, rgb, xyz, res
 
