@@ -105,12 +105,16 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     // The sort-key width of the registration voxel grid is speculated from the last frame of this thread (the scene's extent in
     // voxels barely changes from frame to frame): its read-back inside the call is one host round trip less; a frame that needs
     // more bits is detected with the counts and done again the careful way.
+    // The registration clouds leave the voxel grid along the Z-curve of their voxel indices (one point per voxel: the order the
+    // culled search would otherwise establish with a Morton sort of its own -- 12 dispatches per frame); nothing downstream depends
+    // on their order: normals and nearest neighbours are per point, the update sums are exact.  KPX_FRAME_ZORDER=0: A/B switch.
+    static const bool zorder = [] { const char *e = getenv("KPX_FRAME_ZORDER"); return !(e && e[0] == '0'); }();
     static thread_local int spec_bits = 0;
     static const bool speculate = [] { const char *e = getenv("KPX_FRAME_SPECULATE"); return !(e && e[0] == '0'); }();      // A/B switch
     if (!speculate) spec_bits = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         KPX_SUB(voxel_downsample_batch_spec(S, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, h_i + 32, L.op_ws, L.op_bytes, st,
-                                            attempt == 0 ? spec_bits : 0, h_i + 50));
+                                            attempt == 0 ? spec_bits : 0, h_i + 50, zorder));
         KPX_HIP(hipStreamSynchronize(st));
         const int need = h_i[50];
         const bool narrow = attempt == 0 && spec_bits > 0 && need > spec_bits;
@@ -129,8 +133,8 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
             KPX_REQUIRE(dk[(size_t)i] >= 1 && dk[0] >= 1, "kpx_frame_step: sensor %d has no valid pixel", dk[0] >= 1 ? i : 0);
             subs[(size_t)i - 1] = p_out[(size_t)i];
         }
-        KPX_SUB(kpx_icp_batch(S - 1, subs.data(), dk.data() + 1, L.down_pts, plane ? L.normals : nullptr, dk[0], prm->icp_max_dist, h_init, prm->icp_mode,
-                              prm->icp_max_iteration, 1e-6, 1e-6, L.icp_res, L.op_ws, L.op_bytes, st));
+        KPX_SUB(icp_batch_ordered(S - 1, subs.data(), dk.data() + 1, L.down_pts, plane ? L.normals : nullptr, dk[0], prm->icp_max_dist, h_init, prm->icp_mode,
+                                  prm->icp_max_iteration, 1e-6, 1e-6, L.icp_res, L.op_ws, L.op_bytes, st, zorder));
         // the results reach the host with the NEXT read-back: the fuse below takes the transforms from device memory, in stream order
     }
     // fuse: pcd.transform(T_i) + np.vstack + voxel_down_sample in one fp64 pass, remove_statistical_outlier, selection

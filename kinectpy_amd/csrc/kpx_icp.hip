@@ -1916,6 +1916,13 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
                              int32_t max_iteration, double relative_fitness, double relative_rmse, double *d_results, void *ws,
                              size_t ws_bytes, void *stream)
 {
+    return kpx::icp_batch_ordered(count, h_src, h_n_src, tgt, tgt_normals, n_tgt, max_dist, h_init, mode, max_iteration, relative_fitness, relative_rmse,
+                                  d_results, ws, ws_bytes, stream, false);
+}
+int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
+                           double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness, double relative_rmse,
+                           double *d_results, void *ws, size_t ws_bytes, void *stream, bool presorted)
+{
     KPX_REQUIRE(count >= 1 && count <= 64 && h_src && h_n_src, "kpx_icp_batch: bad batch");
     KPX_REQUIRE(mode == KPX_ICP_POINT_TO_POINT || mode == KPX_ICP_POINT_TO_PLANE, "kpx_icp: unknown estimation mode");
     KPX_REQUIRE(mode != KPX_ICP_POINT_TO_PLANE || tgt_normals,
@@ -1972,7 +1979,7 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
             mb.bbox[c] = !on ? nullptr : (c == 0 ? bufs[0].sort_t.bbox : bufs[c - 1].sort_s.bbox);
             mb.off[c + 1] = mb.off[c] + (!on ? 0 : (c == 0 ? n_tgt : h_n_src[c - 1]));
         }
-        rc = morton_order_batch(mb, ms, st);
+        rc = morton_order_batch(mb, ms, st, presorted);
         if (rc) return rc;
     }
     rc = nn_prep(tgt, tplan, bufs[0], st, ordered);

@@ -49,15 +49,23 @@ int lanes_join(LaneSet *l, hipStream_t caller, int used);
 // kpx_voxel_downsample_batch with a speculated sort-key width (kpx_frame_step): spec_bits > 0 skips the width's read-back (one host
 // round trip per call); *d_bits receives the width the batch needs (0 = the call did not speculate) and the caller repeats the call
 // with spec_bits = 0 when that is larger than spec_bits.  spec_bits = 0, d_bits = NULL: the exported behaviour.
+// morton: the voxels of every cloud leave in Morton (Z-curve) order of their grid indices instead of ascending (ix, iy, iz) -- same
+// voxels, same means; for consumers that only need SOME spatially coherent order (the registration inside kpx_frame_step).
 int voxel_downsample_batch_spec(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n, double voxel,
                                 float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws, size_t ws_bytes, void *stream,
-                                int spec_bits, int32_t *d_bits);
+                                int spec_bits, int32_t *d_bits, bool morton = false);
 
 // kpx_fuse_voxel_downsample whose transforms may live in device memory: h_dT[i] non-null = cloud i's row-major 4x4 is read there
 // (h_T[16 i ..] is then ignored); h_dT == NULL: the exported behaviour.
 int fuse_voxel_downsample_dev(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n, const double *h_T,
                               const double *const *h_dT, double voxel, float *opts, float *ocol, int32_t *d_count, void *ws, size_t ws_bytes,
                               void *stream);
+
+// kpx_icp_batch for clouds that already lie along a space-filling curve (presorted = true: no Morton sort inside; the culled
+// search's tiles are then 16 consecutive points of the caller's order).  presorted = false: the exported behaviour.
+int icp_batch_ordered(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
+                      double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness, double relative_rmse,
+                      double *d_results, void *ws, size_t ws_bytes, void *stream, bool presorted);
 
 // Column tiles (16 rows x 16 columns, 2048 flops each) the culled nearest-neighbour sweep has multiplied since the
 // last call; resets the device counter (kpx_icp.hip).

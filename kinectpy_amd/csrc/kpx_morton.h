@@ -218,12 +218,26 @@ static __global__ __launch_bounds__(256) void morton_batch_split_kernel(MortonBa
     const int c = morton_batch_cloud(b, i);          // sorted position i lies in cloud c's range
     b.perm[c][i - b.off[c]] = vals[i] - (int32_t)b.off[c];
 }
-static int morton_order_batch(const MortonBatch &b, const MortonBatchScratch &s, hipStream_t st)
+static __global__ __launch_bounds__(256) void morton_batch_iota_kernel(MortonBatch b)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.off[b.count]) return;
+    const int c = morton_batch_cloud(b, i);
+    b.perm[c][i - b.off[c]] = (int32_t)(i - b.off[c]);
+}
+// presorted: the caller's clouds already lie along a space-filling curve (the frame loop's voxel clouds, kpx_voxel.hip): the boxes
+// are computed, the permutations are the identity, and the key / sort / split launches (12 of the 14) are skipped
+static int morton_order_batch(const MortonBatch &b, const MortonBatchScratch &s, hipStream_t st, bool presorted = false)
 {
     const int64_t total = b.off[b.count];
     hipLaunchKernelGGL(morton_batch_bbox_partial_kernel, dim3(kMortonBatchBboxBlocks, b.count), dim3(256), 0, st, b, s.part);
     hipLaunchKernelGGL(morton_batch_bbox_final_kernel, dim3(b.count), dim3(64), 0, st, b, s.part);
     const unsigned nb = (unsigned)cdiv(total, 256);
+    if (presorted) {
+        hipLaunchKernelGGL(morton_batch_iota_kernel, dim3(nb), dim3(256), 0, st, b);
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
     hipLaunchKernelGGL(morton_batch_key_kernel, dim3(nb), dim3(256), 0, st, b, s.keys_in, s.vals_in);
     size_t bytes = s.tmp_bytes;
     KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, 34, st));

@@ -141,7 +141,23 @@ struct VoxelBatch {
     float *ocol[kVoxelBatchMax];
     int64_t off[kVoxelBatchMax + 1];      // cloud c owns [off[c], off[c+1]) of the concatenated index space
     int32_t count;
+    int32_t morton;                       // keys = cloud | Z-curve code of (ix, iy, iz) instead of cloud | (ix, iy, iz) row-major
 };
+// bits per axis of the Z-curve code: enough for the largest extent of the batch
+__device__ __forceinline__ int voxel_batch_axis_bits(const double d[3])
+{
+    const unsigned long long m = (unsigned long long)fmax(d[0], fmax(d[1], d[2])) - 1ull;      // largest index
+    int n = 1;
+    while (n < 21 && (m >> n) != 0ull) ++n;
+    return n;
+}
+__device__ __forceinline__ unsigned long long voxel_zcode(unsigned long long x, unsigned long long y, unsigned long long z, int bits)
+{
+    unsigned long long k = 0ull;
+    for (int q = 0; q < bits; ++q)
+        k |= (((x >> q) & 1ull) << (3 * q)) | (((y >> q) & 1ull) << (3 * q + 1)) | (((z >> q) & 1ull) << (3 * q + 2));
+    return k;
+}
 __device__ __forceinline__ int voxel_batch_cloud(const VoxelBatch &b, int64_t i)
 {
     int c = 0;
@@ -206,7 +222,12 @@ __global__ void voxel_batch_bits_kernel(VoxelBatch b, const double *__restrict__
     int overflow;
     voxel_batch_dims(b, bbox, voxel, d, &overflow);
     int n = 64;
-    if (!overflow) {
+    if (!overflow && b.morton) {
+        int cb = 0;
+        while ((1 << cb) < b.count) ++cb;
+        n = 3 * voxel_batch_axis_bits(d) + cb;
+        n = n < 1 ? 1 : (n > 64 ? 64 : n);
+    } else if (!overflow) {
         const unsigned long long range = (((unsigned long long)b.count * (unsigned long long)d[0]) * (unsigned long long)d[1]) * (unsigned long long)d[2];
         n = 1;
         while (n < 64 && (range >> n) != 0ull) ++n;
@@ -218,13 +239,16 @@ __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, cons
                                                               Key *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ err)
 {
     __shared__ double dims[3];
-    __shared__ int overflow;
+    __shared__ int overflow, axis_bits;
     if (threadIdx.x == 0) {
         double d[3];
         int ov;
         voxel_batch_dims(b, bbox, voxel, d, &ov);
         dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
-        overflow = ov;
+        axis_bits = voxel_batch_axis_bits(d);
+        int cb = 0;
+        while ((1 << cb) < b.count) ++cb;
+        overflow = (ov || (b.morton && 3 * axis_bits + cb > 64)) ? 1 : 0;
     }
     __syncthreads();
     const uint64_t DX = (uint64_t)dims[0], DY = (uint64_t)dims[1], DZ = (uint64_t)dims[2];
@@ -239,7 +263,8 @@ __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, cons
         double fz = floor(((double)pts[3 * j + 2] - oz) / voxel);
         const bool bad = overflow || !(fx >= 0.0) || !(fy >= 0.0) || !(fz >= 0.0) || fx >= 2097152.0 || fy >= 2097152.0 || fz >= 2097152.0;
         if (bad) { err[c] = 1; fx = fy = fz = 0.0; }
-        keys[i] = (Key)((((uint64_t)c * DX + (uint64_t)fx) * DY + (uint64_t)fy) * DZ + (uint64_t)fz);
+        if (b.morton) keys[i] = (Key)(((uint64_t)c << (3 * axis_bits)) | voxel_zcode((uint64_t)fx, (uint64_t)fy, (uint64_t)fz, axis_bits));
+        else keys[i] = (Key)((((uint64_t)c * DX + (uint64_t)fx) * DY + (uint64_t)fy) * DZ + (uint64_t)fz);
         vals[i] = (int32_t)i;
     }
 }
@@ -659,11 +684,11 @@ KPX_EXPORT int kpx_voxel_downsample_batch(int32_t count, const float *const *h_p
                                           double voxel, float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws,
                                           size_t ws_bytes, void *stream)
 {
-    return kpx::voxel_downsample_batch_spec(count, h_pts, h_col, h_n, voxel, h_opts, h_ocol, d_counts, ws, ws_bytes, stream, 0, nullptr);
+    return kpx::voxel_downsample_batch_spec(count, h_pts, h_col, h_n, voxel, h_opts, h_ocol, d_counts, ws, ws_bytes, stream, 0, nullptr, false);
 }
 int kpx::voxel_downsample_batch_spec(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n, double voxel,
                                      float *const *h_opts, float *const *h_ocol, int32_t *d_counts, void *ws, size_t ws_bytes, void *stream,
-                                     int spec_bits, int32_t *d_bits)
+                                     int spec_bits, int32_t *d_bits, bool morton)
 {
     KPX_REQUIRE(voxel > 0.0, "voxel_size <= 0");
     KPX_REQUIRE(count >= 1 && count <= 64 && h_pts && h_n && h_opts && d_counts && ws, "kpx_voxel_downsample_batch: bad arguments");
@@ -673,9 +698,12 @@ int kpx::voxel_downsample_batch_spec(int32_t count, const float *const *h_pts, c
     hipStream_t st = (hipStream_t)stream;
     int64_t total = 0;
     for (int i = 0; i < count; ++i) total += h_n[i];
+    // (the Z-curve order exists in the one-pass form only; the other forms keep the row-major order -- callers that asked for it only
+    // lose locality, never correctness)
     if (count <= kVoxelBatchMax && total > 0 && total < ((int64_t)1 << 31)) {         // one pass over the concatenated clouds
         VoxelBatch b;
         b.count = count;
+        b.morton = morton ? 1 : 0;
         b.off[0] = 0;
         for (int i = 0; i < kVoxelBatchMax; ++i) {
             const bool on = i < count;
@@ -703,6 +731,7 @@ int kpx::voxel_downsample_batch_spec(int32_t count, const float *const *h_pts, c
                 const int gc = count - g0 < kVoxelBatchMax ? count - g0 : kVoxelBatchMax;
                 VoxelBatch b;
                 b.count = gc;
+                b.morton = 0;
                 b.off[0] = 0;
                 for (int i = 0; i < kVoxelBatchMax; ++i) {
                     const bool on = i < gc;

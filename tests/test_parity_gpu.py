@@ -1378,7 +1378,10 @@ def test_native_frame_step_equals_python_pipeline_and_oracle(four_sensor_oracle)
     for f in range(2):
         gp, gc, gT = nat.step(d[f], c[f])
         pp, pc, pT = py.step(d[f], c[f])
-        assert torch.equal(gp, pp) and torch.equal(gc, pc) and np.array_equal(gT, pT)
+        # same clouds; the transforms agree to the last bits only: the native loop hands the registration clouds over in Z-curve
+        # order (no Morton sort inside the ICP), so a block's 64 rows -- whose fp64 partial sums feed the exact accumulators -- are
+        # other rows than in the Python pipeline
+        assert torch.equal(gp, pp) and torch.equal(gc, pc) and np.abs(gT - pT).max() < 1e-11
         assert nat.last["n_down"] == py.last["n_down"] and nat.last["n_voxel"] == py.last["n_voxel"]
         assert [s[0] for s in nat.last["icp"]] == [s[0] for s in py.last["icp"]]
         rp, rc, rT, _ = ref[f]
@@ -1403,7 +1406,7 @@ def test_native_frame_step_equals_python_pipeline_and_oracle(four_sensor_oracle)
         prm = PipelineParams(reg_voxel=voxel)
         gp, gc, gT = NativeFramePipeline(xy, 4, inits, prm).step(d[0], c[0])
         pp, pc, pT = SensorShardPipeline(xy, 4, inits, prm).step(d[0], c[0])
-        assert torch.equal(gp, pp) and torch.equal(gc, pc) and np.array_equal(gT, pT), voxel
+        assert torch.equal(gp, pp) and torch.equal(gc, pc) and np.abs(gT - pT).max() < 1e-11, voxel
 
 
 def test_sor_and_normals_with_thousands_of_duplicates(ops, oracle, base_cloud):
