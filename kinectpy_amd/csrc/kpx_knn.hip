@@ -324,9 +324,16 @@ __global__ __launch_bounds__(1024) void sor_stats_small_kernel(const double *__r
             const int b = b0 + vb;
             double acc = 0.0;
             if (b < nb)
-                for (int64_t i = (int64_t)b * 256 + t; i < n; i += (int64_t)nb * 256) {
-                    const double v = avg[i];
-                    if (v > 0.0) acc += pass ? (v - mean) * (v - mean) : v;
+                for (int64_t i0 = (int64_t)b * 256 + t; i0 < n; i0 += 8 * (int64_t)nb * 256) {      // 8 loads in flight, added in the same order
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t i = i0 + (int64_t)u * nb * 256;
+                        v[u] = i < n ? avg[i] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (v[u] > 0.0) acc += pass ? (v[u] - mean) * (v[u] - mean) : v[u];
                 }
             // block_sum of a 256-thread block: wave sums, then the four waves in order
             acc = wave_sum(acc);

@@ -143,19 +143,29 @@ struct VoxelBatch {
     int32_t count;
     int32_t morton;                       // keys = cloud | Z-curve code of (ix, iy, iz) instead of cloud | (ix, iy, iz) row-major
 };
-// bits per axis of the Z-curve code: enough for the largest extent of the batch
-__device__ __forceinline__ int voxel_batch_axis_bits(const double d[3])
+// bits of the Z-curve code per axis: enough for the axis' largest index in the batch.  The code interleaves bit q of every axis that
+// still has a bit q (x lowest), so its width is the SUM of the three widths -- a long axis costs its own extra bits only, not
+// three times them (a frame's 26-bit cube code would be a fourth radix pass; 7 + 7 + 8 bits + 2 for the cloud stay within three)
+__device__ __forceinline__ void voxel_batch_axis_bits(const double d[3], int bits[3])
 {
-    const unsigned long long m = (unsigned long long)fmax(d[0], fmax(d[1], d[2])) - 1ull;      // largest index
-    int n = 1;
-    while (n < 21 && (m >> n) != 0ull) ++n;
-    return n;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const unsigned long long m = (unsigned long long)d[a] - 1ull;          // largest index
+        int n = 1;
+        while (n < 21 && (m >> n) != 0ull) ++n;
+        bits[a] = n;
+    }
 }
-__device__ __forceinline__ unsigned long long voxel_zcode(unsigned long long x, unsigned long long y, unsigned long long z, int bits)
+__device__ __forceinline__ unsigned long long voxel_zcode(unsigned long long x, unsigned long long y, unsigned long long z, const int bits[3])
 {
     unsigned long long k = 0ull;
-    for (int q = 0; q < bits; ++q)
-        k |= (((x >> q) & 1ull) << (3 * q)) | (((y >> q) & 1ull) << (3 * q + 1)) | (((z >> q) & 1ull) << (3 * q + 2));
+    int o = 0;
+    const int top = bits[0] > bits[1] ? (bits[0] > bits[2] ? bits[0] : bits[2]) : (bits[1] > bits[2] ? bits[1] : bits[2]);
+    for (int q = 0; q < top; ++q) {
+        if (q < bits[0]) k |= ((x >> q) & 1ull) << o++;
+        if (q < bits[1]) k |= ((y >> q) & 1ull) << o++;
+        if (q < bits[2]) k |= ((z >> q) & 1ull) << o++;
+    }
     return k;
 }
 __device__ __forceinline__ int voxel_batch_cloud(const VoxelBatch &b, int64_t i)
@@ -223,9 +233,10 @@ __global__ void voxel_batch_bits_kernel(VoxelBatch b, const double *__restrict__
     voxel_batch_dims(b, bbox, voxel, d, &overflow);
     int n = 64;
     if (!overflow && b.morton) {
-        int cb = 0;
+        int cb = 0, ab[3];
         while ((1 << cb) < b.count) ++cb;
-        n = 3 * voxel_batch_axis_bits(d) + cb;
+        voxel_batch_axis_bits(d, ab);
+        n = ab[0] + ab[1] + ab[2] + cb;
         n = n < 1 ? 1 : (n > 64 ? 64 : n);
     } else if (!overflow) {
         const unsigned long long range = (((unsigned long long)b.count * (unsigned long long)d[0]) * (unsigned long long)d[1]) * (unsigned long long)d[2];
@@ -239,16 +250,17 @@ __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, cons
                                                               Key *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ err)
 {
     __shared__ double dims[3];
-    __shared__ int overflow, axis_bits;
+    __shared__ int overflow, axis_bits[3];
     if (threadIdx.x == 0) {
         double d[3];
         int ov;
         voxel_batch_dims(b, bbox, voxel, d, &ov);
         dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
-        axis_bits = voxel_batch_axis_bits(d);
-        int cb = 0;
+        int ab[3], cb = 0;
+        voxel_batch_axis_bits(d, ab);
+        axis_bits[0] = ab[0]; axis_bits[1] = ab[1]; axis_bits[2] = ab[2];
         while ((1 << cb) < b.count) ++cb;
-        overflow = (ov || (b.morton && 3 * axis_bits + cb > 64)) ? 1 : 0;
+        overflow = (ov || (b.morton && ab[0] + ab[1] + ab[2] + cb > 64)) ? 1 : 0;
     }
     __syncthreads();
     const uint64_t DX = (uint64_t)dims[0], DY = (uint64_t)dims[1], DZ = (uint64_t)dims[2];
@@ -263,7 +275,10 @@ __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, cons
         double fz = floor(((double)pts[3 * j + 2] - oz) / voxel);
         const bool bad = overflow || !(fx >= 0.0) || !(fy >= 0.0) || !(fz >= 0.0) || fx >= 2097152.0 || fy >= 2097152.0 || fz >= 2097152.0;
         if (bad) { err[c] = 1; fx = fy = fz = 0.0; }
-        if (b.morton) keys[i] = (Key)(((uint64_t)c << (3 * axis_bits)) | voxel_zcode((uint64_t)fx, (uint64_t)fy, (uint64_t)fz, axis_bits));
+        if (b.morton) {
+            const int ab[3] = { axis_bits[0], axis_bits[1], axis_bits[2] };
+            keys[i] = (Key)(((uint64_t)c << (ab[0] + ab[1] + ab[2])) | voxel_zcode((uint64_t)fx, (uint64_t)fy, (uint64_t)fz, ab));
+        }
         else keys[i] = (Key)((((uint64_t)c * DX + (uint64_t)fx) * DY + (uint64_t)fy) * DZ + (uint64_t)fz);
         vals[i] = (int32_t)i;
     }
