@@ -285,21 +285,25 @@ struct IdxEmit {
     int32_t *idx;
     __device__ void operator()(int64_t i, int, int32_t dst) const { idx[dst] = (int32_t)i; }
 };
-// keep list AND the kept rows of up to two (n,3) attribute arrays: `cl, ind = remove_statistical_outlier(...)` in one pass
+// keep list AND the kept rows of up to two (n,3) attribute arrays: `cl, ind = remove_statistical_outlier(...)` without a host round trip
 struct SorGather {
     const float *a0, *a1;
     float *o0, *o1;
 };
-struct IdxGatherEmit {
-    int32_t *idx;
-    SorGather g;
-    __device__ void operator()(int64_t i, int, int32_t dst) const
-    {
-        idx[dst] = (int32_t)i;
-        if (g.a0) { g.o0[3 * (int64_t)dst] = g.a0[3 * i]; g.o0[3 * (int64_t)dst + 1] = g.a0[3 * i + 1]; g.o0[3 * (int64_t)dst + 2] = g.a0[3 * i + 2]; }
-        if (g.a1) { g.o1[3 * (int64_t)dst] = g.a1[3 * i]; g.o1[3 * (int64_t)dst + 1] = g.a1[3 * i + 1]; g.o1[3 * (int64_t)dst + 2] = g.a1[3 * i + 2]; }
+// the kept rows, gathered by a launch of its own whose length is read on the DEVICE (the keep list's count): inside the compaction's
+// emit the eight items of a thread gathered one after the other (17 us for 23k points against 6 + 4 for compaction + this kernel)
+// d_count: in device memory (every thread reads it); count_out: the caller's count word, which may be host-visible pinned memory
+__global__ __launch_bounds__(256) void sor_gather_kernel(SorGather g, const int32_t *__restrict__ idx, const int32_t *__restrict__ d_count,
+                                                         int32_t *__restrict__ count_out)
+{
+    const int64_t n = *d_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = (int32_t)n;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = idx[k];
+        if (g.a0) { g.o0[3 * k] = g.a0[3 * s]; g.o0[3 * k + 1] = g.a0[3 * s + 1]; g.o0[3 * k + 2] = g.a0[3 * s + 2]; }
+        if (g.a1) { g.o1[3 * k] = g.a1[3 * s]; g.o1[3 * k + 1] = g.a1[3 * s + 1]; g.o1[3 * k + 2] = g.a1[3 * s + 2]; }
     }
-};
+}
 
 static int sor_block_threads(int k)
 {
@@ -367,8 +371,13 @@ static int sor_stats_compact(const double *avg, int64_t n, double std_ratio, dou
         }
     }
     KPX_LAUNCH_CHECK();
-    if (ga) return compact(SorPred{ avg, d_stats }, IdxGatherEmit{ keep_idx, *ga }, n, 1, counts, d_count, st, state_is_clear);
-    return compact(SorPred{ avg, d_stats }, IdxEmit{ keep_idx }, n, 1, counts, d_count, st, state_is_clear);
+    int32_t *dev_count = reinterpret_cast<int32_t *>(part + 1023);              // the gather reads the count on the device
+    const int rc = compact(SorPred{ avg, d_stats }, IdxEmit{ keep_idx }, n, 1, counts, ga ? dev_count : d_count, st, state_is_clear);
+    if (rc || !ga) return rc;
+    const int64_t gb = cdiv(n, 256);
+    hipLaunchKernelGGL(sor_gather_kernel, dim3((unsigned)(gb < 1 ? 1 : (gb > 4096 ? 4096 : gb))), dim3(256), 0, st, *ga, keep_idx, dev_count, d_count);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
 }
 
 __global__ __launch_bounds__(256) void sor_unsort_kernel(const double *__restrict__ avg_sorted, const int32_t *__restrict__ order, int64_t n,
