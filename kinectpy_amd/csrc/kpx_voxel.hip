@@ -226,11 +226,8 @@ __device__ __forceinline__ void voxel_batch_dims(const VoxelBatch &b, const doub
 }
 // bits the keys of this batch occupy: batches above rocPRIM's merge-sort limit are sorted by Onesweep, one pass per 8 bits --
 // a 4-sensor frame needs ~24 of the 64
-__global__ void voxel_batch_bits_kernel(VoxelBatch b, const double *__restrict__ bbox, double voxel, int32_t *__restrict__ bits)
+__device__ __forceinline__ int voxel_batch_key_bits(const VoxelBatch &b, const double d[3], int overflow)
 {
-    double d[3];
-    int overflow;
-    voxel_batch_dims(b, bbox, voxel, d, &overflow);
     int n = 64;
     if (!overflow && b.morton) {
         int cb = 0, ab[3];
@@ -243,11 +240,19 @@ __global__ void voxel_batch_bits_kernel(VoxelBatch b, const double *__restrict__
         n = 1;
         while (n < 64 && (range >> n) != 0ull) ++n;
     }
-    *bits = n;
+    return n;
+}
+__global__ void voxel_batch_bits_kernel(VoxelBatch b, const double *__restrict__ bbox, double voxel, int32_t *__restrict__ bits)
+{
+    double d[3];
+    int overflow;
+    voxel_batch_dims(b, bbox, voxel, d, &overflow);
+    *bits = voxel_batch_key_bits(b, d, overflow);
 }
 template <class Key>
 __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, const double *__restrict__ bbox, double voxel,
-                                                              Key *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ err)
+                                                              Key *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ err,
+                                                              int32_t *__restrict__ bits_out)
 {
     __shared__ double dims[3];
     __shared__ int overflow, axis_bits[3];
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, cons
         double d[3];
         int ov;
         voxel_batch_dims(b, bbox, voxel, d, &ov);
+        if (bits_out && blockIdx.x == 0) *bits_out = voxel_batch_key_bits(b, d, ov);      // speculated width: the caller checks it afterwards
         dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
         int ab[3], cb = 0;
         voxel_batch_axis_bits(d, ab);
@@ -392,8 +398,9 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
     hipLaunchKernelGGL(voxel_batch_bbox_final_kernel, dim3(b.count), dim3(64), 0, st, s.part, s.bbox, s.err);
     const int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
     int end_bit = 64;
+    int32_t *bits_out = nullptr;
     if (spec_bits > 0 && d_bits) {
-        hipLaunchKernelGGL(voxel_batch_bits_kernel, dim3(1), dim3(1), 0, st, b, s.bbox, voxel, d_bits);
+        bits_out = d_bits;                               // written by the key kernel itself
         end_bit = spec_bits > 64 ? 64 : spec_bits;
     } else if (total > (int64_t)1024 * 1024) {
         // above rocPRIM's merge-sort limit the sort is an Onesweep with one pass per 8 key bits: reading the width back (one
@@ -413,7 +420,7 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
     int rc;
     if (end_bit <= 32) {
         uint32_t *k_in = reinterpret_cast<uint32_t *>(s.keys_in), *k_out = reinterpret_cast<uint32_t *>(s.keys_out);
-        hipLaunchKernelGGL(voxel_batch_key_kernel<uint32_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, k_in, s.vals_in, s.err);
+        hipLaunchKernelGGL(voxel_batch_key_kernel<uint32_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, k_in, s.vals_in, s.err, bits_out);
         static const bool vendor_sort = [] { const char *e = getenv("KPX_RADIX"); return e && e[0] == '0'; }();       // A/B switch
         bool cleared = false;
         if (total <= kRadixMaxPairs && !vendor_sort) {
@@ -425,7 +432,7 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
         }
         rc = compact(HeadPredT<uint32_t>{ k_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st, cleared);
     } else {
-        hipLaunchKernelGGL(voxel_batch_key_kernel<uint64_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err);
+        hipLaunchKernelGGL(voxel_batch_key_kernel<uint64_t>, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err, bits_out);
         KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, end_bit, st));
         rc = compact(HeadPred{ s.keys_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, s.d_total, st);
     }
