@@ -677,7 +677,8 @@ __device__ void icp_finish(const double *acc, int64_t n, int mode, int k, int ma
 // Mathematically the same update; rounding differs from the LDL^T order at the 1e-16 level (T is tolerance-checked).
 // Blocks that provably cannot find a partner are not swept again (icp_iter_body).  A block whose four waves all found NO target
 // group within reach records key = motion + g, g = the smallest distance from a wave's box to any group box (> reach).  Every
-// later update moves a source point by at most  |U s - s| <= ||R_u - I||_F |s| + |t_u|,  |s| <= |p|max + |t_T|  (rigid T), which
+// later update moves a source point by at most  |U s - s| <= ||R_u - I||_F |s| + |t_u|,  |s| <= max over the corners c of the source's
+// box of |T c|  (|.| is convex: holds for any affine T), which
 // the update step adds to `motion`; `reach` bounds the square root of any row's search bound under the current T (the clamp of
 // max_correspondence_distance plus the rounding margins of nn_local's metric).  While motion + reach < key no row of the block
 // can have a target point within its bound, so the sweep would report "no partner" for all of them -- exactly what the rows
@@ -696,12 +697,18 @@ struct FinishScratch {
 __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, int mode, int k, int max_iter, double rel_fit, double rel_rmse,
                                                 IcpState *st, double *__restrict__ result, FinishScratch &fs, int lane, const LightSkip ls = LightSkip{ nullptr, 0.0, 0.0 })
 {
-    double pmax = 0.0;
-    if (ls.sbbox && lane == 0) {
+    // largest |T p| over the source: |.| is convex, so it is attained at a corner of the source's bounding box (any affine T)
+    auto reach_of_source = [&](const double *T) {
+        double m2 = 0.0;
+        for (int c = 0; c < 8; ++c) {
+            const double x = ls.sbbox[(c & 1) ? 3 : 0], y = ls.sbbox[(c & 2) ? 4 : 1], z = ls.sbbox[(c & 4) ? 5 : 2];
+            double n2 = 0.0;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) pmax += fmax(ls.sbbox[a] * ls.sbbox[a], ls.sbbox[3 + a] * ls.sbbox[3 + a]);
-        pmax = sqrt(pmax) * (1.0 + 1e-9);
-    }
+            for (int r = 0; r < 3; ++r) { const double v = T[4 * r] * x + T[4 * r + 1] * y + T[4 * r + 2] * z + T[4 * r + 3]; n2 += v * v; }
+            m2 = fmax(m2, n2);
+        }
+        return sqrt(m2) * (1.0 + 1e-9);
+    };
     if (lane == 0) {
         const double cnt = acc[0];
         const double fit = (n > 0 && cnt > 0) ? cnt / (double)n : 0.0;
@@ -775,9 +782,8 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { const double d = fs.U[4 * r + c] - (r == c ? 1.0 : 0.0); rot += d * d; }
-            const double told = sqrt(st->T[3] * st->T[3] + st->T[7] * st->T[7] + st->T[11] * st->T[11]);
             const double tu = sqrt(fs.U[3] * fs.U[3] + fs.U[7] * fs.U[7] + fs.U[11] * fs.U[11]);
-            st->motion += (sqrt(rot) * (pmax + told) + tu) * (1.0 + 1e-9) + 1e-9;
+            st->motion += (sqrt(rot) * reach_of_source(st->T) + tu) * (1.0 + 1e-9) + 1e-9;
         }
         if (lane < 16) {
             const int r = lane >> 2, c = lane & 3;
@@ -791,8 +797,7 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
     }
     wave_lds_fence();
     if (ls.sbbox && lane == 0) {                           // reach of a row's search under the transform the next sweep uses
-        const double tn = sqrt(st->T[3] * st->T[3] + st->T[7] * st->T[7] + st->T[11] * st->T[11]);
-        const double smax = (pmax + tn) * (1.0 + 1e-9);
+        const double smax = reach_of_source(st->T);
         // upper bound of nn_local's row bound rb = (clamp - 1)(1 + 2^-30) + eps with clamp, eps as in icp_iter_body / sweep_wave
         const double r2 = ls.max_d2 * (1.0 + 3.7252902984619140625e-9) + 3.7252902984619140625e-9 + 1.4551915228366851806640625e-11 * (smax * smax + ls.t2max + 2.0);
         st->reach = sqrt(r2) * (1.0 + 1e-9);
