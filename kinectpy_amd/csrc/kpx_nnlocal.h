@@ -10,8 +10,9 @@
 //     owns 16 consecutive sorted rows.  Its box (from the transformed rows) and its radius R^2 = max_i bound_i - 1
 //     select the groups, then the tiles, with gap^2(row box, tile box) <= R^2 (+ a margin 2^-38 (K + |t|^2) that
 //     covers the rounding of the expanded metric; the skipped columns are STRICTLY farther than every row's bound, so
-//     neither the minimum nor a tie can hide there).  Surviving tiles go to a list in LDS and are multiplied four per
-//     trip behind the same 32-bit high-word prefilter as the dense sweep.
+//     neither the minimum nor a tie can hide there).  Surviving tiles go to a list in LDS and are multiplied with their
+//     operands requested kMulBatch at a time, behind the same 32-bit high-word prefilter as the dense sweep (per tile).
+//     (The frame loop hands its clouds over already Z-ordered -- kpx_voxel.hip -- and the sort is skipped: presorted.)
 //   * bounds: the previous partner (ICP iterations >= 1), clamped to max_correspondence_distance^2 inside a
 //     registration (rows with nothing inside report "no partner": they are not correspondences by definition,
 //     pipelines/registration/Registration.cpp semantics [O3D]); without either, the far-corner distance to the
@@ -163,8 +164,8 @@ struct WaveRows {
     d4 seed;                   // C operand: K of the lane's rows
     double *rows;              // LDS: the wave's 16 transformed rows, record r at rows[kRowStride r ..]: x, y, z, then the row's current
                                // bound on d^2 (kRowBound, written by the sweep).  The culling tests read rows from here instead of
-                               // holding them in registers: the kernel fits 128 VGPRs = 4 waves per SIMD, and a latency-bound sweep
-                               // lives on resident waves
+                               // holding them in registers (the iteration kernel is built for 168 VGPRs = 3 waves per SIMD, KPX_ICP_WPE;
+                               // a latency-bound sweep lives on resident waves)
     double best[4];            // running minimum (per lane: over the columns j of the tiles seen)
     int32_t bcol[4];           // its ORIGINAL target index
     double light_gap2;         // out: no group box was within reach of the wave's box -> the smallest squared box-to-box gap; else -1
