@@ -108,7 +108,8 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     // The registration clouds leave the voxel grid along the Z-curve of their voxel indices (one point per voxel: the order the
     // culled search would otherwise establish with a Morton sort of its own -- 12 dispatches per frame); nothing downstream depends
     // on their order: normals and nearest neighbours are per point, the update sums are exact.  KPX_FRAME_ZORDER=0: A/B switch.
-    static const bool zorder = [] { const char *e = getenv("KPX_FRAME_ZORDER"); return !(e && e[0] == '0'); }();
+    static const bool zorder_on = [] { const char *e = getenv("KPX_FRAME_ZORDER"); return !(e && e[0] == '0'); }();
+    const bool zorder = zorder_on && S <= 8;         // the voxel batch's one-pass form (the only one with the Z-curve order) takes 8 clouds
     static thread_local int spec_bits = 0;
     static const bool speculate = [] { const char *e = getenv("KPX_FRAME_SPECULATE"); return !(e && e[0] == '0'); }();      // A/B switch
     if (!speculate) spec_bits = 0;

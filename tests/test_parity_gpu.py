@@ -1505,6 +1505,19 @@ def test_sor_select_equals_filter_then_selection(ops):
     assert pe.shape[0] == 0 and ie.shape[0] == 0
 
 
+def test_native_frame_step_ten_sensors_equals_oracle(oracle):
+    """ten sensors: nine registrations = two launch chains side by side on the library's lanes (each with its own update-in-the-
+    last-block tickets and skip keys), the voxel batch in two groups (row-major clouds: the ICP batch sorts them itself)"""
+    from kinectpy_amd.pipeline import NativeFramePipeline, PipelineParams
+    xy, depth, rgb, inits, truth, ref = _oracle_steps(oracle, 10, 1)
+    nat = NativeFramePipeline(xy, 10, inits, PipelineParams())
+    gp, gc, gT = nat.step(torch.as_tensor(depth[0]).cuda(), torch.as_tensor(rgb[0]).cuda())
+    rp, rc, rT, aux = ref[0]
+    assert np.abs(gT - np.stack(rT)).max() < TOL_T
+    assert [s[0] for s in nat.last["icp"]] == [it for it, _, _ in aux["icp"]]
+    assert np.array_equal(npy(gp), rp) and np.array_equal(npy(gc), rc)
+
+
 def test_native_frame_step_eight_sensors_equals_oracle(oracle):
     """BASELINE configs[4]'s rig on one GPU through kpx_frame_step: seven registrations in one launch chain (the batch limit), three
     cloud bits in the Z-curve voxel keys, 2.2M pairs in the library's radix sort -- fused cloud and colours identical to the oracle
