@@ -1531,3 +1531,15 @@ def test_native_frame_step_eight_sensors_equals_oracle(oracle):
     assert [s[0] for s in nat.last["icp"]] == [it for it, _, _ in aux["icp"]]
     assert nat.last["n_down"] == [len(x) for x in aux["downs"]] and nat.last["n_fused"] == len(aux["fused"])
     assert np.array_equal(npy(gp), rp) and np.array_equal(npy(gc), rc)
+
+
+def test_native_frame_step_without_a_person(four_sensor_oracle):
+    """all masks empty: the registrations still run (they use every valid pixel), the fused frame is empty, nothing is read past it"""
+    from kinectpy_amd.pipeline import NativeFramePipeline, PipelineParams
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    nat = NativeFramePipeline(xy, 4, inits, PipelineParams())
+    gp, gc, gT = nat.step(torch.as_tensor(depth[0]).cuda(), torch.zeros_like(torch.as_tensor(rgb[0])).cuda())
+    assert gp.shape[0] == 0 and gc.shape[0] == 0
+    assert np.abs(gT - np.stack(ref[0][2])).max() < TOL_T
+    gp2, gc2, gT2 = nat.step(torch.as_tensor(depth[0]).cuda(), torch.as_tensor(rgb[0]).cuda())       # and the next frame is a normal one
+    assert np.array_equal(npy(gp2), ref[0][0]) and np.array_equal(npy(gc2), ref[0][1])
