@@ -203,6 +203,10 @@ class SensorShardPipeline:
         else:
             if self.order is not None:
                 self.order[0].skip(self.order[1], 2)                                       # this frame has no third collective
+            if hasattr(o, "sor_select"):                                                   # filter + selection without a count read-back between them
+                out_p, out_c, keep, _ = o.sor_select(vp, vc, p.filt_k, p.filt_ratio)
+                self.last.update(n_voxel=M, n_out=int(out_p.shape[0]))
+                return out_p, out_c, Ts
             keep, _, _ = o.sor(vp, p.filt_k, p.filt_ratio)
         out_p, out_c, _ = o.select_by_index([vp, vc], keep, trusted=True)
         self.last.update(n_voxel=M, n_out=int(out_p.shape[0]))
