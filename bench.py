@@ -17,7 +17,9 @@ A "step" is one pass of the hot path over one synchronised frame set of S sensor
 registers its own sensors, ONE all-gather of the masked clouds + transforms, filter on the FUSED cloud (sharded SOR with
 one all-gather of the slabs' mean distances, or on rank 0 alone).  The sensor count is fixed as GPUs are added up to 4
 ("scaling": "strong"; 8 GPUs run the 8-sensor configuration).  --partition group is round 1's layout (every rank owns an
-independent 4-sensor group, weak scaling).
+independent 4-sensor group, weak scaling).  --partition frame deals FRAMES out instead (every rank runs whole frames of the rig
+through the native frame loop, no data-path collective, weak scaling): consecutive frames are independent, so this is how a
+stream is fed to several GPUs when throughput is all that matters.
 
 `value` counts input depth pixels per second with the frames already resident in HBM when the timed region starts
 (the contract of this bench); `from_pinned_host` is the same loop fed from pinned host memory (H2D inside the step).
@@ -286,7 +288,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--partition", choices=["sensor", "group"], default="sensor")
+    ap.add_argument("--partition", choices=["sensor", "group", "frame"], default="sensor")
     ap.add_argument("--sensors", type=int, default=0, help="sensors of the rig (--partition sensor); 0 = 4, or 8 at 8 GPUs")
     ap.add_argument("--fused-filter", choices=["sharded", "rank0"], default="sharded")
     ap.add_argument("--sensors-per-gpu", type=int, default=4, help="--partition group only")
@@ -318,22 +320,23 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     F, P = args.frames, PipelineParams()
-    overlap = args.overlap if args.overlap > 0 else (4 if (world == 1 and not args.python_step and args.partition == "sensor") else 2)
-    sensor_mode = args.partition == "sensor"
+    frame_mode = args.partition == "frame"        # every rank runs whole frames of the rig through the native loop (frames, not sensors, are dealt out)
+    overlap = args.overlap if args.overlap > 0 else (4 if ((world == 1 or frame_mode) and not args.python_step and args.partition != "group") else 2)
+    sensor_mode = args.partition in ("sensor", "frame")
     if sensor_mode:
-        S = args.sensors or (8 if world >= 8 else 4)
-        mine = parallel.shard_sensors(S, rank, world)
-        xy, depth_h, rgb_h, inits, truth = synth.sensor_ring(S, F, sensors=mine)
-        groups = [parallel.new_group() for _ in range(overlap)] if world > 1 else [None] * overlap
+        S = args.sensors or (4 if frame_mode else (8 if world >= 8 else 4))
+        mine = list(range(S)) if frame_mode else parallel.shard_sensors(S, rank, world)
+        xy, depth_h, rgb_h, inits, truth = synth.sensor_ring(S, F, sensors=mine, first_frame=rank * F if frame_mode else 0)
+        groups = [parallel.new_group() for _ in range(overlap)] if (world > 1 and not frame_mode) else [None] * overlap
         for g in groups:
             parallel.warm(g, dev)
-        native = world == 1 and not args.python_step
+        native = (world == 1 or frame_mode) and not args.python_step
         if native:                                  # one GPU: the whole frame loop is ONE native call per frame (kpx_frame_step)
             pipes = [NativeFramePipeline(xy, S, inits, P) for _ in groups]
         else:
             pipes = [SensorShardPipeline(xy, S, inits, P, group=g, fused_filter=args.fused_filter) for g in groups]
         pipe = pipes[0]
-        px_per_step = S * N_PX                      # whole rig, all ranks together
+        px_per_step = (world if frame_mode else 1) * S * N_PX      # sensor partition: whole rig, all ranks together; frame partition: a frame per rank
         local_inits = inits
     else:
         spg = args.sensors_per_gpu
@@ -446,7 +449,13 @@ def main():
             terr = np.abs(gT - np.stack(ref[2])).reshape(len(gT), -1).max(1)
             same = gp.shape[0] == ref[0].shape[0] and np.array_equal(gp.cpu().numpy(), ref[0])
             print(f"# check vs oracle: transform errors {terr}, cloud sizes {gp.shape[0]}/{ref[0].shape[0]}, identical={same}", file=sys.stderr)
-    if sensor_mode:
+    if frame_mode:
+        scaling = "weak"
+        cfg = {"workload": f"BASELINE configs[3] as a STREAM: every GPU runs whole {S}-sensor frames of its own through the native frame loop "
+                           f"(extract -> point-to-plane ICP of every sub onto the master -> fused fp64 transform + voxel -> SOR); frames, not sensors, are "
+                           f"dealt out, no data-path collective -- the throughput-optimal deployment; the north-star partition is --partition sensor",
+               "partition": "frame", "sensors": S, "host_loop": "native (kpx_frame_step)"}
+    elif sensor_mode:
         scaling = "strong"
         workload = (f"BASELINE configs[{4 if S == 8 else 3}]: {S} synthetic Kinect views (640x576 u16 depth + person mask) per step, sensor g on "
                     f"GPU g ({world} GPU{'s' if world > 1 else ''}: {len(mine)} sensor(s) per GPU): extract -> master-cloud broadcast -> per-GPU "
