@@ -364,6 +364,14 @@ size_t kpx_frame_step_workspace_bytes(int32_t sensors, int64_t n_px);
 int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const float *xy_table, int64_t n_px, int32_t sensors,
                    const double *h_init, const kpx_frame_params *params, float *out_pts, float *out_col, int32_t *h_count,
                    double *h_T, int32_t *h_info, void *ws, size_t ws_bytes, void *stream);
+/* The same frame handed over in HOST memory (pinned for an asynchronous copy) -- SURVEY 8(d)'s interval "depth frame resident in
+ * host pinned memory -> fused registered cloud on the GPU"; the reference's loop starts from the files it has just read
+ * (preprocessing/data.py:87-124).  h_depth u16 [sensors][n_px], h_rgb u8 [sensors][n_px][3] on the host; both are copied into
+ * staging buffers at the head of `ws` on `stream` (no allocation, no extra synchronisation), then kpx_frame_step runs. */
+size_t kpx_frame_step_host_workspace_bytes(int32_t sensors, int64_t n_px);
+int kpx_frame_step_host(const uint16_t *h_depth, const uint8_t *h_rgb, const float *xy_table, int64_t n_px, int32_t sensors,
+                        const double *h_init, const kpx_frame_params *params, float *out_pts, float *out_col, int32_t *h_count,
+                        double *h_T, int32_t *h_info, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it

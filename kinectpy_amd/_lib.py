@@ -78,6 +78,8 @@ SIGNATURES = {
     "kpx_prof_stride": (C.c_int, [_i32]),
     "kpx_frame_step_workspace_bytes": (_sz, [_i32, _i64]),
     "kpx_frame_step": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_frame_step_host_workspace_bytes": (_sz, [_i32, _i64]),
+    "kpx_frame_step_host": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_sor_select": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "kpx_sort_pairs_u32_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "kpx_sort_pairs_u32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
@@ -167,13 +169,24 @@ class Workspace:
 
 
 _ws = {}
+_ws_lock = threading.Lock()
 
 
 def workspace(nbytes):
-    """scratch of the calling thread's current stream (ops of one stream run in order and may share it; another stream or
-    host thread gets its own)"""
-    key = (threading.get_ident(), _raw_stream())
-    ws = _ws.get(key)
-    if ws is None:
-        ws = _ws[key] = Workspace()
+    """scratch of the calling thread's current stream: operators queued on one stream run in order and may share it, another
+    stream gets its own.  Keyed by (device, stream) -- not by host thread: pipeline.FrameStream's worker threads pick frame slots
+    arbitrarily, and a (thread, stream) key would grow to depth^2 frame workspaces of hundreds of MB.  Two host threads must not
+    queue work on the SAME stream concurrently (they would share the scratch; FrameStream gives every frame in flight its own
+    stream and ends each frame with stream.synchronize())."""
+    key = (torch._C._cuda_getDevice(), _raw_stream())
+    with _ws_lock:
+        ws = _ws.get(key)
+        if ws is None:
+            ws = _ws[key] = Workspace()
     return ws.get(nbytes)
+
+
+def release_workspace(stream_handle, dev=None):
+    """drop the scratch of one stream (pipeline.FrameStream.close())"""
+    with _ws_lock:
+        _ws.pop((torch._C._cuda_getDevice() if dev is None else dev, int(stream_handle)), None)

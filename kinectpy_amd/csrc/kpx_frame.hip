@@ -77,11 +77,15 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     FrameLayout L;
     frame_carve(a, S, n_px, &L);
     KPX_ARENA_CHECK(a);
-    static thread_local int32_t *h_i = nullptr;            // pinned read-back area of the calling thread: counts and ICP results
+    // pinned read-back area of the calling thread: counts and ICP results.  ONE allocation (the doubles first), published only when
+    // it succeeded; it lives as long as the thread's runtime context (a few KiB per host thread that ever ran a frame).
     static thread_local double *h_d = nullptr;
+    static thread_local int32_t *h_i = nullptr;
     if (!h_i) {
-        KPX_HIP(hipHostMalloc((void **)&h_i, 256 * sizeof(int32_t), hipHostMallocDefault));
-        KPX_HIP(hipHostMalloc((void **)&h_d, (16 * 20 + 1) * sizeof(double), hipHostMallocDefault));
+        void *blk = nullptr;
+        KPX_HIP(hipHostMalloc(&blk, (16 * 20 + 1) * sizeof(double) + 256 * sizeof(int32_t), hipHostMallocDefault));
+        h_d = static_cast<double *>(blk);
+        h_i = reinterpret_cast<int32_t *>(h_d + (16 * 20 + 1));
     }
     auto negative = [&](const int32_t *c, int n) { for (int i = 0; i < n; ++i) if (c[i] < 0) return c[i]; return 0; };
 
@@ -163,4 +167,35 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     KPX_HIP(hipStreamSynchronize(st));
     *h_count = h_i[49];
     return KPX_OK;
+}
+
+// The same frame handed over in HOST memory ("depth frame resident in host pinned memory -> fused registered cloud
+// resident on the GPU"; the reference's loop starts from files, data.py:87-124).  The two images are copied into staging buffers
+// at the head of the caller's workspace on the frame's own stream -- no allocation, no extra synchronisation; with several
+// frames in flight (one stream each) the copy of frame k+1 runs under the kernels of frame k.
+KPX_EXPORT size_t kpx_frame_step_host_workspace_bytes(int32_t sensors, int64_t n_px)
+{
+    if (sensors < 1 || n_px < 1) return 0;
+    Arena a(nullptr, 0);
+    a.get<uint16_t>((size_t)sensors * (size_t)n_px);
+    a.get<uint8_t>((size_t)sensors * (size_t)n_px * 3);
+    return a.off + kpx_frame_step_workspace_bytes(sensors, n_px);
+}
+
+KPX_EXPORT int kpx_frame_step_host(const uint16_t *h_depth, const uint8_t *h_rgb, const float *xy_table, int64_t n_px, int32_t sensors,
+                                   const double *h_init, const kpx_frame_params *prm, float *out_pts, float *out_col, int32_t *h_count,
+                                   double *h_T, int32_t *h_info, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(sensors >= 1 && sensors <= 16 && n_px > 0 && n_px < ((int64_t)1 << 31) / 16, "kpx_frame_step_host: 1 .. 16 sensors of at most 2^27 pixels");
+    KPX_REQUIRE(h_depth && h_rgb && ws, "kpx_frame_step_host: null pointer");
+    Arena a(ws, ws_bytes);
+    const size_t all = (size_t)sensors * (size_t)n_px;
+    uint16_t *d_depth = a.get<uint16_t>(all);
+    uint8_t *d_rgb = a.get<uint8_t>(all * 3);
+    KPX_ARENA_CHECK(a);
+    hipStream_t st = (hipStream_t)stream;
+    KPX_HIP(hipMemcpyAsync(d_depth, h_depth, all * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    KPX_HIP(hipMemcpyAsync(d_rgb, h_rgb, all * 3, hipMemcpyHostToDevice, st));
+    return kpx_frame_step(d_depth, d_rgb, xy_table, n_px, sensors, h_init, prm, out_pts, out_col, h_count, h_T, h_info, (char *)ws + a.off,
+                          ws_bytes - a.off, stream);
 }

@@ -493,24 +493,38 @@ class FrameParams(C.Structure):
 def frame_step(depth, rgb, xy_table, inits, params: FrameParams, out=None):
     """kpx_frame_step: depth (S, n_px) u16, rgb (S, n_px, 3) u8, xy (n_px*2) f32 on the device; inits: (S-1) 4x4.
     -> points f32 (K,3), colours f32 (K,3), transforms f64 (S,4,4) numpy, info int32 (64) numpy.
+    depth / rgb may also be HOST tensors (pinned: the copy is asynchronous): kpx_frame_step_host stages them through the
+    workspace on the frame's stream -- the frame then starts in host memory, as SURVEY 8(d) defines the end-to-end interval.
     out: optional (points, colours) buffers of S*n_px rows to write into (otherwise allocated)."""
     lib = L.load()
-    depth = _dev(depth, torch.uint16)
+    host = isinstance(depth, torch.Tensor) and not depth.is_cuda
+    if host:
+        if depth.dtype != torch.uint16 or rgb.dtype != torch.uint8 or not (depth.is_contiguous() and rgb.is_contiguous()):
+            raise ValueError("frame_step: host frames must be contiguous uint16 depth / uint8 rgb tensors")
+        dev = L.device()
+    else:
+        depth = _dev(depth, torch.uint16)
+        dev = depth.device
     S = int(depth.shape[0])
     depth = depth.reshape(S, -1)
     n_px = int(depth.shape[1])
-    rgb = _dev(rgb, torch.uint8).reshape(S, n_px, 3)
+    rgb = (rgb if host else _dev(rgb, torch.uint8)).reshape(S, n_px, 3)
     xy = _dev(xy_table, torch.float32).reshape(-1)
-    dev = depth.device
     init = np.ascontiguousarray(np.stack([_T(T) for T in inits])) if S > 1 else np.zeros((1, 4, 4))
     if out is None:
         out = (torch.empty((S * n_px, 3), dtype=torch.float32, device=dev), torch.empty((S * n_px, 3), dtype=torch.float32, device=dev))
     h_count = np.zeros(1, dtype=np.int32)
     h_T = np.zeros((S, 4, 4))
     h_info = np.zeros(64, dtype=np.int32)
-    ws, wsz = L.workspace(lib.kpx_frame_step_workspace_bytes(S, n_px))
-    L.check(lib.kpx_frame_step(L.ptr(depth), L.ptr(rgb), L.ptr(xy), n_px, S, L.hptr(init), C.byref(params), L.ptr(out[0]), L.ptr(out[1]),
-                               h_count.ctypes.data_as(C.c_void_p), L.hptr(h_T), h_info.ctypes.data_as(C.c_void_p), ws, wsz, L.stream_ptr()))
+    # one size for both forms (the host form's staging buffers are a few MB on top): a stream that sees frames of either kind
+    # never regrows its scratch
+    ws, wsz = L.workspace(lib.kpx_frame_step_host_workspace_bytes(S, n_px))
+    if host:
+        fn, dptr, cptr = lib.kpx_frame_step_host, C.c_void_p(depth.data_ptr()), C.c_void_p(rgb.data_ptr())
+    else:
+        fn, dptr, cptr = lib.kpx_frame_step, L.ptr(depth), L.ptr(rgb)
+    L.check(fn(dptr, cptr, L.ptr(xy), n_px, S, L.hptr(init), C.byref(params), L.ptr(out[0]), L.ptr(out[1]),
+               h_count.ctypes.data_as(C.c_void_p), L.hptr(h_T), h_info.ctypes.data_as(C.c_void_p), ws, wsz, L.stream_ptr()))
     k = int(h_count[0])
     return out[0][:k], out[1][:k], h_T, h_info
 

@@ -226,9 +226,14 @@ class NativeFramePipeline:
     frame loop runs in C++ inside the library, the interpreter only hands the frame over -- so several frames in flight on
     host threads (FrameStream) do not queue up behind the GIL."""
 
-    def __init__(self, xy_table, n_sensors: int, init_transforms: List[np.ndarray], params: Optional[PipelineParams] = None):
+    def __init__(self, xy_table, n_sensors: int, init_transforms: List[np.ndarray], params: Optional[PipelineParams] = None,
+                 out_ring: int = 0):
+        """out_ring > 0: the fused clouds are written into a ring of that many pre-allocated output buffers owned by this
+        pipeline (no allocator traffic per frame); a result then stays valid until `out_ring` more frames have been stepped
+        through THIS pipeline -- clone what has to live longer.  0: fresh buffers per frame."""
         self.p = params or PipelineParams()
         self.n_sensors = int(n_sensors)
+        self._ring, self._ring_n, self._ring_k = [], int(out_ring), 0
         if len(init_transforms) != self.n_sensors - 1:
             raise ValueError("init_transforms: one 4x4 per sub sensor (sensors 1 .. n-1)")
         self.init = [np.asarray(T, dtype=np.float64) for T in init_transforms]
@@ -239,8 +244,17 @@ class NativeFramePipeline:
         self.last = {}
 
     def step(self, depth: torch.Tensor, rgb: torch.Tensor):
+        """depth (S, n_px) u16, rgb (S, n_px, 3) u8: device tensors, or (pinned) host tensors -- then the copy to the device is
+        part of the frame, on the frame's stream (kpx_frame_step_host)"""
         S = self.n_sensors
-        out_p, out_c, Ts, info = ops.frame_step(depth, rgb, self.xy, self.init, self._c)
+        out = None
+        if self._ring_n:
+            if len(self._ring) < self._ring_n:
+                rows = S * int(depth.numel() // S)
+                self._ring.append(tuple(torch.empty((rows, 3), dtype=torch.float32, device=self.xy.device) for _ in range(2)))
+            out = self._ring[self._ring_k % len(self._ring)]
+            self._ring_k += 1
+        out_p, out_c, Ts, info = ops.frame_step(depth, rgb, self.xy, self.init, self._c, out=out)
         self.last = {"icp": [(int(info[32 + i]), None, None) for i in range(1, S)], "n_down": [int(v) for v in info[:S]],
                      "n_masked": [int(v) for v in info[16:16 + S]], "n_fused": int(info[16:16 + S].sum()), "n_voxel": int(info[48]),
                      "n_out": int(out_p.shape[0])}
@@ -276,7 +290,8 @@ class FrameStream:
         pipe = self.pipes[slot] if self.pipes else self.pipe
         try:
             with torch.cuda.stream(stream):
-                if not depth.is_cuda:            # frames handed over in pinned host memory: the copy is part of the frame
+                if not depth.is_cuda and not isinstance(pipe, NativeFramePipeline):
+                    # frames handed over in pinned host memory: the copy is part of the frame (the native loop stages them itself)
                     depth = depth.to(self.device, non_blocking=True)
                     rgb = rgb.to(self.device, non_blocking=True)
                 if frame is not None:
@@ -329,3 +344,6 @@ class FrameStream:
         while self.pending:
             self.pop()
         self.pool.shutdown()
+        from . import _lib
+        for s_ in self.streams:                  # the slots' scratch (hundreds of MB per frame workspace) goes with the stream
+            _lib.release_workspace(s_.cuda_stream, self.device)

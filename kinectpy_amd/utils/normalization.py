@@ -17,9 +17,10 @@ def _boxes(x):
     return obb
 
 
-def _apply(x, y, mode, M=None):
+def _apply(x, y, mode, M=None, obb=None):
+    """obb: (B, 16) box tensor [R | centre | extent | status] instead of the clouds' own boxes (pin tests)"""
     xd = ops._dev(x, torch.float64)
-    obb = _boxes(xd)
+    obb = _boxes(xd) if obb is None else obb
     B = xd.shape[0]
     yd = ops._dev(np.asarray(y, dtype=np.float64).reshape(B, -1, 3), torch.float64)
     xo = ops.normalize_batch(xd, obb, mode, M)

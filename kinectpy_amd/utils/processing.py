@@ -16,6 +16,19 @@ def sort_filenames_by_timestamp(list_of_files):
     return np.array(list_of_files)
 
 
+def find_delay_master_sub(timestamps_dataframe):
+    """utils/processing.py:23-51: for every sub device (columns after the first), the row of `master_1` whose timestamp is
+    closest to the sub's FIRST timestamp (first such row on ties).  Host bookkeeping of the extractor's synchronisation
+    step; accepts a pandas DataFrame or a dict of columns."""
+    cols = list(getattr(timestamps_dataframe, "columns", timestamps_dataframe.keys()))
+    master = np.asarray(timestamps_dataframe["master_1"]).astype(np.int64)
+    out = []
+    for device in cols[1:]:
+        first = int(np.asarray(timestamps_dataframe[device])[0])
+        out.append(int(np.argmin(np.abs(first - master))) if master.size else -1)
+    return out
+
+
 def select_points_randomly(pointcloud, number_of_points, seed=None):
     """utils/processing.py:259-275: `number_of_points` of the cloud, without replacement, as a float64 (k,3) array.
     The reference draws from NumPy's global generator; `seed` fixes the draw (default: a seed drawn from that same
@@ -52,10 +65,11 @@ def normalize_pointcloud(pcd, min_range=-1.0, max_range=1.0):
     return pcd
 
 
-def obb_normalization(points, joints, number_of_joints):
-    """utils/processing.py:329-354: (p - centre) @ R of the cloud's oriented bounding box, joints likewise"""
+def obb_normalization(points, joints, number_of_joints, _obb=None):
+    """utils/processing.py:329-354: (p - centre) @ R of the cloud's oriented bounding box, joints likewise
+    (`_obb`: a (1, 16) box tensor instead of the cloud's own -- the pin test feeds the recorded stub box)"""
     x = np.asarray(points, dtype=np.float64)[None]
-    obb, _ = ops.obb_batch(x)
+    obb = _obb if _obb is not None else ops.obb_batch(x)[0]
     j = np.asarray(getattr(joints, "values", joints), dtype=np.float64).reshape(1, number_of_joints, 3)
     xo = ops.normalize_batch(x, obb, ops.NORM_OBB_ROT).cpu().numpy()[0]
     jo = ops.normalize_batch(j, obb, ops.NORM_OBB_ROT).cpu().numpy().reshape(number_of_joints * 3)

@@ -614,12 +614,14 @@ def rotation_matrix_from_yxz(rot):
     return ax("y", rot[0]) @ ax("x", rot[1]) @ ax("z", rot[2])
 
 
-def obb_normalization_batch(x, y, obb=None):
-    """utils/normalization.py:16-64 (as written there: the rotation is the constant Rx(pi), the centre is ADDED)"""
+def obb_normalization_batch(x, y, obb=None, M=None):
+    """utils/normalization.py:16-64 (as written there: the rotation is the constant Rx(pi), the centre is ADDED).
+    M: stands in for get_rotation_matrix_from_yxz([0, pi, 0]) (the golden vectors of tests/golden/ref_norm_kat.json record
+    the matrix their stub box returned)"""
     x = np.asarray(x, dtype=np.float64)
     x = x[None] if x.ndim == 2 else x
     xs, ys = [], []
-    Rc = rotation_matrix_from_yxz([0, np.pi, 0])
+    Rc = rotation_matrix_from_yxz([0, np.pi, 0]) if M is None else np.asarray(M, dtype=np.float64)
     for b in range(x.shape[0]):
         R, c, ext = obb[b] if obb is not None else oriented_bounding_box(x[b])
         L = np.max(ext)
@@ -649,6 +651,14 @@ def translation_normalization_batch(x, y, obb=None):
         xs.append(x[b] - c)
         ys.append((np.asarray(y[b], dtype=np.float64).reshape(-1, 3) - c).reshape(-1))
     return np.array(xs), np.array(ys)
+
+
+def obb_normalization(points, joints, number_of_joints, obb=None):
+    """utils/processing.py:327-354: (p - centre) @ R for the points and the (number_of_joints, 3) joints"""
+    points = np.asarray(points, dtype=np.float64)
+    R, c, ext = obb if obb is not None else oriented_bounding_box(points)
+    j = np.asarray(joints, dtype=np.float64).reshape(number_of_joints, 3)
+    return (points - c) @ R, ((j - c) @ R).reshape(number_of_joints * 3)
 
 
 def normalize_pointcloud(arr, min_range=-1.0, max_range=1.0):

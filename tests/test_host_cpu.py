@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kat.json")))
+NORM_KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_norm_kat.json")))
 
 
 def test_equation_plane_matches_reference_kat(capsys):
@@ -19,6 +20,15 @@ def test_kalman_filter_matches_reference_kat():
     from kinectpy_amd.preprocessing.filtering import kalman_filter
     for c in KAT["kalman_filter"]:
         assert np.array_equal(kalman_filter(np.array(c["x"]), **c["kw"]), np.array(c["y"]))
+
+
+def test_find_delay_master_sub_matches_reference_kat():
+    """utils/processing.py:23-51 (SURVEY KAT7), DataFrame and plain-dict inputs"""
+    import pandas as pd
+    from kinectpy_amd.utils.processing import find_delay_master_sub
+    for c in NORM_KAT["find_delay_master_sub"]:
+        assert find_delay_master_sub(pd.DataFrame(c["table"])) == c["out"]
+        assert find_delay_master_sub(c["table"]) == c["out"]
 
 
 def test_load_depth_round_trip(tmp_path):

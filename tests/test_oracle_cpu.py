@@ -11,6 +11,7 @@ from scipy.spatial import cKDTree
 from kinectpy_amd.utils import synth
 
 KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kat.json")))
+NORM_KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_norm_kat.json")))
 
 
 def test_equation_plane_kat(oracle):
@@ -302,3 +303,28 @@ def test_fused_voxel_grid_decides_on_fp64_values(oracle):
         w64, _, _, d64 = oracle.voxel_downsample(np.concatenate([a.astype(np.float64), oracle.transform(b, T)]), 10.0, return_counts=True)
     assert np.array_equal(c32, c64) and np.array_equal(c64, d64) and np.array_equal(v64, w64)
     assert np.abs(v32.astype(np.float64) - v64).max() < 3e-4
+
+
+# ---- the normalisers' own arithmetic, pinned by the reference executed around a stub box (tests/golden/make_ref_norm_kat.py)
+def _kat_boxes(batch):
+    return [(np.array(b["R"]), np.array(b["centre"]), np.array(b["extent"])) for b in batch["boxes"]]
+
+
+def test_normalisers_match_reference_kat(oracle):
+    for c in NORM_KAT["normalize_pointcloud"]:
+        assert np.allclose(oracle.normalize_pointcloud(np.array(c["pts"]), c["min_range"], c["max_range"]), np.array(c["out"]), rtol=0, atol=1e-12)
+    for c in NORM_KAT["obb_normalization"]:
+        box = (np.array(c["R"]), np.array(c["centre"]), np.array(c["extent"]))
+        xo, jo = oracle.obb_normalization(np.array(c["pts"]), np.array(c["joints"]), c["number_of_joints"], box)
+        assert np.allclose(xo, np.array(c["points_out"]), rtol=0, atol=1e-10) and np.allclose(jo, np.array(c["joints_out"]), rtol=0, atol=1e-10)
+    b = NORM_KAT["batch"]
+    x, y, boxes = np.array(b["x"]), np.array(b["y"]), _kat_boxes(b)
+    gx, gy = oracle.obb_normalization_batch(x, y, boxes, M=np.array(b["M"]))
+    assert np.allclose(gx, np.array(b["obb_normalization_batch"]["x"]), rtol=0, atol=1e-12)
+    assert np.allclose(gy, np.array(b["obb_normalization_batch"]["y"]), rtol=0, atol=1e-12)
+    gx, gy = oracle.obb_normalization_batch(x[0], y[:1], boxes[:1], M=np.array(b["M"]))          # 2-D input branch
+    assert np.allclose(gx, np.array(b["obb_normalization_batch_2d"]["x"]), rtol=0, atol=1e-12) and gx.shape == (1,) + x[0].shape
+    for name in ("obb_rotation_translation_batch", "translation_normalization_batch"):
+        gx, gy = getattr(oracle, name)(x, y, boxes)
+        assert np.allclose(gx, np.array(b[name]["x"]), rtol=0, atol=1e-9), name
+        assert np.allclose(gy, np.array(b[name]["y"]), rtol=0, atol=1e-9), name

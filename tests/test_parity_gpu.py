@@ -14,6 +14,7 @@ from kinectpy_amd.utils import synth
 
 pytestmark = pytest.mark.gpu
 KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kat.json")))
+NORM_KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_norm_kat.json")))
 
 TOL_STATS = 1e-11      # relative, SOR mean/std/threshold (reduction order)
 TOL_PLANE = 1e-10      # absolute, re-fitted plane coefficients (unit normal; d in mm)
@@ -1000,6 +1001,43 @@ def test_normalisation_batches_match_oracle(oracle, base_cloud):
     assert set(Nz.normalization_options) == {"obb_normalization", "obb_rotation_translation", "translation"}
 
 
+def _box_tensor(boxes):
+    """[(R, centre, extent)] -> the (B, 16) box tensor of kpx_obb_batch [R row-major | centre | extent | status]"""
+    rows = [np.concatenate([np.asarray(b["R"], dtype=np.float64).reshape(-1), b["centre"], b["extent"], [8.0]]) for b in boxes]
+    return torch.as_tensor(np.stack(rows)).cuda()
+
+
+def test_normalisers_match_reference_kat(ops):
+    """The HIP normalisers against the reference's OWN outputs (utils/processing.py:313-354, utils/normalization.py:16-159
+    executed around a stub box: tests/golden/make_ref_norm_kat.py).  Tolerance: the kernels evaluate the affine maps in fp64
+    in one fixed order, NumPy's matmul in another: 1e-9 absolute on millimetre-sized values."""
+    from kinectpy_amd import o3d
+    from kinectpy_amd.utils import normalization as Nz
+    from kinectpy_amd.utils import processing as P
+    for c in NORM_KAT["normalize_pointcloud"]:
+        pcd = o3d.geometry.PointCloud(o3d.utility.Vector3dVector(np.array(c["pts"])))
+        got = np.asarray(P.normalize_pointcloud(pcd, c["min_range"], c["max_range"]).points)
+        span = c["max_range"] - c["min_range"]
+        assert np.allclose(got, np.array(c["out"]), rtol=0, atol=span * 2.0 ** -22)      # the cloud is stored as float32 (DESIGN 3)
+    for c in NORM_KAT["obb_normalization"]:
+        xo, jo = P.obb_normalization(np.array(c["pts"]), np.array(c["joints"]), c["number_of_joints"], _obb=_box_tensor([c]))
+        assert np.allclose(xo, np.array(c["points_out"]), rtol=0, atol=1e-9) and np.allclose(jo, np.array(c["joints_out"]), rtol=0, atol=1e-9)
+    b = NORM_KAT["batch"]
+    x, y, obb = np.array(b["x"]), np.array(b["y"]), _box_tensor(b["boxes"])
+    rz90 = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    for name, mode, M in (("obb_normalization_batch", ops.NORM_OBB, np.array(b["M"])), ("obb_rotation_translation_batch", ops.NORM_OBB_ROT_TRANS, rz90),
+                          ("translation_normalization_batch", ops.NORM_TRANSLATE, None)):
+        gx, gy = Nz._apply(x, y, mode, M, obb=obb)
+        assert np.allclose(gx, np.array(b[name]["x"]), rtol=0, atol=1e-9), name
+        assert np.allclose(gy, np.array(b[name]["y"]), rtol=0, atol=1e-9), name
+    gx, gy = Nz.scale_batch(x, y)
+    assert np.array_equal(gx, np.array(b["scale_batch"]["x"])) and np.array_equal(gy, np.array(b["scale_batch"]["y"]))
+    gx, gy = Nz.scale_batch(x, y, 2.5)
+    assert np.array_equal(gx, np.array(b["scale_batch_2p5"]["x"])) and np.array_equal(gy, np.array(b["scale_batch_2p5"]["y"]))
+    gx, gy = Nz.rotate_batch(x, y, degs=b["rotate_batch"]["degs"])
+    assert np.allclose(gx, np.array(b["rotate_batch"]["x"]), rtol=0, atol=1e-9) and np.allclose(gy, np.array(b["rotate_batch"]["y"]), rtol=0, atol=1e-9)
+
+
 def test_processing_mirrors(oracle, base_cloud, tmp_path):
     from kinectpy_amd import o3d
     from kinectpy_amd.utils import processing as P
@@ -1503,6 +1541,35 @@ def test_sor_select_equals_filter_then_selection(ops):
     assert c3 is None and torch.equal(p3, p) and torch.equal(i3, idx)
     pe, ce, ie, _ = ops.sor_select(torch.zeros((0, 3)), None, 20, 2.0)
     assert pe.shape[0] == 0 and ie.shape[0] == 0
+
+
+def test_native_frame_step_from_pinned_host_memory(four_sensor_oracle):
+    """SURVEY 8(d)'s interval: frames handed over in pinned host memory (kpx_frame_step_host stages them through the workspace
+    on the frame's stream) -- same clouds as the oracle step, serially, with four frames in flight and with the output ring"""
+    from kinectpy_amd.pipeline import FrameStream, NativeFramePipeline, PipelineParams
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    dh, ch = torch.as_tensor(depth).pin_memory(), torch.as_tensor(rgb).pin_memory()
+    nat = NativeFramePipeline(xy, 4, inits, PipelineParams())
+    for f in range(2):
+        gp, gc, gT = nat.step(dh[f], ch[f])
+        assert np.array_equal(npy(gp), ref[f][0]) and np.array_equal(npy(gc), ref[f][1]) and np.abs(gT - np.stack(ref[f][2])).max() < TOL_T
+    gp, gc, gT = nat.step(torch.as_tensor(depth[1]), torch.as_tensor(rgb[1]))            # pageable host memory works too (synchronous copy)
+    assert np.array_equal(npy(gp), ref[1][0])
+    pipes = [NativeFramePipeline(xy, 4, inits, PipelineParams(), out_ring=2) for _ in range(4)]
+    fs = FrameStream(pipes, 4)
+    got = []
+    for k in range(11):
+        if fs.full():
+            got.append([npy(t) if isinstance(t, torch.Tensor) else t for t in fs.pop()])      # copied out before the ring wraps
+        fs.submit(dh[k % 2], ch[k % 2]) if k % 3 else fs.submit(torch.as_tensor(depth[k % 2]).cuda(), torch.as_tensor(rgb[k % 2]).cuda())
+    while fs.pending:
+        got.append([npy(t) if isinstance(t, torch.Tensor) else t for t in fs.pop()])
+    fs.close()
+    assert len(got) == 11
+    for k, (gp, gc, gT) in enumerate(got):
+        assert np.array_equal(gp, ref[k % 2][0]) and np.array_equal(gc, ref[k % 2][1]), k
+    with pytest.raises(ValueError):
+        nat.step(torch.as_tensor(depth[0].astype(np.int32)), torch.as_tensor(rgb[0]))
 
 
 def test_native_frame_step_ten_sensors_equals_oracle(oracle):
