@@ -346,8 +346,10 @@ def main():
     ap.add_argument("--spread-blocks", type=int, default=5, help="extra blocks of 20 steps for the run-to-run spread (0 = off)")
     ap.add_argument("--no-targets", action="store_true", help="skip the roofline_targets leg")
     ap.add_argument("--quick-targets", action="store_true", help="quarter-size batches for the roofline_targets leg")
-    ap.add_argument("--python-step", action="store_true", help="one GPU: run the frame loop through the Python pipeline instead of the native "
-                    "kpx_frame_step (several GPUs always use the Python pipeline: the collectives are torch.distributed's)")
+    ap.add_argument("--python-step", action="store_true", help="run the frame loop through the Python pipeline (collectives by torch.distributed) instead "
+                    "of the native kpx_frame_step / kpx_frame_step_sharded")
+    ap.add_argument("--transport", choices=["rccl", "staged"], default="rccl", help="several GPUs, native loop: RCCL from C++ (default) or the "
+                    "host-staged torch.distributed transport (rehearsal with ranks sharing one GPU: KPX_DIST_BACKEND=gloo)")
     ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval for the frame threads (0 = leave the default 5 ms)")
     args = ap.parse_args()
 
@@ -359,7 +361,8 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     from kinectpy_amd import ops, parallel
-    from kinectpy_amd.pipeline import FrameStream, NativeFramePipeline, PipelineParams, SensorGroupPipeline, SensorShardPipeline
+    from kinectpy_amd.pipeline import (FrameStream, NativeFramePipeline, NativeShardPipeline, PipelineParams, SensorGroupPipeline,
+                                       SensorShardPipeline)
     from kinectpy_amd.utils import synth
 
     rank, world, local = parallel.init_distributed()
@@ -367,17 +370,22 @@ def main():
     dev = torch.device("cuda", local)
     F, P = args.frames, PipelineParams()
     frame_mode = args.partition == "frame"        # every rank runs whole frames of the rig through the native loop (frames, not sensors, are dealt out)
-    overlap = args.overlap if args.overlap > 0 else (4 if ((world == 1 or frame_mode) and not args.python_step and args.partition != "group") else 2)
+    overlap = args.overlap if args.overlap > 0 else (4 if (not args.python_step and args.partition != "group") else 2)
     sensor_mode = args.partition in ("sensor", "frame")
     if sensor_mode:
         S = args.sensors or (4 if frame_mode else (8 if world >= 8 else 4))
         mine = list(range(S)) if frame_mode else parallel.shard_sensors(S, rank, world)
         xy, depth_h, rgb_h, inits, truth = synth.sensor_ring(S, F, sensors=mine, first_frame=rank * F if frame_mode else 0)
-        groups = [parallel.new_group() for _ in range(overlap)] if (world > 1 and not frame_mode) else [None] * overlap
+        native = not args.python_step
+        sharded_native = native and world > 1 and not frame_mode
+        groups = [parallel.new_group() for _ in range(overlap)] if (world > 1 and not frame_mode and not native) else [None] * overlap
         for g in groups:
             parallel.warm(g, dev)
-        native = (world == 1 or frame_mode) and not args.python_step
-        if native:                                  # one GPU: the whole frame loop is ONE native call per frame (kpx_frame_step)
+        if sharded_native:                          # several GPUs: the frame loop AND its collectives inside the library (kpx_frame_step_sharded:
+            # RCCL from C++ on the frame's stream, one communicator per frame slot, built here in the same order on every rank)
+            comms = [parallel.NativeComm.rccl() if args.transport == "rccl" else parallel.NativeComm.staged(parallel.new_group()) for _ in range(overlap)]
+            pipes = [NativeShardPipeline(xy, S, inits, P, comm=cm, fused_filter=args.fused_filter, out_ring=2) for cm in comms]
+        elif native:                                # one GPU: the whole frame loop is ONE native call per frame (kpx_frame_step)
             pipes = [NativeFramePipeline(xy, S, inits, P, out_ring=2) for _ in groups]     # per-slot output buffers: no allocator traffic per frame
         else:
             pipes = [SensorShardPipeline(xy, S, inits, P, group=g, fused_filter=args.fused_filter) for g in groups]
@@ -401,7 +409,7 @@ def main():
         return out
 
     frames = FrameStream(pipes if pipes is not None else pipe, overlap) if overlap > 1 else None
-    native_loop = isinstance(pipe, NativeFramePipeline)
+    native_loop = isinstance(pipe, (NativeFramePipeline, NativeShardPipeline))
 
     def run_steps(first, count, d=None, c=None):
         """`count` steps, all finished on return; with --overlap > 1 up to that many frames are in flight"""
@@ -518,7 +526,9 @@ def main():
                     f"GPU g ({world} GPU{'s' if world > 1 else ''}: {len(mine)} sensor(s) per GPU): extract -> master-cloud broadcast -> per-GPU "
                     f"point-to-plane ICP onto the master -> all-gather -> fused fp64 transform + voxel -> SOR on the fused cloud ({args.fused_filter})")
         cfg = {"workload": workload, "partition": "sensor", "sensors": S, "sensors_on_rank0": mine, "fused_filter": args.fused_filter,
-               "host_loop": "native (kpx_frame_step)" if native else "python (SensorShardPipeline)"}
+               "host_loop": (f"native (kpx_frame_step_sharded, {'RCCL from C++' if args.transport == 'rccl' else 'host-staged transport'})" if sharded_native
+                             else "native (kpx_frame_step)") if native
+                            else "python (SensorShardPipeline)"}
     else:
         scaling = "weak"
         cfg = {"workload": "BASELINE configs[3], one independent 4-sensor group per GPU (round-1 layout): extract -> pairwise point-to-plane "

@@ -38,7 +38,8 @@ typedef enum {
     KPX_ERR_INVALID = -1,     /* invalid argument (Open3D raises RuntimeError / ValueError here) */
     KPX_ERR_WORKSPACE = -2,   /* workspace too small */
     KPX_ERR_RANGE = -3,       /* value out of the supported range (e.g. voxel index overflow) */
-    KPX_ERR_HIP = -4          /* a HIP runtime call failed */
+    KPX_ERR_HIP = -4,         /* a HIP runtime call failed */
+    KPX_RETRY = 1             /* kpx_frame_step_sharded: a message outgrew its capacity on every rank alike; run the frame again */
 } kpx_status;
 
 const char *kpx_last_error(void);
@@ -372,6 +373,65 @@ size_t kpx_frame_step_host_workspace_bytes(int32_t sensors, int64_t n_px);
 int kpx_frame_step_host(const uint16_t *h_depth, const uint8_t *h_rgb, const float *xy_table, int64_t n_px, int32_t sensors,
                         const double *h_init, const kpx_frame_params *params, float *out_pts, float *out_col, int32_t *h_count,
                         double *h_T, int32_t *h_info, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- the frame loop over several GPUs (preprocessing/data.py:96-122 loops the devices independently, :44-61 fuses and
+ * filters, :127-161 registers every sub device onto the master) -------------------------------------------------------------------
+ * One PROCESS per GPU, sensor g on GPU g (fewer GPUs than sensors: contiguous blocks in rank order).  The host side of a frame runs
+ * in C++; its three collectives -- master cloud broadcast, all-gather of the masked clouds + registration results, all-gather of
+ * the fused filter's slab distances -- are issued from here on the frame's stream.
+ *
+ * kpx_comm: one communicator over all ranks (one per frame slot when several frames are in flight).  Transports:
+ *   RCCL        kpx_rccl_load(path of librccl.so, NULL = the loader's search path) once per process; rank 0 draws a 128-byte id
+ *               (kpx_rccl_unique_id) and hands it to the other ranks by any means (e.g. torch.distributed.broadcast_object_list);
+ *               every rank then calls kpx_comm_create_rccl (collective, like ncclCommInitRank);
+ *   callbacks   kpx_comm_create_callbacks: the caller moves the bytes (host-staged gloo, in-process ranks): rehearsals without RCCL.
+ * The callbacks get device pointers and the frame's stream; they return 0 on success. */
+typedef struct kpx_comm kpx_comm;
+typedef int (*kpx_bcast_fn)(void *user, void *d_buf, size_t bytes, int32_t root, void *stream);
+typedef int (*kpx_allgather_fn)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+int kpx_rccl_load(const char *path);
+int kpx_rccl_unique_id(void *id128);
+int kpx_comm_create_rccl(const void *id128, int32_t rank, int32_t world, kpx_comm **out);
+int kpx_comm_create_callbacks(int32_t rank, int32_t world, kpx_bcast_fn bcast, kpx_allgather_fn allgather, void *user, kpx_comm **out);
+int kpx_comm_destroy(kpx_comm *comm);
+int kpx_comm_rank(const kpx_comm *comm);
+int kpx_comm_world(const kpx_comm *comm);
+/* in-place broadcast of device memory from `root` / all-gather into d_recv [world][bytes_per_rank], on `stream` */
+int kpx_comm_broadcast(kpx_comm *comm, void *d_buf, size_t bytes, int32_t root, void *stream);
+int kpx_comm_allgather(kpx_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+/* utility for callback transports: copy between any two of host / device memory on `stream`; wait != 0 also waits for the stream */
+int kpx_copy_bytes(void *dst, const void *src, size_t bytes, void *stream, int32_t wait);
+
+/* kpx_order: ONE issue order for the collectives of the frames in flight on a rank.  Frames in flight run on host threads; a
+ * collective kernel spins on the device until its peers arrive, so every rank must enqueue the collectives of its frames in the
+ * same order whatever the timing of its threads: stage s (0 broadcast, 1 exchange, 2 slab all-gather) of frame f has the key 3 f
+ * (s = 0) or 3 (f + depth - 1) + s, and a collective is issued only when every smaller key of the submitted frames is done.  The
+ * main thread calls submit (a frame enters; -> its number), block(frame) while it waits for that frame (block(-1) afterwards) and
+ * finish(frame) when the frame is over; kpx_frame_step_sharded takes its turns itself (turn_begin / turn_end / skip, exported for
+ * tests).  A NULL order means one frame at a time. */
+typedef struct kpx_order kpx_order;
+int kpx_order_create(int32_t depth, kpx_order **out);
+int kpx_order_destroy(kpx_order *order);
+int kpx_order_submit(kpx_order *order, int64_t *frame);
+int kpx_order_block(kpx_order *order, int64_t frame);
+int kpx_order_turn_begin(kpx_order *order, int64_t frame, int32_t stage);
+int kpx_order_turn_end(kpx_order *order, int64_t frame, int32_t stage);
+int kpx_order_skip(kpx_order *order, int64_t frame, int32_t stage);
+int kpx_order_finish(kpx_order *order, int64_t frame);
+int kpx_order_log(kpx_order *order, int64_t *out, int64_t cap, int64_t *count);
+
+/* kpx_frame_step for the rank's share of the rig.  depth / rgb: the images of THIS rank's sensors (sensor order), on the device or
+ * (host_input != 0) in host memory; h_init: the sensors - 1 initial transforms of ALL sub sensors; fused_filter 0 = the filter on
+ * the fused cloud is sharded over the ranks by slabs of its grid order (every rank ends with the filtered frame, bit-identical to
+ * the one-GPU filter), 1 = rank 0 filters alone (the others return *h_count = 0).  h_T f64 [sensors][16] and h_info describe the
+ * WHOLE rig on every rank (they travel in the exchange headers).  Message capacities adapt to the slot's previous frame; when a
+ * frame outgrows one, every rank returns KPX_RETRY (1) and the caller runs the frame again (a new frame number under a kpx_order).
+ * Workspace: kpx_frame_step_sharded_workspace_bytes(sensors, rank, world, n_px, host_input). */
+size_t kpx_frame_step_sharded_workspace_bytes(int32_t sensors, int32_t rank, int32_t world, int64_t n_px, int32_t host_input);
+int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t frame, const uint16_t *depth, const uint8_t *rgb, int32_t host_input,
+                           const float *xy_table, int64_t n_px, int32_t sensors, const double *h_init, const kpx_frame_params *params,
+                           int32_t fused_filter, float *out_pts, float *out_col, int32_t *h_count, double *h_T, int32_t *h_info, void *ws,
+                           size_t ws_bytes, void *stream);
 
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it

@@ -80,6 +80,27 @@ SIGNATURES = {
     "kpx_frame_step": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_frame_step_host_workspace_bytes": (_sz, [_i32, _i64]),
     "kpx_frame_step_host": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_rccl_load": (C.c_int, [_vp]),
+    "kpx_rccl_unique_id": (C.c_int, [_vp]),
+    "kpx_comm_create_rccl": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "kpx_comm_create_callbacks": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp]),
+    "kpx_comm_destroy": (C.c_int, [_vp]),
+    "kpx_comm_rank": (C.c_int, [_vp]),
+    "kpx_comm_world": (C.c_int, [_vp]),
+    "kpx_comm_broadcast": (C.c_int, [_vp, _vp, _sz, _i32, _vp]),
+    "kpx_comm_allgather": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "kpx_copy_bytes": (C.c_int, [_vp, _vp, _sz, _vp, _i32]),
+    "kpx_order_create": (C.c_int, [_i32, _vp]),
+    "kpx_order_destroy": (C.c_int, [_vp]),
+    "kpx_order_submit": (C.c_int, [_vp, _vp]),
+    "kpx_order_block": (C.c_int, [_vp, _i64]),
+    "kpx_order_turn_begin": (C.c_int, [_vp, _i64, _i32]),
+    "kpx_order_turn_end": (C.c_int, [_vp, _i64, _i32]),
+    "kpx_order_skip": (C.c_int, [_vp, _i64, _i32]),
+    "kpx_order_finish": (C.c_int, [_vp, _i64]),
+    "kpx_order_log": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "kpx_frame_step_sharded_workspace_bytes": (_sz, [_i32, _i32, _i32, _i64, _i32]),
+    "kpx_frame_step_sharded": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_sor_select": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "kpx_sort_pairs_u32_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "kpx_sort_pairs_u32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
@@ -109,6 +130,11 @@ def load():
             fn.restype, fn.argtypes = res, args
         _lib = lib
     return _lib
+
+
+BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p)              # kpx_bcast_fn
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)       # kpx_allgather_fn
+RETRY = 1            # kpx_frame_step_sharded: a message outgrew its capacity on every rank alike
 
 
 def check(rc):

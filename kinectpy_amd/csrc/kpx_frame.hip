@@ -199,3 +199,334 @@ KPX_EXPORT int kpx_frame_step_host(const uint16_t *h_depth, const uint8_t *h_rgb
     return kpx_frame_step(d_depth, d_rgb, xy_table, n_px, sensors, h_init, prm, out_pts, out_col, h_count, h_T, h_info, (char *)ws + a.off,
                           ws_bytes - a.off, stream);
 }
+
+// ---- the same frame over several GPUs: the north-star partition, host side in C++ ---------------------------------------------
+// Sensor g lives on GPU g (fewer GPUs than sensors: contiguous blocks, `shard_first`); per frame three collectives on the frame's
+// stream (kpx_comm: RCCL from C++, or the caller's callbacks), issued in the slot-independent order of kpx_order:
+//   0  broadcast of the master's down-sampled cloud + normals from rank 0     (data.py:140-157: every sub registers onto the master)
+//   1  all-gather of the masked clouds, UNMOVED, with their counts and registration results in header rows   (data.py:44-58)
+//   2  all-gather of the slabs' mean neighbour distances (sharded filter_outliers on the fused cloud, data.py:61)
+// Message capacities follow the slot's previous frame (+25 %, the same on every rank because every rank reads the same headers);
+// a frame that outgrows one is NOT patched up with an extra collective (its issue order would depend on timing): every rank sees
+// the overflow in the same header, enlarges the capacity, passes the frame's remaining stages and returns KPX_RETRY -- the caller
+// runs the frame again.  The first frame of a slot uses the worst-case capacities.
+namespace kpx {
+
+int64_t &comm_cap_master(kpx_comm *c);
+int64_t &comm_cap_clouds(kpx_comm *c);
+int &comm_spec_bits(kpx_comm *c);
+
+constexpr int kHdrDoubles = 24;        // per sensor: [0] masked points, [1] down-sampled points, [2..21] registration (T, fitness, rmse, iterations, pairs)
+
+static int shard_first(int n_sensors, int rank, int world)
+{
+    const int base = n_sensors / world, rem = n_sensors % world;
+    return rank * base + (rank < rem ? rank : rem);
+}
+static int shard_count(int n_sensors, int rank, int world) { return n_sensors / world + (rank < n_sensors % world ? 1 : 0); }
+static int64_t round_cap(int64_t need, int64_t worst)
+{
+    int64_t c = (need + need / 4 + 4095) / 4096 * 4096;
+    if (c < 4096) c = 4096;
+    return c < worst ? c : worst;
+}
+
+struct ShardHeaderArgs {
+    int32_t k_max, local, first_is_master;
+    int32_t masked[16], down[16];
+};
+// header rows of this rank's exchange message: counts by value, registration results from device memory (stream order)
+__global__ void shard_header_kernel(double *hdr, ShardHeaderArgs a, const double *icp_res)
+{
+    const int j = blockIdx.x, t = threadIdx.x;
+    if (t >= kHdrDoubles) return;
+    double v = 0.0;
+    if (j < a.local) {
+        const int sub = j - (a.first_is_master ? 1 : 0);        // index into icp_res; -1 = the master itself
+        if (t == 0) v = (double)a.masked[j];
+        else if (t == 1) v = (double)a.down[j];
+        else if (t < 22) v = sub >= 0 ? icp_res[20 * sub + (t - 2)] : ((t - 2) < 16 && (t - 2) % 5 == 0 ? 1.0 : 0.0);
+    } else if (t >= 2 && t < 18 && (t - 2) % 5 == 0) v = 1.0;
+    hdr[j * kHdrDoubles + t] = v;
+}
+
+struct ShardLayout {
+    uint16_t *stage_depth;
+    uint8_t *stage_rgb;
+    float *full_pts, *mask_pts, *mask_col, *down_pts, *normals, *vox_pts, *vox_col;
+    char *msg_master, *xchg_send, *xchg_recv;
+    int32_t *keep_idx, *order_idx, *vox_cnt, *keep_cnt;
+    double *avg_send, *avg_all, *icp_res, *sor_stats;
+    void *op_ws;
+    size_t op_bytes, hdr_bytes;
+    int k_max;
+};
+static void shard_carve(Arena &a, int S, int S_l, int world, int64_t n_px, bool host_input, ShardLayout *L)
+{
+    const size_t px = (size_t)n_px, loc = (size_t)S_l * px, all = (size_t)S * px;
+    L->k_max = (S + world - 1) / world;
+    L->hdr_bytes = ((size_t)L->k_max * kHdrDoubles * sizeof(double) + 255) & ~(size_t)255;
+    L->stage_depth = host_input ? a.get<uint16_t>(loc) : nullptr;
+    L->stage_rgb = host_input ? a.get<uint8_t>(loc * 3) : nullptr;
+    L->full_pts = a.get<float>(loc * 3);
+    L->mask_pts = a.get<float>(loc * 3);
+    L->mask_col = a.get<float>(loc * 3);
+    L->down_pts = a.get<float>(loc * 3);
+    L->normals = a.get<float>(px * 3);
+    L->msg_master = a.get<char>(px * 24 + 256);
+    const size_t xmsg = (size_t)L->k_max * px * 24 + L->hdr_bytes;
+    L->xchg_send = a.get<char>(xmsg);
+    L->xchg_recv = a.get<char>(xmsg * (size_t)world);
+    L->vox_pts = a.get<float>(all * 3);
+    L->vox_col = a.get<float>(all * 3);
+    L->keep_idx = a.get<int32_t>(all);
+    L->order_idx = a.get<int32_t>(all);
+    const size_t rows = (all + (size_t)world - 1) / (size_t)world;
+    L->avg_send = a.get<double>(rows);
+    L->avg_all = a.get<double>(rows * (size_t)world);
+    L->icp_res = a.get<double>((size_t)(S_l > 0 ? S_l : 1) * 20);
+    L->vox_cnt = a.get<int32_t>(64);
+    L->keep_cnt = L->vox_cnt + 1;
+    L->sor_stats = a.get<double>(4);
+    std::vector<int64_t> worst((size_t)(S_l > 0 ? S_l : 1), n_px);
+    size_t w = kpx_depth_to_cloud_workspace_bytes(n_px, S_l);
+    w = max_sz(w, kpx_voxel_batch_workspace_bytes(S_l, worst.data()));
+    w = max_sz(w, kpx_normals_workspace_bytes(n_px, KPX_NORMALS_MAX_NN));
+    w = max_sz(w, kpx_icp_batch_workspace_bytes(S_l > 0 ? S_l : 1, worst.data(), n_px));
+    w = max_sz(w, kpx_fuse_voxel_workspace_bytes((int64_t)all));
+    w = max_sz(w, kpx_sor_workspace_bytes((int64_t)all, KPX_SOR_MAX_K));
+    w = max_sz(w, kpx_sor_finish_workspace_bytes((int64_t)all));
+    w = max_sz(w, kpx_select_workspace_bytes((int64_t)all));
+    L->op_bytes = w;
+    L->op_ws = a.get<char>(w);
+}
+
+// pinned read-back block of the calling thread (32 KiB): [0, 8K) doubles, [8K, 12K) ints, [12K, 32K) gathered headers
+static int pinned_block(char **out)
+{
+    static thread_local char *blk = nullptr;
+    if (!blk) {
+        void *p = nullptr;
+        KPX_HIP(hipHostMalloc(&p, 32768, hipHostMallocDefault));
+        blk = static_cast<char *>(p);
+    }
+    *out = blk;
+    return KPX_OK;
+}
+
+}  // namespace kpx
+
+KPX_EXPORT size_t kpx_frame_step_sharded_workspace_bytes(int32_t sensors, int32_t rank, int32_t world, int64_t n_px, int32_t host_input)
+{
+    if (sensors < 1 || world < 1 || rank < 0 || rank >= world || world > sensors || n_px < 1) return 0;
+    Arena a(nullptr, 0);
+    ShardLayout L;
+    shard_carve(a, sensors, shard_count(sensors, rank, world), world, n_px, host_input != 0, &L);
+    return a.off;
+}
+
+KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t frame, const uint16_t *depth, const uint8_t *rgb, int32_t host_input,
+                                      const float *xy_table, int64_t n_px, int32_t sensors, const double *h_init, const kpx_frame_params *prm,
+                                      int32_t fused_filter, float *out_pts, float *out_col, int32_t *h_count, double *h_T, int32_t *h_info, void *ws,
+                                      size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(comm, "kpx_frame_step_sharded: communicator missing (kpx_comm_create_*)");
+    const int rank = kpx_comm_rank(comm), world = kpx_comm_world(comm), S = sensors;
+    KPX_REQUIRE(S >= 1 && S <= 16 && world <= S && n_px > 0 && n_px < ((int64_t)1 << 31) / 16, "kpx_frame_step_sharded: 1 .. 16 sensors on at most as many ranks");
+    KPX_REQUIRE(depth && rgb && xy_table && prm && out_pts && out_col && h_count && h_T && ws, "kpx_frame_step_sharded: null pointer");
+    KPX_REQUIRE(S == 1 || h_init, "kpx_frame_step_sharded: initial transforms missing");
+    KPX_REQUIRE(prm->icp_mode == KPX_ICP_POINT_TO_POINT || prm->icp_mode == KPX_ICP_POINT_TO_PLANE, "kpx_frame_step_sharded: bad icp_mode");
+    KPX_REQUIRE(fused_filter == 0 || fused_filter == 1, "kpx_frame_step_sharded: fused_filter is 0 (sharded) or 1 (rank 0)");
+    hipStream_t st = (hipStream_t)stream;
+    const int g0 = shard_first(S, rank, world), S_l = shard_count(S, rank, world);
+    const bool owns_master = g0 == 0, plane = prm->icp_mode == KPX_ICP_POINT_TO_PLANE;
+    Arena a(ws, ws_bytes);
+    ShardLayout L;
+    shard_carve(a, S, S_l, world, n_px, host_input != 0, &L);
+    KPX_ARENA_CHECK(a);
+    const int K = L.k_max;
+    char *pin = nullptr;
+    KPX_SUB(pinned_block(&pin));
+    double *h_d = reinterpret_cast<double *>(pin);
+    int32_t *h_i = reinterpret_cast<int32_t *>(pin + 8192);
+    double *h_hdr = reinterpret_cast<double *>(pin + 12288);                     // world x K x kHdrDoubles doubles <= 16 x 24 x 8 B
+    auto negative = [&](const int32_t *c, int n) { for (int i = 0; i < n; ++i) if (c[i] < 0) return c[i]; return 0; };
+    *h_count = 0;
+    if (h_info) memset(h_info, 0, 64 * sizeof(int32_t));
+
+    if (host_input) {
+        KPX_HIP(hipMemcpyAsync(L.stage_depth, depth, (size_t)S_l * n_px * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+        KPX_HIP(hipMemcpyAsync(L.stage_rgb, rgb, (size_t)S_l * n_px * 3, hipMemcpyHostToDevice, st));
+        depth = L.stage_depth;
+        rgb = L.stage_rgb;
+    }
+    // -- this rank's sensors: registration input (every valid pixel) and person clouds (mask + gate + colours)
+    KPX_SUB(kpx_depth_to_cloud(depth, xy_table, nullptr, n_px, S_l, 0, prm->gate, L.full_pts, nullptr, nullptr, h_i, L.op_ws, L.op_bytes, st));
+    KPX_SUB(kpx_depth_to_cloud(depth, xy_table, rgb, n_px, S_l, KPX_COMPACT_COLOR_MASK | KPX_COMPACT_DEPTH_GATE, prm->gate, L.mask_pts, L.mask_col, nullptr,
+                               h_i + 16, L.op_ws, L.op_bytes, st));
+    std::vector<int64_t> fk((size_t)S_l), mk((size_t)S_l), dk((size_t)S_l);
+    std::vector<const float *> p_in((size_t)S_l);
+    std::vector<float *> p_out((size_t)S_l);
+    for (int i = 0; i < S_l; ++i) { p_in[(size_t)i] = L.full_pts + (size_t)i * n_px * 3; p_out[(size_t)i] = L.down_pts + (size_t)i * n_px * 3; }
+    KPX_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < S_l; ++i) { fk[(size_t)i] = h_i[i]; mk[(size_t)i] = h_i[16 + i]; }
+    if (negative(h_i, S_l) || negative(h_i + 16, S_l)) return fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: extraction reported %d", negative(h_i, S_l) | negative(h_i + 16, S_l));
+    static const bool zorder_on = [] { const char *e = getenv("KPX_FRAME_ZORDER"); return !(e && e[0] == '0'); }();
+    const bool zorder = zorder_on && K <= 8;                   // the same decision on every rank: the master arrives in the order rank 0 gave it
+    int &spec_bits = comm_spec_bits(comm);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        KPX_SUB(voxel_downsample_batch_spec(S_l, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, h_i + 32, L.op_ws, L.op_bytes, st,
+                                            attempt == 0 ? spec_bits : 0, h_i + 50, zorder));
+        KPX_HIP(hipStreamSynchronize(st));
+        const int need = h_i[50];
+        const bool narrow = attempt == 0 && spec_bits > 0 && need > spec_bits;
+        spec_bits = need > 0 && need <= 32 ? (need + 7) / 8 * 8 : 0;
+        if (!narrow) break;
+    }
+    if (negative(h_i + 32, S_l)) return fail(KPX_ERR_RANGE, "voxel_size is too small");
+    for (int i = 0; i < S_l; ++i) dk[(size_t)i] = h_i[32 + i];
+
+    // -- collective 0: the master's down-sampled cloud (+ normals) to every rank.  Message: cap rows xyz | cap rows normal | header
+    int64_t &cap_m = comm_cap_master(comm);
+    if (cap_m <= 0) cap_m = n_px;
+    const int64_t capm = cap_m;
+    char *msg = L.msg_master;
+    float *m_xyz = reinterpret_cast<float *>(msg), *m_nrm = reinterpret_cast<float *>(msg + (size_t)capm * 12);
+    double *m_hdr = reinterpret_cast<double *>(msg + (size_t)capm * 24);
+    if (owns_master) {
+        KPX_REQUIRE(dk[0] >= 1, "kpx_frame_step_sharded: sensor 0 has no valid pixel");
+        if (plane) KPX_SUB(kpx_estimate_normals(L.down_pts, dk[0], 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st));
+        const size_t rows = (size_t)(dk[0] < capm ? dk[0] : capm);
+        KPX_HIP(hipMemcpyAsync(m_xyz, L.down_pts, rows * 12, hipMemcpyDeviceToDevice, st));
+        if (plane) KPX_HIP(hipMemcpyAsync(m_nrm, L.normals, rows * 12, hipMemcpyDeviceToDevice, st));
+        h_d[0] = (double)dk[0];
+        KPX_HIP(hipMemcpyAsync(m_hdr, h_d, sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    kpx_order_turn_begin(order, frame, 0);
+    int rc = kpx_comm_broadcast(comm, msg, (size_t)capm * 24 + 256, 0, st);
+    kpx_order_turn_end(order, frame, 0);
+    if (rc) return rc;
+    int64_t m = owns_master ? dk[0] : 0;
+    if (!owns_master) {
+        KPX_HIP(hipMemcpyAsync(h_d, m_hdr, sizeof(double), hipMemcpyDeviceToHost, st));
+        KPX_HIP(hipStreamSynchronize(st));
+        m = (int64_t)h_d[0];
+        KPX_REQUIRE(m >= 1 && m <= n_px, "kpx_frame_step_sharded: bad master header (%lld points)", (long long)m);
+    }
+    cap_m = round_cap(m, n_px);
+    if (m > capm) {                                            // every rank reads the same m: all retry, none goes on
+        kpx_order_finish(order, frame);
+        return KPX_RETRY;
+    }
+    // -- registration of this rank's sub sensors onto the master
+    const int n_sub = S_l - (owns_master ? 1 : 0);
+    if (n_sub > 0) {
+        std::vector<const float *> subs((size_t)n_sub);
+        std::vector<int64_t> ns((size_t)n_sub);
+        for (int j = 0; j < n_sub; ++j) {
+            const int i = j + (owns_master ? 1 : 0);
+            KPX_REQUIRE(dk[(size_t)i] >= 1, "kpx_frame_step_sharded: sensor %d has no valid pixel", g0 + i);
+            subs[(size_t)j] = p_out[(size_t)i];
+            ns[(size_t)j] = dk[(size_t)i];
+        }
+        const float *tgt = owns_master ? L.down_pts : m_xyz, *tn = plane ? (owns_master ? L.normals : m_nrm) : nullptr;
+        const int first_sub = g0 + (owns_master ? 1 : 0);      // global sensor number of subs[0]; h_init[g - 1] belongs to sensor g
+        KPX_SUB(icp_batch_ordered(n_sub, subs.data(), ns.data(), tgt, tn, m, prm->icp_max_dist, h_init + 16 * (size_t)(first_sub - 1), prm->icp_mode,
+                                  prm->icp_max_iteration, 1e-6, 1e-6, L.icp_res, L.op_ws, L.op_bytes, st, zorder));
+    }
+    // -- collective 1: the masked clouds, unmoved, planar (xyz rows, then rgb rows), + header rows
+    int64_t &cap_c = comm_cap_clouds(comm);
+    const int64_t worst_c = (int64_t)K * n_px;
+    if (cap_c <= 0) cap_c = worst_c;
+    const int64_t capc = cap_c;
+    const size_t xbytes = (size_t)capc * 24 + L.hdr_bytes;
+    {
+        ShardHeaderArgs ha;
+        memset(&ha, 0, sizeof(ha));
+        ha.k_max = K; ha.local = S_l; ha.first_is_master = owns_master ? 1 : 0;
+        int64_t off = 0;
+        for (int i = 0; i < S_l; ++i) {
+            ha.masked[i] = (int32_t)mk[(size_t)i]; ha.down[i] = (int32_t)dk[(size_t)i];
+            int64_t k = capc - off < mk[(size_t)i] ? capc - off : mk[(size_t)i];
+            if (k < 0) k = 0;
+            if (k > 0) {
+                KPX_HIP(hipMemcpyAsync(L.xchg_send + (size_t)off * 12, L.mask_pts + (size_t)i * n_px * 3, (size_t)k * 12, hipMemcpyDeviceToDevice, st));
+                KPX_HIP(hipMemcpyAsync(L.xchg_send + (size_t)(capc + off) * 12, L.mask_col + (size_t)i * n_px * 3, (size_t)k * 12, hipMemcpyDeviceToDevice, st));
+            }
+            off += k;
+        }
+        hipLaunchKernelGGL(shard_header_kernel, dim3((unsigned)K), dim3(32), 0, st, reinterpret_cast<double *>(L.xchg_send + (size_t)capc * 24), ha, L.icp_res);
+        KPX_LAUNCH_CHECK();
+    }
+    kpx_order_turn_begin(order, frame, 1);
+    rc = kpx_comm_allgather(comm, L.xchg_send, L.xchg_recv, xbytes, st);
+    kpx_order_turn_end(order, frame, 1);
+    if (rc) return rc;
+    const size_t hrow = (size_t)K * kHdrDoubles * sizeof(double);
+    KPX_HIP(hipMemcpy2DAsync(h_hdr, hrow, L.xchg_recv + (size_t)capc * 24, xbytes, hrow, (size_t)world, hipMemcpyDeviceToHost, st));
+    KPX_HIP(hipStreamSynchronize(st));
+    std::vector<const float *> f_p((size_t)S), f_c((size_t)S);
+    std::vector<int64_t> f_n((size_t)S);
+    int64_t need = 0;
+    for (int r = 0, g = 0; r < world; ++r) {
+        const int own = shard_count(S, r, world);
+        int64_t off = 0;
+        for (int j = 0; j < own; ++j, ++g) {
+            const double *row = h_hdr + ((size_t)r * K + j) * kHdrDoubles;
+            const int64_t n = (int64_t)row[0];
+            KPX_REQUIRE(n >= 0 && n <= n_px, "kpx_frame_step_sharded: bad exchange header (rank %d)", r);
+            f_p[(size_t)g] = reinterpret_cast<const float *>(L.xchg_recv + (size_t)r * xbytes + (size_t)off * 12);
+            f_c[(size_t)g] = reinterpret_cast<const float *>(L.xchg_recv + (size_t)r * xbytes + (size_t)(capc + off) * 12);
+            f_n[(size_t)g] = n;
+            for (int q = 0; q < 16; ++q) h_T[16 * g + q] = row[2 + q];
+            if (h_info) { h_info[g] = (int32_t)row[1]; h_info[16 + g] = (int32_t)n; h_info[32 + g] = g == 0 ? 0 : (int32_t)row[2 + 18]; }
+            off += n;
+        }
+        need = off > need ? off : need;
+    }
+    cap_c = round_cap(need, worst_c);
+    if (need > capc) {
+        kpx_order_finish(order, frame);
+        return KPX_RETRY;
+    }
+    if (fused_filter == 1 && rank != 0) {                      // rank 0 filters alone: the others are done with this frame
+        kpx_order_skip(order, frame, 2);
+        return KPX_OK;
+    }
+    // -- fuse: pcd.transform(T_i) + np.vstack + voxel_down_sample in one fp64 pass (every rank that filters: identical everywhere)
+    KPX_SUB(fuse_voxel_downsample_dev(S, f_p.data(), f_c.data(), f_n.data(), h_T, nullptr, prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws,
+                                      L.op_bytes, st));
+    KPX_HIP(hipMemcpyAsync(h_i + 48, L.vox_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    KPX_HIP(hipStreamSynchronize(st));
+    if (h_i[48] < 0) return fail(KPX_ERR_RANGE, "voxel_size is too small");
+    const int64_t M = h_i[48];
+    if (h_info) h_info[48] = (int32_t)M;
+    if (M == 0) {
+        kpx_order_skip(order, frame, 2);
+        return KPX_OK;
+    }
+    if (fused_filter == 1) {                                   // rank 0, alone: the one-GPU filter + selection
+        kpx_order_skip(order, frame, 2);
+        KPX_SUB(kpx_sor_select(L.vox_pts, L.vox_col, M, prm->filt_k, prm->filt_ratio, out_pts, out_col, L.keep_idx, h_i + 49, L.sor_stats, L.op_ws, L.op_bytes, st));
+        KPX_HIP(hipStreamSynchronize(st));
+        *h_count = h_i[49];
+        return KPX_OK;
+    }
+    // -- sharded filter: this rank searches the neighbours of slab `rank` of the grid order; collective 2 = the slabs' mean distances
+    const int64_t rows = (M + world - 1) / world;
+    const int64_t q0 = rank * rows < M ? rank * rows : M, q1 = (rank + 1) * rows < M ? (rank + 1) * rows : M;
+    KPX_SUB(kpx_sor_partial(L.vox_pts, M, prm->filt_k, q0, q1, L.avg_send, L.order_idx, L.op_ws, L.op_bytes, st));
+    kpx_order_turn_begin(order, frame, 2);
+    rc = kpx_comm_allgather(comm, L.avg_send, L.avg_all, (size_t)rows * sizeof(double), st);
+    kpx_order_turn_end(order, frame, 2);
+    if (rc) return rc;
+    KPX_SUB(kpx_sor_finish(L.avg_all, L.order_idx, M, prm->filt_ratio, L.keep_idx, L.keep_cnt, L.sor_stats, nullptr, L.op_ws, L.op_bytes, st));
+    KPX_HIP(hipMemcpyAsync(h_i + 49, L.keep_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    KPX_HIP(hipStreamSynchronize(st));
+    const int64_t kept = h_i[49];
+    if (kept > 0)
+        KPX_SUB(kpx_select_by_index(L.vox_pts, L.vox_col, nullptr, M, L.keep_idx, kept, KPX_SELECT_GATHER, out_pts, out_col, nullptr, nullptr, L.op_ws,
+                                    L.op_bytes, st));
+    *h_count = (int32_t)kept;
+    return KPX_OK;
+}

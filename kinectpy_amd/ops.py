@@ -529,6 +529,46 @@ def frame_step(depth, rgb, xy_table, inits, params: FrameParams, out=None):
     return out[0][:k], out[1][:k], h_T, h_info
 
 
+def frame_step_sharded(comm, order, frame, depth, rgb, xy_table, n_sensors, inits, params: FrameParams, fused_filter=0, out=None):
+    """kpx_frame_step_sharded: this rank's share of the frame (depth (S_local, n_px) u16, rgb (S_local, n_px, 3) u8, on the device or
+    in host memory), the collectives issued natively through `comm` (parallel.NativeComm).  inits: the n_sensors - 1 initial
+    transforms of ALL sub sensors.  -> (points, colours, transforms (n_sensors,4,4), info) or L.RETRY when a message outgrew its
+    capacity on every rank alike (run the frame again)."""
+    lib = L.load()
+    host = isinstance(depth, torch.Tensor) and not depth.is_cuda
+    if host:
+        if depth.dtype != torch.uint16 or rgb.dtype != torch.uint8 or not (depth.is_contiguous() and rgb.is_contiguous()):
+            raise ValueError("frame_step_sharded: host frames must be contiguous uint16 depth / uint8 rgb tensors")
+        dev = L.device()
+    else:
+        depth = _dev(depth, torch.uint16)
+        rgb = _dev(rgb, torch.uint8)
+        dev = depth.device
+    S, S_l = int(n_sensors), int(depth.shape[0])
+    n_px = int(depth.numel() // max(S_l, 1))
+    xy = _dev(xy_table, torch.float32).reshape(-1)
+    init = np.ascontiguousarray(np.stack([_T(T) for T in inits])) if S > 1 else np.zeros((1, 4, 4))
+    if out is None:
+        out = (torch.empty((S * n_px, 3), dtype=torch.float32, device=dev), torch.empty((S * n_px, 3), dtype=torch.float32, device=dev))
+    h_count = np.zeros(1, dtype=np.int32)
+    h_T = np.zeros((S, 4, 4))
+    h_info = np.zeros(64, dtype=np.int32)
+    # one size for device and host frames: a stream that sees both never regrows its scratch
+    ws, wsz = L.workspace(lib.kpx_frame_step_sharded_workspace_bytes(S, comm.rank, comm.world, n_px, 1))
+    rc = lib.kpx_frame_step_sharded(comm.handle, None if order is None else order.handle, -1 if frame is None else int(frame),
+                                    C.c_void_p(depth.data_ptr()), C.c_void_p(rgb.data_ptr()), 1 if host else 0, L.ptr(xy), n_px, S, L.hptr(init),
+                                    C.byref(params), int(fused_filter), L.ptr(out[0]), L.ptr(out[1]), h_count.ctypes.data_as(C.c_void_p), L.hptr(h_T),
+                                    h_info.ctypes.data_as(C.c_void_p), ws, wsz, L.stream_ptr())
+    if comm.error is not None:
+        e, comm.error = comm.error, None
+        raise e
+    if rc == L.RETRY:
+        return L.RETRY
+    L.check(rc)
+    k = int(h_count[0])
+    return out[0][:k], out[1][:k], h_T, h_info
+
+
 # ---- measurement hooks --------------------------------------------------------------------------------
 NN_ENGINES = ("culled", "dense")
 

@@ -40,7 +40,10 @@ class CollectiveOrder:
 
     STAGES = 3
 
-    def __init__(self, depth: int):
+    def __new__(cls, depth: int = 1, native: bool = False):
+        return super().__new__(NativeCollectiveOrder if (native and cls is CollectiveOrder) else cls)
+
+    def __init__(self, depth: int, native: bool = False):
         import threading
         self.depth = max(1, int(depth))
         self.cv = threading.Condition()
@@ -98,6 +101,200 @@ class CollectiveOrder:
             for s_ in range(self.STAGES):
                 self.pending.discard(self.key(frame, s_))
             self.cv.notify_all()
+
+
+class NativeCollectiveOrder(CollectiveOrder):
+    """The same order kept inside the library (kpx_order, kpx_comm.hip): kpx_frame_step_sharded takes its turns in C++ without
+    coming back to the interpreter.  Same interface as CollectiveOrder (the tests run against both)."""
+
+    def __init__(self, depth: int, native: bool = True):
+        import ctypes as C
+        from . import _lib
+        self.depth = max(1, int(depth))
+        self._L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._L.kpx_order_create(self.depth, C.byref(h)))
+        self.handle = h
+
+    def submit(self) -> int:
+        import ctypes as C
+        f = C.c_int64()
+        self._L.kpx_order_submit(self.handle, C.byref(f))
+        return int(f.value)
+
+    def block(self, frame):
+        self._L.kpx_order_block(self.handle, -1 if frame is None else int(frame))
+
+    def turn(self, frame: int, stage: int):
+        order = self
+
+        class _Turn:
+            def __enter__(self_inner):
+                order._L.kpx_order_turn_begin(order.handle, int(frame), int(stage))
+
+            def __exit__(self_inner, *exc):
+                order._L.kpx_order_turn_end(order.handle, int(frame), int(stage))
+                return False
+        return _Turn()
+
+    def skip(self, frame: int, stage: int):
+        self._L.kpx_order_skip(self.handle, int(frame), int(stage))
+
+    def finish(self, frame: int):
+        self._L.kpx_order_finish(self.handle, int(frame))
+
+    @property
+    def log(self):
+        import ctypes as C
+        import numpy as np
+        n = C.c_int64()
+        self._L.kpx_order_log(self.handle, None, 0, C.byref(n))
+        out = np.zeros(max(1, n.value), dtype=np.int64)
+        self._L.kpx_order_log(self.handle, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+        return out[: n.value].tolist()
+
+    def __del__(self):
+        try:
+            self._L.kpx_order_destroy(self.handle)
+        except Exception:
+            pass
+
+
+# ---- kpx_comm: the native communicator of the sharded frame loop (kpx_frame_step_sharded) -------------------------------------
+class NativeComm:
+    """One communicator over all ranks for the native multi-rank frame loop (one per frame slot).  Transports:
+      NativeComm.rccl(group)    RCCL called from C++ on the frame's stream; rank 0 draws the id, torch.distributed carries it
+                                (collective: every rank calls it in the same order);
+      NativeComm.staged(group)  the bytes travel through torch.distributed on host buffers (gloo): rehearsal of the same loop with
+                                several ranks sharing one GPU;
+      NativeComm.local(hub, r)  in-process ranks (threads of one process, tests): device-to-device copies around a barrier."""
+
+    def __init__(self, handle, rank, world, keep=()):
+        self.handle, self.rank, self.world, self._keep = handle, int(rank), int(world), keep
+        self.error = None
+
+    @staticmethod
+    def _rccl_path():
+        import glob
+        cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + glob.glob("/opt/rocm/lib/librccl.so*")
+        return cands[0] if cands else None
+
+    @classmethod
+    def rccl(cls, group=None):
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        _lib.device()
+        path = cls._rccl_path()
+        _lib.check(L.kpx_rccl_load(path.encode() if path else None))
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = world_size(group)
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(L.kpx_rccl_unique_id(ident))
+        if dist.is_initialized() and world > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        _lib.check(L.kpx_comm_create_rccl(ident, rank, world, C.byref(h)))
+        return cls(h, rank, world)
+
+    @classmethod
+    def _callbacks(cls, rank, world, bcast, allgather):
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        self = cls(None, rank, world)
+
+        def guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except BaseException as e:      # an exception must not cross the C frames: keep it for the caller
+                    self.error = e
+                    return 1
+            return run
+        b, g = _lib.BCAST_FN(guard(bcast)), _lib.ALLGATHER_FN(guard(allgather))
+        h = C.c_void_p()
+        _lib.check(L.kpx_comm_create_callbacks(rank, world, C.cast(b, C.c_void_p), C.cast(g, C.c_void_p), None, C.byref(h)))
+        self.handle, self._keep = h, (b, g)
+        return self
+
+    @classmethod
+    def staged(cls, group=None):
+        """host-staged transport over torch.distributed (gloo): device -> host buffer -> collective -> device"""
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        L = _lib.load()
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = world_size(group)
+
+        def copy(dst, src, n, stream):
+            _lib.check(L.kpx_copy_bytes(C.c_void_p(dst), C.c_void_p(src), n, C.c_void_p(stream), 1))
+
+        def bcast(user, d_buf, n, root, stream):
+            h = np.empty(n, dtype=np.uint8)
+            if rank == root:
+                copy(h.ctypes.data, d_buf, n, stream)
+            if world > 1:
+                dist.broadcast(torch.from_numpy(h), root, group=group)
+            if rank != root:
+                copy(d_buf, h.ctypes.data, n, stream)
+
+        def allgather(user, d_send, d_recv, n, stream):
+            h, out = np.empty(n, dtype=np.uint8), np.empty((world, n), dtype=np.uint8)
+            copy(h.ctypes.data, d_send, n, stream)
+            if world > 1:
+                parts = [torch.from_numpy(out[r]) for r in range(world)]
+                dist.all_gather(parts, torch.from_numpy(h), group=group)
+            else:
+                out[0] = h
+            copy(d_recv, out.ctypes.data, world * n, stream)
+        return cls._callbacks(rank, world, bcast, allgather)
+
+    class LocalHub:
+        """rendezvous of `world` in-process ranks (one thread each)"""
+
+        def __init__(self, world):
+            import threading
+            self.world = int(world)
+            self.barrier = threading.Barrier(self.world)
+            self.slot = [None] * self.world
+
+    @classmethod
+    def local(cls, hub, rank):
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+
+        def copy(dst, src, n, stream):
+            _lib.check(L.kpx_copy_bytes(C.c_void_p(dst), C.c_void_p(src), n, C.c_void_p(stream), 1))
+
+        def bcast(user, d_buf, n, root, stream):
+            copy(None, None, 0, stream)                       # everything queued before the collective has happened
+            hub.slot[rank] = d_buf
+            hub.barrier.wait()
+            if rank != root:
+                copy(d_buf, hub.slot[root], n, stream)
+            hub.barrier.wait()
+
+        def allgather(user, d_send, d_recv, n, stream):
+            copy(None, None, 0, stream)
+            hub.slot[rank] = d_send
+            hub.barrier.wait()
+            for r in range(hub.world):
+                copy(d_recv + r * n, hub.slot[r], n, stream)
+            hub.barrier.wait()
+        return cls._callbacks(rank, hub.world, bcast, allgather)
+
+    def close(self):
+        from . import _lib
+        if self.handle is not None:
+            _lib.load().kpx_comm_destroy(self.handle)
+            self.handle = None
 
 
 def init_distributed(backend: str = None) -> Tuple[int, int, int]:

@@ -261,6 +261,66 @@ class NativeFramePipeline:
         return out_p, out_c, Ts
 
 
+class NativeShardPipeline:
+    """SensorShardPipeline.step with the host side of the frame AND its three collectives inside the library
+    (kpx_frame_step_sharded): sensor g on GPU g, master broadcast, per-rank registration, all-gather of the masked clouds,
+    fused fp64 transform + voxel, sharded (or rank-0) filter.  `comm`: parallel.NativeComm (RCCL on a real node; the staged and
+    in-process transports rehearse the same loop).  depth / rgb of THIS rank's sensors, device or (pinned) host tensors."""
+
+    def __init__(self, xy_table, n_sensors: int, init_transforms: List[np.ndarray], params: Optional[PipelineParams] = None,
+                 comm=None, fused_filter: str = "sharded", out_ring: int = 0):
+        if comm is None:
+            raise ValueError("NativeShardPipeline needs a communicator (parallel.NativeComm.rccl / staged / local)")
+        self.p = params or PipelineParams()
+        self.comm = comm
+        self.n_sensors = int(n_sensors)
+        if comm.world > self.n_sensors:
+            raise ValueError(f"{comm.world} ranks for {self.n_sensors} sensors: a rank needs at least one sensor")
+        self.sensors = parallel.shard_sensors(self.n_sensors, comm.rank, comm.world)
+        if len(init_transforms) != self.n_sensors - 1:
+            raise ValueError("init_transforms: one 4x4 per sub sensor (sensors 1 .. n-1)")
+        self.init = [np.asarray(T, dtype=np.float64) for T in init_transforms]
+        if fused_filter not in ("rank0", "sharded"):
+            raise ValueError("fused_filter must be 'rank0' or 'sharded'")
+        self.fused_filter = fused_filter
+        self.xy = ops._dev(xy_table, torch.float32).reshape(-1)
+        p = self.p
+        self._c = ops.FrameParams(p.reg_voxel, p.icp_max_dist, p.filt_voxel, p.filt_ratio, p.gate, p.normals_nn,
+                                  {"p2p": 0, "p2plane": 1}[p.icp_mode], p.icp_max_iteration, p.filt_k)
+        self._ring, self._ring_n, self._ring_k = [], int(out_ring), 0
+        self.order = None                 # (parallel.NativeCollectiveOrder, frame number) while a FrameStream runs this step
+        self.native_order = True
+        self.retries = 0
+        self.last = {}
+
+    def step(self, depth: torch.Tensor, rgb: torch.Tensor):
+        """-> (points, colours, transforms) -- points / colours empty on ranks > 0 with fused_filter == "rank0" -- or the RETRY
+        marker when this frame runs under a FrameStream (which submits it again in program order); serially it is retried here."""
+        from . import _lib
+        S = self.n_sensors
+        out = None
+        if self._ring_n:
+            if len(self._ring) < self._ring_n:
+                rows = S * int(depth.numel() // max(1, len(self.sensors)))
+                self._ring.append(tuple(torch.empty((rows, 3), dtype=torch.float32, device=self.xy.device) for _ in range(2)))
+            out = self._ring[self._ring_k % len(self._ring)]
+            self._ring_k += 1
+        order, frame = self.order if self.order is not None else (None, None)
+        while True:
+            res = ops.frame_step_sharded(self.comm, order, frame, depth, rgb, self.xy, S, self.init, self._c,
+                                         1 if self.fused_filter == "rank0" else 0, out=out)
+            if res is not _lib.RETRY:
+                break
+            self.retries += 1
+            if order is not None:
+                return _lib.RETRY
+        out_p, out_c, Ts, info = res
+        self.last = {"icp": [(int(info[32 + i]), None, None) for i in range(1, S)], "n_down": [int(v) for v in info[:S]],
+                     "n_masked": [int(v) for v in info[16:16 + S]], "n_fused": int(info[16:16 + S].sum()), "n_voxel": int(info[48]),
+                     "n_out": int(out_p.shape[0])}
+        return out_p, out_c, Ts
+
+
 class FrameStream:
     """Several frames of a stream in flight.  A frame is a chain of short, mostly latency-bound kernels (the ICP loop alone
     is ~75 dependent launches that keep a fraction of the CUs busy), and consecutive frames are independent, so `depth`
@@ -280,9 +340,10 @@ class FrameStream:
         self.pending = deque()
         self.submitted = 0
         # several ranks: the frames' collectives are issued in one global order on every rank (parallel.CollectiveOrder)
+        native = self.pipes is not None and all(getattr(p_, "native_order", False) for p_ in self.pipes)
         ordered = self.pipes is not None and self.depth > 1 and all(hasattr(p_, "order") for p_ in self.pipes) and \
-            parallel.collectives_on(getattr(self.pipes[0], "group", None))
-        self.order = parallel.CollectiveOrder(self.depth) if ordered else None
+            (native or parallel.collectives_on(getattr(self.pipes[0], "group", None)))
+        self.order = parallel.CollectiveOrder(self.depth, native=native) if ordered else None
 
     def _run(self, slot, depth, rgb, frame=None):
         torch.cuda.set_device(self.device)
@@ -290,7 +351,7 @@ class FrameStream:
         pipe = self.pipes[slot] if self.pipes else self.pipe
         try:
             with torch.cuda.stream(stream):
-                if not depth.is_cuda and not isinstance(pipe, NativeFramePipeline):
+                if not depth.is_cuda and not isinstance(pipe, (NativeFramePipeline, NativeShardPipeline)):
                     # frames handed over in pinned host memory: the copy is part of the frame (the native loop stages them itself)
                     depth = depth.to(self.device, non_blocking=True)
                     rgb = rgb.to(self.device, non_blocking=True)
@@ -314,7 +375,7 @@ class FrameStream:
         self.submitted += 1
         frame = self.order.submit() if self.order is not None else None
         fut = self.pool.submit(self._run, slot, depth, rgb, frame)
-        fut.frame = frame
+        fut.frame, fut.args = frame, (slot, depth, rgb)
         self.pending.append(fut)
 
     def pop(self):
@@ -322,14 +383,25 @@ class FrameStream:
         stream: they are handed to the caller's current stream with record_stream(), so that the caching allocator does not
         give their blocks back to the side stream (whose next frame would overwrite them) while kernels the caller queued
         asynchronously are still reading them."""
+        from . import _lib
         fut = self.pending.popleft()
-        if self.order is not None:
-            self.order.block(fut.frame)          # no frame can be submitted before this one is done: see CollectiveOrder
-        try:
-            out = fut.result()
-        finally:
+        while True:
             if self.order is not None:
-                self.order.block(None)
+                self.order.block(fut.frame)      # no frame can be submitted before this one is done: see CollectiveOrder
+            try:
+                out = fut.result()
+            finally:
+                if self.order is not None:
+                    self.order.block(None)
+            if out is not _lib.RETRY:
+                break
+            # a message outgrew its capacity on EVERY rank alike (kpx_frame_step_sharded): the frame runs again under a new frame
+            # number, submitted here -- the same point of the main thread's program on every rank
+            slot, depth, rgb = fut.args
+            frame = self.order.submit() if self.order is not None else None
+            args = fut.args
+            fut = self.pool.submit(self._run, slot, depth, rgb, frame)
+            fut.frame, fut.args = frame, args
         cur = torch.cuda.current_stream(self.device)
         for t in out:
             if isinstance(t, torch.Tensor) and t.is_cuda:

@@ -46,7 +46,7 @@ def test_ctypes_signatures_match_the_header():
 
     def cls(param):
         param = " ".join(param.split())
-        if "*" in param:
+        if "*" in param or "_fn " in param:          # kpx_bcast_fn / kpx_allgather_fn: function pointers
             return "ptr"
         for key, name in (("uint64_t", "i64"), ("int64_t", "i64"), ("size_t", "i64"), ("int32_t", "i32"), ("double", "f64"), ("int ", "i32")):
             if key in param + " ":

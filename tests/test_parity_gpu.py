@@ -1231,18 +1231,19 @@ def test_sharded_sor_bit_identical_to_one_call(ops, oracle, base_cloud, k, ratio
     assert empty.numel() == 0
 
 
-@pytest.mark.parametrize("world,mode", [(2, "sharded"), (4, "sharded"), (4, "rank0")])
-def test_sensor_partition_equals_single_process_oracle(tmp_path, oracle, four_sensor_oracle, world, mode):
+@pytest.mark.parametrize("world,mode,native", [(2, "sharded", 0), (4, "sharded", 0), (4, "rank0", 0), (2, "sharded", 1), (4, "sharded", 1), (4, "rank0", 1)])
+def test_sensor_partition_equals_single_process_oracle(tmp_path, oracle, four_sensor_oracle, world, mode, native):
     """BASELINE configs[3] as the north star states it: sensor g on rank g (gloo ranks sharing the one GPU; world 2 = two
     sensors per rank), master-cloud broadcast, per-rank registration, all-gather, filter on the FUSED cloud -- every rank ends
     up with what the single-process oracle computes for the same four sensors: clouds identical, transforms within TOL_T;
-    the same with two frames in flight (one communicator per slot)"""
+    the same with two frames in flight (one communicator per slot).  native = 1: the host loop AND the collectives inside the library
+    (kpx_frame_step_sharded through a host-staged gloo transport; collectives ordered by the library's kpx_order)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KPX_DIST_BACKEND="gloo", OUT_DIR=str(tmp_path), N_SENSORS="4", FUSED_FILTER=mode)
+    env = dict(os.environ, KPX_DIST_BACKEND="gloo", OUT_DIR=str(tmp_path), N_SENSORS="4", FUSED_FILTER=mode, NATIVE_LOOP=str(native))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-                        "--master-port", str(29600 + world + (10 if mode == "rank0" else 0)), os.path.join(root, "tests", "dist_shard_worker.py")],
+                        "--master-port", str(29600 + world + (10 if mode == "rank0" else 0) + 20 * native), os.path.join(root, "tests", "dist_shard_worker.py")],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     ref = four_sensor_oracle[5]
@@ -1256,6 +1257,138 @@ def test_sensor_partition_equals_single_process_oracle(tmp_path, oracle, four_se
                 assert pk not in z
                 continue
             assert np.array_equal(z[pk], rp) and np.array_equal(z[ck], rc), (rank, key)
+
+
+def _local_ranks(world, S, xy, depth, rgb, inits, mode, frames, slots=1, host=False):
+    """`world` in-process ranks (one thread each, all on this GPU) through the native sharded loop: -> per rank [(p, c, T, last)]"""
+    import threading
+    from kinectpy_amd import parallel
+    from kinectpy_amd.pipeline import FrameStream, NativeShardPipeline, PipelineParams
+    hubs = [parallel.NativeComm.LocalHub(world) for _ in range(slots)]
+    results, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            mine = parallel.shard_sensors(S, r, world)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                pipes = [NativeShardPipeline(xy, S, inits, PipelineParams(), comm=parallel.NativeComm.local(h, r), fused_filter=mode) for h in hubs]
+                feed = lambda f: ((torch.as_tensor(depth[f][mine]).pin_memory(), torch.as_tensor(rgb[f][mine]).pin_memory()) if host else
+                                  (torch.as_tensor(depth[f][mine]).cuda(), torch.as_tensor(rgb[f][mine]).cuda()))
+                out = []
+                if slots == 1:
+                    for f in frames:
+                        p, c, Ts = pipes[0].step(*feed(f))
+                        out.append((npy(p), npy(c), Ts, dict(pipes[0].last)))
+                else:
+                    fs = FrameStream(pipes)
+                    for f in frames:
+                        if fs.full():
+                            p, c, Ts = fs.pop()
+                            out.append((npy(p), npy(c), Ts, {}))
+                        fs.submit(*feed(f))
+                    while fs.pending:
+                        p, c, Ts = fs.pop()
+                        out.append((npy(p), npy(c), Ts, {}))
+                    fs.close()
+                results[r] = out
+        except BaseException as e:
+            errors.append((r, e))
+            for h in hubs:
+                h.barrier.abort()
+
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]
+    [t.join(timeout=600) for t in ths]
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("world,mode", [(1, "sharded"), (2, "sharded"), (3, "sharded"), (4, "sharded"), (4, "rank0")])
+def test_native_sharded_loop_in_process_ranks(four_sensor_oracle, world, mode):
+    """kpx_frame_step_sharded -- host loop and collectives in C++ -- with `world` in-process ranks on this GPU (device-to-device
+    transport around a barrier): every rank ends with what the single-process oracle computes for the four sensors; the second
+    frame runs with the message capacities learnt from the first, the third is handed over in pinned host memory"""
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    res = _local_ranks(world, 4, xy, depth, rgb, inits, mode, frames=(0, 1))
+    res_h = _local_ranks(world, 4, xy, depth, rgb, inits, mode, frames=(1,), host=True)
+    for r in range(world):
+        for (p, c, Ts, last), f in list(zip(res[r], (0, 1))) + [(res_h[r][0], 1)]:
+            rp, rc, rT, aux = ref[f]
+            assert np.abs(Ts - np.stack(rT)).max() < TOL_T
+            assert last["n_down"] == [len(x) for x in aux["downs"]] and last["n_fused"] == len(aux["fused"])
+            assert [it for it, _, _ in last["icp"]] == [it for it, _, _ in aux["icp"]]
+            if mode == "rank0" and r != 0:
+                assert p.shape[0] == 0
+                continue
+            assert np.array_equal(p, rp) and np.array_equal(c, rc), (r, f)
+
+
+def test_native_sharded_loop_eight_ranks_eight_sensors(oracle):
+    """BASELINE configs[4]'s partition -- 8 sensors, one per rank, 8 ranks -- through the native loop (in-process ranks sharing this
+    GPU): k_max = 1 headers, rank 0 owns only the master (no registration of its own), seven ranks register one sub each, the
+    fused filter in eight slabs.  Every rank equals the oracle step over the eight sensors.  Then two frames in flight per rank
+    (one communicator per slot, the library's kpx_order) on four ranks."""
+    xy, depth, rgb, inits, truth, ref = _oracle_steps(oracle, 8, 1)
+    rp, rc, rT, aux = ref[0]
+    res = _local_ranks(8, 8, xy, depth, rgb, inits, "sharded", frames=(0, 0))
+    for r in range(8):
+        for p, c, Ts, last in res[r]:
+            assert np.abs(Ts - np.stack(rT)).max() < TOL_T
+            assert last["n_down"] == [len(x) for x in aux["downs"]] and last["n_fused"] == len(aux["fused"]) and last["n_voxel"] == len(aux["voxel"])
+            assert np.array_equal(p, rp) and np.array_equal(c, rc), r
+    res = _local_ranks(4, 8, xy, depth, rgb, inits, "sharded", frames=(0, 0, 0, 0, 0), slots=2)
+    for r in range(4):
+        assert len(res[r]) == 5
+        for p, c, Ts, _ in res[r]:
+            assert np.abs(Ts - np.stack(rT)).max() < TOL_T and np.array_equal(p, rp) and np.array_equal(c, rc), r
+
+
+def test_native_sharded_loop_retries_a_frame_that_outgrows_its_messages(four_sensor_oracle):
+    """message capacities follow the slot's previous frame (+25 %): a frame with an empty scene first (tiny capacities), then the
+    real one -- every rank sees the overflow in the same header, returns KPX_RETRY and the frame runs again with room"""
+    from kinectpy_amd import parallel
+    from kinectpy_amd.pipeline import NativeShardPipeline, PipelineParams
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    comm = parallel.NativeComm.local(parallel.NativeComm.LocalHub(1), 0)
+    pipe = NativeShardPipeline(xy, 4, inits, PipelineParams(), comm=comm)
+    far = np.where(depth[0] > 0, np.uint16(60000), np.uint16(0)).astype(np.uint16)
+    far[:, ::7] = 0                                    # a thin, far scene: few voxels in the registration grid, no person pixels kept
+    try:
+        pipe.step(torch.as_tensor(far).cuda(), torch.zeros_like(torch.as_tensor(rgb[0])).cuda())
+    except Exception:
+        pass                                           # (a degenerate registration may refuse; the capacities were learnt before)
+    gp, gc, gT = pipe.step(torch.as_tensor(depth[0]).cuda(), torch.as_tensor(rgb[0]).cuda())
+    assert pipe.retries >= 1
+    assert np.array_equal(npy(gp), ref[0][0]) and np.array_equal(npy(gc), ref[0][1]) and np.abs(gT - np.stack(ref[0][2])).max() < TOL_T
+
+
+def test_native_sharded_loop_through_rccl_one_rank(four_sensor_oracle):
+    """the RCCL transport itself, as far as one GPU allows: a one-rank communicator built by kpx_comm_create_rccl (librccl dlopen'ed by
+    the library, id from kpx_rccl_unique_id); broadcast, both all-gathers on the frame's stream from C++; two frames in flight on
+    two communicators"""
+    from kinectpy_amd import parallel
+    from kinectpy_amd.pipeline import FrameStream, NativeShardPipeline, PipelineParams
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    d, c = torch.as_tensor(depth).cuda(), torch.as_tensor(rgb).cuda()
+    comms = [parallel.NativeComm.rccl() for _ in range(2)]
+    pipes = [NativeShardPipeline(xy, 4, inits, PipelineParams(), comm=cm) for cm in comms]
+    for f in range(2):
+        gp, gc, gT = pipes[0].step(d[f], c[f])
+        assert np.array_equal(npy(gp), ref[f][0]) and np.array_equal(npy(gc), ref[f][1]) and np.abs(gT - np.stack(ref[f][2])).max() < TOL_T
+    fs = FrameStream(pipes)
+    got = []
+    for k in range(5):
+        if fs.full():
+            got.append(fs.pop())
+        fs.submit(d[k % 2], c[k % 2])
+    while fs.pending:
+        got.append(fs.pop())
+    fs.close()
+    for k, (gp, gc, gT) in enumerate(got):
+        assert np.array_equal(npy(gp), ref[k % 2][0]) and np.array_equal(npy(gc), ref[k % 2][1])
+    for cm in comms:
+        cm.close()
 
 
 @pytest.mark.parametrize("mode", ["p2p", "p2plane"])

@@ -52,7 +52,8 @@ def _reference(n_sensors):
     return O.pipeline_step(xy, depth[0], rgb[0], inits, PipelineParams())
 
 
-@pytest.mark.parametrize("world,n_sensors,mode", [(2, 4, "sharded"), (4, 4, "sharded"), (4, 4, "rank0"), (3, 4, "sharded")])
+@pytest.mark.parametrize("world,n_sensors,mode", [(2, 4, "sharded"), (4, 4, "sharded"), (4, 4, "rank0"), (3, 4, "sharded"),
+                                                  (8, 8, "sharded"), (4, 8, "rank0")])       # (8, 8): BASELINE configs[4]'s partition
 def test_sensor_partition_equals_single_process_oracle_cpu(world, n_sensors, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -79,8 +80,9 @@ def test_sensor_partition_equals_single_process_oracle_cpu(world, n_sensors, mod
             assert last["n_voxel"] == len(aux["voxel"])
 
 
-def test_collective_order_is_the_same_on_every_rank_whatever_the_timing():
-    """parallel.CollectiveOrder: frames in flight on host threads with random delays in front of every collective, a main thread
+@pytest.mark.parametrize("native", [False, True])
+def test_collective_order_is_the_same_on_every_rank_whatever_the_timing(native):
+    """parallel.CollectiveOrder (native=True: the library's kpx_order, which kpx_frame_step_sharded drives from C++): frames in flight on host threads with random delays in front of every collective, a main thread
     that submits / pops like bench.py -- every simulated rank issues its collectives in ONE order (the software-pipelined key
     order), including the drain at the end and a frame that skips its third collective"""
     import random
@@ -90,7 +92,7 @@ def test_collective_order_is_the_same_on_every_rank_whatever_the_timing():
 
     def rank_run(seed, depth, n_frames, skip3):
         rnd = random.Random(seed)
-        order = CollectiveOrder(depth)
+        order = CollectiveOrder(depth, native=native)
         pool = ThreadPoolExecutor(max_workers=depth)
 
         def frame(f):
@@ -130,6 +132,11 @@ def test_collective_order_is_the_same_on_every_rank_whatever_the_timing():
         [t.start() for t in ths]
         [t.join(timeout=60) for t in ths]
         assert len(logs) == 4 and all(lg == logs[0] for lg in logs), (depth, logs)
+        if native:                       # and the library's order is the Python one's
+            from kinectpy_amd.parallel import CollectiveOrder as CO
+            native = False
+            assert logs[0] == rank_run(99, depth, 9, {4})
+            native = True
         o = CollectiveOrder(depth)
         want = sorted(o.key(f, s_) for f in range(9) for s_ in range(3) if not (s_ == 2 and f == 4))
         assert sorted(logs[0]) == want
