@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     int32_t my_row = 0, my_prev = -1;
     if (lane < 16) {
         const int64_t r = row_base + lane < last ? row_base + lane : last;
-        my_row = row_of[r];
+        if (idx_cur || d2_cur) my_row = row_of[r];           // only the caller-order outputs need the original row number
 #pragma unroll
         for (int a = 0; a < 3; ++a) my_src[a] = src_sorted[3 * r + a];
         if (k > 0) {
@@ -1174,20 +1174,27 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
             const int32_t bj = rowi[wave][lane][0];
             const int64_t i = rowi[wave][lane][1];
             const bool none = bj < 0 || bj == INT_MAX;
-            idx_cur[i] = none ? -1 : bj;
-            idx_sorted[row_base + lane] = none ? -1 : bj;
+            // Partners in the caller's row order (idx_cur / d2_cur: scattered 4- and 8-byte stores) only where a caller asked for
+            // them (kpx_icp with idx / d2 outputs); the sorted-order copies the NEXT launch bounds its rows with only when the
+            // partner changed -- in the late iterations of a registration almost no row changes its partner.
+            const int32_t out_j = none ? -1 : bj;
+            const bool changed = k == 0 || out_j != my_prev;
+            if (idx_cur) idx_cur[i] = out_j;
+            if (changed) idx_sorted[row_base + lane] = out_j;
             if (none) {
-                d2_cur[i] = INFINITY;
+                if (d2_cur) d2_cur[i] = INFINITY;
             } else {
                 const double s[3] = { rowd[wave][lane][0], rowd[wave][lane][1], rowd[wave][lane][2] };
                 const float *tp = tgt + 3 * (int64_t)bj;
                 const float tf[3] = { tp[0], tp[1], tp[2] };
                 const double t[3] = { (double)tf[0], (double)tf[1], (double)tf[2] };
+                if (changed) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) ptgt_sorted[3 * (row_base + lane) + c] = tf[c];     // the next launch bounds this row with it
+                    for (int c = 0; c < 3; ++c) ptgt_sorted[3 * (row_base + lane) + c] = tf[c]; // the next launch bounds this row with it
+                }
                 const double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
                 const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-                d2_cur[i] = d2;
+                if (d2_cur) d2_cur[i] = d2;
                 if (d2 < max_d2) {
                     sh[0][col] = 1.0; sh[1][col] = d2;
 #pragma unroll
@@ -1590,13 +1597,13 @@ static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b,
 // one ICP iteration (search k + update) of the culled engine: two launches
 static void icp_iter_launch(const float *src, const float *tgt, const float *tn, const NnPlan &p, const NnBuffers &b, double max_d2, int mode,
                             int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st,
-                            unsigned long long *progress = nullptr, unsigned long long tag = 0)
+                            unsigned long long *progress = nullptr, unsigned long long tag = 0, bool want_pairs = true)
 {
     {
         ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
         hipLaunchKernelGGL(icp_iter_kernel, dim3((unsigned)cdiv(p.n_src, kIRows)), dim3(kIThreads), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t,
-                           b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.ptgt_sorted, b.idx_cur, b.d2_cur,
-                           max_d2, mode, k, b.state,
+                           b.tile_box, b.group_box, p.l_groups, b.sort_t.bbox, b.row_of, b.src_sorted, b.idx_sorted, b.ptgt_sorted,
+                           want_pairs ? b.idx_cur : (int32_t *)nullptr, want_pairs ? b.d2_cur : (double *)nullptr, max_d2, mode, k, b.state,
                            b.acc_fixed, prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, IcpFuse{});
     }
     hipLaunchKernelGGL(icp_solve_fixed_kernel, dim3(1), dim3(256), 0, st, b.acc_fixed, p.n_src, mode, k, max_iter, rel_fit, rel_rmse, b.state,
@@ -1812,7 +1819,8 @@ KPX_EXPORT int kpx_icp(const float *src, int64_t n_src, const float *tgt, const 
         // one launch per iteration; kernels queued behind a raised `done` return at once, so the flag is only read back
         // every poll_interval iterations (0 = never)
         for (int k = 0; k <= max_iteration; ++k) {
-            icp_iter_launch(src, tgt, tgt_normals, p, b, md2, mode, k, max_iteration, relative_fitness, relative_rmse, d_result, st);
+            icp_iter_launch(src, tgt, tgt_normals, p, b, md2, mode, k, max_iteration, relative_fitness, relative_rmse, d_result, st, nullptr, 0,
+                            idx != nullptr || d2 != nullptr);
             if (poll_interval > 0 && (k + 1) % poll_interval == 0 && k < max_iteration) {
                 int32_t h_done = 0;
                 KPX_HIP(hipMemcpyAsync(&h_done, &b.state->done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -2052,7 +2060,8 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                 const int i = i0 + c < i1 ? i0 + c : i1 - 1;      // unused slots repeat the last problem (never addressed: count bounds the search)
                 IcpProblem &P = A[g].p[c];
                 P.src = h_src[i]; P.row_of = bufs[i].row_of; P.src_sorted = bufs[i].src_sorted; P.idx_sorted = bufs[i].idx_sorted;
-                P.ptgt_sorted = bufs[i].ptgt_sorted; P.idx_cur = bufs[i].idx_cur; P.d2_cur = bufs[i].d2_cur; P.pair = bufs[i].state;
+                P.ptgt_sorted = bufs[i].ptgt_sorted; P.pair = bufs[i].state;
+                P.idx_cur = nullptr; P.d2_cur = nullptr;          // a batch reports transforms, not correspondence lists
                 P.ring = bufs[i].acc_fixed; P.result = d_results + 20 * i; P.progress = &h_progress[i]; P.n = h_n_src[i];
                 P.light_key = bufs[i].light_key; P.sbbox = bufs[i].sort_s.bbox;
                 P.block0 = b0; P.blocks = (unsigned)cdiv(h_n_src[i], kIRows);
