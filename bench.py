@@ -215,6 +215,24 @@ def roofline_targets(torch, ops, quick=False):
         if cnt:
             mfma(f"all-pairs NN distance GEMM {len(src)} x {len(tgt)} (KPX_NN_ENGINE=dense, a14/a16)", KERNEL_OF[k], ms_k / cnt, work / cnt,
                  launches=cnt, **({"peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(work / ms_k / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)} if k == "nn_screen" else {}))
+    # the same GEMM where the north star puts it -- inside the ICP loop (registration_icp, manual_pointcloud_registration.py:96-98): every
+    # iteration after the first bounds its rows with the previous partner under the new transform, and the sweep takes its chunked
+    # form (MFMAs + one v_min_u32 per result register; a chunk is examined exactly only when a row's smallest high word reaches its bound)
+    prev = ops.nn_engine("dense_fp64")
+    try:
+        ops.icp(s, t, 100.0, None, "p2p", None, 30)
+        torch.cuda.synchronize()
+        ops.prof_stride(1)
+        ops.prof_begin(1024)
+        reg = ops.icp(s, t, 100.0, None, "p2p", None, 30)
+        torch.cuda.synchronize()
+        pr = ops.prof_end()
+    finally:
+        ops.nn_engine(prev)
+    ms_k, cnt, work = pr["nn_mfma"]
+    if cnt:
+        mfma(f"ICP NN distance GEMM {len(src)} x {len(tgt)} inside registration_icp, {reg['iterations']} iterations (dense fp64 engine, a14/a16)", "nn_mfma_kernel<true> (first launch <false>)",
+             ms_k / cnt, work / cnt, launches=cnt)
     del s, t
     # ---- MFMA: 33-D feature matching GEMM (a13)
     xy = synth.xy_table()

@@ -276,6 +276,7 @@ int kpx_icp_batch(int32_t count, const float *const *h_src, const int64_t *h_n_s
  * engine that was active (e < 0: query only).  Initial value: environment KPX_NN_ENGINE=dense|culled. */
 #define KPX_NN_ENGINE_CULLED 0
 #define KPX_NN_ENGINE_DENSE 1
+#define KPX_NN_ENGINE_DENSE_FP64 2 /* the all-pairs engine with every search on the fp64 MFMA sweep (no float32 screening) */
 int kpx_nn_engine(int32_t engine);
 
 /* ---- the sampler / normaliser after the path ------------------------------------ */

@@ -45,6 +45,11 @@ constexpr int kRT = 2;                       // 16-row tiles per wave (the sweep
 constexpr int kWaves = 4;
 constexpr int kRowsPerBlock = kWaves * kRT * 16;   // 128
 constexpr int kCT = 32;                      // 16-column tiles per LDS stage (16 KiB)
+#ifndef KPX_NN_CHUNK
+#define KPX_NN_CHUNK 4                       // measured 100k x 100k inside a registration: 2 -> 38.7, 4 -> 39.1, 8 -> 36.5, 16 -> 35.9 TFLOP/s
+#endif
+
+constexpr int kChunk = KPX_NN_CHUNK;         // column tiles per fast-pass chunk of the dense sweep (nn_mfma_kernel)
 constexpr int kStageDoubles = kCT * 64;
 constexpr int kSeedStride = 64;              // the seed sweep visits every 64th target tile
 constexpr double kSentinel = 1e300;
@@ -330,6 +335,12 @@ __global__ __launch_bounds__(256) void nn_overflow_kernel(const float *__restric
 
 // ---- the MFMA nearest-neighbour sweep ------------------------------------------------------------------
 // tile_stride: 1 for the full operand, kSeedStride for the seed operand (column = tile * tile_stride * 16 + lane&15)
+// FAST: the rows arrive with TIGHT bounds (the previous partner under the new transform: every ICP iteration after the first) -- the
+// stage is swept in chunks whose hot loop is MFMAs + one v_min_u32 per result register, and a chunk is swept again the exact way
+// only when some row's smallest high word reaches its bound (measured 100k x 100k: 50.6 TFLOP/s for the hot loop alone = 0.64 of the
+// 78.6 vendor peak, the instruction's measured issue ceiling; the per-trip prefilter form runs at 31).  !FAST: loose bounds (seed
+// sweep, first search) -- nearly every chunk would be swept twice, so every trip is examined behind the prefilter as it comes.
+template <bool FAST>
 __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double *__restrict__ B, int32_t tiles_per_split,
                                                          int32_t tile_stride, const int32_t *__restrict__ done,
                                                          const double *__restrict__ A64, const double *__restrict__ K64,
@@ -388,60 +399,97 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
         if (st + 1 < nstages) stage_load(st + 1, buf ^ 1);
         const double *lb = lds[buf] + lane;
         const int32_t tile0 = (int32_t)t0 + st * kCT;
-        // two column tiles (four MFMAs) per trip; the B values of the next trip are read before the results
-        // of this one are examined
-        double b0 = lb[0], b1 = lb[64];
-#pragma unroll 1
-        for (int ct = 0; ct < kCT; ct += 2) {
-            const d4 c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b0, seed[0], 0, 0, 0);
-            const d4 c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b0, seed[1], 0, 0, 0);
-            const d4 c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b1, seed[0], 0, 0, 0);
-            const d4 c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b1, seed[1], 0, 0, 0);
-            const int nx = (ct + 2) & (kCT - 1);                   // wraps on the last trip (value unused)
-            b0 = lb[nx * 64];
-            b1 = lb[nx * 64 + 64];
-            // prefilter on the high words (D > 0: unsigned order of the bit patterns == numeric order)
+        // One trip = two column tiles x two row tiles = four MFMAs; examine() looks at a trip's 16 result registers: prefilter on the
+        // high words (D > 0: the unsigned order of the bit patterns is the numeric order), exact (value, column) update only when
+        // some lane passes (wave-uniform, rare once the bound is tight).
+        auto examine = [&](const d4 &c00, const d4 &c10, const d4 &c01, const d4 &c11, const int ct) {
             bool pass = false;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned h0 = hi32(best[0][r]), h1 = hi32(best[1][r]);
-                pass |= (bool)((int)(hi32(c00[r]) <= h0) | (int)(hi32(c01[r]) <= h0) | (int)(hi32(c10[r]) <= h1) | (int)(hi32(c11[r]) <= h1));
+                pass |= (bool)((int)(min(hi32(c00[r]), hi32(c01[r])) <= h0) | (int)(min(hi32(c10[r]), hi32(c11[r])) <= h1));
             }
-            if (__builtin_amdgcn_ballot_w64(pass) != 0) {   // wave-uniform, rare once the bound is tight
-                const int32_t col0 = (tile0 + ct) * tile_stride * 16 + (lane & 15);
-                const int32_t col1 = col0 + tile_stride * 16;
-                bool anyeq = false;
+            if (__builtin_amdgcn_ballot_w64(pass) == 0) return;
+            const int32_t col0 = (tile0 + ct) * tile_stride * 16 + (lane & 15);
+            const int32_t col1 = col0 + tile_stride * 16;
+            bool anyeq = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned h0 = hi32(best[0][r]), h1 = hi32(best[1][r]);
+                anyeq |= (bool)((int)(hi32(c00[r]) == h0) | (int)(hi32(c01[r]) == h0) | (int)(hi32(c10[r]) == h1) | (int)(hi32(c11[r]) == h1));
+                // two candidates of one row with equal high words: the second must be compared exactly with the first
+                // once that has become the running best (found by the random cross-engine test: far-apart line clouds)
+                anyeq |= (bool)((int)(hi32(c00[r]) == hi32(c01[r])) | (int)(hi32(c10[r]) == hi32(c11[r])));
+            }
+            if (__builtin_amdgcn_ballot_w64(anyeq) == 0) {
+                // every high word differs from its bound: the high words alone decide "<" (no fp64 op)
+#define KPX_NN_HI(ACC, RT, COL)                                                                     \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
+                    const bool t = hi32(ACC[r]) < hi32(best[RT][r]);                               \
+                    best[RT][r] = t ? ACC[r] : best[RT][r];                                        \
+                    bcol[RT][r] = t ? (COL) : bcol[RT][r];                                         \
+                }
+                KPX_NN_HI(c00, 0, col0) KPX_NN_HI(c01, 0, col1) KPX_NN_HI(c10, 1, col0) KPX_NN_HI(c11, 1, col1)
+#undef KPX_NN_HI
+            } else {
+                // near-ties (equal high words, e.g. the bound's own column): exact lexicographic (value, column)
+#define KPX_NN_EXACT(ACC, RT, COL)                                                                  \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
+                    const bool t = (int)(ACC[r] < best[RT][r]) | ((int)(ACC[r] == best[RT][r]) & (int)((COL) < bcol[RT][r])); \
+                    best[RT][r] = t ? ACC[r] : best[RT][r];                                        \
+                    bcol[RT][r] = t ? (COL) : bcol[RT][r];                                         \
+                }
+                KPX_NN_EXACT(c00, 0, col0) KPX_NN_EXACT(c01, 0, col1) KPX_NN_EXACT(c10, 1, col0) KPX_NN_EXACT(c11, 1, col1)
+#undef KPX_NN_EXACT
+            }
+        };
+#define KPX_NN_TRIP(P, CT)                                                                          \
+        const double P##b0 = lb[(CT) * 64], P##b1 = lb[(CT) * 64 + 64];                             \
+        const d4 P##00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], P##b0, seed[0], 0, 0, 0);       \
+        const d4 P##10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], P##b0, seed[1], 0, 0, 0);       \
+        const d4 P##01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], P##b1, seed[0], 0, 0, 0);       \
+        const d4 P##11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], P##b1, seed[1], 0, 0, 0);
+        if (!FAST) {
+#pragma unroll 1
+        for (int ct = 0; ct < kCT; ct += 2) {
+            KPX_NN_TRIP(p, ct)
+            examine(p00, p10, p01, p11, ct);
+        }
+        } else {
+        // A stage is swept in chunks of kChunk column tiles.  FAST pass of a chunk: nothing but the MFMAs and one v_min_u32 per result
+        // register -- the smallest HIGH WORD any column of the chunk produced for each of the lane's rows.  Only when some row's
+        // minimum reaches the high word of its running best (hi(D) > hi(best) implies D > best, so a chunk that never does cannot
+        // change any row's (value, column) minimum) is the chunk swept again the exact way.
+#pragma unroll 1
+        for (int c0 = 0; c0 < kCT; c0 += kChunk) {
+            unsigned hmin[kRT][4];
+#pragma unroll
+            for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hmin[rt][r] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int ct = 0; ct < kChunk; ct += 2) {
+                KPX_NN_TRIP(f, c0 + ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const unsigned h0 = hi32(best[0][r]), h1 = hi32(best[1][r]);
-                    anyeq |= (bool)((int)(hi32(c00[r]) == h0) | (int)(hi32(c01[r]) == h0) | (int)(hi32(c10[r]) == h1) | (int)(hi32(c11[r]) == h1));
-                    // two candidates of one row with equal high words: the second must be compared exactly with the first
-                    // once that has become the running best (found by the random cross-engine test: far-apart line clouds)
-                    anyeq |= (bool)((int)(hi32(c00[r]) == hi32(c01[r])) | (int)(hi32(c10[r]) == hi32(c11[r])));
-                }
-                if (__builtin_amdgcn_ballot_w64(anyeq) == 0) {
-                    // every high word differs from its bound: the high words alone decide "<" (no fp64 op)
-#define KPX_NN_HI(ACC, RT, COL)                                                                     \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
-                        const bool t = hi32(ACC[r]) < hi32(best[RT][r]);                           \
-                        best[RT][r] = t ? ACC[r] : best[RT][r];                                    \
-                        bcol[RT][r] = t ? (COL) : bcol[RT][r];                                     \
-                    }
-                    KPX_NN_HI(c00, 0, col0) KPX_NN_HI(c01, 0, col1) KPX_NN_HI(c10, 1, col0) KPX_NN_HI(c11, 1, col1)
-#undef KPX_NN_HI
-                } else {
-                    // near-ties (equal high words, e.g. the bound's own column): exact lexicographic (value, column)
-#define KPX_NN_EXACT(ACC, RT, COL)                                                                  \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
-                        const bool t = (int)(ACC[r] < best[RT][r]) | ((int)(ACC[r] == best[RT][r]) & (int)((COL) < bcol[RT][r])); \
-                        best[RT][r] = t ? ACC[r] : best[RT][r];                                    \
-                        bcol[RT][r] = t ? (COL) : bcol[RT][r];                                     \
-                    }
-                    KPX_NN_EXACT(c00, 0, col0) KPX_NN_EXACT(c01, 0, col1) KPX_NN_EXACT(c10, 1, col0) KPX_NN_EXACT(c11, 1, col1)
-#undef KPX_NN_EXACT
+                    hmin[0][r] = min(hmin[0][r], min(hi32(f00[r]), hi32(f01[r])));
+                    hmin[1][r] = min(hmin[1][r], min(hi32(f10[r]), hi32(f11[r])));
                 }
             }
+            bool pass = false;
+#pragma unroll
+            for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pass |= hmin[rt][r] <= hi32(best[rt][r]);
+            if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+#pragma unroll 1
+            for (int ct = c0; ct < c0 + kChunk; ct += 2) {
+                KPX_NN_TRIP(p, ct)
+                examine(p00, p10, p01, p11, ct);
+            }
         }
+        }
+#undef KPX_NN_TRIP
         __syncthreads();
     }
 
@@ -1448,6 +1496,7 @@ double nn_local_take_visits()
 }
 
 static int g_nn_engine = -1;          // KPX_NN_ENGINE_*; -1 = not chosen yet (environment decides at first use)
+static bool g_nn_fp64_only = false;   // KPX_NN_ENGINE_DENSE_FP64: the all-pairs engine without its float32 screening sweep
 static bool local_engine()
 {
     if (g_nn_engine < 0) { const char *e = getenv("KPX_NN_ENGINE"); g_nn_engine = (e && e[0] == 'd') ? KPX_NN_ENGINE_DENSE : KPX_NN_ENGINE_CULLED; }
@@ -1573,7 +1622,7 @@ static bool screening_enabled()
 {
     static int on = -1;
     if (on < 0) { const char *e = getenv("KPX_NN_SCREEN"); on = (e && e[0] == '0') ? 0 : 1; }
-    return on != 0;
+    return on != 0 && !g_nn_fp64_only;
 }
 static __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t n, const int32_t *__restrict__ row_of,
                                                                  float *__restrict__ out)
@@ -1691,7 +1740,7 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
         return KPX_OK;
     }
     if (!have_prev) {
-        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, 1), thr, 0, st, n, b.Bseed, (int32_t)p.seed_tiles_pad, (int32_t)kSeedStride,
+        hipLaunchKernelGGL(nn_mfma_kernel<false>, dim3(p.row_blocks, 1), thr, 0, st, n, b.Bseed, (int32_t)p.seed_tiles_pad, (int32_t)kSeedStride,
                            done, b.A64, b.K64, (const double *)nullptr, (const int32_t *)nullptr, b.part_val, b.part_idx);
         hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx, 1,
                            0.0, -2, b.init_idx, (double *)nullptr, b.init_val, b.part_acc, (const int32_t *)nullptr, (const int32_t *)nullptr,
@@ -1699,8 +1748,14 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
     }
     {
         ProfScope prof(KPX_PROF_NN_MFMA, 8.0 * (double)p.n_src * (double)p.n_tgt, st);     // 4 MAC per (source, target) pair
-        hipLaunchKernelGGL(nn_mfma_kernel, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
-                           b.init_val, b.init_idx, b.part_val, b.part_idx);
+        static const int fast_env = [] { const char *e = getenv("KPX_NN_FAST"); return e ? atoi(e) : -1; }();     // A/B switch: 0 / 1 force a form
+        const bool fast = fast_env >= 0 ? fast_env != 0 : have_prev;
+        if (fast)
+            hipLaunchKernelGGL(nn_mfma_kernel<true>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
+                               b.init_val, b.init_idx, b.part_val, b.part_idx);
+        else
+            hipLaunchKernelGGL(nn_mfma_kernel<false>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
+                               b.init_val, b.init_idx, b.part_val, b.part_idx);
     }
     hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
                        p.splits, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, (const int32_t *)nullptr,
@@ -1727,10 +1782,11 @@ KPX_EXPORT int kpx_prof_icp_phases(double *h_out8)
 }
 KPX_EXPORT int kpx_nn_engine(int32_t engine)
 {
-    const int cur = local_engine() ? KPX_NN_ENGINE_CULLED : KPX_NN_ENGINE_DENSE;
+    const int cur = local_engine() ? KPX_NN_ENGINE_CULLED : (g_nn_fp64_only ? KPX_NN_ENGINE_DENSE_FP64 : KPX_NN_ENGINE_DENSE);
     if (engine < 0) return cur;
-    KPX_REQUIRE(engine == KPX_NN_ENGINE_CULLED || engine == KPX_NN_ENGINE_DENSE, "kpx_nn_engine: unknown engine %d", engine);
-    g_nn_engine = engine;
+    KPX_REQUIRE(engine == KPX_NN_ENGINE_CULLED || engine == KPX_NN_ENGINE_DENSE || engine == KPX_NN_ENGINE_DENSE_FP64, "kpx_nn_engine: unknown engine %d", engine);
+    g_nn_engine = engine == KPX_NN_ENGINE_CULLED ? KPX_NN_ENGINE_CULLED : KPX_NN_ENGINE_DENSE;
+    g_nn_fp64_only = engine == KPX_NN_ENGINE_DENSE_FP64;
     return cur;
 }
 

@@ -570,7 +570,7 @@ def frame_step_sharded(comm, order, frame, depth, rgb, xy_table, n_sensors, init
 
 
 # ---- measurement hooks --------------------------------------------------------------------------------
-NN_ENGINES = ("culled", "dense")
+NN_ENGINES = ("culled", "dense", "dense_fp64")
 
 
 def nn_engine(name=None):

@@ -405,9 +405,10 @@ def test_segment_plane_inliers_bit_exact(ops, oracle, n, rn, iters, prob, seed):
 
 
 # ------------------------------------------------------------------------------------------- registration
-@pytest.fixture(params=["culled", "dense"])
+@pytest.fixture(params=["culled", "dense", "dense_fp64"])
 def engine(request, ops):
-    """both correspondence-search implementations: the culled sweep (default) and the all-pairs sweeps"""
+    """the correspondence-search implementations: the culled sweep (default), the all-pairs sweeps (fp64 MFMA + float32 screening),
+    and the all-pairs engine with every search on the fp64 MFMA sweep (cold form first, chunked warm form in later iterations)"""
     prev = ops.nn_engine(request.param)
     yield request.param
     ops.nn_engine(prev)
