@@ -150,7 +150,9 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     char *tmp = a.get<char>(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
     RadixScratch rx{};
     const bool own_sort = (int64_t)nn > 65536 && (int64_t)nn <= kRadixMaxPairs;     // the sort build's sizes that kpx_radix.h serves
-    if (own_sort) radix_carve(a, (int64_t)nn, &rx);
+    // carved for every size (capped at the sort's limit): the workspace a caller sized for a worst-case count then also holds any
+    // smaller cloud's build -- bytes(n) is monotonic (kpx_frame_step sizes one scratch region from the worst case)
+    radix_carve(a, (int64_t)nn <= kRadixMaxPairs ? (int64_t)nn : kRadixMaxPairs, &rx);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     double *bbox = part + (size_t)kBboxBlocks * 6;

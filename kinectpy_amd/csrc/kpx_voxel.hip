@@ -380,7 +380,7 @@ static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->sort_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 64,
                                              (hipStream_t) nullptr);
     s->sort_tmp = a.get<char>(s->sort_bytes);
-    if (total <= kRadixMaxPairs) radix_carve(a, total, &s->rx);
+    radix_carve(a, total <= kRadixMaxPairs ? total : kRadixMaxPairs, &s->rx);      // unconditional: the workspace size stays monotonic in the point count
     s->counts = a.get<int32_t>((size_t)compact_ws_ints(total));          // right behind the sort's cleared histograms: one memset for both
     s->counts_end = reinterpret_cast<char *>(s->counts + (size_t)compact_ws_ints(total));
 }
@@ -402,15 +402,16 @@ static int voxel_batch_impl(const VoxelBatch &b, double voxel, int32_t *d_counts
     if (spec_bits > 0 && d_bits) {
         bits_out = d_bits;                               // written by the key kernel itself
         end_bit = spec_bits > 64 ? 64 : spec_bits;
-    } else if (total > (int64_t)1024 * 1024) {
-        // above rocPRIM's merge-sort limit the sort is an Onesweep with one pass per 8 key bits: reading the width back (one
-        // small round trip; the caller waits for the counts anyway) saves four or five of the eight ~27 us passes -- and keys of at
-        // most 32 bits (a 4-sensor frame needs ~25) are written, sorted and compared as 32-bit words: half the key traffic
+    } else if (total > (int64_t)128 * 1024) {
+        // reading the key width back (one small round trip; the caller waits for the counts anyway) lets keys of at most 32 bits
+        // (a 4-sensor frame needs ~25, a 1M-point room at 10 mm 25) be written, sorted and compared as 32-bit words by the library's
+        // own radix sort -- three 8-bit passes instead of the vendor sort's eight over 64-bit keys.  Below ~128k points the vendor's
+        // merge sort of a handful of launches is as fast as the round trip.
         static thread_local int32_t *h_bits = nullptr;
         if (!h_bits) KPX_HIP(hipHostMalloc((void **)&h_bits, sizeof(int32_t), hipHostMallocDefault));
         hipLaunchKernelGGL(voxel_batch_bits_kernel, dim3(1), dim3(1), 0, st, b, s.bbox, voxel, s.head);
         KPX_HIP(hipMemcpyAsync(h_bits, s.head, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        if (d_bits) KPX_HIP(hipMemcpyAsync(d_bits, s.head, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        if (d_bits) KPX_HIP(hipMemcpyAsync(d_bits, s.head, sizeof(int32_t), hipMemcpyDefault, st));      // d_bits may be pinned host memory (kpx_frame_step)
         KPX_HIP(hipStreamSynchronize(st));
         end_bit = *h_bits < 1 ? 1 : (*h_bits > 64 ? 64 : *h_bits);
     } else if (d_bits) {
@@ -672,7 +673,10 @@ KPX_EXPORT size_t kpx_voxel_workspace_bytes(int64_t n)
 {
     Arena a(nullptr, 0);
     voxel_impl(nullptr, nullptr, nullptr, n, 1.0, nullptr, nullptr, nullptr, nullptr, a, nullptr);
-    return a.off;
+    Arena one(nullptr, 0);
+    VoxelBatchScratch s;
+    voxel_batch_carve(one, n, &s);
+    return a.off > one.off ? a.off : one.off;
 }
 KPX_EXPORT int kpx_voxel_downsample(const float *pts, const float *col, const float *nrm, int64_t n, double voxel,
                                     float *opts, float *ocol, float *onrm, int32_t *d_count, void *ws, size_t ws_bytes,
@@ -685,6 +689,24 @@ KPX_EXPORT int kpx_voxel_downsample(const float *pts, const float *col, const fl
     if (n == 0) { KPX_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return KPX_OK; }
     KPX_REQUIRE(pts && opts, "kpx_voxel_downsample: null pointer");
     Arena a(ws, ws_bytes);
+    // Without normals a single cloud takes the one-pass batch form too (a batch of one): keys of <= 32 bits whenever the grid allows
+    // (a 1M-point room at 10 mm needs 25), sorted by the library's own radix sort and the staged mean kernel -- the 63-bit key +
+    // vendor-sort path below remains for clouds with normals.  KPX_VOXEL_SINGLE=0: A/B switch.
+    static const bool single_batch = [] { const char *e = getenv("KPX_VOXEL_SINGLE"); return !(e && e[0] == '0'); }();
+    if (!nrm && single_batch) {
+        VoxelBatch b;
+        b.count = 1;
+        b.morton = 0;
+        b.off[0] = 0;
+        for (int i = 0; i < kVoxelBatchMax; ++i) {
+            b.pts[i] = i == 0 ? pts : nullptr;
+            b.col[i] = i == 0 ? col : nullptr;
+            b.opts[i] = i == 0 ? opts : nullptr;
+            b.ocol[i] = (i == 0 && col) ? ocol : nullptr;
+            b.off[i + 1] = n;
+        }
+        return voxel_batch_impl(b, voxel, d_count, a, st);
+    }
     return voxel_impl(pts, col, nrm, n, voxel, opts, ocol, onrm, d_count, a, st);
 }
 
@@ -742,15 +764,25 @@ int kpx::voxel_downsample_batch_spec(int32_t count, const float *const *h_pts, c
     if (count > kVoxelBatchMax && total > 0) {
         // more clouds than one pass takes: groups of kVoxelBatchMax, one concatenated pass each, one after the other on `stream`
         // (64 clouds of 1M points: 11 ms cloud by cloud on the lanes -- every cloud its own 8-pass sort -- against eight 8M-key sorts)
+        // groups of kVoxelBatchMax consecutive clouds.  (Groups capped at the library's own radix sort -- 4M pairs, four 1M-point
+        // clouds -- were measured SLOWER than eight clouds per group on the vendor's Onesweep: 8.4 vs 7.1 ms for 64 x 1M points; at
+        // 4M pairs the own sort's four 8-bit passes cost 31 + 9 us each, and half as many groups halve the per-group launches.)
+        int gstart[65], ng = 0;
         bool ok = true;
-        for (int g0 = 0; g0 < count && ok; g0 += kVoxelBatchMax) {
+        for (int i = 0; i < count;) {
+            gstart[ng++] = i;
             int64_t gt = 0;
-            for (int i = g0; i < count && i < g0 + kVoxelBatchMax; ++i) gt += h_n[i];
-            ok = gt > 0 && gt < ((int64_t)1 << 31);
+            int gc = 0;
+            while (i < count && gc < kVoxelBatchMax) { gt += h_n[i]; ++gc; ++i; }
+            ok = ok && gt < ((int64_t)1 << 31);
         }
+        gstart[ng] = count;
         if (ok) {
-            for (int g0 = 0; g0 < count; g0 += kVoxelBatchMax) {
-                const int gc = count - g0 < kVoxelBatchMax ? count - g0 : kVoxelBatchMax;
+            for (int g = 0; g < ng; ++g) {
+                const int g0 = gstart[g], gc = gstart[g + 1] - g0;
+                int64_t gt = 0;
+                for (int i = 0; i < gc; ++i) gt += h_n[g0 + i];
+                if (gt == 0) { KPX_HIP(hipMemsetAsync(d_counts + g0, 0, (size_t)gc * sizeof(int32_t), st)); continue; }
                 VoxelBatch b;
                 b.count = gc;
                 b.morton = 0;
