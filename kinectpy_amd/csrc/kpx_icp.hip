@@ -1150,6 +1150,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     __shared__ int32_t lists[kIWaves][kLScratch];
     __shared__ double rowd[kIWaves][16][kRowStride]; // s_x, s_y, s_z, (the sweep's row bound), K, bound / result value
     __shared__ int32_t rowi[kIWaves][16][2];         // partner (bound / result), original row
+    __shared__ float rowf[kIWaves][16][kRowFStride]; // float32 mirror of the rows for the sweep's culling tests
     __shared__ double sh[kAcc][kIRows + 1];
     if (tile_visits && threadIdx.x == 0 && bid < kStampBlocks) {     // only launches that sweep stamp (not the converged / closing ones)
         g_icp_stamp[bid][0] = t_block_start;
@@ -1186,6 +1187,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     WaveRows w;
     w.a = q < 3 ? rowd[wave][j][q] : 1.0;
     w.rows = &rowd[wave][0][0];
+    w.rowsf = &rowf[wave][0][0];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int rr = q + 4 * r;

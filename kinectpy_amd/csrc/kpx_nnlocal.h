@@ -158,6 +158,32 @@ __device__ __forceinline__ double wave_uniform_max(double v)
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// Directed roundings of a double to float (the culling tests below run in float32 on outward-rounded operands: a cull only has to
+// be SAFE -- every decision that selects a partner is still taken on exact fp64 values -- and an fp64 vector instruction costs twice a
+// float32 one on this part, plus a conversion per box coordinate).
+__device__ __forceinline__ float f32_down(double x)
+{
+    float f = (float)x;
+    if ((double)f > x) f = f > 0.0f ? __int_as_float(__float_as_int(f) - 1) : (f < 0.0f ? __int_as_float(__float_as_int(f) + 1) : -1.401298464e-45f);
+    return f;
+}
+__device__ __forceinline__ float f32_up(double x)
+{
+    float f = (float)x;
+    if ((double)f < x) f = f > 0.0f ? __int_as_float(__float_as_int(f) + 1) : (f < 0.0f ? __int_as_float(__float_as_int(f) - 1) : 1.401298464e-45f);
+    return f;
+}
+// LOWER bound of the squared distance between a point known as [plo, phi] per axis (its coordinates rounded down / up to float) and
+// the box [lo, hi]: per axis max(0, lo - phi, plo - hi) <= the true gap up to the subtraction's rounding (2^-24 relative), the three
+// squares and two additions another 3 x 2^-24; the factor 1 - 2^-20 covers all of it.  Underflow only lowers the result further.
+__device__ __forceinline__ float pt_gap2_lb(const float *__restrict__ pf, const float lo[3], const float hi[3])
+{
+    const float gx = fmaxf(0.0f, fmaxf(lo[0] - pf[3], pf[0] - hi[0]));
+    const float gy = fmaxf(0.0f, fmaxf(lo[1] - pf[4], pf[1] - hi[1]));
+    const float gz = fmaxf(0.0f, fmaxf(lo[2] - pf[5], pf[2] - hi[2]));
+    return fmaf(gz, gz, fmaf(gy, gy, gx * gx)) * 0.99999904632568359375f;
+}
+
 // Per-lane state of one wave's 16 rows.  Lane (q = lane>>4, j = lane&15) owns rows q, q+4, q+8, q+12 (the MFMA D layout).
 struct WaveRows {
     double a;                  // A operand: component q of row j
@@ -166,11 +192,14 @@ struct WaveRows {
                                // bound on d^2 (kRowBound, written by the sweep).  The culling tests read rows from here instead of
                                // holding them in registers (the iteration kernel is built for 168 VGPRs = 3 waves per SIMD, KPX_ICP_WPE;
                                // a latency-bound sweep lives on resident waves)
+    float *rowsf;              // LDS: float32 mirror for the culling tests, record r at rowsf[kRowFStride r ..]: the row's coordinates rounded
+                               // down (0..2) and up (3..5), its bound rounded up (6); written by the sweep itself
     double best[4];            // running minimum (per lane: over the columns j of the tiles seen)
     int32_t bcol[4];           // its ORIGINAL target index
     double light_gap2;         // out: no group box was within reach of the wave's box -> the smallest squared box-to-box gap; else -1
 };
 constexpr int kRowStride = 6, kRowBound = 3;
+constexpr int kRowFStride = 8, kRowFBound = 6;
 
 // LDS scratch of one wave (ints): the tile list, 16 candidate groups (box + id), up to 16 surviving groups (id, row mask)
 constexpr int kLCand = 16, kLSurv = 16;
@@ -281,12 +310,22 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         for (int r = 0; r < 4; ++r) rb[r] = fmin(rb[r], row16_all_min(u[r]) * kRel + eps);
         R2 = wave_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     }
+    float rbf[4];              // the bounds rounded up to float: what the float32 culling tests compare with
     auto publish_bounds = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rbf[r] = f32_up(rb[r]);
         if (j == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w.rows[kRowStride * (q + 4 * r) + kRowBound] = rb[r];
+            for (int r = 0; r < 4; ++r) {
+                w.rows[kRowStride * (q + 4 * r) + kRowBound] = rb[r];
+                w.rowsf[kRowFStride * (q + 4 * r) + kRowFBound] = rbf[r];
+            }
         }
     };
+    if (q < 3) {               // lane (q, j): component q of row j, rounded outward
+        w.rowsf[kRowFStride * j + q] = f32_down(w.a);
+        w.rowsf[kRowFStride * j + 3 + q] = f32_up(w.a);
+    }
     publish_bounds();
 
     const double bpad = q == 3 ? kSentinel : 0.0;
@@ -365,7 +404,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (4 * p >= ns) break;
-            const double lo[3] = { (double)bx[p][0], (double)bx[p][1], (double)bx[p][2] }, hi[3] = { (double)bx[p][3], (double)bx[p][4], (double)bx[p][5] };
+            const float lo[3] = { bx[p][0], bx[p][1], bx[p][2] }, hi[3] = { bx[p][3], bx[p][4], bx[p][5] };
             // the rows any of the pass's four groups needs, two per trip (wave-uniform loop, broadcast LDS reads issued together)
             unsigned um = (unsigned)(__builtin_amdgcn_readlane((int)rmask[p], 0) | __builtin_amdgcn_readlane((int)rmask[p], 16) |
                                      __builtin_amdgcn_readlane((int)rmask[p], 32) | __builtin_amdgcn_readlane((int)rmask[p], 48));
@@ -375,10 +414,12 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
                 um &= um - 1u;
                 const int r1 = um ? __builtin_ctz(um) : r0;
                 um &= um - 1u;
-                const double *p0 = w.rows + kRowStride * r0, *p1 = w.rows + kRowStride * r1;
-                const double x0 = p0[0], y0 = p0[1], z0 = p0[2], b0 = p0[kRowBound], x1 = p1[0], y1 = p1[1], z1 = p1[2], b1 = p1[kRowBound];
-                hit |= (bool)((int)((rmask[p] >> r0) & 1u) & (int)(pt_gap2(x0, y0, z0, lo, hi) <= b0));
-                hit |= (bool)((int)((rmask[p] >> r1) & 1u) & (int)(pt_gap2(x1, y1, z1, lo, hi) <= b1));
+                const float *p0 = w.rowsf + kRowFStride * r0, *p1 = w.rowsf + kRowFStride * r1;
+                float f0[8], f1[8];
+#pragma unroll
+                for (int e = 0; e < 7; ++e) { f0[e] = p0[e]; f1[e] = p1[e]; }
+                hit |= (bool)((int)((rmask[p] >> r0) & 1u) & (int)(pt_gap2_lb(f0, lo, hi) <= f0[kRowFBound]));
+                hit |= (bool)((int)((rmask[p] >> r1) & 1u) & (int)(pt_gap2_lb(f1, lo, hi) <= f1[kRowFBound]));
             }
             const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
             if (hit) list[nlist + __builtin_popcountll(hm & lt)] = grp[p] * kLGroupTiles + j;
@@ -429,13 +470,16 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
             bool h[4] = { false, false, false, false };
             int32_t gid = -1;
             if (j < nc) {
-                const double lo[3] = { (double)__int_as_float(cand[7 * j]), (double)__int_as_float(cand[7 * j + 1]), (double)__int_as_float(cand[7 * j + 2]) };
-                const double hi[3] = { (double)__int_as_float(cand[7 * j + 3]), (double)__int_as_float(cand[7 * j + 4]), (double)__int_as_float(cand[7 * j + 5]) };
+                const float lo[3] = { __int_as_float(cand[7 * j]), __int_as_float(cand[7 * j + 1]), __int_as_float(cand[7 * j + 2]) };
+                const float hi[3] = { __int_as_float(cand[7 * j + 3]), __int_as_float(cand[7 * j + 4]), __int_as_float(cand[7 * j + 5]) };
                 gid = cand[7 * j + 6];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double *pr = w.rows + kRowStride * (q + 4 * r);
-                    h[r] = pt_gap2(pr[0], pr[1], pr[2], lo, hi) <= rb[r];
+                    const float *pr = w.rowsf + kRowFStride * (q + 4 * r);
+                    float f[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) f[e] = pr[e];
+                    h[r] = pt_gap2_lb(f, lo, hi) <= rbf[r];
                 }
             }
             // mask of the rows (bit q + 4 r) that reach candidate j, assembled from the four ballots
@@ -497,6 +541,7 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
     if (done && *done) return;
     __shared__ int32_t list[kLScratch];
     __shared__ double rows[kLRows * kRowStride];
+    __shared__ float rowsf[kLRows * kRowFStride];
     const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
     const double t2max = target_t2max(tbbox);
     const int64_t row_base = (int64_t)blockIdx.x * kLRows;
@@ -508,6 +553,7 @@ __global__ __launch_bounds__(64) void nn_local_kernel(int64_t n, const double *_
     if (q < 3) rows[kRowStride * j + q] = w.a;
     wave_lds_fence();
     w.rows = rows;
+    w.rowsf = rowsf;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = row_base + q + 4 * r < last ? row_base + q + 4 * r : last;
