@@ -1,6 +1,6 @@
 #!/bin/bash
 # one frame at a time under rocprofv3 --kernel-trace: per-kernel busy time and gaps of the median frame (tools/frame_timeline.py);
-# extra environment (A/B switches) is inherited.  Usage: tools/exp_frame_timeline.sh [tag]
+# extra environment (A/B switches) is inherited.  Usage: tools/frame_timeline.sh [tag]
 export TMPDIR=/tmp
 ROOT=$PWD
 tag=${1:-cur}

@@ -19,9 +19,9 @@ for _ in range(3):
     ops.feature_nn(fa, fb)
 src, tgt, _ = synth.icp_pair(100_000)
 s, t = torch.as_tensor(src).to(dev), torch.as_tensor(tgt).to(dev)
-for eng in ("dense", "culled"):
+for eng in ("dense", "dense_fp64", "culled"):      # dense_fp64: every iteration on the fp64 sweep (its warm, chunked form after the first)
     ops.nn_engine(eng)
-    ops.icp(s, t, 100.0, None, "p2p", None, 6)
+    ops.icp(s, t, 100.0, None, "p2p", None, 12 if eng == "dense_fp64" else 6)
 ops.nn_engine("culled")
 # the batch form of the culled sweep (one launch per iteration for all registrations: what the frame pipeline runs)
 subs = [s[: 30000 + 500 * i].contiguous() for i in range(3)]
