@@ -49,7 +49,6 @@ sys.path.insert(0, ROOT)
 N_PX = 576 * 640
 FP64_MFMA_PEAK_TFLOPS = 78.6          # MI355X dense fp64 matrix peak (vendor figure)
 FP32_MFMA_PEAK_TFLOPS = 157.3         # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
-FP64_VALU_PEAK_TFLOPS = 78.6          # MI355X fp64 vector peak (vendor figure; SURVEY.md 8d prices plane scoring against it)
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E (MI355X_MICROARCH.md; ~6.3 TB/s is what a copy kernel reaches)
 KERNEL_OF = {"nn_local": "icp_iter_batch_kernel", "nn_screen": "nn_screen_kernel", "nn_mfma": "nn_mfma_kernel"}
 
@@ -323,9 +322,11 @@ def roofline_targets(torch, ops, quick=False):
         Mqueries_per_s=round(fv.shape[0] / ms / 1e3, 2), binds="LDS / VALU / latency, not HBM")
     del keeps, vb
 
+    # segment_plane: the (point, hypothesis) distances are a K = 4 fp64 GEMM on the matrix cores (8 flop per pair); the row
+    # prices the WHOLE call (hypotheses, scoring, tie-break sums, replay, inlier list, refit) against the fp64 matrix peak
     def vpeak(op, kernel, ms, flops, nbytes, **extra):
         tf = flops / (ms * 1e-3) / 1e12
-        rows.append(dict({"op": op, "kernel": kernel, "bound": "fp64 valu", "achieved": round(tf, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+        rows.append(dict({"op": op, "kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 4), "ms": round(ms, 4), "flops": int(flops), "algorithmic_bytes": int(nbytes),
                           "hbm_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}, **extra))
 
@@ -336,13 +337,13 @@ def roofline_targets(torch, ops, quick=False):
     for tag, cloud in (("the floor slab of config 3", lo_pts), ("config 3's 1M-point cloud", c3)):
         n_ = int(cloud.shape[0])
         ms, (_, inl) = ev_timed(torch, lambda: ops.segment_plane(cloud, 30.0, 30, 2000, probability=1.0, seed=7), reps=3, warm=1)
-        vpeak(f"segment_plane(30, 30, 2000), {n_} points ({tag}; a21)", "plane_hyp + plane_score_kernel + refit", ms, 8.0 * 2000 * n_,
+        vpeak(f"segment_plane(30, 30, 2000), {n_} points ({tag}; a21)", "plane_hyp + plane_count_mfma_kernel (fp64 MFMA scoring) + rmse of the tied hypotheses + refit", ms, 8.0 * 2000 * n_,
               12 * n_ * 2 + 4 * int(inl.shape[0]), points=n_, inliers=int(inl.shape[0]), hypotheses_per_sweep=2000)
     def plane_many():
         return [ops.segment_plane(c, 30.0, 30, 2000, probability=1.0, seed=7)[1] for c in clouds]
     ms, inls = ev_timed(torch, plane_many, reps=1, warm=1)
     n_ = sum(int(c.shape[0]) for c in clouds)
-    vpeak(f"segment_plane(30, 30, 2000), {len(clouds)} x 1M points one after the other ({n_ * 12 / 1e9:.2f} GB)", "plane_hyp + plane_score_kernel + refit", ms,
+    vpeak(f"segment_plane(30, 30, 2000), {len(clouds)} x 1M points one after the other ({n_ * 12 / 1e9:.2f} GB)", "plane_hyp + plane_count_mfma_kernel (fp64 MFMA scoring) + rmse of the tied hypotheses + refit", ms,
           8.0 * 2000 * n_, 12 * n_ * 2 + 4 * sum(int(i.shape[0]) for i in inls), points=n_, hypotheses_per_sweep=2000)
     return rows
 

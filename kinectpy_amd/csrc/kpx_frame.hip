@@ -9,6 +9,10 @@
 
 namespace kpx {
 
+// measurement hook: KPX_FRAME_EXTRA_DISPATCHES=n queues n empty kernels behind the extraction of every frame (how much of the frame
+// rate is the dispatch count itself?)
+__global__ void frame_empty_kernel() {}
+
 struct FrameLayout {
     float *full_pts, *mask_pts, *mask_col, *down_pts, *normals, *vox_pts, *vox_col;
     int32_t *vox_cnt, *keep_idx;
@@ -98,6 +102,8 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     // (every operator runs on `st`: stream order alone makes the shared scratch region safe)
     KPX_SUB(kpx_depth_to_cloud(depth, xy_table, rgb, n_px, S, KPX_COMPACT_COLOR_MASK | KPX_COMPACT_DEPTH_GATE, prm->gate, L.mask_pts, L.mask_col, nullptr,
                                h_i + 16, L.op_ws, L.op_bytes, st));
+    static const int extra_dispatches = [] { const char *e = getenv("KPX_FRAME_EXTRA_DISPATCHES"); return e ? atoi(e) : 0; }();
+    for (int e = 0; e < extra_dispatches; ++e) hipLaunchKernelGGL(frame_empty_kernel, dim3(1), dim3(64), 0, st);
     std::vector<int64_t> fk((size_t)S), mk((size_t)S), dk((size_t)S);
     // registration: voxel_down_sample(reg_voxel) of every sensor's cloud, normals of the master's, point-to-plane ICP of every sub
     std::vector<const float *> p_in((size_t)S), c_in((size_t)S);

@@ -90,8 +90,10 @@ constexpr int kScoreThreads = 256;
 
 __global__ __launch_bounds__(kScoreThreads) void plane_score_kernel(const float *__restrict__ pts, int64_t n, int64_t chunk,
                                                                     const double *__restrict__ hyp, int H, double thr,
-                                                                    uint32_t *__restrict__ part_cnt, double *__restrict__ part_err)
+                                                                    uint32_t *__restrict__ part_cnt, double *__restrict__ part_err,
+                                                                    const int32_t *__restrict__ gate)
 {
+    if (gate && !*gate) return;                     // (matrix-core path: the full scoring only runs when too many hypotheses tie)
     const int h = blockIdx.x * kScoreThreads + threadIdx.x;
     const int hh = h < H ? h : H - 1;
     const double a = hyp[4 * hh], b = hyp[4 * hh + 1], c = hyp[4 * hh + 2], d = hyp[4 * hh + 3];
@@ -112,9 +114,210 @@ __global__ __launch_bounds__(kScoreThreads) void plane_score_kernel(const float 
     }
 }
 
-__global__ __launch_bounds__(256) void plane_reduce_kernel(const uint32_t *__restrict__ part_cnt, const double *__restrict__ part_err,
-                                                           int chunks, int H, int64_t *__restrict__ cnt, double *__restrict__ err)
+
+// ---- scoring on the matrix cores --------------------------------------------------------------------------------------
+// The signed distance of point p to hypothesis h, fma(a,x, fma(b,y, fma(c,z,d))), is one row of a K = 4 GEMM: v_mfma_f64_16x16x4_f64
+// accumulates k = 0..3 in order onto its C operand and is bit for bit that fma chain, so with A = (c, b, a, 0) per
+// hypothesis, B = (z, y, x, 0) per point and C = d the matrix pipe produces exactly the contract's value for 16 hypotheses x 16
+// points per instruction.  What is left for the vector unit is the inlier COUNT: |t| < thr on the bit patterns (positive doubles
+// order like unsigned integers) -- high words first (one v_and, one v_cmp, one v_addc per result register), the low words only in
+// the rare tile where some high word equals the threshold's.  The error sums sum|d| (tie-breaker of Open3D's better-than test) are
+// NOT formed here: plane_need_kernel marks the hypotheses whose rmse the sequential replay can ask for (count equal to the running
+// maximum at its position) and the sequential-order kernel below evaluates those alone, so every sum keeps its defined order.
+typedef double pd4 __attribute__((ext_vector_type(4)));
+#ifndef KPX_PLANE_TILES
+#define KPX_PLANE_TILES 4
+#endif
+constexpr int kPcTiles = KPX_PLANE_TILES;        // hypothesis tiles (16 each) per wave: 64 kPcTiles hypotheses per block of four waves
+__device__ __forceinline__ uint32_t pc_hi(double v) { return (uint32_t)((uint64_t)__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ uint32_t pc_lo(double v) { return (uint32_t)(uint64_t)__double_as_longlong(v); }
+
+constexpr int kPcSlab = 2048;                    // points staged in LDS per trip (24 KiB as floats); every wave of the block sweeps them
+__global__ __launch_bounds__(256, KPX_PLANE_TILES <= 4 ? 4 : 2) void plane_count_mfma_kernel(const float *__restrict__ pts, int64_t n, int64_t chunk, const double *__restrict__ hyp,
+                                                               int H, uint32_t thr_hi, uint32_t thr_lo, uint32_t *__restrict__ part_cnt)
 {
+    __shared__ float sp[kPcSlab * 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
+    const int h0 = (blockIdx.x * 4 + wave) * (16 * kPcTiles);
+    const int64_t i0 = (int64_t)blockIdx.y * chunk;
+    const int64_t i1 = i0 + chunk < n ? i0 + chunk : n;
+    // A: lane (k = q, row = j) holds component k of hypothesis row in the order (c, b, a, 0); C: d of the lane's four D rows
+    double a[kPcTiles];
+    pd4 c[kPcTiles];
+    uint32_t cnt[kPcTiles][4];
+#pragma unroll
+    for (int t = 0; t < kPcTiles; ++t) {
+        const int h = h0 + 16 * t + j;
+        a[t] = (q < 3 && h < H) ? hyp[4 * h + (2 - q)] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hr = h0 + 16 * t + q + 4 * r;
+            c[t][r] = hr < H ? hyp[4 * hr + 3] : 0.0;
+            cnt[t][r] = 0u;
+        }
+    }
+    const float nanf32 = __int_as_float(0x7FC00000);          // points past the end: NaN distances, never inliers
+    const float thr_f = __int_as_float((int)thr_hi);
+    for (int64_t s0 = i0; s0 < i1; s0 += kPcSlab) {
+        const int m = (int)(i1 - s0 < kPcSlab ? i1 - s0 : kPcSlab);
+        __syncthreads();                                       // the previous slab has been swept by every wave
+        for (int e = threadIdx.x; e < kPcSlab * 3; e += 256) sp[e] = e < 3 * m ? pts[3 * s0 + e] : nanf32;
+        __syncthreads();
+        const int tiles = (m + 15) >> 4;
+        const float *lp = sp + 3 * j + (2 - q);                // component (z, y, x) of point j of a tile; lanes q == 3 feed zeros
+        for (int tl = 0; tl < tiles; ++tl) {
+            const double b = q < 3 ? (double)lp[48 * tl] : 0.0;
+            pd4 d[kPcTiles];
+#pragma unroll
+            for (int t = 0; t < kPcTiles; ++t) d[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b, c[t], 0, 0, 0);
+            // |t| < thr on the HIGH WORDS, read as float32 patterns: for non-negative doubles the high words order like the values, and
+            // so do they as float32 bit patterns (sign in the same place, NaN / infinity patterns = huge doubles: never below thr) --
+            // which makes the absolute value a free source modifier of v_cmp_lt_f32: three vector instructions per result register
+            // (compare, add-with-carry, equality probe).  The host falls back to the sequential kernel for thresholds whose high word
+            // is not a normal float32 pattern.
+            unsigned long long amb = 0ull;                     // (ballots OR-ed on the scalar unit: one v_cmp + one s_or per register)
+#pragma unroll
+            for (int t = 0; t < kPcTiles; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hf = __builtin_fabsf(__int_as_float((int)pc_hi(d[t][r])));
+                    cnt[t][r] += hf < thr_f ? 1u : 0u;
+                    amb |= __builtin_amdgcn_ballot_w64(hf == thr_f);
+                }
+            if (amb != 0ull) {                                 // some |t| shares the threshold's high word: the low words decide
+#pragma unroll
+                for (int t = 0; t < kPcTiles; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cnt[t][r] += ((pc_hi(d[t][r]) & 0x7FFFFFFFu) == thr_hi && pc_lo(d[t][r]) < thr_lo) ? 1u : 0u;
+            }
+        }
+    }
+    // counts of the 16 point columns of every hypothesis row -> lane j == 0 of its quad row
+#pragma unroll
+    for (int t = 0; t < kPcTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uint32_t v = cnt[t][r];
+#pragma unroll
+            for (int msk = 1; msk < 16; msk <<= 1) v += __shfl_xor(v, msk, 64);
+            const int hr = h0 + 16 * t + q + 4 * r;
+            if (j == 0 && hr < H) part_cnt[(int64_t)blockIdx.y * H + hr] = v;
+        }
+}
+
+__global__ __launch_bounds__(256) void plane_reduce_cnt_kernel(const uint32_t *__restrict__ part_cnt, int chunks, int H, int64_t *__restrict__ cnt)
+{
+    int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    int64_t c = 0;
+    for (int k0 = 0; k0 < chunks; k0 += 16) {                     // integers: 16 independent loads per trip
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = k0 + u < chunks ? part_cnt[(int64_t)(k0 + u) * H + h] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c += v[u];
+    }
+    cnt[h] = c;
+}
+
+// Which hypotheses can the sequential replay (plane_select_kernel) ask an rmse of?  Only those whose inlier count equals the largest
+// count seen up to and including their own position: a record needs its rmse stored, a tie needs it compared.  list[0 .. *n_list) =
+// those hypotheses in ascending order (at most kPlaneNeedMax; more -- e.g. every hypothesis ties on an exactly planar cloud -- sets
+// *need_all and the full sequential scoring runs instead).
+constexpr int kPlaneNeedMax = 256;
+__global__ __launch_bounds__(1024) void plane_need_kernel(const double *__restrict__ hyp, const int64_t *__restrict__ cnt, int H, int32_t *__restrict__ list,
+                                                          int32_t *__restrict__ n_list, int32_t *__restrict__ need_all)
+{
+    // thread t owns hypotheses [t per, (t + 1) per): segment maxima -> exclusive max-scan over the threads -> every thread re-walks its
+    // segment with the running maximum in front of it -> positions by an exclusive sum-scan
+    __shared__ long long smax[1024];
+    __shared__ int sh[20];
+    const int per = (H + 1023) / 1024, t = threadIdx.x;
+    const int h_lo = t * per, h_hi = h_lo + per < H ? h_lo + per : H;
+    auto live = [&](int h) { return !(hyp[4 * h] == 0.0 && hyp[4 * h + 1] == 0.0 && hyp[4 * h + 2] == 0.0 && hyp[4 * h + 3] == 0.0); };
+    long long mx = -1;
+    for (int h = h_lo; h < h_hi; ++h)
+        if (live(h)) mx = cnt[h] > mx ? cnt[h] : mx;
+    smax[t] = mx;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                // inclusive max-scan (Hillis-Steele)
+        const long long o = t >= off ? smax[t - off] : -1;
+        __syncthreads();
+        smax[t] = o > smax[t] ? o : smax[t];
+        __syncthreads();
+    }
+    long long run = t ? smax[t - 1] : -1;
+    run = run < 0 ? 0 : run;                                   // the replay starts from best = 0
+    int mine = 0;
+    for (int h = h_lo; h < h_hi; ++h)
+        if (live(h) && cnt[h] >= run) { run = cnt[h]; ++mine; }
+    int total;
+    int pos = block_excl_scan(mine, sh, &total);
+    run = t ? smax[t - 1] : -1;
+    run = run < 0 ? 0 : run;
+    for (int h = h_lo; h < h_hi; ++h)
+        if (live(h) && cnt[h] >= run) {
+            run = cnt[h];
+            if (pos < kPlaneNeedMax) list[pos] = h;
+            ++pos;
+        }
+    if (t == 0) {
+        *n_list = total < kPlaneNeedMax ? total : kPlaneNeedMax;
+        *need_all = total > kPlaneNeedMax ? 1 : 0;
+    }
+}
+
+// plane_score_kernel's sums for the listed hypotheses only (same chunks, same order inside a chunk: the same doubles)
+__global__ __launch_bounds__(kPlaneNeedMax) void plane_err_list_kernel(const float *__restrict__ pts, int64_t n, int64_t chunk, const double *__restrict__ hyp,
+                                                                       const int32_t *__restrict__ list, const int32_t *__restrict__ n_list,
+                                                                       const int32_t *__restrict__ need_all, double thr, double *__restrict__ part_err)
+{
+    if (*need_all) return;
+    __shared__ float sp[kPcSlab * 3];                             // the chunk's points, a slab at a time: the sequential walk reads LDS
+    const int m = *n_list;
+    const bool active = (int)(threadIdx.x & ~63u) < m;            // whole waves beyond the list only help with the loads
+    const int slot = (int)threadIdx.x < m ? (int)threadIdx.x : (m > 0 ? m - 1 : 0);
+    const int h = m > 0 ? list[slot] : 0;
+    const double a = hyp[4 * h], b = hyp[4 * h + 1], c = hyp[4 * h + 2], d = hyp[4 * h + 3];
+    const int64_t i0 = (int64_t)blockIdx.x * chunk;
+    const int64_t i1 = i0 + chunk < n ? i0 + chunk : n;
+    double err = 0.0;
+    for (int64_t s0 = i0; s0 < i1; s0 += kPcSlab) {
+        const int cnt = (int)(i1 - s0 < kPcSlab ? i1 - s0 : kPcSlab);
+        __syncthreads();
+        for (int e = threadIdx.x; e < 3 * cnt; e += kPlaneNeedMax) sp[e] = pts[3 * s0 + e];
+        __syncthreads();
+        if (active)
+            for (int i = 0; i < cnt; ++i) {                       // ascending point index, as plane_score_kernel: the same doubles
+                const double x = (double)sp[3 * i], y = (double)sp[3 * i + 1], z = (double)sp[3 * i + 2];
+                const double dist = fabs(fma(a, x, fma(b, y, fma(c, z, d))));
+                err += dist < thr ? dist : 0.0;
+            }
+    }
+    if ((int)threadIdx.x < m) part_err[(int64_t)blockIdx.x * kPlaneNeedMax + threadIdx.x] = err;
+}
+__global__ __launch_bounds__(kPlaneNeedMax) void plane_err_list_reduce_kernel(const double *__restrict__ part_err, int chunks, const int32_t *__restrict__ list,
+                                                                              const int32_t *__restrict__ n_list, const int32_t *__restrict__ need_all,
+                                                                              double *__restrict__ err)
+{
+    if (*need_all || (int)threadIdx.x >= *n_list) return;
+    double e = 0.0;
+    for (int k0 = 0; k0 < chunks; k0 += 16) {                     // 16 loads in flight, added in chunk order
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = k0 + u < chunks ? part_err[(int64_t)(k0 + u) * kPlaneNeedMax + threadIdx.x] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (k0 + u < chunks) e += v[u];
+    }
+    err[list[threadIdx.x]] = e;
+}
+
+__global__ __launch_bounds__(256) void plane_reduce_kernel(const uint32_t *__restrict__ part_cnt, const double *__restrict__ part_err,
+                                                           int chunks, int H, int64_t *__restrict__ cnt, double *__restrict__ err,
+                                                           const int32_t *__restrict__ gate)
+{
+    if (gate && !*gate) return;
     int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= H) return;
     int64_t c = 0; double e = 0.0;
@@ -122,30 +325,47 @@ __global__ __launch_bounds__(256) void plane_reduce_kernel(const uint32_t *__res
     cnt[h] = c; err[h] = e;
 }
 
-// replay of the sequential loop of [O3D] SegmentPlane (better-than test + probabilistic early exit)
-__global__ void plane_select_kernel(const double *__restrict__ hyp, const int64_t *__restrict__ cnt, const double *__restrict__ err,
-                                    int H, int64_t n, int ransac_n, double probability, double *__restrict__ best)
+// replay of the sequential loop of [O3D] SegmentPlane (better-than test + probabilistic early exit).  One thread replays; the block
+// stages the hypotheses' (plane, count, error sum) through LDS 512 at a time, so the serial walk reads LDS instead of making three
+// dependent global loads per hypothesis (2000 hypotheses: ~0.4 ms -> ~40 us)
+constexpr int kSelTile = 512;
+__global__ __launch_bounds__(256) void plane_select_kernel(const double *__restrict__ hyp, const int64_t *__restrict__ cnt, const double *__restrict__ err,
+                                                           int H, int64_t n, int ransac_n, double probability, double *__restrict__ best)
 {
-    if (threadIdx.x || blockIdx.x) return;
+    __shared__ double s_hyp[kSelTile * 4], s_err[kSelTile];
+    __shared__ long long s_cnt[kSelTile];
+    __shared__ int s_stop;
     double best_fit = 0.0, best_rmse = 0.0, bp[4] = { 0, 0, 0, 0 };
     double break_it = INFINITY;
-    for (int it = 0; it < H; ++it) {
-        if ((double)it > break_it) break;
-        double a = hyp[4 * it], b = hyp[4 * it + 1], c = hyp[4 * it + 2], d = hyp[4 * it + 3];
-        if (a == 0.0 && b == 0.0 && c == 0.0 && d == 0.0) continue;
-        int64_t k = cnt[it];
-        double fit = k ? (double)k / (double)n : 0.0;
-        double rmse = k ? err[it] / sqrt((double)k) : 0.0;
-        if (fit > best_fit || (fit == best_fit && rmse < best_rmse)) {
-            best_fit = fit; best_rmse = rmse; bp[0] = a; bp[1] = b; bp[2] = c; bp[3] = d;
-            if (fit < 1.0) {
-                double bi = log(1.0 - probability) / log(1.0 - pow(fit, (double)ransac_n));
-                bi = bi < (double)H ? bi : (double)H;
-                break_it = floor(bi);
-            } else break_it = 0.0;
+    if (threadIdx.x == 0) s_stop = 0;
+    for (int base = 0; base < H; base += kSelTile) {
+        __syncthreads();
+        if (s_stop) break;
+        const int m = H - base < kSelTile ? H - base : kSelTile;
+        for (int e = threadIdx.x; e < 4 * m; e += blockDim.x) s_hyp[e] = hyp[4 * (int64_t)base + e];
+        for (int e = threadIdx.x; e < m; e += blockDim.x) { s_cnt[e] = cnt[base + e]; s_err[e] = err[base + e]; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int e = 0; e < m; ++e) {
+                const int it = base + e;
+                if ((double)it > break_it) { s_stop = 1; break; }
+                double a = s_hyp[4 * e], b = s_hyp[4 * e + 1], c = s_hyp[4 * e + 2], d = s_hyp[4 * e + 3];
+                if (a == 0.0 && b == 0.0 && c == 0.0 && d == 0.0) continue;
+                int64_t k = s_cnt[e];
+                double fit = k ? (double)k / (double)n : 0.0;
+                double rmse = k ? s_err[e] / sqrt((double)k) : 0.0;
+                if (fit > best_fit || (fit == best_fit && rmse < best_rmse)) {
+                    best_fit = fit; best_rmse = rmse; bp[0] = a; bp[1] = b; bp[2] = c; bp[3] = d;
+                    if (fit < 1.0) {
+                        double bi = log(1.0 - probability) / log(1.0 - pow(fit, (double)ransac_n));
+                        bi = bi < (double)H ? bi : (double)H;
+                        break_it = floor(bi);
+                    } else break_it = 0.0;
+                }
+            }
         }
     }
-    best[0] = bp[0]; best[1] = bp[1]; best[2] = bp[2]; best[3] = bp[3];
+    if (threadIdx.x == 0) { best[0] = bp[0]; best[1] = bp[1]; best[2] = bp[2]; best[3] = bp[3]; }
 }
 
 struct PlaneInlierPred {
@@ -185,11 +405,15 @@ __global__ __launch_bounds__(256) void plane_refit_sum_kernel(const float *__res
         if (threadIdx.x == 0) part[(int64_t)blockIdx.x * 6 + q] = v;
     }
 }
-__global__ void plane_refit_final_kernel(const double *__restrict__ part, int nb, int pass, double *__restrict__ cen, double *__restrict__ plane)
+__global__ __launch_bounds__(256) void plane_refit_final_kernel(const double *__restrict__ part, int nb, int pass, double *__restrict__ cen,
+                                                                double *__restrict__ plane)
 {
-    if (threadIdx.x || blockIdx.x) return;
+    __shared__ double sp[1024 * 6];                               // nb <= 1024 block partials, loaded by the block, folded in block order by one thread
+    for (int e = threadIdx.x; e < nb * 6; e += blockDim.x) sp[e] = part[e];
+    __syncthreads();
+    if (threadIdx.x) return;
     double s[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int b = 0; b < nb; ++b) for (int q = 0; q < 6; ++q) s[q] += part[(int64_t)b * 6 + q];
+    for (int b = 0; b < nb; ++b) for (int q = 0; q < 6; ++q) s[q] += sp[b * 6 + q];
     if (pass == 0) {
         double m = s[3];
         cen[3] = m;
@@ -226,26 +450,52 @@ static int plane_impl(const float *pts, int64_t n, double thr, int ransac_n, int
     double *best = a.get<double>(8);
     double *rpart = a.get<double>(1024 * 6);
     int32_t *counts = a.get<int32_t>((size_t)compact_ws_ints(n));
+    int32_t *need_list = a.get<int32_t>(kPlaneNeedMax + 2);
+    double *part_err_list = a.get<double>((size_t)chunks * kPlaneNeedMax);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
+    static const bool mfma_on = [] { const char *e = getenv("KPX_PLANE_MFMA"); return !(e && e[0] == '0'); }();       // A/B switch
     if (H > 0) {
         hipLaunchKernelGGL(plane_hyp_kernel, dim3((unsigned)cdiv(H, 64)), dim3(64), 0, st, pts, n, ransac_n, H, (uint32_t)seed,
                            (uint32_t)(seed >> 32), ids, hyp);
-        {
-            ProfScope prof(KPX_PROF_PLANE_SCORE, 12.0 * (double)n, st);      // one algorithmic sweep of the points for all H
-            hipLaunchKernelGGL(plane_score_kernel, dim3((unsigned)cdiv(H, kScoreThreads), chunks), dim3(kScoreThreads), 0, st, pts, n,
-                               chunk, hyp, H, thr, part_cnt, part_err);
+        const dim3 grid((unsigned)cdiv(H, kScoreThreads), (unsigned)chunks);
+        uint64_t tbits;
+        memcpy(&tbits, &thr, sizeof(tbits));
+        const uint32_t thi = (uint32_t)(tbits >> 32);
+        // (thresholds whose high word is not a normal, positive float32 pattern -- below 2^-1015, above 2^1017, negative, NaN -- take the
+        // sequential kernel)
+        if (mfma_on && thi >= 0x00800000u && thi < 0x7F800000u) {
+            // counts on the matrix cores; rmse only for the hypotheses the replay can ask about; the full sequential scoring only when
+            // more than kPlaneNeedMax hypotheses tie with the running best (its blocks return at once otherwise)
+            const uint64_t tb = tbits;
+            int32_t *n_list = need_list + kPlaneNeedMax, *need_all = need_list + kPlaneNeedMax + 1;
+            {
+                ProfScope prof(KPX_PROF_PLANE_SCORE, 12.0 * (double)n, st);  // one algorithmic sweep of the points for all H
+                hipLaunchKernelGGL(plane_count_mfma_kernel, dim3((unsigned)cdiv(H, 64 * kPcTiles), (unsigned)chunks), dim3(256), 0, st, pts, n, chunk, hyp, H, (uint32_t)(tb >> 32), (uint32_t)tb, part_cnt);
+            }
+            hipLaunchKernelGGL(plane_reduce_cnt_kernel, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, part_cnt, chunks, H, cnt);
+            hipLaunchKernelGGL(plane_need_kernel, dim3(1), dim3(1024), 0, st, hyp, cnt, H, need_list, n_list, need_all);
+            hipLaunchKernelGGL(plane_err_list_kernel, dim3((unsigned)chunks), dim3(kPlaneNeedMax), 0, st, pts, n, chunk, hyp, need_list, n_list, need_all, thr,
+                               part_err_list);
+            hipLaunchKernelGGL(plane_err_list_reduce_kernel, dim3(1), dim3(kPlaneNeedMax), 0, st, part_err_list, chunks, need_list, n_list, need_all, err);
+            hipLaunchKernelGGL(plane_score_kernel, grid, dim3(kScoreThreads), 0, st, pts, n, chunk, hyp, H, thr, part_cnt, part_err, need_all);
+            hipLaunchKernelGGL(plane_reduce_kernel, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, part_cnt, part_err, chunks, H, cnt, err, need_all);
+        } else {
+            {
+                ProfScope prof(KPX_PROF_PLANE_SCORE, 12.0 * (double)n, st);
+                hipLaunchKernelGGL(plane_score_kernel, grid, dim3(kScoreThreads), 0, st, pts, n, chunk, hyp, H, thr, part_cnt, part_err, (const int32_t *)nullptr);
+            }
+            hipLaunchKernelGGL(plane_reduce_kernel, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, part_cnt, part_err, chunks, H, cnt, err, (const int32_t *)nullptr);
         }
-        hipLaunchKernelGGL(plane_reduce_kernel, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, part_cnt, part_err, chunks, H, cnt, err);
     }
-    hipLaunchKernelGGL(plane_select_kernel, dim3(1), dim3(1), 0, st, hyp, cnt, err, H, n, ransac_n, probability, best);
+    hipLaunchKernelGGL(plane_select_kernel, dim3(1), dim3(256), 0, st, hyp, cnt, err, H, n, ransac_n, probability, best);
     int rc = compact(PlaneInlierPred{ pts, best, thr }, PlaneIdxEmit{ inl_idx }, n, 1, counts, d_count, st);
     if (rc) return rc;
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
     double *cen = best + 4;
     for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(plane_refit_sum_kernel, dim3(nb), dim3(256), 0, st, pts, n, best, thr, cen, pass, rpart);
-        hipLaunchKernelGGL(plane_refit_final_kernel, dim3(1), dim3(1), 0, st, rpart, nb, pass, cen, d_plane);
+        hipLaunchKernelGGL(plane_refit_final_kernel, dim3(1), dim3(256), 0, st, rpart, nb, pass, cen, d_plane);
     }
     KPX_LAUNCH_CHECK();
     return KPX_OK;

@@ -404,6 +404,37 @@ def test_segment_plane_inliers_bit_exact(ops, oracle, n, rn, iters, prob, seed):
     assert np.abs(gpl - rpl).max() < TOL_PLANE
 
 
+def test_segment_plane_ties_thresholds_and_sequential_path(ops, oracle):
+    """the matrix-core scoring (counts by fp64 MFMA, rmse only for the hypotheses the replay can ask about) at its edges: an exactly
+    planar cloud where EVERY hypothesis ties (more ties than the list holds: the full sequential scoring takes over), distances that
+    share the threshold's high word (the low words decide), thresholds outside the float32-pattern range (sequential kernel), and
+    the same answers with the matrix path switched off in a child process"""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    gx, gy = np.meshgrid(np.arange(120, dtype=np.float32), np.arange(100, dtype=np.float32))
+    flat = np.stack([gx.ravel() * 7, np.full(gx.size, 900.0, np.float32), gy.ravel() * 5], -1).astype(np.float32)
+    cases = [(flat, 30.0, 3, 600), (flat, 30.0, 30, 300)]
+    # a slab whose distances to the winning plane land ON the threshold's high word: y = 900 +- exactly 30 and a hair inside / outside
+    edge = flat.copy()
+    edge[::3, 1] += np.float32(30.0)
+    edge[1::3, 1] -= np.float32(29.999998)
+    cases.append((edge, 30.0, 3, 400))
+    noisy = (flat + rng.normal(scale=4.0, size=flat.shape)).astype(np.float32)
+    cases += [(noisy, 1e-320, 3, 50), (noisy, 30.0, 5, 500), (noisy, 2.5, 3, 1000)]
+    for pts, thr, rn, iters in cases:
+        gpl, gidx = ops.segment_plane(pts, thr, rn, iters, 1.0, 11)
+        rpl, ridx = oracle.segment_plane(pts, thr, rn, iters, 1.0, 11)
+        assert np.array_equal(npy(gidx), ridx), (thr, rn, iters)
+        assert np.abs(gpl - rpl).max() < TOL_PLANE
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from kinectpy_amd import ops; from kinectpy_amd.utils import synth; "
+            "c = synth.filter_cloud(200000); pl, idx = ops.segment_plane(c, 30.0, 30, 2000, 1.0, 7); "
+            "print(repr(pl.tolist()), int(idx.sum().item()), int(idx.shape[0]))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KPX_PLANE_MFMA=v), capture_output=True, text=True, timeout=300) for v in ("1", "0")]
+    assert all(o.returncode == 0 for o in outs), outs[0].stderr[-2000:] + outs[1].stderr[-2000:]
+    assert outs[0].stdout.strip().splitlines()[-1] == outs[1].stdout.strip().splitlines()[-1]
+
+
 # ------------------------------------------------------------------------------------------- registration
 @pytest.fixture(params=["culled", "dense", "dense_fp64"])
 def engine(request, ops):
