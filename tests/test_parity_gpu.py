@@ -1339,6 +1339,7 @@ def _local_ranks(world, S, xy, depth, rgb, inits, mode, frames, slots=1, host=Fa
     from kinectpy_amd.pipeline import FrameStream, NativeShardPipeline, PipelineParams
     hubs = [parallel.NativeComm.LocalHub(world) for _ in range(slots)]
     results, errors = [None] * world, []
+    _local_ranks.retries = [0] * world
 
     def rank_main(r):
         try:
@@ -1365,6 +1366,7 @@ def _local_ranks(world, S, xy, depth, rgb, inits, mode, frames, slots=1, host=Fa
                         out.append((npy(p), npy(c), Ts, {}))
                     fs.close()
                 results[r] = out
+                _local_ranks.retries[r] = sum(p_.retries for p_ in pipes)
         except BaseException as e:
             errors.append((r, e))
             for h in hubs:
@@ -1434,6 +1436,25 @@ def test_native_sharded_loop_retries_a_frame_that_outgrows_its_messages(four_sen
     gp, gc, gT = pipe.step(torch.as_tensor(depth[0]).cuda(), torch.as_tensor(rgb[0]).cuda())
     assert pipe.retries >= 1
     assert np.array_equal(npy(gp), ref[0][0]) and np.array_equal(npy(gc), ref[0][1]) and np.abs(gT - np.stack(ref[0][2])).max() < TOL_T
+
+
+def test_native_sharded_loop_retries_under_a_frame_stream(four_sensor_oracle):
+    """the retry with frames in flight: two in-process ranks, two slots each; every slot first sees a thinned frame (one pixel in
+    eight: small messages, small capacities), then the full one -- both ranks get KPX_RETRY for the same frames, FrameStream.pop()
+    submits them again in program order (new frame numbers in the library's kpx_order) and every result equals the oracle step"""
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    thin = depth[0].copy()
+    keep = (np.arange(thin.shape[1]) % 8) == 0
+    thin[:, ~keep] = 0
+    d2 = np.stack([thin, depth[0], depth[1]])
+    c2 = np.stack([rgb[0], rgb[0], rgb[1]])
+    res = _local_ranks(2, 4, xy, d2, c2, inits, "sharded", frames=(0, 0, 1, 2, 1, 2), slots=2)
+    assert _local_ranks.retries[0] >= 2 and _local_ranks.retries[0] == _local_ranks.retries[1]       # both slots, the same frames on both ranks
+    for r in range(2):
+        assert len(res[r]) == 6
+        for k, f in ((2, 0), (3, 1), (4, 0), (5, 1)):
+            p, c, Ts, _ = res[r][k]
+            assert np.array_equal(p, ref[f][0]) and np.array_equal(c, ref[f][1]) and np.abs(Ts - np.stack(ref[f][2])).max() < TOL_T, (r, k)
 
 
 def test_native_sharded_loop_through_rccl_one_rank(four_sensor_oracle):
