@@ -1292,6 +1292,12 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // the barrier orders the block's ticket behind them, and the block that draws the last ticket of its registration reads the
     // totals -- 8 x 44 pairs of words -- with device-coherent loads, clears them for the next launch and performs the update.
     // Only relaxed atomics: no release fence, which on this part writes back the XCD's L2 (measured 10x slower, once per block).
+    // This is the `sc1` form of the valid hand-offs of MI355X_MICROARCH.md ("Correctness boundaries"): the handed-off bytes are
+    // produced by atomics (performed at the memory side, never resident in a CU's L1), drained before the ticket because every
+    // add RETURNS, and read by the winner with device-coherent (sc1) loads only (fixed_total_coherent) -- no plain load of them
+    // anywhere.  It rests on gfx950 behaviour, not on the HIP memory model: KPX_ICP_SPLIT=1 (update in its own kernel, ordered by the
+    // kernel boundary) is the portable fall-back, and test_update_placements_agree_with_four_frames_in_flight compares the three
+    // placements bit for bit under four frames in flight.
     // The state is written with plain stores: its readers are the blocks of the NEXT launch, behind the kernel boundary.
     __shared__ unsigned s_ticket;
     __syncthreads();

@@ -1733,6 +1733,30 @@ def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
     assert its.max() >= 10, its                                        # a chain long enough for blocks to be skipped
 
 
+def test_update_placements_agree_with_four_frames_in_flight(tmp_path):
+    """The same comparison under load: 24 frames through FrameStream with FOUR frames in flight (every kernel of four ICP chains
+    sharing the device), update step in the last block of the sweep (default; its hand-off rests on returning device-scope atomics,
+    a relaxed ticket and sc1 loads in the winning block -- the `sc1` form of the guide's valid hand-offs), in its own kernel, and in the
+    next sweep's prologue: every fused cloud and every transform identical to the last bit, and the repeats of a frame identical
+    among themselves."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("2", "1", "0"):
+        f = str(tmp_path / f"split{mode}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_frames.py"), f, "4", "3"], cwd=root, capture_output=True, text=True,
+                           timeout=600, env={**os.environ, "KPX_ICP_SPLIT": mode, "GPU_MAX_HW_QUEUES": "8"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[mode] = dict(np.load(f))
+    for mode in ("1", "0"):
+        for key, v in got["2"].items():
+            assert np.array_equal(v, got[mode][key]), (mode, key)
+    for k in range(8):
+        for rep in (1, 2):
+            assert np.array_equal(got["2"][f"p{k}"], got["2"][f"p{k + 8 * rep}"]) and np.array_equal(got["2"][f"T{k}"], got["2"][f"T{k + 8 * rep}"])
+
+
 @pytest.mark.parametrize("n,end_bit", [(1, 32), (63, 8), (2048, 9), (2049, 24), (100_003, 27), (1_130_000, 24), (1_130_000, 32), (300_000, 1),
                                        (4_194_304, 17), (4_200_000, 22)])
 def test_radix_sort_pairs_is_the_stable_sort(ops, n, end_bit):
