@@ -53,6 +53,35 @@ struct Arena {
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// 16-byte loads / stores of data that is touched once (streaming operators): non-temporal, so that a pass over a cloud does not
+// evict what other kernels of the frame keep in L2 / Infinity Cache.  -DKPX_STREAM_PLAIN: ordinary accesses (A/B switch).
+typedef unsigned int kpx_u4 __attribute__((ext_vector_type(4)));
+template <class V> __device__ __forceinline__ V stream_load16(const V *p)
+{
+    static_assert(sizeof(V) == 16, "16-byte vectors only");
+#ifdef KPX_STREAM_PLAIN
+    return *p;
+#else
+    const kpx_u4 r = __builtin_nontemporal_load(reinterpret_cast<const kpx_u4 *>(p));
+    V v;
+    __builtin_memcpy(&v, &r, 16);
+    return v;
+#endif
+}
+template <class V> __device__ __forceinline__ void stream_store16(const V &v, V *p)
+{
+    static_assert(sizeof(V) == 16, "16-byte vectors only");
+#ifdef KPX_STREAM_PLAIN
+    *p = v;
+#else
+    kpx_u4 r;
+    __builtin_memcpy(&r, &v, 16);
+    __builtin_nontemporal_store(r, reinterpret_cast<kpx_u4 *>(p));
+#endif
+}
+#define KPX_STREAM_LOAD(p) stream_load16(p)
+#define KPX_STREAM_STORE(v, p) stream_store16((v), (p))
+
 // ---- HIP-event profiler (armed by kpx_prof_begin; a no-op otherwise) ----------------------------
 bool prof_armed();
 struct ProfScope {

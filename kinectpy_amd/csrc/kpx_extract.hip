@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void unproject_vec8_lds_kernel(const uint16_t 
         const float xt[8] = { t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z };
         const float yt[8] = { t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w };
         for (int f = f0; f < f1; ++f) {
-            const uint4 dv = *reinterpret_cast<const uint4 *>(depth + (int64_t)f * n_px + g * 8);
+            const uint4 dv = KPX_STREAM_LOAD(reinterpret_cast<const uint4 *>(depth + (int64_t)f * n_px + g * 8));
             const uint16_t d[8] = { (uint16_t)(dv.x & 0xffff), (uint16_t)(dv.x >> 16), (uint16_t)(dv.y & 0xffff), (uint16_t)(dv.y >> 16),
                                     (uint16_t)(dv.z & 0xffff), (uint16_t)(dv.z >> 16), (uint16_t)(dv.w & 0xffff), (uint16_t)(dv.w >> 16) };
             union { int16_t s[24]; uint4 v[3]; } o;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void unproject_vec8_lds_kernel(const uint16_t 
             wave_lds_fence();
             uint4 *dst = reinterpret_cast<uint4 *>(xyz + ((int64_t)f * n_px) * 3 + g0 * 24);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) dst[64 * r + lane] = stage[wave][64 * r + lane];
+            for (int r = 0; r < 3; ++r) KPX_STREAM_STORE(stage[wave][64 * r + lane], dst + 64 * r + lane);
             wave_lds_fence();
         }
     }

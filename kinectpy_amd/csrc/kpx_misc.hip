@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void transform_lds_kernel(const float *__restr
     for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < chunks; c += (int64_t)gridDim.x * 4) {
         const float4 *src = reinterpret_cast<const float4 *>(in + c * 768);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) stage[wave][64 * r + lane] = src[64 * r + lane];
+        for (int r = 0; r < 3; ++r) stage[wave][64 * r + lane] = KPX_STREAM_LOAD(src + 64 * r + lane);
         wave_lds_fence();
         const float4 a = stage[wave][3 * lane], b = stage[wave][3 * lane + 1], cc = stage[wave][3 * lane + 2];
         const float v[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, cc.x, cc.y, cc.z, cc.w };
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void transform_lds_kernel(const float *__restr
         wave_lds_fence();
         float4 *dst = reinterpret_cast<float4 *>(out + c * 768);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) dst[64 * r + lane] = stage[wave][64 * r + lane];
+        for (int r = 0; r < 3; ++r) KPX_STREAM_STORE(stage[wave][64 * r + lane], dst + 64 * r + lane);
         wave_lds_fence();
     }
 }
