@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kCompactThreads) void compact_pts_flag_kernel(const
         const float4 *src = reinterpret_cast<const float4 *>(pts + 3 * wbase);
         float4 *dst = reinterpret_cast<float4 *>(stage[wave]);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) dst[64 * r + lane] = src[64 * r + lane];
+        for (int r = 0; r < 6; ++r) dst[64 * r + lane] = stream_load16(src + 64 * r + lane);       // the points are read once: non-temporal
         wave_lds_fence();
     }
     unsigned long long ma = 0, mb = 0;          // lane k < 8 keeps the ballot of row k
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(kCompactThreads) void compact_pts_onepass_kernel(co
         const float4 *src = reinterpret_cast<const float4 *>(pts + 3 * wbase);
         float4 *dst = reinterpret_cast<float4 *>(stage[wave]);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) dst[64 * r + lane] = src[64 * r + lane];
+        for (int r = 0; r < 6; ++r) dst[64 * r + lane] = stream_load16(src + 64 * r + lane);       // the points are read once: non-temporal
         wave_lds_fence();
     }
     unsigned long long m[8];
