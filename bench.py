@@ -327,7 +327,7 @@ def roofline_targets(torch, ops, quick=False):
     def vpeak(op, kernel, ms, flops, nbytes, **extra):
         tf = flops / (ms * 1e-3) / 1e12
         rows.append(dict({"op": op, "kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 4), "ms": round(ms, 4), "flops": int(flops), "algorithmic_bytes": int(nbytes),
+                          "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "ms": round(ms, 4), "flops": int(flops), "algorithmic_bytes": int(nbytes),
                           "hbm_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}, **extra))
 
     keep1 = ops.sor(v1, 20, 2.0)[0]
