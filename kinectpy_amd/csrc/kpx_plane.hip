@@ -325,47 +325,74 @@ __global__ __launch_bounds__(256) void plane_reduce_kernel(const uint32_t *__res
     cnt[h] = c; err[h] = e;
 }
 
-// replay of the sequential loop of [O3D] SegmentPlane (better-than test + probabilistic early exit).  One thread replays; the block
-// stages the hypotheses' (plane, count, error sum) through LDS 512 at a time, so the serial walk reads LDS instead of making three
-// dependent global loads per hypothesis (2000 hypotheses: ~0.4 ms -> ~40 us)
-constexpr int kSelTile = 512;
-__global__ __launch_bounds__(256) void plane_select_kernel(const double *__restrict__ hyp, const int64_t *__restrict__ cnt, const double *__restrict__ err,
-                                                           int H, int64_t n, int ransac_n, double probability, double *__restrict__ best)
+// The sequential loop of [O3D] SegmentPlane (better-than test + probabilistic early exit), evaluated in parallel -- same result:
+//   * a hypothesis replaces the best when its fitness is larger, or equal with a smaller rmse, so the survivor of iterations
+//     [0, stop) is the first one in the order (fitness descending, rmse ascending, iteration ascending) among the non-degenerate
+//     hypotheses with fitness > 0;
+//   * the early-exit bound only changes when the best FITNESS changes and is a function of it alone, so at iteration `it` it is
+//     f(largest fitness among the iterations before it) (infinite while that is 0), and the loop stops at the first it > bound.
+// (One thread replaying 2000 hypotheses from LDS took 0.3-0.6 ms when no early exit cuts it short -- probability = 1.)
+__device__ __forceinline__ double plane_break_bound(double fit, int ransac_n, double probability, int H)
 {
-    __shared__ double s_hyp[kSelTile * 4], s_err[kSelTile];
-    __shared__ long long s_cnt[kSelTile];
+    if (!(fit > 0.0)) return INFINITY;
+    if (!(fit < 1.0)) return 0.0;
+    double bi = log(1.0 - probability) / log(1.0 - pow(fit, (double)ransac_n));
+    bi = bi < (double)H ? bi : (double)H;
+    return floor(bi);
+}
+__global__ __launch_bounds__(1024) void plane_select_kernel(const double *__restrict__ hyp, const int64_t *__restrict__ cnt, const double *__restrict__ err,
+                                                            int H, int64_t n, int ransac_n, double probability, double *__restrict__ best)
+{
+    __shared__ double smax[1024], s_fit[1024], s_rmse[1024];
+    __shared__ int s_idx[1024];
     __shared__ int s_stop;
-    double best_fit = 0.0, best_rmse = 0.0, bp[4] = { 0, 0, 0, 0 };
-    double break_it = INFINITY;
-    if (threadIdx.x == 0) s_stop = 0;
-    for (int base = 0; base < H; base += kSelTile) {
+    const int t = threadIdx.x, per = (H + 1023) / 1024;
+    const int h_lo = t * per < H ? t * per : H, h_hi = h_lo + per < H ? h_lo + per : H;
+    auto live = [&](int h) { return !(hyp[4 * h] == 0.0 && hyp[4 * h + 1] == 0.0 && hyp[4 * h + 2] == 0.0 && hyp[4 * h + 3] == 0.0); };
+    auto fitness = [&](int h) { const int64_t k = cnt[h]; return k ? (double)k / (double)n : 0.0; };
+    if (t == 0) s_stop = H;
+    double mx = 0.0;
+    for (int h = h_lo; h < h_hi; ++h)
+        if (live(h)) mx = fmax(mx, fitness(h));
+    smax[t] = mx;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                // inclusive max-scan over the threads' segments
+        const double o = t >= off ? smax[t - off] : 0.0;
         __syncthreads();
-        if (s_stop) break;
-        const int m = H - base < kSelTile ? H - base : kSelTile;
-        for (int e = threadIdx.x; e < 4 * m; e += blockDim.x) s_hyp[e] = hyp[4 * (int64_t)base + e];
-        for (int e = threadIdx.x; e < m; e += blockDim.x) { s_cnt[e] = cnt[base + e]; s_err[e] = err[base + e]; }
+        smax[t] = fmax(smax[t], o);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int e = 0; e < m; ++e) {
-                const int it = base + e;
-                if ((double)it > break_it) { s_stop = 1; break; }
-                double a = s_hyp[4 * e], b = s_hyp[4 * e + 1], c = s_hyp[4 * e + 2], d = s_hyp[4 * e + 3];
-                if (a == 0.0 && b == 0.0 && c == 0.0 && d == 0.0) continue;
-                int64_t k = s_cnt[e];
-                double fit = k ? (double)k / (double)n : 0.0;
-                double rmse = k ? s_err[e] / sqrt((double)k) : 0.0;
-                if (fit > best_fit || (fit == best_fit && rmse < best_rmse)) {
-                    best_fit = fit; best_rmse = rmse; bp[0] = a; bp[1] = b; bp[2] = c; bp[3] = d;
-                    if (fit < 1.0) {
-                        double bi = log(1.0 - probability) / log(1.0 - pow(fit, (double)ransac_n));
-                        bi = bi < (double)H ? bi : (double)H;
-                        break_it = floor(bi);
-                    } else break_it = 0.0;
-                }
-            }
-        }
     }
-    if (threadIdx.x == 0) { best[0] = bp[0]; best[1] = bp[1]; best[2] = bp[2]; best[3] = bp[3]; }
+    // first iteration the loop does not enter
+    double run = t ? smax[t - 1] : 0.0;
+    for (int h = h_lo; h < h_hi; ++h) {
+        if ((double)h > plane_break_bound(run, ransac_n, probability, H)) { atomicMin(&s_stop, h); break; }
+        if (live(h)) run = fmax(run, fitness(h));
+    }
+    __syncthreads();
+    const int stop = s_stop;
+    // the survivor among [0, stop)
+    double bf = 0.0, br = 0.0;
+    int bi = INT_MAX;
+    for (int h = h_lo; h < h_hi && h < stop; ++h) {
+        if (!live(h)) continue;
+        const int64_t k = cnt[h];
+        const double fit = k ? (double)k / (double)n : 0.0;
+        if (!(fit > 0.0)) continue;
+        const double rmse = err[h] / sqrt((double)k);
+        if (bi == INT_MAX || fit > bf || (fit == bf && rmse < br)) { bf = fit; br = rmse; bi = h; }
+    }
+    s_fit[t] = bf; s_rmse[t] = br; s_idx[t] = bi;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (t < off) {
+            const double of = s_fit[t + off], orr = s_rmse[t + off];
+            const int oi = s_idx[t + off];
+            const bool take = oi != INT_MAX && (s_idx[t] == INT_MAX || of > s_fit[t] || (of == s_fit[t] && (orr < s_rmse[t] || (orr == s_rmse[t] && oi < s_idx[t]))));
+            if (take) { s_fit[t] = of; s_rmse[t] = orr; s_idx[t] = oi; }
+        }
+        __syncthreads();
+    }
+    if (t < 4) best[t] = s_idx[0] != INT_MAX ? hyp[4 * s_idx[0] + t] : 0.0;
 }
 
 struct PlaneInlierPred {
@@ -488,7 +515,7 @@ static int plane_impl(const float *pts, int64_t n, double thr, int ransac_n, int
             hipLaunchKernelGGL(plane_reduce_kernel, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, part_cnt, part_err, chunks, H, cnt, err, (const int32_t *)nullptr);
         }
     }
-    hipLaunchKernelGGL(plane_select_kernel, dim3(1), dim3(256), 0, st, hyp, cnt, err, H, n, ransac_n, probability, best);
+    hipLaunchKernelGGL(plane_select_kernel, dim3(1), dim3(1024), 0, st, hyp, cnt, err, H, n, ransac_n, probability, best);
     int rc = compact(PlaneInlierPred{ pts, best, thr }, PlaneIdxEmit{ inl_idx }, n, 1, counts, d_count, st);
     if (rc) return rc;
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8)));
