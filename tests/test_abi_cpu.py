@@ -82,6 +82,43 @@ def test_version_and_error_channel(lib):
     assert rc == -1 and b"max_correspondence_distance" in lib.kpx_last_error()
 
 
+def test_comm_and_order_objects_without_a_gpu(lib):
+    """the exchange layer's host objects: a callback communicator, the collectives' issue order, argument checks of the sharded
+    frame step -- nothing here touches a device"""
+    from kinectpy_amd import _lib
+    calls = []
+    b = _lib.BCAST_FN(lambda user, buf, n, root, stream: calls.append(("b", n, root)) or 0)
+    g = _lib.ALLGATHER_FN(lambda user, s, r, n, stream: calls.append(("g", n)) or 0)
+    h = C.c_void_p()
+    assert lib.kpx_comm_create_callbacks(1, 4, C.cast(b, C.c_void_p), C.cast(g, C.c_void_p), None, C.byref(h)) == 0
+    assert lib.kpx_comm_rank(h) == 1 and lib.kpx_comm_world(h) == 4
+    assert lib.kpx_comm_broadcast(h, C.c_void_p(4096), 100, 0, None) == 0 and lib.kpx_comm_allgather(h, C.c_void_p(4096), C.c_void_p(8192), 64, None) == 0
+    assert calls == [("b", 100, 0), ("g", 64)]
+    assert lib.kpx_comm_broadcast(h, C.c_void_p(4096), 100, 7, None) == -1 and b"bad arguments" in lib.kpx_last_error()
+    assert lib.kpx_comm_destroy(h) == 0
+    assert lib.kpx_comm_create_callbacks(0, 2, None, None, None, C.byref(h)) == -1              # several ranks need a transport
+    assert lib.kpx_comm_create_rccl(None, 0, 1, C.byref(h)) == -1
+    # the order: two frames in flight, keys 3 f (broadcast) and 3 (f + depth - 1) + s
+    o = C.c_void_p()
+    assert lib.kpx_order_create(2, C.byref(o)) == 0
+    f0, f1 = C.c_int64(), C.c_int64()
+    lib.kpx_order_submit(o, C.byref(f0)); lib.kpx_order_submit(o, C.byref(f1))
+    for frame, stage in ((0, 0), (1, 0), (0, 1), (0, 2)):
+        lib.kpx_order_turn_begin(o, frame, stage); lib.kpx_order_turn_end(o, frame, stage)
+    lib.kpx_order_block(o, 1)                                                                    # the main thread waits for frame 1: its stages may go
+    lib.kpx_order_turn_begin(o, 1, 1); lib.kpx_order_turn_end(o, 1, 1)
+    lib.kpx_order_finish(o, 1)
+    log, n = (C.c_int64 * 16)(), C.c_int64()
+    lib.kpx_order_log(o, log, 16, C.byref(n))
+    assert list(log[: n.value]) == [0, 3, 4, 5, 7]
+    lib.kpx_order_destroy(o)
+    # the sharded frame step refuses to run without a communicator / with more ranks than sensors
+    assert lib.kpx_frame_step_sharded_workspace_bytes(4, 0, 8, 368640, 0) == 0
+    assert lib.kpx_frame_step_sharded_workspace_bytes(8, 7, 8, 368640, 1) > lib.kpx_frame_step_sharded_workspace_bytes(8, 7, 8, 368640, 0) > 0
+    rc = lib.kpx_frame_step_sharded(None, None, 0, None, None, 0, None, 368640, 4, None, None, 0, None, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"communicator" in lib.kpx_last_error()
+
+
 def test_workspace_queries_are_pure_host_arithmetic(lib):
     assert lib.kpx_median_workspace_bytes(4) >= 4 * 512 * 4
     assert lib.kpx_compact_workspace_bytes(368640, 8) >= 8 * 180 * 4
