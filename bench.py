@@ -571,6 +571,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64 decisions / f32 storage", "data": "synthetic",
         "config": cfg, "roofline": roof, "cpu_baseline": cpu,
+        # `value` keeps the bench contract (inputs resident in HBM when the timed region starts); SURVEY 8(d)'s own interval -- the frame
+        # starts in pinned host memory -- is measured under the same protocol and reported beside it, never as `value`
+        "value_from_pinned_host": None if dt_pin is None else round(px_per_step * args.steps / dt_pin / 1e6, 3),
         "from_pinned_host": None if dt_pin is None else {
             "value": round(px_per_step * args.steps / dt_pin / 1e6, 3), "unit": "Mpoints/s", "ms_per_step": round(dt_pin / args.steps * 1e3, 3),
             "steps": args.steps, "warmup": args.warmup,
