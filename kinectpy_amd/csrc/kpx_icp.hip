@@ -51,7 +51,10 @@ constexpr int kCT = 32;                      // 16-column tiles per LDS stage (1
 
 constexpr int kChunk = KPX_NN_CHUNK;         // column tiles per fast-pass chunk of the dense sweep (nn_mfma_kernel)
 constexpr int kStageDoubles = kCT * 64;
-constexpr int kSeedStride = 64;              // the seed sweep visits every 64th target tile
+#ifndef KPX_SEED_STRIDE
+#define KPX_SEED_STRIDE 16                  // measured 100k x 100k, whole bare search (seed + main sweep): 64 -> 2.60 ms, 16 -> 2.48, 8 -> 2.66
+#endif
+constexpr int kSeedStride = KPX_SEED_STRIDE;  // the seed sweep visits every kSeedStride-th target tile
 constexpr double kSentinel = 1e300;
 constexpr int kFRT = 4;                      // f32 screening sweep: 16-row tiles per wave
 constexpr int kFRowsPerBlock = kWaves * kFRT * 16; // 256
@@ -1747,6 +1750,10 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
+    {
+    // (timed as ONE unit: a bare search's seed sweep + its merge belong to the all-pairs sweep they make cheaper -- with bounds from
+    // every 16th tile the main sweep alone runs at 38 TFLOP/s, from every 64th at 33, but the seed sweep costs what it saves beyond that)
+    ProfScope prof(KPX_PROF_NN_MFMA, 8.0 * (double)p.n_src * (double)p.n_tgt, st);     // 4 MAC per (source, target) pair
     if (!have_prev) {
         hipLaunchKernelGGL(nn_mfma_kernel<false>, dim3(p.row_blocks, 1), thr, 0, st, n, b.Bseed, (int32_t)p.seed_tiles_pad, (int32_t)kSeedStride,
                            done, b.A64, b.K64, (const double *)nullptr, (const int32_t *)nullptr, b.part_val, b.part_idx);
@@ -1754,16 +1761,14 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
                            0.0, -2, b.init_idx, (double *)nullptr, b.init_val, b.part_acc, (const int32_t *)nullptr, (const int32_t *)nullptr,
                            ColorTerms{});
     }
-    {
-        ProfScope prof(KPX_PROF_NN_MFMA, 8.0 * (double)p.n_src * (double)p.n_tgt, st);     // 4 MAC per (source, target) pair
-        static const int fast_env = [] { const char *e = getenv("KPX_NN_FAST"); return e ? atoi(e) : -1; }();     // A/B switch: 0 / 1 force a form
-        const bool fast = fast_env >= 0 ? fast_env != 0 : have_prev;
-        if (fast)
-            hipLaunchKernelGGL(nn_mfma_kernel<true>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
-                               b.init_val, b.init_idx, b.part_val, b.part_idx);
-        else
-            hipLaunchKernelGGL(nn_mfma_kernel<false>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
-                               b.init_val, b.init_idx, b.part_val, b.part_idx);
+    static const int fast_env = [] { const char *e = getenv("KPX_NN_FAST"); return e ? atoi(e) : -1; }();     // A/B switch: 0 / 1 force a form
+    const bool fast = fast_env >= 0 ? fast_env != 0 : have_prev;
+    if (fast)
+        hipLaunchKernelGGL(nn_mfma_kernel<true>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
+                           b.init_val, b.init_idx, b.part_val, b.part_idx);
+    else
+        hipLaunchKernelGGL(nn_mfma_kernel<false>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
+                           b.init_val, b.init_idx, b.part_val, b.part_idx);
     }
     hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
                        p.splits, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, (const int32_t *)nullptr,
