@@ -402,7 +402,24 @@ def main():
             parallel.warm(g, dev)
         if sharded_native:                          # several GPUs: the frame loop AND its collectives inside the library (kpx_frame_step_sharded:
             # RCCL from C++ on the frame's stream, one communicator per frame slot, built here in the same order on every rank)
-            comms = [parallel.NativeComm.rccl() if args.transport == "rccl" else parallel.NativeComm.staged(parallel.new_group()) for _ in range(overlap)]
+            transport, comms, why = args.transport, [], None
+            if transport == "rccl":
+                # If the RCCL communicators cannot be built (library not found, init refused) the bench falls back to the host-staged
+                # transport and SAYS so in config.host_loop; the decision is taken by all ranks together (a failure on any rank counts).
+                try:
+                    comms = [parallel.NativeComm.rccl() for _ in range(overlap)]
+                except Exception as e:          # noqa: BLE001 -- whatever went wrong, the other ranks have to learn of it
+                    why = f"{type(e).__name__}: {e}"
+                if parallel.allreduce_max(0.0 if why is None else 1.0, dev) > 0.0:
+                    for cm in comms:
+                        cm.close()
+                    transport, comms = "staged", []
+                    if rank == 0:
+                        print(f"bench: RCCL communicators unavailable ({why or 'on another rank'}): host-staged transport", file=sys.stderr, flush=True)
+            if transport == "staged":
+                import torch.distributed as dist
+                host_group = lambda: (dist.new_group(ranks=list(range(world)), backend="gloo") if dist.get_backend() != "gloo" else parallel.new_group())
+                comms = [parallel.NativeComm.staged(host_group()) for _ in range(overlap)]
             pipes = [NativeShardPipeline(xy, S, inits, P, comm=cm, fused_filter=args.fused_filter, out_ring=2) for cm in comms]
         elif native:                                # one GPU: the whole frame loop is ONE native call per frame (kpx_frame_step)
             pipes = [NativeFramePipeline(xy, S, inits, P, out_ring=2) for _ in groups]     # per-slot output buffers: no allocator traffic per frame
@@ -554,7 +571,7 @@ def main():
                     f"GPU g ({world} GPU{'s' if world > 1 else ''}: {len(mine)} sensor(s) per GPU): extract -> master-cloud broadcast -> per-GPU "
                     f"point-to-plane ICP onto the master -> all-gather -> fused fp64 transform + voxel -> SOR on the fused cloud ({args.fused_filter})")
         cfg = {"workload": workload, "partition": "sensor", "sensors": S, "sensors_on_rank0": mine, "fused_filter": args.fused_filter,
-               "host_loop": (f"native (kpx_frame_step_sharded, {'RCCL from C++' if args.transport == 'rccl' else 'host-staged transport'})" if sharded_native
+               "host_loop": (f"native (kpx_frame_step_sharded, {'RCCL from C++' if transport == 'rccl' else 'host-staged transport'})" if sharded_native
                              else "native (kpx_frame_step)") if native
                             else "python (SensorShardPipeline)"}
     else:
