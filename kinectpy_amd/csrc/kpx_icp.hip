@@ -34,6 +34,9 @@
 namespace kpx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+#ifndef KPX_ICP_ACQ_FENCE
+#define KPX_ICP_ACQ_FENCE 0
+#endif
 #ifndef KPX_ICP_SPLIT_DEFAULT
 #define KPX_ICP_SPLIT_DEFAULT 2
 #endif
@@ -1307,6 +1310,9 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     if (threadIdx.x == 0) s_ticket = (unsigned)__hip_atomic_fetch_add(fuse.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != nblocks - 1u) return;
+#if KPX_ICP_ACQ_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the winner only: one per registration and launch
+#endif
     if (threadIdx.x < kAcc) s_sums[threadIdx.x] = (int)threadIdx.x < nacc ? fixed_total_coherent(acc, threadIdx.x) : 0.0;
     __syncthreads();
     for (int e = threadIdx.x; e < kAccSet; e += kIThreads) __hip_atomic_store(acc + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
