@@ -35,7 +35,7 @@ namespace kpx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #ifndef KPX_ICP_ACQ_FENCE
-#define KPX_ICP_ACQ_FENCE 0
+#define KPX_ICP_ACQ_FENCE 1                      // the block that performs the update acquires at agent scope (one buffer_inv per registration and launch)
 #endif
 #ifndef KPX_ICP_SPLIT_DEFAULT
 #define KPX_ICP_SPLIT_DEFAULT 2
@@ -1297,7 +1297,9 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // "The last block finishes the job": every add above has RETURNED (it has been performed at the device's point of coherence),
     // the barrier orders the block's ticket behind them, and the block that draws the last ticket of its registration reads the
     // totals -- 8 x 44 pairs of words -- with device-coherent loads, clears them for the next launch and performs the update.
-    // Only relaxed atomics: no release fence, which on this part writes back the XCD's L2 (measured 10x slower, once per block).
+    // Only relaxed atomics on the producers' side: no release fence, which on this part writes back the XCD's L2 (measured 10x slower,
+    // once per block).  The CONSUMER side is by the book: the winner -- one block per registration and launch -- acquires at agent
+    // scope behind its ticket (a single buffer_inv; same-box A/B against none: equal within noise, profiles/r03/exp_icp_acquire_fence.txt).
     // This is the `sc1` form of the valid hand-offs of MI355X_MICROARCH.md ("Correctness boundaries"): the handed-off bytes are
     // produced by atomics (performed at the memory side, never resident in a CU's L1), drained before the ticket because every
     // add RETURNS, and read by the winner with device-coherent (sc1) loads only (fixed_total_coherent) -- no plain load of them
