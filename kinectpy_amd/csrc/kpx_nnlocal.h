@@ -208,6 +208,10 @@ constexpr int kLScratch = kLList + 7 * kLCand + 2 * kLSurv;
 #define KPX_MUL_BATCH 8
 #endif
 constexpr int kMulBatch = KPX_MUL_BATCH;         // column tiles whose operands are requested together
+#ifndef KPX_TIGHTEN_GAIN
+#define KPX_TIGHTEN_GAIN 0.5
+#endif
+constexpr double kTightenGain = KPX_TIGHTEN_GAIN; // multiply(): bounds are tightened when some row's would fall below this share of its value
 
 // Group boxes the caller loaded ahead of time: box of group 64 t + lane in pre[t] (t < kGroupPre; an empty box beyond n_groups).
 // The loads do not depend on the transform, so the ICP kernel issues them first and the culling finds them in registers
@@ -372,8 +376,16 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         }
         visited += (unsigned)nlist;
         nlist = 0;
+        // tighten the row bounds with the best value any of the row's 16 lanes holds -- when that pays: the reductions below cost
+        // ~0.2 us per trip, and a sweep seeded with last iteration's partners finds bounds it can hardly improve (the partner's own
+        // distance); only a row whose bound would shrink to kTightenGain of its value (a cold start, a new and much nearer partner)
+        // prunes enough of what is left of the sweep.  A bound that is not tightened stays valid.
+        bool gain = false;
         if (updated) {
-            // tighten the row bounds with the best value any of the row's 16 lanes holds
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gain |= (w.best[r] - 1.0) < kTightenGain * rb[r];
+        }
+        if (updated && __builtin_amdgcn_ballot_w64(gain) != 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) rb[r] = fmin(rb[r], (row16_all_min(w.best[r]) - 1.0) * kRel + eps);
             R2 = wave_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
