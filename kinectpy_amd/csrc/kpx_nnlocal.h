@@ -158,6 +158,12 @@ __device__ __forceinline__ double wave_uniform_max(double v)
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// the same for a value every 16-lane row already holds uniformly (per-row quantities of the MFMA D layout): no reduction inside the rows
+__device__ __forceinline__ double quad_uniform_max(double v)
+{
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
 // Directed roundings of a double to float (the culling tests below run in float32 on outward-rounded operands: a cull only has to
 // be SAFE -- every decision that selects a partner is still taken on exact fp64 values -- and an fp64 vector instruction costs twice a
 // float32 one on this part, plus a conversion per box coordinate).
@@ -287,13 +293,13 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
 #pragma unroll
         for (int k = 0; k < 3; ++k) { slo[k] = readlane_f64(mn, 16 * k); shi[k] = readlane_f64(mx, 16 * k); }
     }
-    const double kmax = wave_uniform_max(fmax(fmax(w.seed[0], w.seed[1]), fmax(w.seed[2], w.seed[3])));
+    const double kmax = quad_uniform_max(fmax(fmax(w.seed[0], w.seed[1]), fmax(w.seed[2], w.seed[3])));      // seeds and bounds: one value per row
     const double eps = ldexp(kmax + t2max + 1.0, -38);
     // rb[r]: the row's bound on d^2 (same value in the 16 lanes of a quad); R2: the largest of them
     double rb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) rb[r] = (w.best[r] - 1.0) * kRel + eps;             // +inf stays +inf
-    double R2 = wave_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
+    double R2 = quad_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     if (!(R2 < 1e290)) {
         // some row has no finite bound: every group holds a real point, so the distance to the farthest corner of
         // the nearest group box bounds that row's nearest-neighbour distance
@@ -312,7 +318,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) rb[r] = fmin(rb[r], row16_all_min(u[r]) * kRel + eps);
-        R2 = wave_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
+        R2 = quad_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     }
     float rbf[4];              // the bounds rounded up to float: what the float32 culling tests compare with
     auto publish_bounds = [&]() {
@@ -388,7 +394,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         if (updated && __builtin_amdgcn_ballot_w64(gain) != 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) rb[r] = fmin(rb[r], (row16_all_min(w.best[r]) - 1.0) * kRel + eps);
-            R2 = wave_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
+            R2 = quad_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
             publish_bounds();
         }
         wave_lds_fence();
