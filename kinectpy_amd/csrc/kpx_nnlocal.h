@@ -534,13 +534,16 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         v = take ? ov : v;                                                 \
         c = take ? oc : c;                                                 \
     }
+    // (a wave that multiplied nothing -- half of them -- still holds what it was given: one value per row in all 16 lanes)
+    if (visited != 0u) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        double v = w.best[r];
-        int32_t c = w.bcol[r];
-        KPX_NNL_ROWMIN(kRor1) KPX_NNL_ROWMIN(kRor2) KPX_NNL_ROWMIN(kRor4) KPX_NNL_ROWMIN(kRor8)
-        w.best[r] = v;
-        w.bcol[r] = c;
+        for (int r = 0; r < 4; ++r) {
+            double v = w.best[r];
+            int32_t c = w.bcol[r];
+            KPX_NNL_ROWMIN(kRor1) KPX_NNL_ROWMIN(kRor2) KPX_NNL_ROWMIN(kRor4) KPX_NNL_ROWMIN(kRor8)
+            w.best[r] = v;
+            w.bcol[r] = c;
+        }
     }
 #undef KPX_NNL_ROWMIN
     return (unsigned long long)(visited & 0xFFFFu) | ((unsigned long long)(box_trips & 0xFFFFu) << 16) | ((unsigned long long)(mul_trips & 0xFFFFu) << 32) |
