@@ -1095,7 +1095,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // transform is requested FIRST -- the wave's rows, their previous partners (index AND coordinates, kept in sorted-row
     // order by the previous launch: no gather through the index), the first 128 group boxes -- and arrives while the update
     // algebra of the previous iteration runs below.
-    float my_src[3] = { 0.0f, 0.0f, 0.0f }, my_pt[3] = { 0.0f, 0.0f, 0.0f };
+    float my_src[3] = { 0.0f, 0.0f, 0.0f }, my_pt[3] = { 0.0f, 0.0f, 0.0f }, my_nrm[3] = { 0.0f, 0.0f, 0.0f };
     int32_t my_row = 0, my_prev = -1;
     if (lane < 16) {
         const int64_t r = row_base + lane < last ? row_base + lane : last;
@@ -1105,7 +1105,11 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         if (k > 0) {
             my_prev = idx_sorted[r];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) my_pt[a] = ptgt_sorted[3 * r + a];
+            for (int a = 0; a < 3; ++a) my_pt[a] = ptgt_sorted[6 * r + a];
+            if (mode == 1) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) my_nrm[a] = ptgt_sorted[6 * r + 3 + a];
+            }
         }
     }
     GroupPre gpre;
@@ -1241,13 +1245,28 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                 if (d2_cur) d2_cur[i] = INFINITY;
             } else {
                 const double s[3] = { rowd[wave][lane][0], rowd[wave][lane][1], rowd[wave][lane][2] };
-                const float *tp = tgt + 3 * (int64_t)bj;
-                const float tf[3] = { tp[0], tp[1], tp[2] };
-                const double t[3] = { (double)tf[0], (double)tf[1], (double)tf[2] };
+                // The partner's coordinates (and its normal) are gathered through the index only where the partner CHANGED: the record
+                // of the unchanged partner came with the row at the launch's start (ptgt_sorted: [x y z nx ny nz] per row).  In the
+                // late iterations whole waves skip this dependent round trip; both parts of a changed record are requested together.
+                float tf[3] = { my_pt[0], my_pt[1], my_pt[2] }, nf[3] = { my_nrm[0], my_nrm[1], my_nrm[2] };
                 if (changed) {
+                    const float *tp = tgt + 3 * (int64_t)bj;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) ptgt_sorted[3 * (row_base + lane) + c] = tf[c]; // the next launch bounds this row with it
+                    for (int c = 0; c < 3; ++c) tf[c] = tp[c];
+                    if (mode == 1) {
+                        const float *np_ = tn + 3 * (int64_t)bj;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) nf[c] = np_[c];
+                    }
+                    float *rec = ptgt_sorted + 6 * (row_base + lane);                            // the next launch bounds this row with it
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) rec[c] = tf[c];
+                    if (mode == 1) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) rec[3 + c] = nf[c];
+                    }
                 }
+                const double t[3] = { (double)tf[0], (double)tf[1], (double)tf[2] };
                 const double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
                 const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
                 if (d2_cur) d2_cur[i] = d2;
@@ -1260,8 +1279,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
 #pragma unroll
                         for (int c = 0; c < 3; ++c) sh[8 + 3 * a + c][col] = t[a] * s[c];
                     if (mode == 1) {
-                        const float *np_ = tn + 3 * (int64_t)bj;
-                        const double nx = np_[0], ny = np_[1], nz = np_[2];
+                        const double nx = nf[0], ny = nf[1], nz = nf[2];
                         const double res = (s[0] - t[0]) * nx + (s[1] - t[1]) * ny + (s[2] - t[2]) * nz;
                         const double J[6] = { s[1] * nz - s[2] * ny, s[2] * nx - s[0] * nz, s[0] * ny - s[1] * nx, nx, ny, nz };
                         int slot = 17;
@@ -1585,7 +1603,7 @@ struct NnBuffers {
     // culled sweep
     double *Bs;
     int32_t *orig_t, *row_of, *idx_sorted;
-    float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates of each row's last partner, same order
+    float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates + normal of each row's last partner, same order ([N][6])
     unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
     double *light_key;                                  // per block of the iteration kernel (LightSkip)
     float *tile_box, *group_box;
@@ -1626,7 +1644,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->row_of = a.get<int32_t>(nn);
     b->idx_sorted = a.get<int32_t>(nn);
     b->src_sorted = a.get<float>(nn * 3);
-    b->ptgt_sorted = a.get<float>(nn * 3);
+    b->ptgt_sorted = a.get<float>(nn * 6);               // [x y z nx ny nz] of every row's last partner
     b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * 2);      // ring of three sets (icp_iter_kernel, IcpFuse)
     b->light_key = a.get<double>((size_t)cdiv((int64_t)nn, kIRows));
     sort_carve(a, n, &b->sort_s);
