@@ -80,6 +80,14 @@ def measure(label, fn, n_threads=1):
                 print(f"      {name:12s} mean {v.mean():6.2f}  p50 {np.percentile(v, 50):5.1f}  p90 {np.percentile(v, 90):5.1f}  p99 {np.percentile(v, 99):5.1f}  max {v.max():4d}   corr with sweep us {np.corrcoef(v, us)[0, 1]:+.2f}")
             print("      slowest 12 waves (us, tiles, box_trips, mul_trips, groups_kept, sampled rows with partner):",
                   [(round(float(us[i]), 1), int(wv["tiles"][i]), int(wv["box_trips"][i]), int(wv["mul_trips"][i]), int(wv["groups_kept"][i]), int(wv["with_partner"][i])) for i in order[-12:]])
+            # what sharing the work INSIDE a block could give at best: a block lasts as long as its slowest wave; with its four waves'
+            # work dealt out evenly it would last their mean
+            nb = len(us) // 4
+            if nb:
+                blk = us[: nb * 4].reshape(nb, 4)
+                bmax, bmean = blk.max(1), blk.mean(1)
+                print(f"      blocks {nb}: slowest wave of a block  mean {bmax.mean():.2f}  p99 {np.percentile(bmax, 99):.2f}  max {bmax.max():.2f};"
+                      f"  mean of a block's four waves  mean {bmean.mean():.2f}  p99 {np.percentile(bmean, 99):.2f}  max {bmean.max():.2f}")
             # least-squares cost model: sweep us ~ a + b box_trips + c mul_trips
             A = np.stack([np.ones_like(us), wv["box_trips"], wv["mul_trips"]], 1).astype(float)
             coef = np.linalg.lstsq(A, us, rcond=None)[0]
