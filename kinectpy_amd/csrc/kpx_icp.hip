@@ -1105,15 +1105,19 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         if (k > 0) {
             my_prev = idx_sorted[r];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) my_pt[a] = ptgt_sorted[6 * r + a];
-            if (mode == 1) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) my_nrm[a] = ptgt_sorted[6 * r + 3 + a];
-            }
+            for (int a = 0; a < 3; ++a) my_pt[a] = ptgt_sorted[3 * r + a];
         }
     }
     GroupPre gpre;
     group_pre_load(gpre, group_box, n_groups, lane);
+    if (mode == 1 && k > 0 && lane < 16) {
+        // the previous partner's normal, requested through the index as soon as that has arrived (behind everything that does not
+        // depend on anything): it is not needed before the pair epilogue, where an unchanged partner -- the rule in the late
+        // iterations -- then costs no round trip at all
+        const float *np_ = tn + 3 * (int64_t)(my_prev > 0 ? my_prev : 0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) my_nrm[a] = np_[a];
+    }
     const double *Tk = st->T;
     if (fuse.pair) {
         const IcpState *in = fuse.pair + ((k + 1) & 1);
@@ -1245,9 +1249,10 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                 if (d2_cur) d2_cur[i] = INFINITY;
             } else {
                 const double s[3] = { rowd[wave][lane][0], rowd[wave][lane][1], rowd[wave][lane][2] };
-                // The partner's coordinates (and its normal) are gathered through the index only where the partner CHANGED: the record
-                // of the unchanged partner came with the row at the launch's start (ptgt_sorted: [x y z nx ny nz] per row).  In the
-                // late iterations whole waves skip this dependent round trip; both parts of a changed record are requested together.
+                // The partner's coordinates and its normal are gathered through the index only where the partner CHANGED: those of an
+                // unchanged partner came at the launch's start (coordinates with the row: ptgt_sorted; the normal through the previous
+                // index).  In the late iterations whole waves skip this dependent round trip; both parts of a changed partner are
+                // requested together.
                 float tf[3] = { my_pt[0], my_pt[1], my_pt[2] }, nf[3] = { my_nrm[0], my_nrm[1], my_nrm[2] };
                 if (changed) {
                     const float *tp = tgt + 3 * (int64_t)bj;
@@ -1258,13 +1263,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
 #pragma unroll
                         for (int c = 0; c < 3; ++c) nf[c] = np_[c];
                     }
-                    float *rec = ptgt_sorted + 6 * (row_base + lane);                            // the next launch bounds this row with it
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) rec[c] = tf[c];
-                    if (mode == 1) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) rec[3 + c] = nf[c];
-                    }
+                    for (int c = 0; c < 3; ++c) ptgt_sorted[3 * (row_base + lane) + c] = tf[c]; // the next launch bounds this row with it
                 }
                 const double t[3] = { (double)tf[0], (double)tf[1], (double)tf[2] };
                 const double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
@@ -1603,7 +1603,7 @@ struct NnBuffers {
     // culled sweep
     double *Bs;
     int32_t *orig_t, *row_of, *idx_sorted;
-    float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates + normal of each row's last partner, same order ([N][6])
+    float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates of each row's last partner, same order
     unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
     double *light_key;                                  // per block of the iteration kernel (LightSkip)
     float *tile_box, *group_box;
@@ -1644,7 +1644,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->row_of = a.get<int32_t>(nn);
     b->idx_sorted = a.get<int32_t>(nn);
     b->src_sorted = a.get<float>(nn * 3);
-    b->ptgt_sorted = a.get<float>(nn * 6);               // [x y z nx ny nz] of every row's last partner
+    b->ptgt_sorted = a.get<float>(nn * 3);
     b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * 2);      // ring of three sets (icp_iter_kernel, IcpFuse)
     b->light_key = a.get<double>((size_t)cdiv((int64_t)nn, kIRows));
     sort_carve(a, n, &b->sort_s);
