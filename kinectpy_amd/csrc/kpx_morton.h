@@ -48,8 +48,44 @@ __device__ __forceinline__ uint32_t morton_spread10(uint32_t v)
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
+// 30-bit Hilbert index of three 10-bit cell coordinates (Skilling, "Programming the Hilbert curve", 2004: axes -> transpose, the
+// transposed words' bits interleaved from the top).  The culled search orders rows and target columns along this curve: its
+// consecutive cells are neighbours, the Z-curve's are not, and 16 consecutive points -- a wave's rows, a column tile -- are a third
+// more compact (kpx_voxel.hip: voxel_hcode has the numbers).  Any order gives the same results; KPX_CURVE=z restores the Z-curve.
+__device__ __forceinline__ uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t X[3] = { x & 1023u, y & 1023u, z & 1023u };
+#pragma unroll
+    for (uint32_t Q = 512u; Q > 1u; Q >>= 1) {
+        const uint32_t P = Q - 1u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t t = (X[0] ^ X[i]) & P;
+            const bool up = (X[i] & Q) != 0u;
+            X[0] ^= up ? P : t;
+            X[i] ^= up ? 0u : t;
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    uint32_t t = 0u;
+#pragma unroll
+    for (uint32_t Q = 512u; Q > 1u; Q >>= 1) t ^= (X[2] & Q) ? Q - 1u : 0u;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    // X[0]'s bit b is the most significant of the triple: spread and interleave
+    return (morton_spread10(X[0]) << 2) | (morton_spread10(X[1]) << 1) | morton_spread10(X[2]);
+}
+__device__ __forceinline__ uint32_t curve_code30(const uint32_t q[3], int curve)
+{
+    return curve == 1 ? (morton_spread10(q[0]) | (morton_spread10(q[1]) << 1) | (morton_spread10(q[2]) << 2)) : hilbert30(q[0], q[1], q[2]);
+}
+static inline int curve_choice()
+{
+    static const int c = [] { const char *e = getenv("KPX_CURVE"); return (e && e[0] == 'z') ? 1 : 2; }();      // 1 Z-curve, 2 Hilbert (A/B switch)
+    return c;
+}
 static __global__ __launch_bounds__(256) void morton_key_kernel(const float *__restrict__ pts, int64_t n, const double *__restrict__ bbox,
-                                                         uint32_t *__restrict__ keys, int32_t *__restrict__ vals)
+                                                         uint32_t *__restrict__ keys, int32_t *__restrict__ vals, int curve)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -61,7 +97,7 @@ static __global__ __launch_bounds__(256) void morton_key_kernel(const float *__r
         const double v = ((double)pts[3 * i + a] - bbox[a]) * scale;
         q[a] = v >= 0.0 ? (uint32_t)(v < 1023.0 ? v : 1023.0) : 0u;          // NaN -> cell 0
     }
-    keys[i] = morton_spread10(q[0]) | (morton_spread10(q[1]) << 1) | (morton_spread10(q[2]) << 2);
+    keys[i] = curve_code30(q, curve);
     vals[i] = (int32_t)i;
 }
 
@@ -109,7 +145,7 @@ static int morton_order(const float *pts, int64_t n, const SortScratch &s, int32
 {
     int rc = bbox_f32(pts, n, s.bbox, s.bbox_part, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, pts, n, s.bbox, s.keys_in, s.vals_in);
+    hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, pts, n, s.bbox, s.keys_in, s.vals_in, curve_choice());
     size_t bytes = s.tmp_bytes;
     KPX_HIP(sort_pairs(s.tmp, bytes, s.keys_in, s.keys_out, s.vals_in, d_perm, n, 30, st));
     return KPX_OK;
@@ -191,7 +227,7 @@ static __global__ __launch_bounds__(64) void morton_batch_bbox_final_kernel(Mort
     for (int a = 0; a < 6; ++a)
         if (lane == a) b.bbox[c][a] = v[a];
 }
-static __global__ __launch_bounds__(256) void morton_batch_key_kernel(MortonBatch b, uint64_t *__restrict__ keys, int32_t *__restrict__ vals)
+static __global__ __launch_bounds__(256) void morton_batch_key_kernel(MortonBatch b, uint64_t *__restrict__ keys, int32_t *__restrict__ vals, int curve)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.off[b.count]) return;
@@ -207,8 +243,7 @@ static __global__ __launch_bounds__(256) void morton_batch_key_kernel(MortonBatc
         const double v = ((double)pts[3 * j + a] - bbox[a]) * scale;
         q[a] = v >= 0.0 ? (uint32_t)(v < 1023.0 ? v : 1023.0) : 0u;          // NaN -> cell 0
     }
-    const uint32_t m = morton_spread10(q[0]) | (morton_spread10(q[1]) << 1) | (morton_spread10(q[2]) << 2);
-    keys[i] = ((uint64_t)c << 30) | m;
+    keys[i] = ((uint64_t)c << 30) | curve_code30(q, curve);
     vals[i] = (int32_t)i;
 }
 static __global__ __launch_bounds__(256) void morton_batch_split_kernel(MortonBatch b, const int32_t *__restrict__ vals)
@@ -238,7 +273,7 @@ static int morton_order_batch(const MortonBatch &b, const MortonBatchScratch &s,
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
-    hipLaunchKernelGGL(morton_batch_key_kernel, dim3(nb), dim3(256), 0, st, b, s.keys_in, s.vals_in);
+    hipLaunchKernelGGL(morton_batch_key_kernel, dim3(nb), dim3(256), 0, st, b, s.keys_in, s.vals_in, curve_choice());
     size_t bytes = s.tmp_bytes;
     KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, 34, st));
     hipLaunchKernelGGL(morton_batch_split_kernel, dim3(nb), dim3(256), 0, st, b, s.vals_out);
