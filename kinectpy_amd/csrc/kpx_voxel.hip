@@ -172,7 +172,7 @@ __device__ __forceinline__ unsigned long long voxel_zcode(unsigned long long x, 
 // of the three transposed words interleaved from the top).  Consecutive cells of the curve are neighbours, which the Z-curve's
 // are not: 16 consecutive points of a surface cloud -- a wave's rows, a target tile of the culled ICP sweep (kpx_nnlocal.h) -- span
 // 177 instead of 246 mm (median; p99 677 instead of 1255) on the bench's 35 mm clouds, a wave multiplies 2.0 instead of 3.0 tiles
-// on average (p99 9 instead of 13).  KPX_VOXEL_CURVE=z restores the Z-curve (A/B switch).
+// on average (p99 9 instead of 13).  KPX_VOXEL_CURVE=z restores the Z-curve (A/B switch).  `bits` >= 1.
 __device__ __forceinline__ unsigned long long voxel_hcode(unsigned long long x, unsigned long long y, unsigned long long z, int bits)
 {
     unsigned long long X[3] = { x, y, z };
@@ -197,6 +197,39 @@ __device__ __forceinline__ unsigned long long voxel_hcode(unsigned long long x, 
         for (int i = 0; i < 3; ++i) k = (k << 1) | ((X[i] >> b) & 1ull);
     }
     return k;
+}
+// Width m of the cube the Hilbert code covers when the axes need ab[0..2] bits: the largest m <= max(ab) whose key -- the axes' bits
+// above m, row-major, then the 3 m bits of the cube's code -- takes no more 8-bit sort passes than the Z-code's ab[0] + ab[1] + ab[2]
+// bits (cloud number included: cb bits).  m = min(ab) always qualifies; a frame's 7 + 7 + 8 bits give m = 7: two cubes stacked
+// along z, one jump of the curve between them, three passes as before.
+__device__ __forceinline__ int voxel_hilbert_cube_bits(const int ab[3], int cb)
+{
+    const int top = ab[0] > ab[1] ? (ab[0] > ab[2] ? ab[0] : ab[2]) : (ab[1] > ab[2] ? ab[1] : ab[2]);
+    const int low = ab[0] < ab[1] ? (ab[0] < ab[2] ? ab[0] : ab[2]) : (ab[1] < ab[2] ? ab[1] : ab[2]);
+    const int passes = (ab[0] + ab[1] + ab[2] + cb + 7) / 8;
+    for (int m = top; m > low; --m) {
+        int n = 3 * m + cb;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) n += ab[a] > m ? ab[a] - m : 0;
+        if (n <= 64 && (n + 7) / 8 <= passes) return m;
+    }
+    return low;
+}
+__device__ __forceinline__ int voxel_hilbert_key_bits(const int ab[3], int m)
+{
+    int n = 3 * m;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) n += ab[a] > m ? ab[a] - m : 0;
+    return n;
+}
+// key of one voxel: [x >> m | y >> m | z >> m] (row-major over the cubes) above the cube's Hilbert code of the low m bits
+__device__ __forceinline__ unsigned long long voxel_hilbert_key(unsigned long long x, unsigned long long y, unsigned long long z, const int ab[3], int m)
+{
+    const unsigned long long mask = (1ull << m) - 1ull;
+    const int ex = ab[0] > m ? ab[0] - m : 0, ey = ab[1] > m ? ab[1] - m : 0, ez = ab[2] > m ? ab[2] - m : 0;
+    (void)ex;
+    const unsigned long long hi = (((x >> m) << ey | (y >> m)) << ez) | (z >> m);
+    return (hi << (3 * m)) | voxel_hcode(x & mask, y & mask, z & mask, m);
 }
 __device__ __forceinline__ int voxel_batch_cloud(const VoxelBatch &b, int64_t i)
 {
@@ -263,8 +296,7 @@ __device__ __forceinline__ int voxel_batch_key_bits(const VoxelBatch &b, const d
         int cb = 0, ab[3];
         while ((1 << cb) < b.count) ++cb;
         voxel_batch_axis_bits(d, ab);
-        const int top = ab[0] > ab[1] ? (ab[0] > ab[2] ? ab[0] : ab[2]) : (ab[1] > ab[2] ? ab[1] : ab[2]);
-        n = (b.morton == 2 ? 3 * top : ab[0] + ab[1] + ab[2]) + cb;        // the Hilbert code is the cube's
+        n = (b.morton == 2 ? voxel_hilbert_key_bits(ab, voxel_hilbert_cube_bits(ab, cb)) : ab[0] + ab[1] + ab[2]) + cb;
         n = n < 1 ? 1 : (n > 64 ? 64 : n);
     } else if (!overflow) {
         const unsigned long long range = (((unsigned long long)b.count * (unsigned long long)d[0]) * (unsigned long long)d[1]) * (unsigned long long)d[2];
@@ -286,7 +318,7 @@ __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, cons
                                                               int32_t *__restrict__ bits_out)
 {
     __shared__ double dims[3];
-    __shared__ int overflow, axis_bits[3];
+    __shared__ int overflow, axis_bits[3], cube_bits;
     if (threadIdx.x == 0) {
         double d[3];
         int ov;
@@ -297,8 +329,8 @@ __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, cons
         voxel_batch_axis_bits(d, ab);
         axis_bits[0] = ab[0]; axis_bits[1] = ab[1]; axis_bits[2] = ab[2];
         while ((1 << cb) < b.count) ++cb;
-        const int top = ab[0] > ab[1] ? (ab[0] > ab[2] ? ab[0] : ab[2]) : (ab[1] > ab[2] ? ab[1] : ab[2]);
-        overflow = (ov || (b.morton == 1 && ab[0] + ab[1] + ab[2] + cb > 64) || (b.morton == 2 && 3 * top + cb > 64)) ? 1 : 0;
+        cube_bits = voxel_hilbert_cube_bits(ab, cb);
+        overflow = (ov || (b.morton == 1 && ab[0] + ab[1] + ab[2] + cb > 64) || (b.morton == 2 && voxel_hilbert_key_bits(ab, cube_bits) + cb > 64)) ? 1 : 0;
     }
     __syncthreads();
     const uint64_t DX = (uint64_t)dims[0], DY = (uint64_t)dims[1], DZ = (uint64_t)dims[2];
@@ -315,8 +347,8 @@ __global__ __launch_bounds__(256) void voxel_batch_key_kernel(VoxelBatch b, cons
         if (bad) { err[c] = 1; fx = fy = fz = 0.0; }
         if (b.morton == 2) {
             const int ab[3] = { axis_bits[0], axis_bits[1], axis_bits[2] };
-            const int top = ab[0] > ab[1] ? (ab[0] > ab[2] ? ab[0] : ab[2]) : (ab[1] > ab[2] ? ab[1] : ab[2]);
-            keys[i] = (Key)(((uint64_t)c << (3 * top)) | voxel_hcode((uint64_t)fx, (uint64_t)fy, (uint64_t)fz, top));
+            const int m = cube_bits;
+            keys[i] = (Key)(((uint64_t)c << voxel_hilbert_key_bits(ab, m)) | voxel_hilbert_key((uint64_t)fx, (uint64_t)fy, (uint64_t)fz, ab, m));
         } else if (b.morton) {
             const int ab[3] = { axis_bits[0], axis_bits[1], axis_bits[2] };
             keys[i] = (Key)(((uint64_t)c << (ab[0] + ab[1] + ab[2])) | voxel_zcode((uint64_t)fx, (uint64_t)fy, (uint64_t)fz, ab));
