@@ -348,6 +348,37 @@ def roofline_targets(torch, ops, quick=False):
     return rows
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` started bare: start the N ranks as CHILD processes (one torch.distributed.run agent, the driver's own
+    command line) and relay what they print -- rank 0's JSON line on stdout, everything else on stderr.  This process imports no
+    torch and never touches the GPU (device_count below is read by a short-lived child), and it replaces no program: it waits for the
+    agent and exits with its code.  Fewer GPUs than ranks (a one-GPU box): the ranks share the devices over the gloo rendezvous --
+    a rehearsal of the multi-rank path (RCCL refuses two ranks on one device; the native loop then takes the staged transport)."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        ndev = int(out.stdout.strip().splitlines()[-1])
+    except Exception:                              # noqa: BLE001
+        ndev = 0
+    if ndev < n:
+        env.setdefault("KPX_DIST_BACKEND", "gloo")
+        print(f"bench: {n} ranks on {ndev} visible GPU(s): the ranks share the device(s), rendezvous and collectives over gloo (rehearsal, not a "
+              f"scaling measurement)", file=sys.stderr, flush=True)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    extra = ["--transport", "staged"] if (ndev < n and "--transport" not in sys.argv) else []
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:] + extra
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout:                         # ranks other than 0 print nothing on stdout; the agent's own chatter goes to stderr
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,6 +402,9 @@ def main():
                     "host-staged torch.distributed transport (rehearsal with ranks sharing one GPU: KPX_DIST_BACKEND=gloo)")
     ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval for the frame threads (0 = leave the default 5 ms)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))          # started bare (python bench.py --gpus N): this process only starts the ranks
 
     if args.switch_interval > 0:
         sys.setswitchinterval(args.switch_interval)

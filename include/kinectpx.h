@@ -462,6 +462,11 @@ int kpx_prof_icp_phases(double *h_out8);
  * tile-box fetches << 16 | operand fetches << 32 | groups kept << 48; sampled rows with a partner).  *h_count = the number of
  * waves written (<= cap_waves). */
 int kpx_prof_icp_waves(uint64_t *h_out, int64_t cap_waves, int64_t *h_count);
+/* Self-check of the row certificates of the culled ICP sweep (kpx_icp_batch with KPX_ICP_CERT_CHECK=1 in the environment: rows whose
+ * partner is certified unchanged -- registration_icp's correspondence step, preprocessing/registration.py:78-84 -- are searched all
+ * the same and compared).  h_out8 (8 x uint64, cleared by the call): [0] rows certified, [1] rows searched, [2] certified rows whose
+ * search found another partner (must be 0), [3..7] the first such row: iteration, sorted row, kept and found partner, key bits. */
+int kpx_prof_icp_cert(uint64_t *h_out8);
 
 #ifdef __cplusplus
 }

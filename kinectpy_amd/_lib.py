@@ -106,6 +106,7 @@ SIGNATURES = {
     "kpx_sort_pairs_u32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "kpx_prof_icp_phases": (C.c_int, [_vp]),
     "kpx_prof_icp_waves": (C.c_int, [_vp, C.c_int64, _vp]),
+    "kpx_prof_icp_cert": (C.c_int, [_vp]),
     "kpx_prof_end": (C.c_int, [_vp, _vp, _vp]),
 }
 
@@ -204,15 +205,18 @@ def workspace(nbytes):
     arbitrarily, and a (thread, stream) key would grow to depth^2 frame workspaces of hundreds of MB.  Two host threads must not
     queue work on the SAME stream concurrently (they would share the scratch; FrameStream gives every frame in flight its own
     stream and ends each frame with stream.synchronize())."""
-    key = (torch._C._cuda_getDevice(), _raw_stream())
+    stream = _raw_stream()
+    # The default (null) stream is where every new host thread starts: there the key keeps the thread, so that two threads calling
+    # operators without a stream of their own never interleave multi-kernel operators over one scratch buffer.
+    key = (torch._C._cuda_getDevice(), stream, threading.get_ident() if not stream else 0)
     with _ws_lock:
         ws = _ws.get(key)
         if ws is None:
             ws = _ws[key] = Workspace()
-    return ws.get(nbytes)
+        return ws.get(nbytes)                       # (growing under the lock: a reallocation must not race with another thread's get)
 
 
 def release_workspace(stream_handle, dev=None):
     """drop the scratch of one stream (pipeline.FrameStream.close())"""
     with _ws_lock:
-        _ws.pop((torch._C._cuda_getDevice() if dev is None else dev, int(stream_handle)), None)
+        _ws.pop((torch._C._cuda_getDevice() if dev is None else dev, int(stream_handle), 0), None)

@@ -376,11 +376,16 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     for (int i = 0; i < S_l; ++i) { p_in[(size_t)i] = L.full_pts + (size_t)i * n_px * 3; p_out[(size_t)i] = L.down_pts + (size_t)i * n_px * 3; }
     KPX_HIP(hipStreamSynchronize(st));
     for (int i = 0; i < S_l; ++i) { fk[(size_t)i] = h_i[i]; mk[(size_t)i] = h_i[16 + i]; }
-    if (negative(h_i, S_l) || negative(h_i + 16, S_l)) return fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: extraction reported %d", negative(h_i, S_l) | negative(h_i + 16, S_l));
+    // A data-dependent failure on ONE rank (an occluded camera, a voxel size too small for its cloud) must not leave its peers
+    // spinning inside a collective it never enters: the rank keeps its place in the frame's collectives with an empty payload and a
+    // NEGATIVE count in the header it contributes (master header: rank 0; exchange header rows: every rank), every rank reads the
+    // same headers and all of them return an error behind the same collective -- as the capacity overflow does with KPX_RETRY.
+    int lerr = KPX_OK;
+    if (negative(h_i, S_l) || negative(h_i + 16, S_l)) lerr = fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: extraction reported %d", negative(h_i, S_l) | negative(h_i + 16, S_l));
     static const bool zorder_on = [] { const char *e = getenv("KPX_FRAME_ZORDER"); return !(e && e[0] == '0'); }();
     const bool zorder = zorder_on && K <= 8;                   // the same decision on every rank: the master arrives in the order rank 0 gave it
     int &spec_bits = comm_spec_bits(comm);
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 2 && !lerr; ++attempt) {
         KPX_SUB(voxel_downsample_batch_spec(S_l, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, h_i + 32, L.op_ws, L.op_bytes, st,
                                             attempt == 0 ? spec_bits : 0, h_i + 50, zorder));
         KPX_HIP(hipStreamSynchronize(st));
@@ -389,8 +394,10 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
         spec_bits = need > 0 && need <= 32 ? (need + 7) / 8 * 8 : 0;
         if (!narrow) break;
     }
-    if (negative(h_i + 32, S_l)) return fail(KPX_ERR_RANGE, "voxel_size is too small");
-    for (int i = 0; i < S_l; ++i) dk[(size_t)i] = h_i[32 + i];
+    if (!lerr && negative(h_i + 32, S_l)) lerr = fail(KPX_ERR_RANGE, "voxel_size is too small");
+    for (int i = 0; i < S_l; ++i) dk[(size_t)i] = lerr ? 0 : h_i[32 + i];
+    for (int i = 0; i < S_l && !lerr; ++i)
+        if (dk[(size_t)i] < 1) lerr = fail(KPX_ERR_INVALID, "kpx_frame_step_sharded: sensor %d has no valid pixel", g0 + i);
 
     // -- collective 0: the master's down-sampled cloud (+ normals) to every rank.  Message: cap rows xyz | cap rows normal | header
     int64_t &cap_m = comm_cap_master(comm);
@@ -400,24 +407,33 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     float *m_xyz = reinterpret_cast<float *>(msg), *m_nrm = reinterpret_cast<float *>(msg + (size_t)capm * 12);
     double *m_hdr = reinterpret_cast<double *>(msg + (size_t)capm * 24);
     if (owns_master) {
-        KPX_REQUIRE(dk[0] >= 1, "kpx_frame_step_sharded: sensor 0 has no valid pixel");
-        if (plane) KPX_SUB(kpx_estimate_normals(L.down_pts, dk[0], 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st));
-        const size_t rows = (size_t)(dk[0] < capm ? dk[0] : capm);
-        KPX_HIP(hipMemcpyAsync(m_xyz, L.down_pts, rows * 12, hipMemcpyDeviceToDevice, st));
-        if (plane) KPX_HIP(hipMemcpyAsync(m_nrm, L.normals, rows * 12, hipMemcpyDeviceToDevice, st));
-        h_d[0] = (double)dk[0];
+        if (!lerr) {
+            if (plane) KPX_SUB(kpx_estimate_normals(L.down_pts, dk[0], 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st));
+            const size_t rows = (size_t)(dk[0] < capm ? dk[0] : capm);
+            KPX_HIP(hipMemcpyAsync(m_xyz, L.down_pts, rows * 12, hipMemcpyDeviceToDevice, st));
+            if (plane) KPX_HIP(hipMemcpyAsync(m_nrm, L.normals, rows * 12, hipMemcpyDeviceToDevice, st));
+        }
+        h_d[0] = lerr ? -1.0 : (double)dk[0];                   // a negative count: rank 0 cannot provide the master (every rank returns)
         KPX_HIP(hipMemcpyAsync(m_hdr, h_d, sizeof(double), hipMemcpyHostToDevice, st));
     }
     kpx_order_turn_begin(order, frame, 0);
     int rc = kpx_comm_broadcast(comm, msg, (size_t)capm * 24 + 256, 0, st);
     kpx_order_turn_end(order, frame, 0);
     if (rc) return rc;
+    if (owns_master && lerr) {                                 // (the message of `lerr` is the thread's last error)
+        kpx_order_finish(order, frame);
+        return lerr;
+    }
     int64_t m = owns_master ? dk[0] : 0;
     if (!owns_master) {
         KPX_HIP(hipMemcpyAsync(h_d, m_hdr, sizeof(double), hipMemcpyDeviceToHost, st));
         KPX_HIP(hipStreamSynchronize(st));
         m = (int64_t)h_d[0];
-        KPX_REQUIRE(m >= 1 && m <= n_px, "kpx_frame_step_sharded: bad master header (%lld points)", (long long)m);
+        if (!(m >= 1 && m <= n_px)) {
+            kpx_order_finish(order, frame);
+            return m < 0 ? fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: rank 0 could not provide the master cloud (see its error)")
+                         : fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: bad master header (%lld points)", (long long)m);
+        }
     }
     cap_m = round_cap(m, n_px);
     if (m > capm) {                                            // every rank reads the same m: all retry, none goes on
@@ -426,12 +442,11 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     }
     // -- registration of this rank's sub sensors onto the master
     const int n_sub = S_l - (owns_master ? 1 : 0);
-    if (n_sub > 0) {
+    if (n_sub > 0 && !lerr) {
         std::vector<const float *> subs((size_t)n_sub);
         std::vector<int64_t> ns((size_t)n_sub);
         for (int j = 0; j < n_sub; ++j) {
             const int i = j + (owns_master ? 1 : 0);
-            KPX_REQUIRE(dk[(size_t)i] >= 1, "kpx_frame_step_sharded: sensor %d has no valid pixel", g0 + i);
             subs[(size_t)j] = p_out[(size_t)i];
             ns[(size_t)j] = dk[(size_t)i];
         }
@@ -452,9 +467,9 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
         ha.k_max = K; ha.local = S_l; ha.first_is_master = owns_master ? 1 : 0;
         int64_t off = 0;
         for (int i = 0; i < S_l; ++i) {
-            ha.masked[i] = (int32_t)mk[(size_t)i]; ha.down[i] = (int32_t)dk[(size_t)i];
+            ha.masked[i] = lerr ? -1 : (int32_t)mk[(size_t)i]; ha.down[i] = (int32_t)dk[(size_t)i];   // -1: this rank failed, see above
             int64_t k = capc - off < mk[(size_t)i] ? capc - off : mk[(size_t)i];
-            if (k < 0) k = 0;
+            if (k < 0 || lerr) k = 0;
             if (k > 0) {
                 KPX_HIP(hipMemcpyAsync(L.xchg_send + (size_t)off * 12, L.mask_pts + (size_t)i * n_px * 3, (size_t)k * 12, hipMemcpyDeviceToDevice, st));
                 KPX_HIP(hipMemcpyAsync(L.xchg_send + (size_t)(capc + off) * 12, L.mask_col + (size_t)i * n_px * 3, (size_t)k * 12, hipMemcpyDeviceToDevice, st));
@@ -480,7 +495,12 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
         for (int j = 0; j < own; ++j, ++g) {
             const double *row = h_hdr + ((size_t)r * K + j) * kHdrDoubles;
             const int64_t n = (int64_t)row[0];
-            KPX_REQUIRE(n >= 0 && n <= n_px, "kpx_frame_step_sharded: bad exchange header (rank %d)", r);
+            if (!(n >= 0 && n <= n_px)) {                          // the same rows on every rank: everyone returns here
+                kpx_order_finish(order, frame);
+                if (lerr) return lerr;
+                return n < 0 ? fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: rank %d failed on its own sensors (see its error)", r)
+                             : fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: bad exchange header (rank %d)", r);
+            }
             f_p[(size_t)g] = reinterpret_cast<const float *>(L.xchg_recv + (size_t)r * xbytes + (size_t)off * 12);
             f_c[(size_t)g] = reinterpret_cast<const float *>(L.xchg_recv + (size_t)r * xbytes + (size_t)(capc + off) * 12);
             f_n[(size_t)g] = n;

@@ -72,6 +72,7 @@ struct IcpState {
     double count;
     int32_t iter, done;
     double motion, reach;      // see LightSkip: accumulated bound on how far any source point has moved; reach of a row's search
+    double last_motion;        // what the latest update added to `motion` (row certificates: how calm the registration is)
 };
 
 __device__ __forceinline__ void xform_row(const double *__restrict__ T, const float *__restrict__ p, double s[3])
@@ -837,7 +838,9 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { const double d = fs.U[4 * r + c] - (r == c ? 1.0 : 0.0); rot += d * d; }
             const double tu = sqrt(fs.U[3] * fs.U[3] + fs.U[7] * fs.U[7] + fs.U[11] * fs.U[11]);
-            st->motion += (sqrt(rot) * reach_of_source(st->T) + tu) * (1.0 + 1e-9) + 1e-9;
+            const double moved = (sqrt(rot) * reach_of_source(st->T) + tu) * (1.0 + 1e-9) + 1e-9;
+            st->motion += moved;
+            st->last_motion = moved;
         }
         if (lane < 16) {
             const int r = lane >> 2, c = lane & 3;
@@ -913,7 +916,7 @@ __global__ void icp_init_kernel(IcpState *st, Mat16 T0)
     for (int slot = 0; slot < 2; ++slot) {               // both slots (see IcpFuse)
         for (int q = 0; q < 16; ++q) st[slot].T[q] = T0.m[q];
         st[slot].fitness = 0.0; st[slot].rmse = 0.0; st[slot].count = 0.0; st[slot].iter = 0; st[slot].done = 0;
-        st[slot].motion = 0.0; st[slot].reach = INFINITY;
+        st[slot].motion = 0.0; st[slot].reach = INFINITY; st[slot].last_motion = INFINITY;
     }
 }
 static Mat16 mat16_from(const double *h)
@@ -1056,6 +1059,8 @@ struct IcpFuse {
     unsigned long long *ticket;        // non-null (with pair == nullptr): the LAST block of the launch to deliver its sums performs the update
     double *light_key;                 // with ticket: per block, LightSkip key (0 = sweep); nullptr: every block sweeps
     const double *sbbox;               // with light_key: the source's bounding box
+    float *cert;                       // with light_key: per sorted row, the certificate key (0 = none); nullptr: every row is searched
+    int cert_check;                    // self-check mode: certified rows are searched anyway and compared (g_cert_check)
 };
 constexpr int kAccSet = kAccCopies * kAcc * 2;
 // Phase clock of the iteration kernel (while the profiler is armed): thread 0 of every block stores 100 MHz wall-clock stamps in
@@ -1067,11 +1072,42 @@ __device__ unsigned long long g_icp_stamp[kStampBlocks][8];
 // per WAVE of the last sweep launch: [0] sweep start, [1] sweep end (100 MHz), [2] the packed counters sweep_wave returns, [3] rows
 // of the wave that ended with a partner
 __device__ unsigned long long g_icp_wave[kStampBlocks * 4][4];
+// Certificate self-check (KPX_ICP_CERT_CHECK=1): certified rows are searched all the same and the search's winner is compared with the
+// partner the certificate kept.  [0] rows certified, [1] rows searched, [2] certified rows whose search disagreed, [3..7] the first
+// disagreement: iteration, sorted row, kept partner, found partner, key as float bits.  Read (and cleared) by kpx_prof_icp_cert.
+__device__ unsigned long long g_cert_check[8];
 __device__ __forceinline__ void phase_tick(unsigned long long *__restrict__ armed, int slot, unsigned bid)
 {
     if (!armed || threadIdx.x || bid >= kStampBlocks) return;
     __builtin_nontemporal_store(wall_clock64(), &g_icp_stamp[bid][slot]);
 }
+// Certificates: rows whose partner provably cannot change are not searched again.
+// A sweep knows more than the winner: every column it multiplied gives D, every box it culled was farther than the row's culling
+// bound.  L = sqrt(min(final culling bound, smallest D - 1 among the multiplied columns OTHER than the winner)) is therefore a lower
+// bound of the distance from the row to every other target point -- kept as key = L + motion (IcpState::motion: the accumulated
+// bound on any source point's displacement, LightSkip's bookkeeping).  In a later iteration the row has moved by at most motion' -
+// motion, every other target is still >= L - (motion' - motion) away, and if the partner's own (exactly evaluated) distance d1 is
+// smaller than that -- d1 + motion' < key, with relative margins -- the partner is the STRICT nearest neighbour: an exact search
+// would return it, ties and all, so the row keeps it without one.  Rows without a partner use the reach of any row's search in
+// place of d1.  A key is worth something only if the search looked beyond its partner: once the registration is calm (the last
+// update moved no point by more than kCertCalm x the correspondence distance) uncertified rows are searched with a skin around
+// their partner, kCertSkinFactor x that motion (between kCertSkinMin and kCertSkinMax x the correspondence distance): a few more
+// tiles multiplied once, no search at all in the iterations that follow.  Waves whose 16 rows are all certified skip the sweep,
+// the others cull with the box and bounds of their uncertified rows only.  Partners, sums and transforms are those of the full
+// search, bit for bit (KPX_ICP_CERT=0 switches the certificates off: test_icp_update_placements_and_light_skip_are_bit_identical).
+#ifndef KPX_CERT_CALM
+#define KPX_CERT_CALM 0.05
+#endif
+#ifndef KPX_CERT_SKIN_FACTOR
+#define KPX_CERT_SKIN_FACTOR 8.0
+#endif
+#ifndef KPX_CERT_SKIN_MIN
+#define KPX_CERT_SKIN_MIN 0.02
+#endif
+#ifndef KPX_CERT_SKIN_MAX
+#define KPX_CERT_SKIN_MAX 0.2
+#endif
+constexpr double kCertCalm = KPX_CERT_CALM, kCertSkinFactor = KPX_CERT_SKIN_FACTOR, kCertSkinMin = KPX_CERT_SKIN_MIN, kCertSkinMax = KPX_CERT_SKIN_MAX;
 // bid / nblocks: this block's index among the blocks of ITS registration (one launch may carry several, see icp_iter_batch_kernel)
 __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned nblocks, const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
@@ -1097,6 +1133,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // algebra of the previous iteration runs below.
     float my_src[3] = { 0.0f, 0.0f, 0.0f }, my_pt[3] = { 0.0f, 0.0f, 0.0f }, my_nrm[3] = { 0.0f, 0.0f, 0.0f };
     int32_t my_row = 0, my_prev = -1;
+    float my_cert = 0.0f;
+    const bool certs = fuse.ticket && fuse.light_key && fuse.cert;
     if (lane < 16) {
         const int64_t r = row_base + lane < last ? row_base + lane : last;
         if (idx_cur || d2_cur) my_row = row_of[r];           // only the caller-order outputs need the original row number
@@ -1106,6 +1144,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
             my_prev = idx_sorted[r];
 #pragma unroll
             for (int a = 0; a < 3; ++a) my_pt[a] = ptgt_sorted[3 * r + a];
+            if (certs) my_cert = fuse.cert[r];
         }
     }
     GroupPre gpre;
@@ -1172,6 +1211,14 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     }
     phase_tick(tile_visits, 1, bid);
 
+    // Row certificates (kpx_icp.hip, "Certificates" above icp_iter_body): how calm the registration is decides the skin
+    const double c_motion = certs ? st->motion : 0.0, c_reach = certs ? st->reach : 0.0;
+    double c_skin = 0.0;
+    if (certs && k > 0) {
+        const double lm = st->last_motion, md = sqrt(max_d2);
+        if (lm <= kCertCalm * md) c_skin = fmin(fmax(kCertSkinFactor * lm, kCertSkinMin * md), kCertSkinMax * md);
+    }
+    bool my_active = true, my_certd = false;
     if (lane < 16) {
         const int64_t i = my_row;
         double s[3];
@@ -1193,10 +1240,31 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         }
         const double clamp = (max_d2 + 1.0) * (1.0 + 9.31322574615478515625e-10) + ldexp(seed + t2max + 1.0, -38);
         if (!(bv <= clamp)) { bv = clamp; bj = INT_MAX; }
+        double rb0 = bv - 1.0;
+        if (certs) {
+            // d1: an upper bound of the distance from the row to its partner (a row without one: the reach of any row's search)
+            double d1 = c_reach;
+            if (bj != INT_MAX) {
+                const double dx = s[0] - (double)my_pt[0], dy = s[1] - (double)my_pt[1], dz = s[2] - (double)my_pt[2];
+                d1 = sqrt(fma(dz, dz, fma(dy, dy, dx * dx))) * (1.0 + 1e-12);
+            }
+            // certified: every other target point was >= L away when the key = L + motion was written, the row has moved by at most
+            // motion_now - motion_then since, and its partner (or the reach of a row without one) is nearer than what is left of L.
+            // A row that HAD a partner and lost it to the clamp is searched (the key says nothing about that partner).
+            const bool keeps = (my_prev >= 0) == (bj != INT_MAX);
+            const bool certd = my_cert > 0.0f && keeps && (d1 + c_motion) * (1.0 + 1e-6) + 1e-6 < (double)my_cert;
+            my_active = (!certd || fuse.cert_check) && row_base + lane <= last;
+            my_certd = certd && row_base + lane <= last;
+            if (certd && !fuse.cert_check) rb0 = -1.0;
+            else if (c_skin > 0.0) { const double rr = d1 + c_skin; rb0 = fmax(rb0, rr * rr); }
+        }
         rowd[wave][lane][0] = s[0]; rowd[wave][lane][1] = s[1]; rowd[wave][lane][2] = s[2];
+        rowd[wave][lane][3] = rb0;
         rowd[wave][lane][4] = seed; rowd[wave][lane][5] = bv;
         rowi[wave][lane][0] = bj; rowi[wave][lane][1] = (int32_t)i;
     }
+    const unsigned act_mask = (unsigned)(__builtin_amdgcn_ballot_w64(lane < 16 && my_active) & 0xFFFFull);
+    const unsigned certd_mask = (unsigned)(__builtin_amdgcn_ballot_w64(lane < 16 && my_certd) & 0xFFFFull);
     wave_lds_fence();
     WaveRows w;
     w.a = q < 3 ? rowd[wave][j][q] : 1.0;
@@ -1208,12 +1276,57 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         w.seed[r] = rowd[wave][rr][4];
         w.best[r] = rowd[wave][rr][5];
         w.bcol[r] = rowi[wave][rr][0];
+        w.rb0[r] = rowd[wave][rr][3];
     }
+    w.skin = c_skin;
+    w.act_mask = act_mask;
+    w.light_gap2 = -1.0;
     phase_tick(tile_visits, 2, bid);
     const unsigned long long t_sweep = tile_visits ? wall_clock64() : 0ull;
-    const unsigned long long swept = sweep_wave<true>(w, Bs, orig, tile_box, group_box, n_groups, t2max, lists[wave], &gpre);
+    unsigned long long swept = 0ull;
+    if (act_mask != 0u) {                                 // (a wave whose 16 rows are all certified keeps what it came with)
+        wave_lds_fence();                                 // rowd[..][3] is the sweep's own slot from here on
+        swept = sweep_wave<true, true>(w, Bs, orig, tile_box, group_box, n_groups, t2max, lists[wave], &gpre);
+        // new keys for the rows that were searched: L^2 = min(final culling bound, runner-up among the multiplied columns), both on d^2
+        if (certs && fuse.cert_check && j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = q + 4 * r;
+                if (((certd_mask >> rr) & 1u) != 0u && w.bcol[r] != rowi[wave][rr][0]) {
+                    if (atomicAdd(&g_cert_check[2], 1ull) == 0ull) {
+                        g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = (unsigned long long)(row_base + rr);
+                        g_cert_check[5] = (unsigned long long)(unsigned)rowi[wave][rr][0]; g_cert_check[6] = (unsigned long long)(unsigned)w.bcol[r];
+                        g_cert_check[7] = (unsigned long long)__float_as_uint(fuse.cert[row_base + rr]);
+                    }
+                }
+            }
+        }
+        if (certs && j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = q + 4 * r;
+                if (((act_mask >> rr) & 1u) != 0u && ((certd_mask >> rr) & 1u) == 0u) {
+                    typedef unsigned uu2 __attribute__((ext_vector_type(2)));
+                    const uu2 pat = { 0u, w.sec[r] };
+                    const double d2nd = w.sec[r] == 0xFFFFFFFFu ? INFINITY : __builtin_bit_cast(double, pat) - 1.0 - w.eps_out;
+                    const double l2 = fmin(w.rb_out[r], d2nd);
+                    const double key = l2 > 0.0 ? sqrt(l2) * (1.0 - 1e-7) + c_motion : 0.0;
+                    fuse.cert[row_base + rr] = f32_down(key);
+                }
+            }
+        }
+    }
     const unsigned visited = (unsigned)(swept & 0xFFFFu);
-    if (lane == 0) s_light[wave] = w.light_gap2;
+    if (certs && fuse.cert_check && lane == 0) {
+        if (bid == 0 && wave == 0 && g_cert_check[2] == 0ull) {       // no disagreement so far: [3..7] report the chain's state at its last launch
+            g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = __builtin_bit_cast(unsigned long long, st->last_motion);
+            g_cert_check[5] = __builtin_bit_cast(unsigned long long, c_motion); g_cert_check[6] = __builtin_bit_cast(unsigned long long, c_skin);
+        }
+        atomicAdd(&g_cert_check[0], (unsigned long long)__builtin_popcount(certd_mask));
+        atomicAdd(&g_cert_check[1], (unsigned long long)__builtin_popcount(act_mask & ~certd_mask));
+    }
+    // (LightSkip speaks for ALL rows of a block: a wave that left certified rows out of its box does not count as light)
+    if (lane == 0) s_light[wave] = act_mask == 0xFFFFu ? w.light_gap2 : -1.0;
     if (tile_visits && lane == 0 && bid < kStampBlocks && kIWaves <= 4) {
         unsigned long long *o = g_icp_wave[bid * 4 + wave];
         int with = 0;
@@ -1383,6 +1496,7 @@ struct IcpProblem {
     unsigned long long *progress;
     double *light_key;
     const double *sbbox;
+    float *cert;
     int64_t n;
     uint32_t block0, blocks;
 };
@@ -1408,7 +1522,8 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_I
     // split == 2: no update kernel either -- the last block of every registration's sweep performs it (ticket: first word of the
     // second accumulator set, which only the one-launch form uses)
     const IcpFuse fuse{ split ? (IcpState *)nullptr : P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag,
-                        split == 2 ? P.ring + kAccSet : (unsigned long long *)nullptr, light ? P.light_key : (double *)nullptr, P.sbbox };
+                        split == 2 ? P.ring + kAccSet : (unsigned long long *)nullptr, (light & 1) ? P.light_key : (double *)nullptr, P.sbbox,
+                        (light & 2) ? P.cert : (float *)nullptr, (light & 4) ? 1 : 0 };
     icp_iter_body(bid, P.blocks, P.src, P.n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, P.row_of, P.src_sorted, P.idx_sorted, P.ptgt_sorted,
                   P.idx_cur, P.d2_cur, max_d2, mode, k, P.pair, P.ring, tile_visits, fuse);
 }
@@ -1457,7 +1572,7 @@ __global__ __launch_bounds__(256) void icp_batch_init_kernel(IcpBatchArgs args, 
         if (threadIdx.x < 32) {
             IcpState *st = P.pair + (threadIdx.x >> 4);
             st->T[threadIdx.x & 15] = T0.m[pi][threadIdx.x & 15];
-            if ((threadIdx.x & 15) == 0) { st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0; st->motion = 0.0; st->reach = INFINITY; }
+            if ((threadIdx.x & 15) == 0) { st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0; st->motion = 0.0; st->reach = INFINITY; st->last_motion = INFINITY; }
         }
     }
 }
@@ -1606,6 +1721,7 @@ struct NnBuffers {
     float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates of each row's last partner, same order
     unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
     double *light_key;                                  // per block of the iteration kernel (LightSkip)
+    float *cert_sorted;                                 // per sorted row: certificate key (icp_iter_body)
     float *tile_box, *group_box;
     SortScratch sort_t, sort_s;
 };
@@ -1647,6 +1763,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->ptgt_sorted = a.get<float>(nn * 3);
     b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * 2);      // ring of three sets (icp_iter_kernel, IcpFuse)
     b->light_key = a.get<double>((size_t)cdiv((int64_t)nn, kIRows));
+    b->cert_sorted = a.get<float>(nn);
     sort_carve(a, n, &b->sort_s);
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
@@ -1701,7 +1818,7 @@ static void icp_fused_launch(const float *src, const float *tgt, const float *tn
                              int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st,
                              unsigned long long *progress, unsigned long long tag)
 {
-    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag, nullptr, nullptr, nullptr };
+    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag, nullptr, nullptr, nullptr, nullptr, 0 };
     const unsigned blocks = k > max_iter ? 1u : (unsigned)cdiv(p.n_src, kIRows);
     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
     hipLaunchKernelGGL(icp_iter_kernel, dim3(blocks), dim3(kIThreads), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t, b.tile_box, b.group_box,
@@ -1814,6 +1931,16 @@ KPX_EXPORT int kpx_prof_icp_waves(uint64_t *h_out, int64_t cap_waves, int64_t *h
     return *h_count < 0 ? KPX_ERR_HIP : KPX_OK;
 }
 
+KPX_EXPORT int kpx_prof_icp_cert(uint64_t *h_out8)
+{
+    KPX_REQUIRE(h_out8, "kpx_prof_icp_cert: null pointer");
+    unsigned long long *p = nullptr;
+    static const unsigned long long zero[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    KPX_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_cert_check)));
+    KPX_HIP(hipMemcpy(h_out8, p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    KPX_HIP(hipMemcpy(p, zero, sizeof(zero), hipMemcpyHostToDevice));
+    return KPX_OK;
+}
 KPX_EXPORT int kpx_prof_icp_phases(double *h_out8)
 {
     KPX_REQUIRE(h_out8, "kpx_prof_icp_phases: null pointer");
@@ -2158,7 +2285,7 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                 P.ptgt_sorted = bufs[i].ptgt_sorted; P.pair = bufs[i].state;
                 P.idx_cur = nullptr; P.d2_cur = nullptr;          // a batch reports transforms, not correspondence lists
                 P.ring = bufs[i].acc_fixed; P.result = d_results + 20 * i; P.progress = &h_progress[i]; P.n = h_n_src[i];
-                P.light_key = bufs[i].light_key; P.sbbox = bufs[i].sort_s.bbox;
+                P.light_key = bufs[i].light_key; P.sbbox = bufs[i].sort_s.bbox; P.cert = bufs[i].cert_sorted;
                 P.block0 = b0; P.blocks = (unsigned)cdiv(h_n_src[i], kIRows);
                 Ac[g].p[c] = P;
                 Ac[g].p[c].block0 = (unsigned)c; Ac[g].p[c].blocks = 1u;
@@ -2178,7 +2305,13 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
         // KPX_ICP_SPLIT=2: in the LAST block of the sweep itself (no update kernel, no redundant prologue).
         static const int split = [] { const char *e = getenv("KPX_ICP_SPLIT"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : KPX_ICP_SPLIT_DEFAULT; }();
         const int last_k = split ? max_iteration : max_iteration + 1;     // the fused chain ends with an update-only launch
-        static const int light = [] { const char *e = getenv("KPX_ICP_LIGHT_SKIP"); return (e && e[0] == '0') ? 0 : 1; }();   // A/B switch (LightSkip)
+        // A/B switches: bit 0 LightSkip, bit 1 row certificates (they rest on LightSkip's motion bookkeeping)
+        static const int light = [] {
+            const char *e = getenv("KPX_ICP_LIGHT_SKIP"), *c = getenv("KPX_ICP_CERT");
+            const char *ck = getenv("KPX_ICP_CERT_CHECK");
+            const int l = (e && e[0] == '0') ? 0 : 1;
+            return l | ((l && !(c && c[0] == '0')) ? 2 : 0) | ((ck && ck[0] == '1') ? 4 : 0);
+        }();
         for (bool pending = true; pending && !rc;) {
             pending = false;
             bool advanced = false;

@@ -203,6 +203,14 @@ struct WaveRows {
     double best[4];            // running minimum (per lane: over the columns j of the tiles seen)
     int32_t bcol[4];           // its ORIGINAL target index
     double light_gap2;         // out: no group box was within reach of the wave's box -> the smallest squared box-to-box gap; else -1
+    // ---- certificates (sweep_wave<PRE, true>, the ICP kernels; see icp_iter_body) ----
+    double rb0[4];             // in: the bound on d^2 each of the lane's rows is searched with (>= its partner's; larger = a skin around it);
+                               //     < 0: the row is certified, it takes no part in the culling
+    double skin;               // in: wave-uniform; a bound tightened inside the sweep keeps this much distance beyond the new partner
+    unsigned act_mask;         // in: bit j = row j takes part (wave-uniform)
+    unsigned sec[4];           // out (all 16 lanes of a row): high word of a LOWER bound of the smallest D among the multiplied columns other than
+                               //     the row's winner (0xFFFFFFFF: none was multiplied)
+    double rb_out[4], eps_out; // out: the rows' final culling bounds (every culled column has d^2 > rb_out) and the metric's rounding margin
 };
 constexpr int kRowStride = 6, kRowBound = 3;
 constexpr int kRowFStride = 8, kRowFBound = 6;
@@ -278,7 +286,7 @@ __device__ __forceinline__ double wave_uniform_min(double v)
 //      loads are issued together); a tile is tested against the rows of its group's mask only;
 //   M  ONE round trip per kMulBatch listed tiles: B operands and original column ids requested together, then the fp64 MFMAs
 //      behind the 32-bit high-word prefilter; the row bounds tighten afterwards (registers and LDS).
-template <bool PRE>
+template <bool PRE, bool CERT = false>
 __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
                                                          const float *__restrict__ tile_box, const float *__restrict__ group_box,
                                                          int32_t n_groups, const double t2max, int32_t *scr, const GroupPre *pre)
@@ -289,7 +297,9 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
     constexpr double kRel = 1.0 + 9.31322574615478515625e-10;      // 1 + 2^-30
     double slo[3], shi[3];
     {
-        const double mn = row16_all_min(w.a), mx = row16_all_max(w.a);
+        // (CERT: the box of the rows that take part -- a certified row neither reaches anything nor widens the coarse test)
+        const bool act_j = !CERT || ((w.act_mask >> j) & 1u) != 0u;
+        const double mn = row16_all_min(act_j ? w.a : INFINITY), mx = row16_all_max(act_j ? w.a : -INFINITY);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { slo[k] = readlane_f64(mn, 16 * k); shi[k] = readlane_f64(mx, 16 * k); }
     }
@@ -298,7 +308,11 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
     // rb[r]: the row's bound on d^2 (same value in the 16 lanes of a quad); R2: the largest of them
     double rb[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rb[r] = (w.best[r] - 1.0) * kRel + eps;             // +inf stays +inf
+    for (int r = 0; r < 4; ++r) rb[r] = (CERT ? w.rb0[r] : w.best[r] - 1.0) * kRel + eps;             // +inf stays +inf
+    if (CERT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.sec[r] = 0xFFFFFFFFu;
+    }
     double R2 = quad_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     if (!(R2 < 1e290)) {
         // some row has no finite bound: every group holds a real point, so the distance to the farthest corner of
@@ -320,15 +334,14 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         for (int r = 0; r < 4; ++r) rb[r] = fmin(rb[r], row16_all_min(u[r]) * kRel + eps);
         R2 = quad_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
     }
-    float rbf[4];              // the bounds rounded up to float: what the float32 culling tests compare with
-    auto publish_bounds = [&]() {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rbf[r] = f32_up(rb[r]);
+    // The bounds live in LDS from here on (fp64 in the row records, rounded up to float in the mirror the culling tests read): the
+    // multiply loop needs every register it can get, and the bounds are touched again only when a trip tightens them.
+    auto publish_bounds = [&](const double rbv[4]) {
         if (j == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                w.rows[kRowStride * (q + 4 * r) + kRowBound] = rb[r];
-                w.rowsf[kRowFStride * (q + 4 * r) + kRowFBound] = rbf[r];
+                w.rows[kRowStride * (q + 4 * r) + kRowBound] = rbv[r];
+                w.rowsf[kRowFStride * (q + 4 * r) + kRowFBound] = f32_up(rbv[r]);
             }
         }
     };
@@ -336,7 +349,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         w.rowsf[kRowFStride * j + q] = f32_down(w.a);
         w.rowsf[kRowFStride * j + 3 + q] = f32_up(w.a);
     }
-    publish_bounds();
+    publish_bounds(rb);
 
     const double bpad = q == 3 ? kSentinel : 0.0;
     int nlist = 0, ns = 0;
@@ -371,9 +384,15 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
                         updated = true;                                                             \
                         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                            \
                             const bool tk = (int)(ACC[r] < w.best[r]) | ((int)(ACC[r] == w.best[r]) & (int)((COL) < w.bcol[r])); \
+                            if (CERT) {     /* the loser is a runner-up candidate, unless it is the winner's own column met again */ \
+                                const unsigned lose = tk ? hi32(w.best[r]) : ((COL) == w.bcol[r] ? 0xFFFFFFFFu : hi32(ACC[r])); \
+                                w.sec[r] = lose < w.sec[r] ? lose : w.sec[r];                       \
+                            }                                                                       \
                             w.best[r] = tk ? ACC[r] : w.best[r];                                   \
                             w.bcol[r] = tk ? (COL) : w.bcol[r];                                    \
                         }                                                                           \
+                    } else if (CERT) {      /* nothing near any row's best: four v_min_u32 keep the runner-up bound */ \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r) w.sec[r] = hi32(ACC[r]) < w.sec[r] ? hi32(ACC[r]) : w.sec[r]; \
                     }                                                                               \
                 }
                 KPX_NNL_TILE(c0, oc[h0]) KPX_NNL_TILE(c1, oc[h0 + 1]) KPX_NNL_TILE(c2, oc[h0 + 2]) KPX_NNL_TILE(c3, oc[h0 + 3])
@@ -387,15 +406,27 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         // distance); only a row whose bound would shrink to kTightenGain of its value (a cold start, a new and much nearer partner)
         // prunes enough of what is left of the sweep.  A bound that is not tightened stays valid.
         bool gain = false;
+        // the bound a row would get: its best (CERT: plus the skin -- any value >= best - 1 is a valid culling bound, so the float
+        // square root only has to be rounded upward once)
+        auto next_bound = [&](int r) {
+            double nb = w.best[r] - 1.0;
+            if (CERT && w.skin > 0.0) {
+                const double rr = (double)(sqrtf(f32_up(fmax(nb, 0.0))) * 1.0000002384185791015625f) + w.skin;
+                nb = fmax(nb, rr * rr);
+            }
+            return nb;
+        };
         if (updated) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gain |= (w.best[r] - 1.0) < kTightenGain * rb[r];
+            for (int r = 0; r < 4; ++r) gain |= next_bound(r) < kTightenGain * (double)w.rowsf[kRowFStride * (q + 4 * r) + kRowFBound];
         }
         if (updated && __builtin_amdgcn_ballot_w64(gain) != 0) {
+            double nrb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rb[r] = fmin(rb[r], (row16_all_min(w.best[r]) - 1.0) * kRel + eps);
-            R2 = quad_uniform_max(fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3])));
-            publish_bounds();
+            for (int r = 0; r < 4; ++r) nrb[r] = fmin(w.rows[kRowStride * (q + 4 * r) + kRowBound], row16_all_min(next_bound(r)) * kRel + eps);
+            R2 = quad_uniform_max(fmax(fmax(nrb[0], nrb[1]), fmax(nrb[2], nrb[3])));
+            wave_lds_fence();                                  // every lane has read the old bounds
+            publish_bounds(nrb);
         }
         wave_lds_fence();
     };
@@ -494,10 +525,10 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float *pr = w.rowsf + kRowFStride * (q + 4 * r);
-                    float f[6];
+                    float f[7];
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) f[e] = pr[e];
-                    h[r] = pt_gap2_lb(f, lo, hi) <= rbf[r];
+                    for (int e = 0; e < 7; ++e) f[e] = pr[e];
+                    h[r] = pt_gap2_lb(f, lo, hi) <= f[kRowFBound];
                 }
             }
             // mask of the rows (bit q + 4 r) that reach candidate j, assembled from the four ballots
@@ -541,9 +572,26 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
             double v = w.best[r];
             int32_t c = w.bcol[r];
             KPX_NNL_ROWMIN(kRor1) KPX_NNL_ROWMIN(kRor2) KPX_NNL_ROWMIN(kRor4) KPX_NNL_ROWMIN(kRor8)
+            if (CERT) {
+                // runner-up bound of the row: every lane's own, and the best of every lane that does not hold the winner (the lanes still
+                // holding the partner the row came with hold ONE column, the same in all of them)
+                unsigned u = w.bcol[r] == c ? w.sec[r] : (hi32(w.best[r]) < w.sec[r] ? hi32(w.best[r]) : w.sec[r]);
+                unsigned o;
+                o = (unsigned)dpp_i32<kRor1>((int)u); u = o < u ? o : u;
+                o = (unsigned)dpp_i32<kRor2>((int)u); u = o < u ? o : u;
+                o = (unsigned)dpp_i32<kRor4>((int)u); u = o < u ? o : u;
+                o = (unsigned)dpp_i32<kRor8>((int)u); u = o < u ? o : u;
+                w.sec[r] = u;
+            }
             w.best[r] = v;
             w.bcol[r] = c;
         }
+    }
+    if (CERT) {
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.rb_out[r] = w.rows[kRowStride * (q + 4 * r) + kRowBound];
+        w.eps_out = eps;
     }
 #undef KPX_NNL_ROWMIN
     return (unsigned long long)(visited & 0xFFFFu) | ((unsigned long long)(box_trips & 0xFFFFu) << 16) | ((unsigned long long)(mul_trips & 0xFFFFu) << 32) |

@@ -627,6 +627,18 @@ def sort_pairs_u32(keys, vals, end_bit=32):
     return ko, vo
 
 
+def prof_icp_cert():
+    """-> counters of the certificate self-check (KPX_ICP_CERT_CHECK=1): rows certified / searched / certified rows whose search
+    disagreed (must be 0) and the first disagreement; cleared by the call"""
+    out = np.zeros(8, dtype=np.uint64)
+    L.check(L.load().kpx_prof_icp_cert(out.ctypes.data_as(C.c_void_p)))
+    if int(out[2]) == 0:        # no disagreement: the chain's state at its last launch
+        return dict(certified=int(out[0]), searched=int(out[1]), mismatches=0, iteration=int(out[3]), last_motion=float(out[4:5].view(np.float64)[0]),
+                    motion=float(out[5:6].view(np.float64)[0]), skin=float(out[6:7].view(np.float64)[0]))
+    return dict(certified=int(out[0]), searched=int(out[1]), mismatches=int(out[2]),
+                first=dict(iteration=int(out[3]), row=int(out[4]), kept=int(out[5]), found=int(out[6]), key=float(np.uint32(out[7]).view(np.float32))))
+
+
 def prof_icp_waves(cap=16384):
     """-> per wave of the LAST sweep launch: dict of numpy arrays (sweep_us, tiles, box_trips, mul_trips, groups_kept, with_partner)"""
     raw = np.zeros((cap, 4), dtype=np.uint64)

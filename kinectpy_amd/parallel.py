@@ -181,23 +181,51 @@ class NativeComm:
 
     @classmethod
     def rccl(cls, group=None):
+        """Collective: every rank calls it, in the same order.  Every step that can fail on ONE rank (loading librccl, drawing the
+        id, ncclCommInitRank) is followed by an agreement over the default group, so that either every rank returns a communicator
+        or every rank raises -- no rank is left inside broadcast_object_list or ncclCommInitRank waiting for a peer that has
+        already given up (bench.py falls back to the staged transport on the exception)."""
         import ctypes as C
         from . import _lib
         L = _lib.load()
-        _lib.device()
-        path = cls._rccl_path()
-        _lib.check(L.kpx_rccl_load(path.encode() if path else None))
+        dev = _lib.device()
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = world_size(group)
-        ident = C.create_string_buffer(128)
-        if rank == 0:
-            _lib.check(L.kpx_rccl_unique_id(ident))
-        if dist.is_initialized() and world > 1:
+        together = dist.is_initialized() and world > 1
+
+        def agree(err, what):
+            """raises on EVERY rank when any rank failed at this step"""
+            bad = allreduce_max(0.0 if err is None else 1.0, dev) if together else (0.0 if err is None else 1.0)
+            if bad > 0.0:
+                raise RuntimeError(f"NativeComm.rccl: {what} failed on {'this rank: ' + repr(err) if err is not None else 'another rank'}")
+
+        ident, err = C.create_string_buffer(128), None
+        try:
+            path = cls._rccl_path()
+            _lib.check(L.kpx_rccl_load(path.encode() if path else None))
+            if rank == 0:
+                _lib.check(L.kpx_rccl_unique_id(ident))
+        except Exception as e:          # noqa: BLE001 -- the peers have to learn of it before anyone blocks
+            err = e
+        agree(err, "loading RCCL / drawing the communicator id")
+        if together:
             box = [bytes(ident.raw)]
             dist.broadcast_object_list(box, src=0, group=group)
             ident = C.create_string_buffer(box[0], 128)
-        h = C.c_void_p()
-        _lib.check(L.kpx_comm_create_rccl(ident, rank, world, C.byref(h)))
+        h, err = C.c_void_p(), None
+        try:
+            _lib.check(L.kpx_comm_create_rccl(ident, rank, world, C.byref(h)))
+        except Exception as e:          # noqa: BLE001
+            err = e
+        try:
+            agree(err, "ncclCommInitRank")
+        except RuntimeError:
+            if err is None:             # this rank's communicator exists, a peer's does not: nobody may use it
+                try:
+                    L.kpx_comm_destroy(h)
+                except Exception:       # noqa: BLE001
+                    pass
+            raise
         return cls(h, rank, world)
 
     @classmethod

@@ -313,6 +313,8 @@ class NativeShardPipeline:
                 break
             self.retries += 1
             if order is not None:
+                if self._ring_n:
+                    self._ring_k -= 1     # the ring slot belongs to the logical frame: the resubmitted attempt writes the same buffer
                 return _lib.RETRY
         out_p, out_c, Ts, info = res
         self.last = {"icp": [(int(info[32 + i]), None, None) for i in range(1, S)], "n_down": [int(v) for v in info[:S]],

@@ -621,10 +621,10 @@ def test_icp_batch_equals_single_problems(ops, oracle, base_cloud, engine):
         batch = ops.icp_batch(srcs, tgt, 100.0, inits, mode, nrm, 12)
         for s, i0, b in zip(srcs, inits, batch):
             one = ops.icp(s, tgt, 100.0, i0, mode, nrm, 12)
-            assert b["iterations"] == one["iterations"] and b["fitness"] == one["fitness"]
-            assert np.array_equal(b["transformation"], one["transformation"])       # same kernels, same order
             rT, rf, _, rit = oracle.registration_icp(s, tgt, 100.0, i0, mode, nrm, 12)
-            assert rit == b["iterations"] and rf == b["fitness"] and np.abs(rT - b["transformation"]).max() < TOL_T
+            assert rit == b["iterations"] and rf == b["fitness"] and np.abs(rT - b["transformation"]).max() < TOL_T, (mode, "batch vs oracle")
+            assert rit == one["iterations"] and rf == one["fitness"] and np.abs(rT - one["transformation"]).max() < TOL_T, (mode, "single vs oracle")
+            assert np.array_equal(b["transformation"], one["transformation"]), mode       # same kernels, same order
 
 
 def test_icp_batch_more_problems_than_lanes(ops, base_cloud):
@@ -1457,6 +1457,46 @@ def test_native_sharded_loop_retries_under_a_frame_stream(four_sensor_oracle):
             assert np.array_equal(p, ref[f][0]) and np.array_equal(c, ref[f][1]) and np.abs(Ts - np.stack(ref[f][2])).max() < TOL_T, (r, k)
 
 
+def test_native_sharded_loop_one_rank_failing_on_its_data_fails_every_rank(four_sensor_oracle):
+    """an occluded camera on ONE rank (sensor 3: no valid pixel) -- a data-dependent error in front of the collectives: that rank keeps
+    its place in them with a negative count in its header rows, so BOTH ranks return an error behind the same collective instead of
+    one of them spinning in it; the communicators stay usable and the next (good) frame equals the oracle step.  Then the same for
+    rank 0 (the master's camera occluded: the master header carries the failure)."""
+    import threading
+    from kinectpy_amd import parallel, _lib
+    from kinectpy_amd.pipeline import NativeShardPipeline, PipelineParams
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    for bad_sensor, bad_rank in ((3, 1), (0, 0)):
+        hub = parallel.NativeComm.LocalHub(2)
+        got, errs = [None, None], [None, None]
+        dbad = depth[0].copy()
+        dbad[bad_sensor] = 0
+
+        def rank_main(r):
+            torch.cuda.set_device(0)
+            mine = parallel.shard_sensors(4, r, 2)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                pipe = NativeShardPipeline(xy, 4, inits, PipelineParams(), comm=parallel.NativeComm.local(hub, r))
+                try:
+                    pipe.step(torch.as_tensor(dbad[mine]).cuda(), torch.as_tensor(rgb[0][mine]).cuda())
+                except _lib.KinectPxError as e:
+                    errs[r] = str(e)
+                p, c, Ts = pipe.step(torch.as_tensor(depth[0][mine]).cuda(), torch.as_tensor(rgb[0][mine]).cuda())
+                got[r] = (npy(p), npy(c), Ts)
+
+        ths = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(2)]
+        [t.start() for t in ths]
+        [t.join(timeout=120) for t in ths]
+        stuck = any(t.is_alive() for t in ths)
+        if stuck:
+            hub.barrier.abort()
+        assert not stuck, "a rank is still waiting inside a collective"
+        assert errs[0] is not None and errs[1] is not None, errs
+        assert "no valid pixel" in errs[bad_rank] and ("rank %d" % bad_rank in errs[1 - bad_rank] or "master" in errs[1 - bad_rank]), errs
+        for r in range(2):
+            assert np.array_equal(got[r][0], ref[0][0]) and np.array_equal(got[r][1], ref[0][1]) and np.abs(got[r][2] - np.stack(ref[0][2])).max() < TOL_T
+
+
 def test_native_sharded_loop_through_rccl_one_rank(four_sensor_oracle):
     """the RCCL transport itself, as far as one GPU allows: a one-rank communicator built by kpx_comm_create_rccl (librccl dlopen'ed by
     the library, id from kpx_rccl_unique_id); broadcast, both all-gathers on the frame's stream from C++; two frames in flight on
@@ -1714,19 +1754,21 @@ np.savez(sys.argv[1], **out)
 
 def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
     """The update step in its own kernel (KPX_ICP_SPLIT=1), in the last block of the sweep (2, the default) and with the blocks
-    that provably cannot find a partner left out of the sweeps (KPX_ICP_LIGHT_SKIP, default on): the exact fixed-point sums do
-    not depend on which blocks add to them or when, so transforms, fitness, rmse, iterations and counts agree to the last bit."""
+    that provably cannot find a partner left out of the sweeps (KPX_ICP_LIGHT_SKIP, default on) and the rows whose partner provably
+    cannot change left out of the search (KPX_ICP_CERT, default on): the exact fixed-point sums do not depend on which blocks add to
+    them or when, and a certified row keeps exactly the partner a search would return, so transforms, fitness, rmse, iterations and
+    counts agree to the last bit."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for name, env in (("tail+skip", {}), ("tail", {"KPX_ICP_LIGHT_SKIP": "0"}), ("kernel", {"KPX_ICP_SPLIT": "1"})):
+    for name, env in (("tail+skip", {}), ("nocert", {"KPX_ICP_CERT": "0"}), ("tail", {"KPX_ICP_LIGHT_SKIP": "0"}), ("kernel", {"KPX_ICP_SPLIT": "1"})):
         f = str(tmp_path / (name.replace("+", "_") + ".npz"))
         r = subprocess.run([sys.executable, "-c", _ICP_UPDATE_MODES, f], cwd=root, capture_output=True, text=True, timeout=300,
                            env={**os.environ, **env})
         assert r.returncode == 0, r.stderr[-2000:]
         got[name] = dict(np.load(f))
-    for name in ("tail", "kernel"):
+    for name in ("nocert", "tail", "kernel"):
         for key, v in got["tail+skip"].items():
             assert np.array_equal(v, got[name][key]), (name, key)
     its = got["tail+skip"]["p2plane_s"][:, 2]
