@@ -1049,6 +1049,9 @@ constexpr int kIRows = kIWaves * kLRows;
 // state, the result and the progress word -- then sweeps with the new transform.  Three accumulator sets in a ring
 // (launch k reads set k-1, adds to set k, block 0 clears set k+1) and two state slots (launch k reads slot k-1, writes
 // slot k) keep the launches free of races.  pair == nullptr: two-kernel mode, icp_solve_fixed_kernel does the update.
+struct CertPolicy {
+    float calm, factor, smin, smax;      // KPX_CERT_CALM / _FACTOR / _SKIN_MIN / _SKIN_MAX (fractions of the correspondence distance)
+};
 struct IcpFuse {
     IcpState *pair;
     unsigned long long *ring;
@@ -1059,8 +1062,9 @@ struct IcpFuse {
     unsigned long long *ticket;        // non-null (with pair == nullptr): the LAST block of the launch to deliver its sums performs the update
     double *light_key;                 // with ticket: per block, LightSkip key (0 = sweep); nullptr: every block sweeps
     const double *sbbox;               // with light_key: the source's bounding box
-    float *cert;                       // with light_key: per sorted row, the certificate key (0 = none); nullptr: every row is searched
+    float4 *cert;                      // with light_key: per sorted row, the certificate (position at the search, L; L = 0: none); nullptr: every row is searched
     int cert_check;                    // self-check mode: certified rows are searched anyway and compared (g_cert_check)
+    CertPolicy pol;
 };
 constexpr int kAccSet = kAccCopies * kAcc * 2;
 // Phase clock of the iteration kernel (while the profiler is armed): thread 0 of every block stores 100 MHz wall-clock stamps in
@@ -1084,30 +1088,18 @@ __device__ __forceinline__ void phase_tick(unsigned long long *__restrict__ arme
 // Certificates: rows whose partner provably cannot change are not searched again.
 // A sweep knows more than the winner: every column it multiplied gives D, every box it culled was farther than the row's culling
 // bound.  L = sqrt(min(final culling bound, smallest D - 1 among the multiplied columns OTHER than the winner)) is therefore a lower
-// bound of the distance from the row to every other target point -- kept as key = L + motion (IcpState::motion: the accumulated
-// bound on any source point's displacement, LightSkip's bookkeeping).  In a later iteration the row has moved by at most motion' -
-// motion, every other target is still >= L - (motion' - motion) away, and if the partner's own (exactly evaluated) distance d1 is
-// smaller than that -- d1 + motion' < key, with relative margins -- the partner is the STRICT nearest neighbour: an exact search
-// would return it, ties and all, so the row keeps it without one.  Rows without a partner use the reach of any row's search in
-// place of d1.  A key is worth something only if the search looked beyond its partner: once the registration is calm (the last
-// update moved no point by more than kCertCalm x the correspondence distance) uncertified rows are searched with a skin around
-// their partner, kCertSkinFactor x that motion (between kCertSkinMin and kCertSkinMax x the correspondence distance): a few more
-// tiles multiplied once, no search at all in the iterations that follow.  Waves whose 16 rows are all certified skip the sweep,
-// the others cull with the box and bounds of their uncertified rows only.  Partners, sums and transforms are those of the full
-// search, bit for bit (KPX_ICP_CERT=0 switches the certificates off: test_icp_update_placements_and_light_skip_are_bit_identical).
-#ifndef KPX_CERT_CALM
-#define KPX_CERT_CALM 0.05
-#endif
-#ifndef KPX_CERT_SKIN_FACTOR
-#define KPX_CERT_SKIN_FACTOR 8.0
-#endif
-#ifndef KPX_CERT_SKIN_MIN
-#define KPX_CERT_SKIN_MIN 0.02
-#endif
-#ifndef KPX_CERT_SKIN_MAX
-#define KPX_CERT_SKIN_MAX 0.2
-#endif
-constexpr double kCertCalm = KPX_CERT_CALM, kCertSkinFactor = KPX_CERT_SKIN_FACTOR, kCertSkinMin = KPX_CERT_SKIN_MIN, kCertSkinMax = KPX_CERT_SKIN_MAX;
+// bound of the distance from the row to every other target point.  The row keeps (p_c, L): its position at that search and L.  In a
+// later iteration it stands at p, every other target is still >= L - |p - p_c| away (triangle inequality, the row's OWN displacement:
+// no global bound), and if the partner's own (exactly evaluated) distance d1 is smaller than that -- d1 + |p - p_c| < L, with margins
+// for the float32 copy of p_c and the roundings -- the partner is the STRICT nearest neighbour: an exact search would return it, ties
+// and all, so the row keeps it without one.  Rows without a partner use the reach of any row's search in place of d1.  A certificate
+// is worth something only if the search looked beyond its partner: once the registration is calm (the last update moved no point by
+// more than `calm` x the correspondence distance; IcpState::last_motion, LightSkip's bookkeeping) uncertified rows are searched with a
+// skin around their partner, `factor` x that motion (between `smin` and `smax` x the correspondence distance): a few more tiles
+// multiplied once, no search at all in the iterations that follow.  Waves whose 16 rows are all certified skip the sweep, the others
+// cull with the box and bounds of their uncertified rows only.  Partners, sums and transforms are those of the full search, bit for
+// bit.  The policy is CertPolicy, above IcpFuse.  (KPX_ICP_CERT=0 switches the certificates off: test_icp_update_placements_and_light_skip_are_bit_identical; KPX_ICP_CERT_CHECK=1
+// searches the certified rows all the same and counts disagreements: test_icp_certificates_never_contradict_the_search).
 // bid / nblocks: this block's index among the blocks of ITS registration (one launch may carry several, see icp_iter_batch_kernel)
 __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned nblocks, const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
@@ -1133,7 +1125,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // algebra of the previous iteration runs below.
     float my_src[3] = { 0.0f, 0.0f, 0.0f }, my_pt[3] = { 0.0f, 0.0f, 0.0f }, my_nrm[3] = { 0.0f, 0.0f, 0.0f };
     int32_t my_row = 0, my_prev = -1;
-    float my_cert = 0.0f;
+    float4 my_cert = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const bool certs = fuse.ticket && fuse.light_key && fuse.cert;
     if (lane < 16) {
         const int64_t r = row_base + lane < last ? row_base + lane : last;
@@ -1204,6 +1196,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     __shared__ double rowd[kIWaves][16][kRowStride]; // s_x, s_y, s_z, (the sweep's row bound), K, bound / result value
     __shared__ int32_t rowi[kIWaves][16][2];         // partner (bound / result), original row
     __shared__ float rowf[kIWaves][16][kRowFStride]; // float32 mirror of the rows for the sweep's culling tests
+    __shared__ float rowk[kIWaves][16][8];           // what a row carries across the sweep (its previous partner: coordinates, normal, index),
+                                                     // parked here: a value in 16 lanes costs a whole register through the multiply loop
     __shared__ double sh[kAcc][kIRows + 1];
     if (tile_visits && threadIdx.x == 0 && bid < kStampBlocks) {     // only launches that sweep stamp (not the converged / closing ones)
         g_icp_stamp[bid][0] = t_block_start;
@@ -1212,11 +1206,11 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     phase_tick(tile_visits, 1, bid);
 
     // Row certificates (kpx_icp.hip, "Certificates" above icp_iter_body): how calm the registration is decides the skin
-    const double c_motion = certs ? st->motion : 0.0, c_reach = certs ? st->reach : 0.0;
+    const double c_reach = certs ? st->reach : 0.0;
     double c_skin = 0.0;
     if (certs && k > 0) {
         const double lm = st->last_motion, md = sqrt(max_d2);
-        if (lm <= kCertCalm * md) c_skin = fmin(fmax(kCertSkinFactor * lm, kCertSkinMin * md), kCertSkinMax * md);
+        if (lm <= (double)fuse.pol.calm * md) c_skin = fmin(fmax((double)fuse.pol.factor * lm, (double)fuse.pol.smin * md), (double)fuse.pol.smax * md);
     }
     bool my_active = true, my_certd = false;
     if (lane < 16) {
@@ -1248,11 +1242,14 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                 const double dx = s[0] - (double)my_pt[0], dy = s[1] - (double)my_pt[1], dz = s[2] - (double)my_pt[2];
                 d1 = sqrt(fma(dz, dz, fma(dy, dy, dx * dx))) * (1.0 + 1e-12);
             }
-            // certified: every other target point was >= L away when the key = L + motion was written, the row has moved by at most
-            // motion_now - motion_then since, and its partner (or the reach of a row without one) is nearer than what is left of L.
-            // A row that HAD a partner and lost it to the clamp is searched (the key says nothing about that partner).
+            // certified: every other target point was >= L away from p_c, the row has moved by |p - p_c| since (p_c is kept as float32:
+            // 2^-24 relative per coordinate, covered by the 1e-6 relative margin on the coordinates' scale), and its partner (or the
+            // reach of a row without one) is nearer than what is left of L.  A row that HAD a partner and lost it to the clamp is
+            // searched (the certificate says nothing about that partner).
             const bool keeps = (my_prev >= 0) == (bj != INT_MAX);
-            const bool certd = my_cert > 0.0f && keeps && (d1 + c_motion) * (1.0 + 1e-6) + 1e-6 < (double)my_cert;
+            const double ex = s[0] - (double)my_cert.x, ey = s[1] - (double)my_cert.y, ez = s[2] - (double)my_cert.z;
+            const double moved = sqrt(fma(ez, ez, fma(ey, ey, ex * ex))) + 1e-6 * (fabs(s[0]) + fabs(s[1]) + fabs(s[2]) + 1.0);
+            const bool certd = my_cert.w > 0.0f && keeps && (d1 + moved) * (1.0 + 1e-6) + 1e-6 < (double)my_cert.w;
             my_active = (!certd || fuse.cert_check) && row_base + lane <= last;
             my_certd = certd && row_base + lane <= last;
             if (certd && !fuse.cert_check) rb0 = -1.0;
@@ -1262,6 +1259,9 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         rowd[wave][lane][3] = rb0;
         rowd[wave][lane][4] = seed; rowd[wave][lane][5] = bv;
         rowi[wave][lane][0] = bj; rowi[wave][lane][1] = (int32_t)i;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { rowk[wave][lane][a] = my_pt[a]; rowk[wave][lane][3 + a] = my_nrm[a]; }
+        rowk[wave][lane][6] = __int_as_float(my_prev);
     }
     const unsigned act_mask = (unsigned)(__builtin_amdgcn_ballot_w64(lane < 16 && my_active) & 0xFFFFull);
     const unsigned certd_mask = (unsigned)(__builtin_amdgcn_ballot_w64(lane < 16 && my_certd) & 0xFFFFull);
@@ -1296,7 +1296,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                     if (atomicAdd(&g_cert_check[2], 1ull) == 0ull) {
                         g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = (unsigned long long)(row_base + rr);
                         g_cert_check[5] = (unsigned long long)(unsigned)rowi[wave][rr][0]; g_cert_check[6] = (unsigned long long)(unsigned)w.bcol[r];
-                        g_cert_check[7] = (unsigned long long)__float_as_uint(fuse.cert[row_base + rr]);
+                        g_cert_check[7] = (unsigned long long)__float_as_uint(fuse.cert[row_base + rr].w);
                     }
                 }
             }
@@ -1310,8 +1310,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                     const uu2 pat = { 0u, w.sec[r] };
                     const double d2nd = w.sec[r] == 0xFFFFFFFFu ? INFINITY : __builtin_bit_cast(double, pat) - 1.0 - w.eps_out;
                     const double l2 = fmin(w.rb_out[r], d2nd);
-                    const double key = l2 > 0.0 ? sqrt(l2) * (1.0 - 1e-7) + c_motion : 0.0;
-                    fuse.cert[row_base + rr] = f32_down(key);
+                    const double *pr = &rowd[wave][rr][0];
+                    fuse.cert[row_base + rr] = make_float4((float)pr[0], (float)pr[1], (float)pr[2], l2 > 0.0 ? f32_down(sqrt(l2) * (1.0 - 1e-7)) : 0.0f);
                 }
             }
         }
@@ -1320,7 +1320,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     if (certs && fuse.cert_check && lane == 0) {
         if (bid == 0 && wave == 0 && g_cert_check[2] == 0ull) {       // no disagreement so far: [3..7] report the chain's state at its last launch
             g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = __builtin_bit_cast(unsigned long long, st->last_motion);
-            g_cert_check[5] = __builtin_bit_cast(unsigned long long, c_motion); g_cert_check[6] = __builtin_bit_cast(unsigned long long, c_skin);
+            g_cert_check[5] = __builtin_bit_cast(unsigned long long, st->motion); g_cert_check[6] = __builtin_bit_cast(unsigned long long, c_skin);
         }
         atomicAdd(&g_cert_check[0], (unsigned long long)__builtin_popcount(certd_mask));
         atomicAdd(&g_cert_check[1], (unsigned long long)__builtin_popcount(act_mask & ~certd_mask));
@@ -1355,7 +1355,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
             // them (kpx_icp with idx / d2 outputs); the sorted-order copies the NEXT launch bounds its rows with only when the
             // partner changed -- in the late iterations of a registration almost no row changes its partner.
             const int32_t out_j = none ? -1 : bj;
-            const bool changed = k == 0 || out_j != my_prev;
+            const int32_t prev_j = __float_as_int(rowk[wave][lane][6]);
+            const bool changed = k == 0 || out_j != prev_j;
             if (idx_cur) idx_cur[i] = out_j;
             if (changed) idx_sorted[row_base + lane] = out_j;
             if (none) {
@@ -1366,7 +1367,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                 // unchanged partner came at the launch's start (coordinates with the row: ptgt_sorted; the normal through the previous
                 // index).  In the late iterations whole waves skip this dependent round trip; both parts of a changed partner are
                 // requested together.
-                float tf[3] = { my_pt[0], my_pt[1], my_pt[2] }, nf[3] = { my_nrm[0], my_nrm[1], my_nrm[2] };
+                float tf[3] = { rowk[wave][lane][0], rowk[wave][lane][1], rowk[wave][lane][2] }, nf[3] = { rowk[wave][lane][3], rowk[wave][lane][4], rowk[wave][lane][5] };
                 if (changed) {
                     const float *tp = tgt + 3 * (int64_t)bj;
 #pragma unroll
@@ -1496,7 +1497,7 @@ struct IcpProblem {
     unsigned long long *progress;
     double *light_key;
     const double *sbbox;
-    float *cert;
+    float4 *cert;
     int64_t n;
     uint32_t block0, blocks;
 };
@@ -1509,7 +1510,8 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_I
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
                                                        const float *__restrict__ group_box, int32_t n_groups,
                                                        const double *__restrict__ tbbox, double max_d2, int mode, int k, int max_iter, double rel_fit,
-                                                       double rel_rmse, unsigned long long tag, unsigned long long *__restrict__ tile_visits, int split, int light)
+                                                       double rel_rmse, unsigned long long tag, unsigned long long *__restrict__ tile_visits, int split, int light,
+                                                       CertPolicy pol)
 {
     int pi = 0;
 #pragma unroll
@@ -1523,7 +1525,7 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_I
     // second accumulator set, which only the one-launch form uses)
     const IcpFuse fuse{ split ? (IcpState *)nullptr : P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag,
                         split == 2 ? P.ring + kAccSet : (unsigned long long *)nullptr, (light & 1) ? P.light_key : (double *)nullptr, P.sbbox,
-                        (light & 2) ? P.cert : (float *)nullptr, (light & 4) ? 1 : 0 };
+                        (light & 2) ? P.cert : (float4 *)nullptr, (light & 4) ? 1 : 0, pol };
     icp_iter_body(bid, P.blocks, P.src, P.n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, P.row_of, P.src_sorted, P.idx_sorted, P.ptgt_sorted,
                   P.idx_cur, P.d2_cur, max_d2, mode, k, P.pair, P.ring, tile_visits, fuse);
 }
@@ -1721,7 +1723,7 @@ struct NnBuffers {
     float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates of each row's last partner, same order
     unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
     double *light_key;                                  // per block of the iteration kernel (LightSkip)
-    float *cert_sorted;                                 // per sorted row: certificate key (icp_iter_body)
+    float4 *cert_sorted;                                // per sorted row: certificate (icp_iter_body)
     float *tile_box, *group_box;
     SortScratch sort_t, sort_s;
 };
@@ -1763,7 +1765,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->ptgt_sorted = a.get<float>(nn * 3);
     b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * 2);      // ring of three sets (icp_iter_kernel, IcpFuse)
     b->light_key = a.get<double>((size_t)cdiv((int64_t)nn, kIRows));
-    b->cert_sorted = a.get<float>(nn);
+    b->cert_sorted = a.get<float4>(nn);
     sort_carve(a, n, &b->sort_s);
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
@@ -1818,7 +1820,7 @@ static void icp_fused_launch(const float *src, const float *tgt, const float *tn
                              int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st,
                              unsigned long long *progress, unsigned long long tag)
 {
-    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag, nullptr, nullptr, nullptr, nullptr, 0 };
+    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag, nullptr, nullptr, nullptr, nullptr, 0, CertPolicy{ 0.0f, 0.0f, 0.0f, 0.0f } };
     const unsigned blocks = k > max_iter ? 1u : (unsigned)cdiv(p.n_src, kIRows);
     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
     hipLaunchKernelGGL(icp_iter_kernel, dim3(blocks), dim3(kIThreads), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t, b.tile_box, b.group_box,
@@ -2312,6 +2314,10 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
             const int l = (e && e[0] == '0') ? 0 : 1;
             return l | ((l && !(c && c[0] == '0')) ? 2 : 0) | ((ck && ck[0] == '1') ? 4 : 0);
         }();
+        static const CertPolicy cert_policy = [] {
+            auto f = [](const char *name, float dflt) { const char *e = getenv(name); return e ? (float)atof(e) : dflt; };
+            return CertPolicy{ f("KPX_CERT_CALM", 0.15f), f("KPX_CERT_FACTOR", 3.0f), f("KPX_CERT_SKIN_MIN", 0.02f), f("KPX_CERT_SKIN_MAX", 0.2f) };
+        }();
         for (bool pending = true; pending && !rc;) {
             pending = false;
             bool advanced = false;
@@ -2349,7 +2355,7 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                     hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)act.count : ab), dim3(kIThreads), 0, ls, closing ? actc : act, tgt,
                                        tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box, bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2,
                                        mode, gk[g], max_iteration, relative_fitness, relative_rmse, tag,
-                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split, split == 2 ? light : 0);
+                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split, split == 2 ? light : 0, cert_policy);
                     if (split == 1)
                         hipLaunchKernelGGL(icp_solve_batch_kernel, dim3((unsigned)act.count), dim3(256), 0, ls, act, mode, gk[g], max_iteration,
                                            relative_fitness, relative_rmse, tag);

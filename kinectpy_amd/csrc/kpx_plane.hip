@@ -337,6 +337,7 @@ __device__ __forceinline__ double plane_break_bound(double fit, int ransac_n, do
     if (!(fit > 0.0)) return INFINITY;
     if (!(fit < 1.0)) return 0.0;
     double bi = log(1.0 - probability) / log(1.0 - pow(fit, (double)ransac_n));
+    if (!(bi >= 0.0)) bi = (double)H;          // fitness^n vanishes against 1: -inf (NaN for probability 1) -- [O3D]'s size_t takes 2^63 there: no exit
     bi = bi < (double)H ? bi : (double)H;
     return floor(bi);
 }

@@ -588,7 +588,8 @@ KPO_API void kpo_covariances(const real_t *pts, int64_t n, const int32_t *nbr, c
 /* Score: dist = |fma(a,x, fma(b,y, fma(c,z, d)))| ; inlier if dist < thr ; error = sum(dist)   */
 /*        (in index order); fitness = count/N ; rmse = error/sqrt(count) [O3D quirk, recalled]. */
 /* Best: higher fitness, tie -> lower rmse.  Early exit [O3D >= 0.16]: after an improvement     */
-/*        break_iteration = min(log(1-p)/log(1-fitness^n), iters) (0 if fitness == 1);          */
+/*        break_iteration = min(log(1-p)/log(1-fitness^n), iters) (0 if fitness == 1; iters     */
+/*        when fitness^n vanishes against 1 and the quotient is not a number >= 0);             */
 /*        iterations with index > break_iteration are skipped.                                  */
 /* Final: inliers of the best plane (ascending), plane re-fitted to them.                       */
 /* ------------------------------------------------------------------------------------------ */
@@ -683,6 +684,10 @@ KPO_API int kpo_segment_plane(const real_t *pts, int64_t n, double thr, int rans
             best_fit = fit; best_rmse = rmse; memcpy(best_pl, pl, sizeof(pl));
             if (fit < 1.0) {
                 double b = log(1.0 - probability) / log(1.0 - pow(fit, (double)ransac_n));
+                /* fitness^n below 2^-53: the denominator is log(1.0) = 0 and b = -inf (p = 1: NaN).  [O3D] assigns that double
+                 * to a size_t -- undefined, and on x86-64 the conversion yields 2^63: the loop never breaks.  Found by the
+                 * second lineage (oracle/lineage2.py); until round 4 this restatement stopped at the first hypothesis there. */
+                if (!(b >= 0.0)) b = (double)iters;
                 break_it = b < (double)iters ? b : (double)iters;
                 break_it = floor(break_it);              /* size_t truncation in [O3D] */
             } else break_it = 0.0;

@@ -328,3 +328,89 @@ def test_normalisers_match_reference_kat(oracle):
         gx, gy = getattr(oracle, name)(x, y, boxes)
         assert np.allclose(gx, np.array(b[name]["x"]), rtol=0, atol=1e-9), name
         assert np.allclose(gy, np.array(b[name]["y"]), rtol=0, atol=1e-9), name
+
+
+# ---- second lineage (oracle/lineage2.py): NumPy / SciPy restatements of the Open3D-internal algorithms, written from SURVEY.md
+# Appendix A without following oracle/kpx_oracle.c (cKDTree instead of the grid, numpy.linalg instead of Jacobi / LDL^T, vectorised
+# scoring instead of sequential fma chains).  Two independent restatements agree; Open3D itself stays unpinned.
+def _scene(n, seed):
+    """floor + person-like blob + outliers, millimetres, float32-representable"""
+    rng = np.random.default_rng(seed)
+    k = n // 2
+    floor = np.stack([rng.uniform(-1500, 1500, k), 900 + rng.normal(0, 3, k), rng.uniform(1200, 3200, k)], 1)
+    blob = rng.normal(0, 1, (n - k, 3)) * [250, 600, 200] + [0, 100, 2200]
+    return np.vstack([floor, blob]).astype(np.float32)
+
+
+@pytest.mark.parametrize("ransac_n,iters,prob,thr", [(30, 120, 0.99999999, 30.0), (3, 200, 0.99999999, 12.0), (3, 150, 0.9, 20.0), (5, 80, 1.0, 6.0)])
+def test_second_lineage_segment_plane(oracle, ransac_n, iters, prob, thr):
+    """floor_removal.py:70 -- scoring, better-than, probabilistic early exit and refit on the oracle's own Philox samples: the same
+    inlier list, the same number of evaluated hypotheses where the exit cuts the loop short, plane within 1e-10"""
+    from oracle import lineage2
+    for seed in (1, 2, 3):
+        pts = _scene(6000, 10 + seed)
+        plane, inl = oracle.segment_plane(pts, thr, ransac_n, iters, probability=prob, seed=seed)
+        p2, i2, evaluated = lineage2.segment_plane(pts, thr, ransac_n, iters, prob, lambda h: oracle.ransac_sample(len(pts), ransac_n, seed, h))
+        assert np.array_equal(inl, i2), (seed, len(inl), len(i2))
+        assert np.abs(plane - p2).max() < 1e-10 * max(1.0, np.abs(plane).max())
+        if ransac_n == 3 and prob < 1.0:
+            assert evaluated < iters                      # the early exit did cut the loop
+
+
+@pytest.mark.parametrize("mode", ["p2p", "p2plane"])
+def test_second_lineage_registration_icp(oracle, base_cloud, mode):
+    """registration.py:78-84 / manual_pointcloud_registration.py:96-98 -- cKDTree correspondences, SVD (Umeyama without scale) or a
+    6x6 numpy solve + Rz Ry Rx: iteration count and fitness equal, T within 1e-8 (relative to the translation's scale)"""
+    from oracle import lineage2
+    src, tgt, T = synth.icp_pair(6000, base_cloud)
+    tn = oracle.estimate_normals(tgt, 70.0, 40)[0].astype(np.float32) if mode == "p2plane" else None
+    for md, init, iters in ((100.0, None, 30), (40.0, np.linalg.inv(synth.perturb(T, 1.0, 10.0, 3)), 12), (300.0, None, 8)):
+        rT, rf, rr, rit = oracle.registration_icp(src, tgt, md, init, mode, tn, iters)
+        lT, lf, lr, lit = lineage2.registration_icp(src, tgt, md, init, mode, tn, iters)
+        assert rit == lit and rf == lf, (md, rit, lit, rf, lf)
+        assert abs(rr - lr) < 1e-9 * max(1.0, rr)
+        assert np.abs(rT - lT).max() < 1e-8 * max(1.0, np.abs(rT[:3, 3]).max())
+
+
+def test_second_lineage_normals_fpfh_and_matching(oracle, base_cloud):
+    """registration.py:9-20, 50-57 -- hybrid neighbourhoods from a k-d tree, covariance + numpy eigh (normals up to sign), SPFH / FPFH
+    histograms within 1e-9, and the mutual-filter matching (pairs equal wherever the feature-space nearest neighbour is unique)"""
+    from oracle import lineage2
+    rng = np.random.default_rng(5)
+    centre = np.median(base_cloud, axis=0)
+    near = np.argsort(((base_cloud - centre) ** 2).sum(1))[:6000]                  # a compact piece of the scene: real neighbourhoods
+    a = np.ascontiguousarray(base_cloud[np.sort(rng.choice(near, 1500, replace=False))], dtype=np.float32)
+    b = np.ascontiguousarray((oracle.transform(a, synth.t_star()) + rng.normal(0, 1.0, a.shape)).astype(np.float32)[rng.permutation(len(a))[:1300]])
+    feats = []
+    for pts in (a, b):
+        nbr, cnt = oracle.hybrid_knn(pts, 140.0, 20)
+        idx2, cnt2, _ = lineage2.hybrid_neighbours(pts, 140.0, 20)
+        assert np.array_equal(cnt, cnt2) and np.array_equal(nbr, idx2)
+        n1, cov1, c1 = oracle.estimate_normals(pts, 140.0, 20)
+        n2, cov2, c2 = lineage2.estimate_normals(pts, 140.0, 20)
+        full = np.stack([cov2[:, 0, 0], cov2[:, 0, 1], cov2[:, 0, 2], cov2[:, 1, 1], cov2[:, 1, 2], cov2[:, 2, 2]], 1)
+        assert np.allclose(cov1[c1 >= 3], full[c1 >= 3], rtol=1e-9, atol=1e-6)
+        w = np.linalg.eigvalsh(cov2)
+        clear = (c1 >= 3) & (w[:, 1] - w[:, 0] > 1e-6 * np.maximum(w[:, 2], 1.0))           # a well-separated smallest eigenvalue
+        assert (c1 >= 3).sum() > 0.8 * len(pts) and clear.sum() > 0.9 * (c1 >= 3).sum()
+        assert (np.abs((n1[clear] * n2[clear]).sum(1)) > 1.0 - 1e-9).all()
+        assert (n1[c1 < 3] == [0.0, 0.0, 1.0]).all() and (n2[c2 < 3] == [0.0, 0.0, 1.0]).all()
+        nrm = n1.astype(np.float32)                        # both lineages get the SAME normals (signs included): the histograms follow them
+        f1, s1 = oracle.fpfh(pts, nrm, 350.0, 20)
+        f2, s2 = lineage2.compute_fpfh(pts, nrm, 350.0, 20)
+        assert np.abs(s1 - s2).max() < 1e-9 and np.abs(f1 - f2).max() < 1e-9 * max(1.0, np.abs(f1).max())
+        assert s1.sum() > 0
+        feats.append(f1)
+    c1 = oracle.feature_correspondences(feats[0], feats[1], True, 3)
+    c2, gap_st, gap_ts = lineage2.feature_correspondences(feats[0], feats[1], True, 3)
+    one1 = oracle.feature_correspondences(feats[0], feats[1], False, 3)
+    one2, _, _ = lineage2.feature_correspondences(feats[0], feats[1], False, 3)
+    uniq = gap_st > 1e-9
+    assert uniq.sum() > 0.95 * len(uniq) and np.array_equal(one1[uniq], one2[uniq])
+    if (gap_st > 1e-9).all() and (gap_ts > 1e-9).all():
+        assert np.array_equal(c1, c2)
+    else:
+        s1, s2 = {tuple(r) for r in c1.tolist()}, {tuple(r) for r in c2.tolist()}
+        amb = set(np.nonzero(~uniq)[0].tolist()) | {int(i) for i in np.nonzero(gap_ts <= 1e-9)[0]}
+        assert all((i in amb or j in amb) for i, j in (s1 ^ s2)) or len(s1 ^ s2) <= 2 * (len(uniq) - int(uniq.sum()) + int((gap_ts <= 1e-9).sum()))
+    assert len(c1) >= 9

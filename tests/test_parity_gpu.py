@@ -404,6 +404,23 @@ def test_segment_plane_inliers_bit_exact(ops, oracle, n, rn, iters, prob, seed):
     assert np.abs(gpl - rpl).max() < TOL_PLANE
 
 
+def test_segment_plane_vanishing_exit_bound(ops, oracle):
+    """a cloud where the best plane holds a few per cent of the points and ransac_n = 30: fitness^30 vanishes against 1, the early-exit
+    bound log(1-p) / log(1 - fitness^n) is -inf -- Open3D assigns it to a size_t (2^63 on x86-64: the loop runs on), and so do the
+    oracle and the kernels since the second lineage found them stopping at the first hypothesis there (tests/test_oracle_cpu.py)"""
+    rng = np.random.default_rng(11)
+    k = 3000
+    floor = np.stack([rng.uniform(-1500, 1500, k), 900 + rng.normal(0, 3, k), rng.uniform(1200, 3200, k)], 1)
+    blob = rng.normal(0, 1, (k, 3)) * [250, 600, 200] + [0, 100, 2200]
+    pts = np.vstack([floor, blob]).astype(np.float32)
+    for rn, iters, prob in ((30, 120, 0.99999999), (30, 120, 1.0), (12, 200, 0.99999999)):
+        gpl, gidx = ops.segment_plane(pts, 30.0, rn, iters, prob, 1)
+        rpl, ridx, hyp = oracle.segment_plane(pts, 30.0, rn, iters, prob, 1, return_hypotheses=True)
+        assert np.array_equal(npy(gidx), ridx) and np.abs(gpl - rpl).max() < TOL_PLANE
+        if rn == 30:
+            assert len(ridx) == int(hyp[:, 4].max())             # the best of ALL hypotheses, not the first one
+
+
 def test_segment_plane_ties_thresholds_and_sequential_path(ops, oracle):
     """the matrix-core scoring (counts by fp64 MFMA, rmse only for the hypotheses the replay can ask about) at its edges: an exactly
     planar cloud where EVERY hypothesis ties (more ties than the list holds: the full sequential scoring takes over), distances that
@@ -1773,6 +1790,50 @@ def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
             assert np.array_equal(v, got[name][key]), (name, key)
     its = got["tail+skip"]["p2plane_s"][:, 2]
     assert its.max() >= 10, its                                        # a chain long enough for blocks to be skipped
+
+
+_ICP_CERT_CHECK = r"""
+import os, sys, json, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from kinectpy_amd import ops
+from kinectpy_amd.pipeline import PipelineParams
+from kinectpy_amd.utils import synth
+P = PipelineParams()
+xy, depth, rgb, inits, _ = synth.sensor_ring(4, 1)
+d = torch.as_tensor(depth[0]).cuda()
+fp, _, _, cnt = ops.depth_to_cloud(d, xy, None, 4, False, False, sync=False)
+k = ops._count(cnt)
+downs = [x[0] for x in ops.voxel_downsample_batch([fp[i, :k[i]] for i in range(4)], P.reg_voxel)]
+tn = ops.estimate_normals(downs[0], 2.0 * P.reg_voxel, P.normals_nn)
+ops.prof_icp_cert()
+out = []
+for mode in ("p2plane", "p2p"):
+    for md in (P.icp_max_dist, 40.0):
+        r = ops.icp_batch(downs[1:], downs[0], md, inits, mode, tn, P.icp_max_iteration)
+        torch.cuda.synchronize()
+        c = ops.prof_icp_cert()
+        out.append(dict(mode=mode, max_dist=md, iterations=[x["iterations"] for x in r], certified=c["certified"], searched=c["searched"], mismatches=c["mismatches"]))
+print(json.dumps(out))
+"""
+
+
+def test_icp_certificates_never_contradict_the_search():
+    """KPX_ICP_CERT_CHECK=1: the rows a certificate would leave out of the correspondence search are searched all the same, and the
+    search's winner is compared with the partner the certificate kept (kpx_prof_icp_cert): no disagreement in any iteration of the
+    bench's registrations, both estimation modes, two correspondence distances -- and the certificates do cover most of the late
+    iterations (otherwise the check checks nothing)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ICP_CERT_CHECK], cwd=root, capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "KPX_ICP_CERT_CHECK": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = json.loads(r.stdout.strip().splitlines()[-1])
+    for row in rows:
+        assert row["mismatches"] == 0, row
+    plane = rows[0]
+    assert max(plane["iterations"]) >= 10 and plane["certified"] > plane["searched"], plane
 
 
 def test_update_placements_agree_with_four_frames_in_flight(tmp_path):
