@@ -379,6 +379,127 @@ def launch_ranks(n):
     return proc.wait()
 
 
+def stage_breakdown(torch, ops, xy, depth, rgb, inits, P, reps=12):
+    """SURVEY 8(d) "also report per-stage Mpoints/s": the step's stages one after the other on one stream, each closed by a
+    synchronise (so the figures ADD UP to more than the native loop's frame, which overlaps host and device and keeps no stage
+    boundary): extract (both extractions) / voxel 35 of the full clouds + master normals / point-to-plane ICP of every sub /
+    fused transform + stack + voxel / SOR + selection.  Median of `reps` frames; Mpoints/s = the frame's input pixels / stage time."""
+    import time as _t
+    S = depth.shape[1]
+    px = S * N_PX
+    names = ("extract", "voxel+normals", "icp", "fuse+voxel", "sor")
+    acc = {k: [] for k in names}
+
+    def timed(key, fn):
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        acc[key].append((_t.perf_counter() - t0) * 1e6)
+        return out
+
+    for r in range(reps + 2):
+        d, c = depth[r % depth.shape[0]], rgb[r % rgb.shape[0]]
+
+        def extract():
+            a = ops.depth_to_cloud(d, xy, None, S, False, False, sync=False)
+            b = ops.depth_to_cloud(d, xy, c, S, True, True, gate=P.gate, sync=False)
+            return a, b, ops._count(a[3]), ops._count(b[3])
+        (fp, _, _, _), (mp, mc, _, _), fk, mk = timed("extract", extract)
+
+        def grids():
+            downs = [x[0] for x in ops.voxel_downsample_batch([fp[i, :fk[i]] for i in range(S)], P.reg_voxel)]
+            return downs, (ops.estimate_normals(downs[0], 2.0 * P.reg_voxel, P.normals_nn) if P.icp_mode == "p2plane" else None)
+        downs, tn = timed("voxel+normals", grids)
+        res = timed("icp", lambda: ops.icp_batch(downs[1:], downs[0], P.icp_max_dist, inits, P.icp_mode, tn, P.icp_max_iteration))
+        Ts = [np.eye(4)] + [x["transformation"] for x in res]
+        vp, vc = timed("fuse+voxel", lambda: ops.fuse_voxel_downsample([mp[i, :mk[i]] for i in range(S)], [mc[i, :mk[i]] for i in range(S)], Ts, P.filt_voxel))
+        timed("sor", lambda: ops.sor_select(vp, vc, P.filt_k, P.filt_ratio))
+    out = {}
+    for k in names:
+        us = float(np.median(acc[k][2:]))
+        out[k] = {"us": round(us, 1), "Mpoints_per_s": round(px / us, 1)}
+    out["note"] = ("one frame at a time through the Python operators, every stage closed by a synchronise: stage latencies, not shares of "
+                   "the native loop's frame (which overlaps them); Mpoints/s = the frame's %d input pixels / stage time" % px)
+    return out
+
+
+def reference_stream(torch, ops, xy, depth, rgb, inits, truth, steps, gate):
+    """The reference's OWN frame loop as a workload (preprocessing/data.py:31-61): registration ONCE on frame 0 --
+    execute_global_registration + execute_point_to_plane_registration of every sub onto the master, data.py:156-157 -- then per
+    frame extract -> person mask + depth gate -> pcd.transform(T_i) -> vstack -> filter_outliers() with its DEFAULTS
+    (filtering.py:12-17: voxel 0.02, remove_statistical_outlier(200, 3.0)), one frame at a time and with four frames in flight."""
+    import time as _t
+    from kinectpy_amd.geometry import PointCloud
+    from kinectpy_amd.preprocessing import registration as R
+    from kinectpy_amd.pipeline import FrameStream
+    S = depth.shape[1]
+    dev = depth.device
+    # -- calibration on frame 0 (untimed for the rate, reported on its own)
+    fp, _, _, fcnt = ops.depth_to_cloud(depth[0], xy, None, S, False, False, sync=False)
+    fk = ops._count(fcnt)
+    clouds0 = [PointCloud._make(fp[i, :fk[i]].clone(), None) for i in range(S)]
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    Ts, how, err = [np.eye(4)], [], []
+    for i in range(1, S):
+        Tg = R.execute_global_registration(clouds0[0], clouds0[i], seed=20250202 + i)
+        ok = Tg is not None and np.abs(Tg[:3, 3] - truth[i - 1][:3, 3]).max() < 300.0 and np.abs(Tg[:3, :3] - truth[i - 1][:3, :3]).max() < 0.25
+        # (cameras 90 degrees apart share little surface: where the feature matching lands in a wrong basin the run goes on from
+        # the rig's nominal extrinsics, as an operator would from manual_pointcloud_registration.py; recorded below)
+        init = Tg if ok else inits[i - 1]
+        T = R.execute_point_to_plane_registration(clouds0[0], clouds0[i], init)
+        Ts.append(np.asarray(T, dtype=np.float64))
+        how.append("global" if ok else "nominal extrinsics (global registration off by more than 300 mm / 0.25)")
+        err.append(float(np.abs(Ts[-1] - truth[i - 1]).max()))
+    torch.cuda.synchronize()
+    calib_ms = (_t.perf_counter() - t0) * 1e3
+
+    class Stream:
+        last = {}
+
+        def step(self, d, c):
+            mp, mc, _, mcnt = ops.depth_to_cloud(d, xy, c, S, True, True, gate=gate, sync=False)
+            mk = ops._count(mcnt)
+            vp, vc = ops.fuse_voxel_downsample([mp[i, :mk[i]] for i in range(S)], [mc[i, :mk[i]] for i in range(S)], Ts, 0.02)
+            op, oc, _, _ = ops.sor_select(vp, vc, 200, 3.0)
+            self.last = {"n_fused": int(vp.shape[0]), "n_out": int(op.shape[0])}
+            return op, oc, Ts
+    pipe = Stream()
+    F = depth.shape[0]
+    for k in range(5):
+        pipe.step(depth[k % F], rgb[k % F])
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    for k in range(steps):
+        pipe.step(depth[k % F], rgb[k % F])
+    torch.cuda.synchronize()
+    serial = (_t.perf_counter() - t0) / steps
+    fs = FrameStream(pipe, 4)
+    def run(n):
+        for k in range(n):
+            if fs.full():
+                fs.pop()
+            fs.submit(depth[k % F], rgb[k % F])
+        while fs.pending:
+            fs.pop()
+    run(8)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    flight = (_t.perf_counter() - t0) / steps
+    fs.close()
+    px = S * N_PX
+    return {"workload": "the reference's own frame loop (preprocessing/data.py:31-61): registration once on frame 0 (execute_global_registration + "
+                        "execute_point_to_plane_registration, data.py:156-157), then per frame extract -> person mask + depth gate -> "
+                        "transform + vstack -> filter_outliers() DEFAULTS (voxel 0.02, remove_statistical_outlier(200, 3.0))",
+            "value": round(px / flight / 1e6, 1), "unit": "Mpoints/s", "ms_per_frame": round(flight * 1e3, 3), "frames_in_flight": 4,
+            "one_frame_at_a_time": {"value": round(px / serial / 1e6, 1), "ms_per_frame": round(serial * 1e3, 3)}, "steps": steps,
+            "fused_points": pipe.last.get("n_fused"), "kept_points": pipe.last.get("n_out"),
+            "calibration": {"ms": round(calib_ms, 1), "init_of_each_sub": how, "max_abs_error_vs_truth": [round(e, 4) for e in err]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -400,6 +521,9 @@ def main():
                     "of the native kpx_frame_step / kpx_frame_step_sharded")
     ap.add_argument("--transport", choices=["rccl", "staged"], default="rccl", help="several GPUs, native loop: RCCL from C++ (default) or the "
                     "host-staged torch.distributed transport (rehearsal with ranks sharing one GPU: KPX_DIST_BACKEND=gloo)")
+    ap.add_argument("--workload", choices=["config", "reference-stream"], default="config", help="reference-stream: ALSO time the reference's own "
+                    "frame loop (registration once, then extract -> transform -> fuse -> filter_outliers() defaults) and report it beside the headline")
+    ap.add_argument("--no-stages", action="store_true", help="skip the per-stage breakdown leg")
     ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval for the frame threads (0 = leave the default 5 ms)")
     args = ap.parse_args()
 
@@ -573,6 +697,12 @@ def main():
     if world == 1 and not args.no_targets:
         targets = roofline_targets(torch, ops, quick=args.quick_targets)
 
+    stages = None
+    if world == 1 and sensor_mode and not args.no_stages:
+        stages = stage_breakdown(torch, ops, pipe.xy, depth, rgb, inits, P)
+    ref_stream = None
+    if world == 1 and sensor_mode and args.workload == "reference-stream":
+        ref_stream = reference_stream(torch, ops, pipe.xy, depth, rgb, inits, truth, max(20, min(args.steps, 100)), P.gate)
     cpu = None
     if world == 1 and args.cpu_budget_s > 0:
         from oracle import oracle as O
@@ -588,6 +718,30 @@ def main():
         cpu = {"value": round(n_s * N_PX * n_cpu / t_cpu / 1e6, 4), "unit": "Mpoints/s", "cores": O.num_threads(),
                "kind": "port", "sample": f"{n_cpu} step(s) of the same {n_s}-sensor frame workload through the CPU oracle "
                f"(C/OpenMP restatement, grid-accelerated exact NN), {t_cpu:.1f} s"}
+        # the single-core figure and the Open3D probe.  One core: a bounded sample in a child process with
+        # OMP_NUM_THREADS=1 (the oracle's OpenMP team is sized when its library loads).
+        try:
+            import open3d                                    # noqa: F401 -- only whether the reference's own numerics exist here
+            cpu["open3d"] = getattr(open3d, "__version__", "present")
+        except Exception:                                    # noqa: BLE001
+            cpu["open3d"] = "unavailable"
+        cpu["where_the_time_goes"] = ("an untuned checker whose OpenMP loops barely scale (compare single_core: one core runs the same step in about the "
+                                      "same time as all of them -- the step is a chain of short parallel regions between serial pieces: sorts, sequential "
+                                      "per-voxel sums, the ICP loop's reductions): most of a step goes to the point-to-plane registrations (up to 30 exact "
+                                      "nearest-neighbour sweeps of 31k x 31k points through the grid search), then the voxel grids and the k-nearest-"
+                                      "neighbour filter")
+        if args.cpu_budget_s >= 10:
+            import subprocess
+            code = ("import sys, time, json, numpy as np; sys.path.insert(0, %r); from oracle import oracle as O; from kinectpy_amd.pipeline import PipelineParams; "
+                    "from kinectpy_amd.utils import synth; xy, d, c, inits, _ = synth.sensor_ring(%d, 1); t = time.perf_counter(); "
+                    "O.pipeline_step(xy, d[0], c[0], inits, PipelineParams()); print(json.dumps(time.perf_counter() - t))" % (ROOT, n_s))
+            try:
+                r1 = subprocess.run([sys.executable, "-c", code], env={**os.environ, "OMP_NUM_THREADS": "1"}, capture_output=True, text=True, timeout=150)
+                t1 = float(json.loads(r1.stdout.strip().splitlines()[-1]))
+                cpu["single_core"] = {"value": round(n_s * N_PX / t1 / 1e6, 4), "unit": "Mpoints/s", "cores": 1,
+                                      "sample": f"1 step of the same {n_s}-sensor frame workload, OMP_NUM_THREADS=1 (child process), {t1:.1f} s"}
+            except Exception as e:                           # noqa: BLE001
+                cpu["single_core"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
         if args.check:
             gp, gc, gT = fuse(pipe.step(depth[0], rgb[0]))
             terr = np.abs(gT - np.stack(ref[2])).reshape(len(gT), -1).max(1)
@@ -646,6 +800,7 @@ def main():
         "spread": None if not blocks else {"blocks": len(blocks), "steps_per_block": 20, "median": round(float(np.median(blocks)), 1),
                                           "min": round(min(blocks), 1), "max": round(max(blocks), 1), "unit": "Mpoints/s",
                                           "note": "blocks of the two legs alternate (HBM-resident, pinned-host, ...)"},
+        "stages": stages, "reference_stream": ref_stream,
         "roofline_targets": targets,
     }
     if frames is not None:

@@ -238,6 +238,311 @@ __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *
     }
 }
 
+// ---- a8 SOR, the cell's queries together (round 4) -------------------------------------------------------------------------
+// The wave-per-query kernel above re-gathers the 27-cell block for every query -- binary search over the cell runs, loads, 64-lane
+// ballots per bisection step -- although the queries of a cell share that block.  Here a wave takes 16 consecutive cell-sorted
+// queries; every group of L lanes takes one of the CELLS among them (64 / L cells side by side: their loads are in flight together),
+// stages the cell's 27-cell block ONCE -- nine contiguous runs of the cell-sorted points, one per (x, y) column -- in its LDS region
+// and answers the cell's queries one after the other, each from the two words of the S squared distances a lane holds in REGISTERS
+// (lane gl: candidates gl, gl + L, ...; AC3, fp64; d^2 >= 0, so the IEEE patterns order like the values).  (Keeping the candidates
+// themselves in registers across the cell's queries was tried: the compiler hoists their float -> double conversions and spills.)  Queries the 3 x 3 x 3 block does not cover get the 5 x 5 x 5 block the same way.  The k-th smallest is found by
+// bisection on the high words (a 32-bit compare + add per candidate and step, the count folded over the L lanes by DPP row
+// rotations; it ends as soon as a pivot has exactly k patterns below it), the low words are looked at only when several candidates
+// share the k-th high word.  Exactness is the ring walk's rule: the query is answered here only if its k-th candidate lies inside
+// the distance the block covers (block_cover2), everything else -- blocks that do not cover, blocks with more than L x S points,
+// ties far beyond k -- goes to the wave-per-query passes through a list.  The block, its order (column by column, cell-sorted
+// position inside a column) and with it every sum depend on the query's CELL alone, not on how the queries were dealt out: the
+// slab calls of the sharded filter (kpx_sor_partial) give bitwise the values of the one-GPU call.
+// Roof: per query 6 S L fp64 flops for the distances and ~(2 S + 8) 32-bit operations per bisection step on L lanes -- vector
+// ALU work on LDS-resident operands (12 B per candidate staged once per cell and read G x per query group); DESIGN.md section 5.
+__device__ __forceinline__ int dppi(int v, int ctrl_sel)
+{
+    switch (ctrl_sel) {
+    case 1: return __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false);
+    case 2: return __builtin_amdgcn_update_dpp(v, v, 0x122, 0xF, 0xF, false);
+    case 4: return __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false);
+    default: return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);
+    }
+}
+// reductions over the L lanes of a query group (L = 16: one DPP row; 32, 64: the rows are folded through the LDS crossbar);
+// integer results are the same in every lane of the group
+template <int L> __device__ __forceinline__ int group_sum_i(int v)
+{
+    v += dppi(v, 1); v += dppi(v, 2); v += dppi(v, 4); v += dppi(v, 8);
+    if (L >= 32) v += __shfl_xor(v, 16, 64);
+    if (L >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <int L> __device__ __forceinline__ unsigned group_min_u(unsigned v)
+{
+    unsigned o;
+    o = (unsigned)dppi((int)v, 1); v = o < v ? o : v; o = (unsigned)dppi((int)v, 2); v = o < v ? o : v;
+    o = (unsigned)dppi((int)v, 4); v = o < v ? o : v; o = (unsigned)dppi((int)v, 8); v = o < v ? o : v;
+    if (L >= 32) { o = (unsigned)__shfl_xor((int)v, 16, 64); v = o < v ? o : v; }
+    if (L >= 64) { o = (unsigned)__shfl_xor((int)v, 32, 64); v = o < v ? o : v; }
+    return v;
+}
+template <int L> __device__ __forceinline__ unsigned group_max_u(unsigned v)
+{
+    unsigned o;
+    o = (unsigned)dppi((int)v, 1); v = o > v ? o : v; o = (unsigned)dppi((int)v, 2); v = o > v ? o : v;
+    o = (unsigned)dppi((int)v, 4); v = o > v ? o : v; o = (unsigned)dppi((int)v, 8); v = o > v ? o : v;
+    if (L >= 32) { o = (unsigned)__shfl_xor((int)v, 16, 64); v = o > v ? o : v; }
+    if (L >= 64) { o = (unsigned)__shfl_xor((int)v, 32, 64); v = o > v ? o : v; }
+    return v;
+}
+#ifndef KPX_SOR_CELL_MINB8
+#define KPX_SOR_CELL_MINB8 6
+#endif
+#ifndef KPX_SOR_CELL_MINB
+#define KPX_SOR_CELL_MINB 4
+#endif
+#ifndef KPX_SOR_CELL_MINW
+#define KPX_SOR_CELL_MINW 4
+#endif
+constexpr int kCellQueries = 16;              // consecutive cell-sorted queries per wave and trip
+constexpr int kCellTieRoom = 32;              // candidates tied with the k-th beyond k the selection buffer still holds
+template <int L, int S, int W>
+__global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MINW))) void sor_cell_kernel(
+    const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start, const float *__restrict__ spts, const int32_t *__restrict__ sidx,
+    int64_t q0, int64_t q1, int k, int kbuf, double *__restrict__ avg, int32_t *__restrict__ fb_list, int32_t *__restrict__ fb_count)
+{
+    constexpr int CAP = L * S, G = 64 / L;
+    extern __shared__ __align__(16) double lds[];
+    // per wave and group: a selection buffer of kbuf doubles, the run table of the group's block (32 starts, 32 offsets) and the block's
+    // points (CAP x 3 floats)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane / L, gl = lane % L;
+    const size_t per_group = (size_t)kbuf + 32 + (size_t)(CAP * 3 + 1) / 2;
+    double *selbuf = lds + ((size_t)wave * G + grp) * per_group;
+    uint32_t *run_s0 = reinterpret_cast<uint32_t *>(selbuf + kbuf);
+    int32_t *run_off = reinterpret_cast<int32_t *>(run_s0 + 32);
+    float *cand = reinterpret_cast<float *>(selbuf + kbuf + 32);
+    const GridParams g = *gp;
+    const int64_t nq = q1 - q0;
+    for (int64_t chunk = (int64_t)blockIdx.x * W + wave; chunk * kCellQueries < nq; chunk += (int64_t)gridDim.x * W) {
+        const int64_t base = q0 + chunk * kCellQueries;
+        const int nqc = (int)(q1 - base < kCellQueries ? q1 - base : kCellQueries);
+        // lanes 0 .. nqc-1: the chunk's queries and their cells; a cell's queries are contiguous (cell-sorted)
+        double myq[3] = { 0.0, 0.0, 0.0 };
+        int myc[3] = { 0, 0, 0 };
+        int64_t mycell = -1;
+        if (lane < nqc) {
+            const float *qp = spts + 3 * (base + lane);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { myq[a] = (double)qp[a]; myc[a] = cell_coord(myq[a], g.org[a], g.h, g.dim[a]); }
+            mycell = ((int64_t)myc[0] * g.dim[1] + myc[1]) * g.dim[2] + myc[2];
+        }
+        const int64_t prevcell = __shfl_up(mycell, 1, 64);
+        unsigned segs = (unsigned)__builtin_amdgcn_ballot_w64(lane < nqc && (lane == 0 || mycell != prevcell));     // bit i: query i opens a cell
+        unsigned fbmask = 0u;                                    // queries of this chunk that go to the wave-per-query passes
+        while (segs != 0u) {                                     // G cells at a time, one per group of L lanes
+            int pos = 0, len = 0;
+            {
+                unsigned tt = segs;
+#pragma unroll
+                for (int gg = 0; gg < G; ++gg) {
+                    if (tt != 0u) {
+                        const int p0 = __builtin_ctz(tt);
+                        tt &= tt - 1u;
+                        const int p1 = tt ? __builtin_ctz(tt) : nqc;
+                        if (gg == grp) { pos = p0; len = p1 - p0; }
+                    }
+                }
+                segs = tt;
+            }
+            const int cx = __shfl(myc[0], pos, 64), cy = __shfl(myc[1], pos, 64), cz = __shfl(myc[2], pos, 64);
+            unsigned open = len > 0 ? (1u << len) - 1u : 0u;     // the cell's queries still unanswered (bit = query pos + i)
+            unsigned fbbits = 0u;
+            // the 3 x 3 x 3 block first; the queries it does not cover get the 5 x 5 x 5 block (as long as it fits the lanes)
+            for (int rad = 1; rad <= 2; ++rad) {
+                bool active = open != 0u;
+                if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+                const int side = 2 * rad + 1, nruns = side * side;
+                // the block's runs (one per (x, y) column, ascending), two per lane where the group has fewer lanes than runs
+                uint32_t s0[2] = { 0u, 0u };
+                int ln[2] = { 0, 0 };
+#pragma unroll
+                for (int pss = 0; pss < 2; ++pss) {
+                    const int rr = gl + pss * L;
+                    if (active && rr < nruns) {
+                        const int x = cx + rr / side - rad, y = cy + rr % side - rad;
+                        if (x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1]) {
+                            const int64_t col = ((int64_t)x * g.dim[1] + y) * g.dim[2];
+                            const int za = cz - rad < 0 ? 0 : cz - rad, zb = cz + rad >= g.dim[2] ? g.dim[2] - 1 : cz + rad;
+                            s0[pss] = cell_start[col + za];
+                            ln[pss] = (int)(cell_start[col + zb + 1] - s0[pss]);
+                        }
+                    }
+                }
+                int inc0 = ln[0], inc1 = ln[1];
+#pragma unroll
+                for (int o = 1; o < L; o <<= 1) {
+                    const int t0 = __shfl_up(inc0, o, L), t1 = __shfl_up(inc1, o, L);
+                    if (gl >= o) { inc0 += t0; inc1 += t1; }
+                }
+                const int tot0 = __shfl(inc0, L - 1, L);
+                const int m = tot0 + __shfl(inc1, L - 1, L);
+                if (m > CAP) active = false;                     // more points than the group's lanes hold: the queries stay open
+                if (active) {
+                    if (gl < 32) { run_s0[gl] = s0[0]; run_off[gl] = gl < nruns ? inc0 - ln[0] : INT_MAX; }
+                    if (L < 32 && gl + L < 32) { run_s0[gl + L] = s0[1]; run_off[gl + L] = gl + L < nruns ? tot0 + inc1 - ln[1] : INT_MAX; }
+                }
+                wave_lds_fence();
+                const int mmax = [&] { int v = active ? m : 0;
+#pragma unroll
+                                       for (int o = 32; o > 0; o >>= 1) { const int t2 = __shfl_xor(v, o, 64); v = t2 > v ? t2 : v; }
+                                       return v; }();
+                // the block's points -> the group's LDS region (lane gl brings in candidates gl, gl + L, ...: all loads of a lane in flight together)
+#pragma unroll
+                for (int sl = 0; sl < S; ++sl) {
+                    const int jn = sl * L + gl;
+                    if (sl * L < mmax && active && jn < m) {
+                        int lo_r = 0, hi_r = nruns - 1;          // last run with off <= jn
+                        while (lo_r < hi_r) {
+                            const int mid = (lo_r + hi_r + 1) >> 1;
+                            if (run_off[mid] <= jn) lo_r = mid; else hi_r = mid - 1;
+                        }
+                        const float *pp = spts + 3 * (int64_t)(run_s0[lo_r] + (uint32_t)(jn - run_off[lo_r]));
+                        cand[3 * jn] = pp[0]; cand[3 * jn + 1] = pp[1]; cand[3 * jn + 2] = pp[2];
+                    }
+                }
+                wave_lds_fence();
+                unsigned todo = active ? open : 0u;
+                while (__builtin_amdgcn_ballot_w64(todo != 0u) != 0ull) {       // one open query of every group's cell per trip
+                    const bool have = todo != 0u;
+                    const int qrel = have ? __builtin_ctz(todo) : 0;
+                    todo &= todo - 1u;
+                    const int qi = pos + qrel;
+                    const double q[3] = { __shfl(myq[0], qi, 64), __shfl(myq[1], qi, 64), __shfl(myq[2], qi, 64) };
+                    const int c[3] = { cx, cy, cz };
+                    unsigned hi[S], lo[S];
+#pragma unroll
+                    for (int sl = 0; sl < S; ++sl) {
+                        hi[sl] = 0xFFFFFFFFu; lo[sl] = 0xFFFFFFFFu;
+                        const int jn = sl * L + gl;
+                        if (sl * L < mmax && have && jn < m) {
+                            const double dx = q[0] - (double)cand[3 * jn], dy = q[1] - (double)cand[3 * jn + 1], dz = q[2] - (double)cand[3 * jn + 2];
+                            const unsigned long long pat = (unsigned long long)__double_as_longlong(fma(dz, dz, fma(dy, dy, dx * dx)));
+                            hi[sl] = (unsigned)(pat >> 32); lo[sl] = (unsigned)pat;
+                        }
+                    }
+                    // inside the covered distance: at least kk candidates strictly nearer than the block's cover (the ring walk's rule)
+                    const double cov2 = block_cover2(g, q, c, rad);
+                    const bool whole = cov2 == INFINITY;
+                    const unsigned long long cpat = (unsigned long long)__double_as_longlong(cov2);
+                    const unsigned ch = (unsigned)(cpat >> 32), cl = (unsigned)cpat;
+                    int cnt = 0;
+#pragma unroll
+                    for (int sl = 0; sl < S; ++sl) if (sl * L < mmax) cnt += (hi[sl] < ch || (hi[sl] == ch && lo[sl] < cl)) ? 1 : 0;
+                    cnt = group_sum_i<L>(cnt);
+                    const int kk = whole ? (m < k ? m : k) : k;
+                    bool ok = have && cnt >= kk;
+                    // phase 1: the k-th smallest HIGH word
+                    unsigned vmin = 0xFFFFFFFFu, vmax = 0u;
+#pragma unroll
+                    for (int sl = 0; sl < S; ++sl) if (sl * L < mmax) { vmin = hi[sl] < vmin ? hi[sl] : vmin; const unsigned hv = hi[sl] == 0xFFFFFFFFu ? 0u : hi[sl]; vmax = hv > vmax ? hv : vmax; }
+                    unsigned a = group_min_u<L>(vmin), b = group_max_u<L>(vmax);
+                    bool exact = false;                          // a pivot with exactly kk patterns at or below it was met
+                    bool run = ok && a < b;
+                    while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+                        const unsigned mid = a + ((b - a) >> 1);
+                        int c1 = 0;
+#pragma unroll
+                        for (int sl = 0; sl < S; ++sl) if (sl * L < mmax) c1 += hi[sl] <= mid ? 1 : 0;
+                        c1 = group_sum_i<L>(c1);
+                        if (run) {
+                            if (c1 == kk) { a = b = mid; exact = true; }
+                            else if (c1 > kk) b = mid;
+                            else a = mid + 1;
+                        }
+                        run = ok && a < b;
+                    }
+                    const unsigned P = a;
+                    unsigned Q = 0xFFFFFFFFu;
+                    int n_le = kk;
+                    if (__builtin_amdgcn_ballot_w64(ok && !exact) != 0ull) {
+                        int c_less = 0, c_eq = 0;
+#pragma unroll
+                        for (int sl = 0; sl < S; ++sl) if (sl * L < mmax) { c_less += hi[sl] < P ? 1 : 0; c_eq += hi[sl] == P ? 1 : 0; }
+                        c_less = group_sum_i<L>(c_less); c_eq = group_sum_i<L>(c_eq);
+                        n_le = c_less + c_eq;
+                        // phase 2 (several candidates share the k-th high word and not all of them fit): the low words decide
+                        const int r2 = kk - c_less;
+                        const bool need = ok && !exact && n_le > kk;
+                        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                            unsigned lmin = 0xFFFFFFFFu, lmax = 0u;
+#pragma unroll
+                            for (int sl = 0; sl < S; ++sl) if (hi[sl] == P) { lmin = lo[sl] < lmin ? lo[sl] : lmin; lmax = lo[sl] > lmax ? lo[sl] : lmax; }
+                            unsigned a2 = group_min_u<L>(lmin), b2 = group_max_u<L>(lmax);
+                            bool run2 = need && a2 < b2;
+                            while (__builtin_amdgcn_ballot_w64(run2) != 0ull) {
+                                const unsigned mid = a2 + ((b2 - a2) >> 1);
+                                int c2 = 0;
+#pragma unroll
+                                for (int sl = 0; sl < S; ++sl) c2 += (hi[sl] == P && lo[sl] <= mid) ? 1 : 0;
+                                c2 = group_sum_i<L>(c2);
+                                if (run2) { if (c2 >= r2) b2 = mid; else a2 = mid + 1; }
+                                run2 = need && a2 < b2;
+                            }
+                            int c3 = 0;
+#pragma unroll
+                            for (int sl = 0; sl < S; ++sl) c3 += (hi[sl] == P && lo[sl] <= a2) ? 1 : 0;
+                            c3 = group_sum_i<L>(c3);
+                            if (need) { Q = a2; n_le = c_less + c3; }
+                        }
+                        if (exact) n_le = kk;
+                    }
+                    // the selected patterns (all <= (P, Q)), in the block's own order -> selection buffer -> sum of square roots
+                    const bool tied_out = ok && n_le > kk + kCellTieRoom;     // ties far beyond k (duplicates, lattices): the wave-per-query passes
+                    if (tied_out) ok = false;
+                    int mine = 0;
+#pragma unroll
+                    for (int sl = 0; sl < S; ++sl) if (sl * L < mmax) mine += (hi[sl] < P || (hi[sl] == P && lo[sl] <= Q)) ? 1 : 0;
+                    int before = mine;                            // exclusive prefix over the group's lanes
+#pragma unroll
+                    for (int o = 1; o < L; o <<= 1) { const int t2 = __shfl_up(before, o, L); if (gl >= o) before += t2; }
+                    before -= mine;
+                    if (ok) {
+                        int w = before;
+#pragma unroll
+                        for (int sl = 0; sl < S; ++sl)
+                            if (sl * L < mmax && (hi[sl] < P || (hi[sl] == P && lo[sl] <= Q)))
+                                selbuf[w++] = __longlong_as_double((long long)(((unsigned long long)hi[sl] << 32) | lo[sl]));
+                    }
+                    wave_lds_fence();
+                    double acc = 0.0;
+                    if (ok)
+                        for (int t = gl; t < n_le; t += L) acc += sqrt(selbuf[t]);
+                    // fixed tree over the group's lanes; lane 0 of the group holds THE sum
+#pragma unroll
+                    for (int o = L / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, L);
+                    if (ok && gl == 0) {
+                        const int64_t sq = base + qi;
+                        const double top = __longlong_as_double((long long)(((unsigned long long)P << 32) | Q));
+                        const double total = n_le > kk ? acc - (double)(n_le - kk) * sqrt(top) : acc;
+                        avg[sidx ? (int64_t)sidx[sq] : sq - q0] = kk > 0 ? total / (double)kk : -1.0;
+                    }
+                    if (ok || tied_out) open &= ~(1u << qrel);   // settled, or straight to the list
+                    if (tied_out) fbbits |= 1u << qi;
+                    wave_lds_fence();
+                }
+            }
+            fbbits |= open << pos;                               // neither block settled them
+            // the groups' lists -> the chunk's
+            unsigned fbv = fbbits;
+            if (L < 64) fbv |= (unsigned)__shfl_xor((int)fbv, 32, 64);
+            if (L < 32) fbv |= (unsigned)__shfl_xor((int)fbv, 16, 64);
+            fbmask |= (unsigned)__builtin_amdgcn_readfirstlane((int)fbv);
+        }
+        if (fbmask != 0u) {                                      // ONE counter update per chunk (same-address atomics serialise)
+            int fb_base = 0;
+            if (lane == 0) fb_base = atomicAdd(fb_count, __builtin_popcount(fbmask));
+            fb_base = __shfl(fb_base, 0, 64);
+            if (lane < 16 && ((fbmask >> lane) & 1u)) fb_list[fb_base + __builtin_popcount(fbmask & ((1u << lane) - 1u))] = (int32_t)(base + lane);
+        }
+    }
+}
+
 // Exact ring walk, one thread per query (queries in cell order: neighbouring threads walk neighbouring cells).
 // list != NULL: only the queries list[0 .. *list_count) (the wave kernel's overflow list).
 __global__ void sor_knn_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
@@ -399,8 +704,12 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     int kk = (int64_t)k < n ? k : (int)(n > 0 ? n : 1);
     // cell occupancy (as seen by a point) ~0.4 k: the 27-cell block then holds ~10 k candidates and usually covers the
     // k-th neighbour
-    double occ = 0.4 * (double)kk;
-    occ = occ < 6.0 ? 6.0 : (occ > 96.0 ? 96.0 : occ);
+    // (round 4: with the cell's queries answered together -- sor_cell_kernel -- a query that the 27-cell block does not cover costs a second,
+    // wave-per-query search, so the cells are sized to cover the k-th neighbour of nearly every query: r_k ~ sqrt(k / (pi rho)) against
+    // h = sqrt(occ / rho) on a surface of density rho)
+    static const double occ_factor = [] { const char *e = getenv("KPX_SOR_OCC"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.4; }();
+    double occ = occ_factor * (double)kk;
+    occ = occ < 6.0 ? 6.0 : (occ > 240.0 ? 240.0 : occ);
     int rc = grid_build(pts, n, occ, a, &g, st);
     if (rc) return rc;
     double *avg = a.get<double>((size_t)(n > 0 ? n : 1));
@@ -408,12 +717,13 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     int32_t *counts = a.get<int32_t>((size_t)compact_ws_ints(n));
     int32_t *fb_list = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
     int32_t *fb_list2 = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
+    int32_t *fb_list0 = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     if (d_avg) avg = d_avg;
     const int32_t *out_idx = full ? g.sorted_idx : nullptr;
     const int64_t nq = q1 - q0;
-    int32_t *fb_count = g.spare, *fb_count2 = g.spare + 1;       // cleared by the grid build
+    int32_t *fb_count = g.spare, *fb_count2 = g.spare + 1, *fb_count0 = g.spare + 2;       // cleared by the grid build
     const int threads = sor_block_threads(kk);
     const size_t lds = (size_t)kk * threads * sizeof(double);
     static bool attr_set = false;
@@ -426,17 +736,44 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     {
         ProfScope prof(KPX_PROF_SOR_KNN, 12.0 * (double)n + 8.0 * (double)n, st);     // read points, write mean distances
         const int32_t *none = nullptr;
-        // pass 1: every query, 1024-candidate buffer (k <= KPX_SOR_MAX_K = 288 < 1024; many waves per CU)
+        // pass 0: the queries of a cell together (sor_cell_kernel): L lanes per query, L x S candidates at most; what it cannot settle
+        // goes to the wave-per-query passes below.  KPX_SOR_CELL=0: every query starts at pass 1.
+        // Measured (profiles/r04/sor_cell_kernel.txt): the cell kernel wins where a query's candidates are many -- k = 200 on a 221k-point
+        // fused cloud 4.39 -> 3.63 ms -- and roughly breaks even below (k = 20 at 259k points 1.04 -> 0.94 ms, k = 50 1.72 -> 1.92, a
+        // frame-sized 26k-point cloud 0.17 -> 0.23): there a third of the filter's time is the 5 % of the queries that sit in sparse
+        // space (their k-th neighbour lies many cells away: the wave-per-query passes' re-gathers), and the selection itself is
+        // instruction-bound either way.  So: KPX_SOR_CELL unset = the cell kernel from k > 64 on, 1 = always, 0 = never.
+        static const int cell_mode = [] { const char *e = getenv("KPX_SOR_CELL"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();
+        const bool cell_on = cell_mode == 2 || (cell_mode == 1 && kk > 64);
+        const int32_t *list0 = nullptr, *count0 = nullptr;
+        if (cell_on && nq > 0) {
+            const int kbuf = kk + kCellTieRoom;
+            const int64_t chunks = cdiv(nq, kCellQueries);
+            auto bytes = [&](int cap, int groups, int waves) { return (size_t)waves * groups * ((size_t)kbuf + 32 + (size_t)(cap * 3 + 1) / 2) * 8; };
+#define KPX_SOR_CELL_LAUNCH(LL, SS, WW)                                                                                          \
+            hipLaunchKernelGGL((sor_cell_kernel<LL, SS, WW>), dim3((unsigned)(cdiv(chunks, WW) > 32768 ? 32768 : cdiv(chunks, WW))), dim3(64 * WW), \
+                               bytes(LL * SS, 64 / LL, WW), st, g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk, kbuf, avg, fb_list0, fb_count0)
+            static const int small_cap = [] { const char *e = getenv("KPX_SOR_CELL_SMALL"); return e ? atoi(e) : 1; }();
+            if (kk <= 24 && small_cap) KPX_SOR_CELL_LAUNCH(16, 8, 4);
+            else if (kk <= 32) KPX_SOR_CELL_LAUNCH(16, 16, 4);
+            else if (kk <= 64) KPX_SOR_CELL_LAUNCH(32, 16, 4);
+            else if (kk <= 128) KPX_SOR_CELL_LAUNCH(64, 16, 4);
+            else KPX_SOR_CELL_LAUNCH(64, 32, 1);
+#undef KPX_SOR_CELL_LAUNCH
+            list0 = fb_list0; count0 = fb_count0;
+        }
+        // pass 1: one wave per query, 1024-candidate buffer (k <= KPX_SOR_MAX_K = 288 < 1024; many waves per CU)
         const int cap1 = kk <= 32 ? 512 : 1024;               // small k: smaller buffers, more waves per CU
         if (nq > 0)
-            hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(nq, 4) > 8192 ? 8192 : cdiv(nq, 4))), dim3(256), (size_t)4 * cap1 * 8, st,
-                               g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk, cap1, avg, none, none, fb_list, fb_count);
+            hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(nq, 4) > (list0 ? 2048 : 8192) ? (list0 ? 2048 : 8192) : cdiv(nq, 4))), dim3(256), (size_t)4 * cap1 * 8, st,
+                               g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk, cap1, avg, list0, count0, fb_list, fb_count);
         // pass 2: the queries whose block did not fit (isolated points next to a dense sheet), 8192-candidate buffer
         hipLaunchKernelGGL(sor_wave_kernel<1>, dim3(2048), dim3(64), (size_t)8192 * 8, st, g.params, g.cell_start, g.sorted_pts,
                            out_idx, q0, q1, kk, 8192, avg, fb_list, fb_count, fb_list2, fb_count2);
         // pass 3: whatever is left: thread-per-query ring walk with a k-heap
         hipLaunchKernelGGL(sor_knn_kernel, dim3(256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk,
                            avg, fb_list2, fb_count2);
+        (void)none;
     }
     if (!full) {
         if (d_order) KPX_HIP(hipMemcpyAsync(d_order, g.sorted_idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -596,6 +933,17 @@ static int normals_impl(const float *pts, int64_t n, double radius, int max_nn, 
 
 using namespace kpx;
 
+#ifdef KPX_SOR_CELL_STATS
+KPX_EXPORT int kpx_debug_sor_stats(uint64_t *h_out16)
+{
+    unsigned long long *p = nullptr;
+    static const unsigned long long zero[16] = { 0 };
+    KPX_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_sor_stats)));
+    KPX_HIP(hipMemcpy(h_out16, p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    KPX_HIP(hipMemcpy(p, zero, sizeof(zero), hipMemcpyHostToDevice));
+    return KPX_OK;
+}
+#endif
 KPX_EXPORT size_t kpx_sor_workspace_bytes(int64_t n, int32_t nb_neighbors)
 {
     Arena a(nullptr, 0);
