@@ -725,8 +725,8 @@ def main():
             cpu["open3d"] = getattr(open3d, "__version__", "present")
         except Exception:                                    # noqa: BLE001
             cpu["open3d"] = "unavailable"
-        cpu["where_the_time_goes"] = ("an untuned checker whose OpenMP loops barely scale (compare single_core: one core runs the same step in about the "
-                                      "same time as all of them -- the step is a chain of short parallel regions between serial pieces: sorts, sequential "
+        cpu["where_the_time_goes"] = ("an untuned checker whose OpenMP loops barely scale (compare single_core: all the cores of this box are only a few "
+                                      "times faster than one -- the step is a chain of short parallel regions between serial pieces: sorts, sequential "
                                       "per-voxel sums, the ICP loop's reductions): most of a step goes to the point-to-plane registrations (up to 30 exact "
                                       "nearest-neighbour sweeps of 31k x 31k points through the grid search), then the voxel grids and the k-nearest-"
                                       "neighbour filter")

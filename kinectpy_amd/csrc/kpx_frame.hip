@@ -399,25 +399,27 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     for (int i = 0; i < S_l && !lerr; ++i)
         if (dk[(size_t)i] < 1) lerr = fail(KPX_ERR_INVALID, "kpx_frame_step_sharded: sensor %d has no valid pixel", g0 + i);
 
-    // -- collective 0: the master's down-sampled cloud (+ normals) to every rank.  Message: cap rows xyz | cap rows normal | header
+    // -- collective 0: the master's down-sampled cloud to every rank.  Message: cap rows xyz | header.  The NORMALS do not travel
+    // (round 4): rank 0 used to estimate them in front of the broadcast -- ~0.1 ms during which every other rank waited -- and ship
+    // them as the message's second half.  Every rank now estimates them itself from the broadcast points, beside the others: the same
+    // kernels on the same array give the same normals bit for bit, the message is half as long, and nothing serial is left between
+    // rank 0's voxel grid and everyone's registrations (registration.py:9-13 is a function of the master cloud alone).
     int64_t &cap_m = comm_cap_master(comm);
     if (cap_m <= 0) cap_m = n_px;
     const int64_t capm = cap_m;
     char *msg = L.msg_master;
-    float *m_xyz = reinterpret_cast<float *>(msg), *m_nrm = reinterpret_cast<float *>(msg + (size_t)capm * 12);
-    double *m_hdr = reinterpret_cast<double *>(msg + (size_t)capm * 24);
+    float *m_xyz = reinterpret_cast<float *>(msg);
+    double *m_hdr = reinterpret_cast<double *>(msg + (size_t)capm * 12);
     if (owns_master) {
         if (!lerr) {
-            if (plane) KPX_SUB(kpx_estimate_normals(L.down_pts, dk[0], 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st));
             const size_t rows = (size_t)(dk[0] < capm ? dk[0] : capm);
             KPX_HIP(hipMemcpyAsync(m_xyz, L.down_pts, rows * 12, hipMemcpyDeviceToDevice, st));
-            if (plane) KPX_HIP(hipMemcpyAsync(m_nrm, L.normals, rows * 12, hipMemcpyDeviceToDevice, st));
         }
         h_d[0] = lerr ? -1.0 : (double)dk[0];                   // a negative count: rank 0 cannot provide the master (every rank returns)
         KPX_HIP(hipMemcpyAsync(m_hdr, h_d, sizeof(double), hipMemcpyHostToDevice, st));
     }
     kpx_order_turn_begin(order, frame, 0);
-    int rc = kpx_comm_broadcast(comm, msg, (size_t)capm * 24 + 256, 0, st);
+    int rc = kpx_comm_broadcast(comm, msg, (size_t)capm * 12 + 256, 0, st);
     kpx_order_turn_end(order, frame, 0);
     if (rc) return rc;
     if (owns_master && lerr) {                                 // (the message of `lerr` is the thread's last error)
@@ -450,7 +452,8 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
             subs[(size_t)j] = p_out[(size_t)i];
             ns[(size_t)j] = dk[(size_t)i];
         }
-        const float *tgt = owns_master ? L.down_pts : m_xyz, *tn = plane ? (owns_master ? L.normals : m_nrm) : nullptr;
+        const float *tgt = owns_master ? L.down_pts : m_xyz, *tn = plane ? L.normals : nullptr;
+        if (plane) KPX_SUB(kpx_estimate_normals(tgt, m, 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st));
         const int first_sub = g0 + (owns_master ? 1 : 0);      // global sensor number of subs[0]; h_init[g - 1] belongs to sensor g
         KPX_SUB(icp_batch_ordered(n_sub, subs.data(), ns.data(), tgt, tn, m, prm->icp_max_dist, h_init + 16 * (size_t)(first_sub - 1), prm->icp_mode,
                                   prm->icp_max_iteration, 1e-6, 1e-6, L.icp_res, L.op_ws, L.op_bytes, st, zorder));

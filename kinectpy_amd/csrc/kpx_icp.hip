@@ -40,6 +40,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #ifndef KPX_ICP_SPLIT_DEFAULT
 #define KPX_ICP_SPLIT_DEFAULT 2
 #endif
+#ifndef KPX_ICP_STATE_LDS
+#define KPX_ICP_STATE_LDS 1                      // the last-block update works on an LDS copy of the registration's state (A/B: 0 = in global memory)
+#endif
 #ifndef KPX_ICP_WPE
 #define KPX_ICP_WPE 3                            // waves per SIMD the iteration kernels are register-budgeted for
 #endif
@@ -1150,6 +1153,12 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         for (int a = 0; a < 3; ++a) my_nrm[a] = np_[a];
     }
     const double *Tk = st->T;
+    // (ticket mode) the registration's state, copied into LDS while everything else loads: the block that draws the last ticket runs the
+    // update step on this copy -- fitness / rmse / T / motion were four dependent global round trips inside a step that every launch waits
+    // for -- and writes the new state back in one burst
+    static_assert(sizeof(IcpState) % sizeof(double) == 0, "IcpState is copied as doubles");
+    if (KPX_ICP_STATE_LDS && fuse.ticket && threadIdx.x < sizeof(IcpState) / sizeof(double))
+        reinterpret_cast<double *>(&s_state)[threadIdx.x] = reinterpret_cast<const double *>(st)[threadIdx.x];
     if (fuse.pair) {
         const IcpState *in = fuse.pair + ((k + 1) & 1);
         IcpState *out = fuse.pair + (k & 1);
@@ -1454,10 +1463,13 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     if (wave != 0) return;
     __shared__ FinishScratch s_tail;
     IcpState *stw = const_cast<IcpState *>(st);
-    icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, stw, fuse.result, s_tail, lane,
+    IcpState *work = KPX_ICP_STATE_LDS ? &s_state : stw;
+    icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, fuse.result, s_tail, lane,
                     LightSkip{ fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max });
+    wave_lds_fence();
+    if (KPX_ICP_STATE_LDS && lane < (int)(sizeof(IcpState) / sizeof(double))) reinterpret_cast<double *>(stw)[lane] = reinterpret_cast<const double *>(&s_state)[lane];
     if (lane == 0 && fuse.progress)
-        __hip_atomic_store(fuse.progress, fuse.tag | ((unsigned long long)(stw->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELAXED,
+        __hip_atomic_store(fuse.progress, fuse.tag | ((unsigned long long)(work->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

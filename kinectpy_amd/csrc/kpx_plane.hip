@@ -85,6 +85,76 @@ __global__ __launch_bounds__(64) void plane_hyp_kernel(const float *__restrict__
     fit_plane_ids(pts, ids, ransac_n, pl);
     hyp[4 * h] = pl[0]; hyp[4 * h + 1] = pl[1]; hyp[4 * h + 2] = pl[2]; hyp[4 * h + 3] = pl[3];
 }
+// The same for samples of at most kHypLdsN points (floor_removal.py:70 draws 30): the sample's indices and its points live in LDS
+// (slot t of thread l at [t][l]: conflict-free) -- the kernel above keeps the indices in global memory, re-reads them for every duplicate
+// check (435 dependent loads for a sample of 30) and gathers every point twice (centroid, then moments): 52 us for 2000 hypotheses, a
+// sixth of the whole call on the floor slab.  Same draws, same sums in the same order: the same planes bit for bit.
+constexpr int kHypLdsN = 48;
+__global__ __launch_bounds__(64) void plane_hyp_lds_kernel(const float *__restrict__ pts, int64_t n, int ransac_n, int H, uint32_t seed_lo,
+                                                           uint32_t seed_hi, double *__restrict__ hyp)
+{
+    extern __shared__ __align__(16) int32_t hyp_lds[];
+    int32_t *sid = hyp_lds;                                        // [ransac_n][64]
+    float *sp = reinterpret_cast<float *>(hyp_lds + (size_t)ransac_n * 64);   // [ransac_n][3][64]
+    const int l = threadIdx.x;
+    const int h = blockIdx.x * 64 + l;
+    if (h >= H) return;
+    int got = 0;
+    for (uint32_t blk = 0; got < ransac_n; ++blk) {
+        uint32_t out[4];
+        philox4x32(blk, (uint32_t)h, 0u, 0u, seed_lo, seed_hi, out);
+        for (int w = 0; w < 4 && got < ransac_n; ++w) {
+            const int32_t id = (int32_t)(((uint64_t)out[w] * (uint64_t)n) >> 32);
+            bool dup = false;
+            for (int t = 0; t < got; ++t) dup |= (sid[t * 64 + l] == id);
+            if (!dup) sid[(got++) * 64 + l] = id;
+        }
+    }
+    for (int t0 = 0; t0 < ransac_n; t0 += 8) {                    // the sample's points, eight gathers in flight
+        float v[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t j = t0 + u < ransac_n ? sid[(t0 + u) * 64 + l] : 0;
+            v[u][0] = pts[3 * j]; v[u][1] = pts[3 * j + 1]; v[u][2] = pts[3 * j + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (t0 + u < ransac_n) { sp[((t0 + u) * 3 + 0) * 64 + l] = v[u][0]; sp[((t0 + u) * 3 + 1) * 64 + l] = v[u][1]; sp[((t0 + u) * 3 + 2) * 64 + l] = v[u][2]; }
+    }
+    auto P = [&](int t, int a) { return (double)sp[(t * 3 + a) * 64 + l]; };
+    double pl[4] = { 0.0, 0.0, 0.0, 0.0 };
+    const int m = ransac_n;
+    if (m == 3) {
+        double e0[3], e1[3];
+        for (int a = 0; a < 3; ++a) { e0[a] = P(1, a) - P(0, a); e1[a] = P(2, a) - P(0, a); }
+        double a = e0[1] * e1[2] - e0[2] * e1[1], b = e0[2] * e1[0] - e0[0] * e1[2], c = e0[0] * e1[1] - e0[1] * e1[0];
+        const double nn = sqrt(a * a + b * b + c * c);
+        if (nn != 0.0) {
+            a /= nn; b /= nn; c /= nn;
+            pl[0] = a; pl[1] = b; pl[2] = c; pl[3] = -(a * P(0, 0) + b * P(0, 1) + c * P(0, 2));
+        }
+    } else {
+        double cx = 0, cy = 0, cz = 0;
+        for (int t = 0; t < m; ++t) { cx += P(t, 0); cy += P(t, 1); cz += P(t, 2); }
+        cx /= (double)m; cy /= (double)m; cz /= (double)m;
+        double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+        for (int t = 0; t < m; ++t) {
+            const double rx = P(t, 0) - cx, ry = P(t, 1) - cy, rz = P(t, 2) - cz;
+            xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+        }
+        const double det_x = yy * zz - yz * yz, det_y = xx * zz - xz * xz, det_z = xx * yy - xy * xy;
+        double a, b, c;
+        if (det_x > det_y && det_x > det_z) { a = det_x; b = xz * yz - xy * zz; c = xy * yz - xz * yy; }
+        else if (det_y > det_z)             { a = xz * yz - xy * zz; b = det_y; c = xy * xz - yz * xx; }
+        else                                { a = xy * yz - xz * yy; b = xy * xz - yz * xx; c = det_z; }
+        const double nn = sqrt(a * a + b * b + c * c);
+        if (nn != 0.0) {
+            a /= nn; b /= nn; c /= nn;
+            pl[0] = a; pl[1] = b; pl[2] = c; pl[3] = -(a * cx + b * cy + c * cz);
+        }
+    }
+    hyp[4 * h] = pl[0]; hyp[4 * h + 1] = pl[1]; hyp[4 * h + 2] = pl[2]; hyp[4 * h + 3] = pl[3];
+}
 
 constexpr int kScoreThreads = 256;
 
@@ -289,10 +359,16 @@ __global__ __launch_bounds__(kPlaneNeedMax) void plane_err_list_kernel(const flo
         for (int e = threadIdx.x; e < 3 * cnt; e += kPlaneNeedMax) sp[e] = pts[3 * s0 + e];
         __syncthreads();
         if (active)
-            for (int i = 0; i < cnt; ++i) {                       // ascending point index, as plane_score_kernel: the same doubles
-                const double x = (double)sp[3 * i], y = (double)sp[3 * i + 1], z = (double)sp[3 * i + 2];
-                const double dist = fabs(fma(a, x, fma(b, y, fma(c, z, d))));
-                err += dist < thr ? dist : 0.0;
+            for (int i = 0; i < cnt; i += 8) {                    // ascending point index, as plane_score_kernel: the same doubles (eight
+                double dist[8];                                   // independent distances first, then the adds in order)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int iu = i + u < cnt ? i + u : cnt - 1;
+                    const double x = (double)sp[3 * iu], y = (double)sp[3 * iu + 1], z = (double)sp[3 * iu + 2];
+                    dist[u] = fabs(fma(a, x, fma(b, y, fma(c, z, d))));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) err += (i + u < cnt && dist[u] < thr) ? dist[u] : 0.0;
             }
     }
     if ((int)threadIdx.x < m) part_err[(int64_t)blockIdx.x * kPlaneNeedMax + threadIdx.x] = err;
@@ -484,8 +560,12 @@ static int plane_impl(const float *pts, int64_t n, double thr, int ransac_n, int
     KPX_ARENA_CHECK(a);
     static const bool mfma_on = [] { const char *e = getenv("KPX_PLANE_MFMA"); return !(e && e[0] == '0'); }();       // A/B switch
     if (H > 0) {
-        hipLaunchKernelGGL(plane_hyp_kernel, dim3((unsigned)cdiv(H, 64)), dim3(64), 0, st, pts, n, ransac_n, H, (uint32_t)seed,
-                           (uint32_t)(seed >> 32), ids, hyp);
+        if (ransac_n <= kHypLdsN)
+            hipLaunchKernelGGL(plane_hyp_lds_kernel, dim3((unsigned)cdiv(H, 64)), dim3(64), (size_t)ransac_n * 64 * 16, st, pts, n, ransac_n, H, (uint32_t)seed,
+                               (uint32_t)(seed >> 32), hyp);
+        else
+            hipLaunchKernelGGL(plane_hyp_kernel, dim3((unsigned)cdiv(H, 64)), dim3(64), 0, st, pts, n, ransac_n, H, (uint32_t)seed,
+                               (uint32_t)(seed >> 32), ids, hyp);
         const dim3 grid((unsigned)cdiv(H, kScoreThreads), (unsigned)chunks);
         uint64_t tbits;
         memcpy(&tbits, &thr, sizeof(tbits));

@@ -1,0 +1,27 @@
+"""wall time of one registration (the bench's longest) run to max_iteration = 8 .. 30: is the chain's time a smooth function of its length?"""
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kinectpy_amd import ops
+from kinectpy_amd.pipeline import PipelineParams
+from kinectpy_amd.utils import synth
+P = PipelineParams()
+xy, depth_h, rgb_h, inits, _ = synth.sensor_ring(4, 1)
+depth = torch.as_tensor(depth_h[0]).cuda()
+fp, _, _, fcnt = ops.depth_to_cloud(depth, xy, None, 4, False, False, sync=False)
+fk = ops._count(fcnt)
+downs = [d[0] for d in ops.voxel_downsample_batch([fp[i, :fk[i]] for i in range(4)], P.reg_voxel)]
+tn = ops.estimate_normals(downs[0], 2.0 * P.reg_voxel, P.normals_nn)
+for rep in range(2):
+    row = []
+    for kk in range(8, 31):
+        for _ in range(3):
+            ops.icp_batch([downs[3]], downs[0], P.icp_max_dist, [inits[2]], P.icp_mode, tn, kk)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            ops.icp_batch([downs[3]], downs[0], P.icp_max_dist, [inits[2]], P.icp_mode, tn, kk)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e6)
+        row.append(f"{kk}:{np.median(ts):.0f}/{max(ts):.0f}")
+    print("max_iteration : median/max us   ", " ".join(row))
