@@ -85,6 +85,7 @@ __device__ __forceinline__ void xform_row(const double *__restrict__ T, const fl
     for (int k = 0; k < 3; ++k) s[k] = fma(T[4 * k], x, fma(T[4 * k + 1], y, fma(T[4 * k + 2], z, T[4 * k + 3])));
 }
 __device__ __forceinline__ double row_seed(const double s[3]) { return fma(s[0], s[0], fma(s[1], s[1], s[2] * s[2])) + 1.0; }
+__device__ __forceinline__ int opaque_i(int v) { asm volatile("" : "+v"(v)); return v; }
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 // high word of the IEEE pattern as a 32-bit register reference (a shift of the 64-bit pattern makes hipcc
 // compare zero-extended 64-bit values, i.e. the slow v_cmp_*_u64 this prefilter exists to avoid)
@@ -1052,6 +1053,7 @@ constexpr int kIRows = kIWaves * kLRows;
 // state, the result and the progress word -- then sweeps with the new transform.  Three accumulator sets in a ring
 // (launch k reads set k-1, adds to set k, block 0 clears set k+1) and two state slots (launch k reads slot k-1, writes
 // slot k) keep the launches free of races.  pair == nullptr: two-kernel mode, icp_solve_fixed_kernel does the update.
+constexpr int kCertHist = 64;                 // iterations whose transforms are kept for the certificates (6 bits of the word)
 struct CertPolicy {
     float calm, factor, smin, smax;      // KPX_CERT_CALM / _FACTOR / _SKIN_MIN / _SKIN_MAX (fractions of the correspondence distance)
 };
@@ -1065,7 +1067,9 @@ struct IcpFuse {
     unsigned long long *ticket;        // non-null (with pair == nullptr): the LAST block of the launch to deliver its sums performs the update
     double *light_key;                 // with ticket: per block, LightSkip key (0 = sweep); nullptr: every block sweeps
     const double *sbbox;               // with light_key: the source's bounding box
-    float4 *cert;                      // with light_key: per sorted row, the certificate (position at the search, L; L = 0: none); nullptr: every row is searched
+    uint32_t *cert;                    // with light_key: per sorted row, the certificate: L as a float rounded down to 17 mantissa bits | the iteration
+                                       // of the search in the low 6 bits (0 = none); nullptr: every row is searched
+    double *thist;                     // with cert: the transforms of iterations 0 .. 63, 12 doubles each (the winner writes entry k + 1)
     int cert_check;                    // self-check mode: certified rows are searched anyway and compared (g_cert_check)
     CertPolicy pol;
 };
@@ -1128,7 +1132,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // algebra of the previous iteration runs below.
     float my_src[3] = { 0.0f, 0.0f, 0.0f }, my_pt[3] = { 0.0f, 0.0f, 0.0f }, my_nrm[3] = { 0.0f, 0.0f, 0.0f };
     int32_t my_row = 0, my_prev = -1;
-    float4 my_cert = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t my_cert = 0u;
     const bool certs = fuse.ticket && fuse.light_key && fuse.cert;
     if (lane < 16) {
         const int64_t r = row_base + lane < last ? row_base + lane : last;
@@ -1142,6 +1146,10 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
             if (certs) my_cert = fuse.cert[r];
         }
     }
+    // (certificates) the transforms of the iterations so far: a certified row's position at its search is recomputed from them, exactly
+    __shared__ double s_thist[kCertHist][12];
+    if (certs && k > 0)
+        for (int e = threadIdx.x; e < 12 * (k < kCertHist ? k : kCertHist); e += kIThreads) (&s_thist[0][0])[e] = fuse.thist[e];
     GroupPre gpre;
     group_pre_load(gpre, group_box, n_groups, lane);
     if (mode == 1 && k > 0 && lane < 16) {
@@ -1256,9 +1264,18 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
             // reach of a row without one) is nearer than what is left of L.  A row that HAD a partner and lost it to the clamp is
             // searched (the certificate says nothing about that partner).
             const bool keeps = (my_prev >= 0) == (bj != INT_MAX);
-            const double ex = s[0] - (double)my_cert.x, ey = s[1] - (double)my_cert.y, ez = s[2] - (double)my_cert.z;
-            const double moved = sqrt(fma(ez, ez, fma(ey, ey, ex * ex))) + 1e-6 * (fabs(s[0]) + fabs(s[1]) + fabs(s[2]) + 1.0);
-            const bool certd = my_cert.w > 0.0f && keeps && (d1 + moved) * (1.0 + 1e-6) + 1e-6 < (double)my_cert.w;
+            const int kc = (int)(my_cert & 63u);
+            const float Lc = __uint_as_float(my_cert & ~63u);
+            double pc[3] = { 0.0, 0.0, 0.0 };
+            if (Lc > 0.0f) {                                     // the row's position at that search: AC1 with that iteration's transform
+                const double *Th = s_thist[kc];
+                const double x = my_src[0], y = my_src[1], z = my_src[2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) pc[a] = fma(Th[4 * a], x, fma(Th[4 * a + 1], y, fma(Th[4 * a + 2], z, Th[4 * a + 3])));
+            }
+            const double ex = s[0] - pc[0], ey = s[1] - pc[1], ez = s[2] - pc[2];
+            const double moved = sqrt(fma(ez, ez, fma(ey, ey, ex * ex))) * (1.0 + 1e-12);
+            const bool certd = Lc > 0.0f && keeps && (d1 + moved) * (1.0 + 1e-6) + 1e-6 < (double)Lc;
             my_active = (!certd || fuse.cert_check) && row_base + lane <= last;
             my_certd = certd && row_base + lane <= last;
             if (certd && !fuse.cert_check) rb0 = -1.0;
@@ -1293,41 +1310,51 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     phase_tick(tile_visits, 2, bid);
     const unsigned long long t_sweep = tile_visits ? wall_clock64() : 0ull;
     unsigned long long swept = 0ull;
+    int lane_p = 0, wave_p = 0, q_p = 0, j_p = 0;
+    int64_t row_base_p = 0;
+    auto rederive = [&]() {
+        lane_p = opaque_i((int)(threadIdx.x & 63)); wave_p = opaque_i((int)(threadIdx.x >> 6)); q_p = lane_p >> 4; j_p = lane_p & 15;
+        row_base_p = ((int64_t)bid * kIWaves + wave_p) * kLRows;
+    };
     if (act_mask != 0u) {                                 // (a wave whose 16 rows are all certified keeps what it came with)
         wave_lds_fence();                                 // rowd[..][3] is the sweep's own slot from here on
         swept = sweep_wave<true, true>(w, Bs, orig, tile_box, group_box, n_groups, t2max, lists[wave], &gpre);
+        rederive();
         // new keys for the rows that were searched: L^2 = min(final culling bound, runner-up among the multiplied columns), both on d^2
-        if (certs && fuse.cert_check && j == 0) {
+        if (certs && fuse.cert_check && j_p == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rr = q + 4 * r;
-                if (((certd_mask >> rr) & 1u) != 0u && w.bcol[r] != rowi[wave][rr][0]) {
+                const int rr = q_p + 4 * r;
+                if (((certd_mask >> rr) & 1u) != 0u && w.bcol[r] != rowi[wave_p][rr][0]) {
                     if (atomicAdd(&g_cert_check[2], 1ull) == 0ull) {
-                        g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = (unsigned long long)(row_base + rr);
-                        g_cert_check[5] = (unsigned long long)(unsigned)rowi[wave][rr][0]; g_cert_check[6] = (unsigned long long)(unsigned)w.bcol[r];
-                        g_cert_check[7] = (unsigned long long)__float_as_uint(fuse.cert[row_base + rr].w);
+                        g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = (unsigned long long)(row_base_p + rr);
+                        g_cert_check[5] = (unsigned long long)(unsigned)rowi[wave_p][rr][0]; g_cert_check[6] = (unsigned long long)(unsigned)w.bcol[r];
+                        g_cert_check[7] = (unsigned long long)(fuse.cert[row_base_p + rr] & ~63u);
                     }
                 }
             }
         }
-        if (certs && j == 0) {
+        if (certs && j_p == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rr = q + 4 * r;
+                const int rr = q_p + 4 * r;
                 if (((act_mask >> rr) & 1u) != 0u && ((certd_mask >> rr) & 1u) == 0u) {
                     typedef unsigned uu2 __attribute__((ext_vector_type(2)));
                     const uu2 pat = { 0u, w.sec[r] };
                     const double d2nd = w.sec[r] == 0xFFFFFFFFu ? INFINITY : __builtin_bit_cast(double, pat) - 1.0 - w.eps_out;
                     const double l2 = fmin(w.rb_out[r], d2nd);
-                    const double *pr = &rowd[wave][rr][0];
-                    fuse.cert[row_base + rr] = make_float4((float)pr[0], (float)pr[1], (float)pr[2], l2 > 0.0 ? f32_down(sqrt(l2) * (1.0 - 1e-7)) : 0.0f);
+                    // L rounded DOWN to a float with its low six mantissa bits cleared; those bits carry the iteration (k < 64: later iterations
+                    // of a longer chain are searched every time)
+                    const uint32_t lb = l2 > 0.0 && k < kCertHist ? (__float_as_uint(f32_down(sqrt(l2) * (1.0 - 1e-7))) & ~63u) : 0u;
+                    fuse.cert[row_base_p + rr] = lb > 63u ? (lb | (uint32_t)k) : 0u;
                 }
             }
         }
     }
+    if (act_mask == 0u) rederive();
     const unsigned visited = (unsigned)(swept & 0xFFFFu);
-    if (certs && fuse.cert_check && lane == 0) {
-        if (bid == 0 && wave == 0 && g_cert_check[2] == 0ull) {       // no disagreement so far: [3..7] report the chain's state at its last launch
+    if (certs && fuse.cert_check && lane_p == 0) {
+        if (bid == 0 && wave_p == 0 && g_cert_check[2] == 0ull) {       // no disagreement so far: [3..7] report the chain's state at its last launch
             g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = __builtin_bit_cast(unsigned long long, st->last_motion);
             g_cert_check[5] = __builtin_bit_cast(unsigned long long, st->motion); g_cert_check[6] = __builtin_bit_cast(unsigned long long, c_skin);
         }
@@ -1335,48 +1362,52 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         atomicAdd(&g_cert_check[1], (unsigned long long)__builtin_popcount(act_mask & ~certd_mask));
     }
     // (LightSkip speaks for ALL rows of a block: a wave that left certified rows out of its box does not count as light)
-    if (lane == 0) s_light[wave] = act_mask == 0xFFFFu ? w.light_gap2 : -1.0;
-    if (tile_visits && lane == 0 && bid < kStampBlocks && kIWaves <= 4) {
-        unsigned long long *o = g_icp_wave[bid * 4 + wave];
+    if (lane_p == 0) s_light[wave_p] = act_mask == 0xFFFFu ? w.light_gap2 : -1.0;
+    if (tile_visits && lane_p == 0 && bid < kStampBlocks && kIWaves <= 4) {
+        unsigned long long *o = g_icp_wave[bid * 4 + wave_p];
         int with = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) with += (w.bcol[r] >= 0 && w.bcol[r] != INT_MAX) ? 1 : 0;      // lane 0: rows 0, 4, 8, 12 (a sample)
         o[0] = t_sweep; o[1] = wall_clock64(); o[2] = swept; o[3] = (unsigned long long)with;
     }
     phase_tick(tile_visits, 3, bid);
-    if (tile_visits && lane == 0) atomicAdd(tile_visits + ((bid * kIWaves + wave) & (kVisitSlots - 1)), (unsigned long long)visited);
+    if (tile_visits && lane_p == 0) atomicAdd(tile_visits + ((bid * kIWaves + wave_p) & (kVisitSlots - 1)), (unsigned long long)visited);
     wave_lds_fence();
-    if (j == 0) {
+    if (j_p == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rowi[wave][q + 4 * r][0] = w.bcol[r];
+        for (int r = 0; r < 4; ++r) rowi[wave_p][q_p + 4 * r][0] = w.bcol[r];
     }
     wave_lds_fence();
 
     // the chosen pairs: direct distance, contribution to the sums (one row per lane 0..15)
-    if (lane < 16) {
-        const int col = wave * 16 + lane;
+    // (lane / wave numbers re-derived behind an opaque move: the LDS addresses the epilogue needs are then computed HERE instead of being
+    // carried through the sweep -- the kernel sits on its 168-register budget and carried addresses were spilled to scratch memory,
+    // i.e. to HBM traffic)
+    const int lane_e = lane_p, wave_e = wave_p;
+    if (lane_e < 16) {
+        const int col = wave_e * 16 + lane_e;
         for (int a = 0; a < nacc; ++a) sh[a][col] = 0.0;
-        if (row_base + lane <= last) {
-            const int32_t bj = rowi[wave][lane][0];
-            const int64_t i = rowi[wave][lane][1];
+        if (row_base_p + lane_e <= last) {
+            const int32_t bj = rowi[wave_e][lane_e][0];
+            const int64_t i = rowi[wave_e][lane_e][1];
             const bool none = bj < 0 || bj == INT_MAX;
             // Partners in the caller's row order (idx_cur / d2_cur: scattered 4- and 8-byte stores) only where a caller asked for
             // them (kpx_icp with idx / d2 outputs); the sorted-order copies the NEXT launch bounds its rows with only when the
             // partner changed -- in the late iterations of a registration almost no row changes its partner.
             const int32_t out_j = none ? -1 : bj;
-            const int32_t prev_j = __float_as_int(rowk[wave][lane][6]);
+            const int32_t prev_j = __float_as_int(rowk[wave_e][lane_e][6]);
             const bool changed = k == 0 || out_j != prev_j;
             if (idx_cur) idx_cur[i] = out_j;
-            if (changed) idx_sorted[row_base + lane] = out_j;
+            if (changed) idx_sorted[row_base_p + lane_e] = out_j;
             if (none) {
                 if (d2_cur) d2_cur[i] = INFINITY;
             } else {
-                const double s[3] = { rowd[wave][lane][0], rowd[wave][lane][1], rowd[wave][lane][2] };
+                const double s[3] = { rowd[wave_e][lane_e][0], rowd[wave_e][lane_e][1], rowd[wave_e][lane_e][2] };
                 // The partner's coordinates and its normal are gathered through the index only where the partner CHANGED: those of an
                 // unchanged partner came at the launch's start (coordinates with the row: ptgt_sorted; the normal through the previous
                 // index).  In the late iterations whole waves skip this dependent round trip; both parts of a changed partner are
                 // requested together.
-                float tf[3] = { rowk[wave][lane][0], rowk[wave][lane][1], rowk[wave][lane][2] }, nf[3] = { rowk[wave][lane][3], rowk[wave][lane][4], rowk[wave][lane][5] };
+                float tf[3] = { rowk[wave_e][lane_e][0], rowk[wave_e][lane_e][1], rowk[wave_e][lane_e][2] }, nf[3] = { rowk[wave_e][lane_e][3], rowk[wave_e][lane_e][4], rowk[wave_e][lane_e][5] };
                 if (changed) {
                     const float *tp = tgt + 3 * (int64_t)bj;
 #pragma unroll
@@ -1387,7 +1418,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                         for (int c = 0; c < 3; ++c) nf[c] = np_[c];
                     }
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) ptgt_sorted[3 * (row_base + lane) + c] = tf[c]; // the next launch bounds this row with it
+                    for (int c = 0; c < 3; ++c) ptgt_sorted[3 * (row_base_p + lane_e) + c] = tf[c]; // the next launch bounds this row with it
                 }
                 const double t[3] = { (double)tf[0], (double)tf[1], (double)tf[2] };
                 const double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
@@ -1468,6 +1499,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                     LightSkip{ fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max });
     wave_lds_fence();
     if (KPX_ICP_STATE_LDS && lane < (int)(sizeof(IcpState) / sizeof(double))) reinterpret_cast<double *>(stw)[lane] = reinterpret_cast<const double *>(&s_state)[lane];
+    if (fuse.cert && fuse.thist && k + 1 < kCertHist && lane < 12) fuse.thist[12 * (k + 1) + lane] = work->T[lane];     // what iteration k + 1 transforms with
     if (lane == 0 && fuse.progress)
         __hip_atomic_store(fuse.progress, fuse.tag | ((unsigned long long)(work->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1509,7 +1541,8 @@ struct IcpProblem {
     unsigned long long *progress;
     double *light_key;
     const double *sbbox;
-    float4 *cert;
+    uint32_t *cert;
+    double *thist;
     int64_t n;
     uint32_t block0, blocks;
 };
@@ -1537,7 +1570,7 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_I
     // second accumulator set, which only the one-launch form uses)
     const IcpFuse fuse{ split ? (IcpState *)nullptr : P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag,
                         split == 2 ? P.ring + kAccSet : (unsigned long long *)nullptr, (light & 1) ? P.light_key : (double *)nullptr, P.sbbox,
-                        (light & 2) ? P.cert : (float4 *)nullptr, (light & 4) ? 1 : 0, pol };
+                        (light & 2) ? P.cert : (uint32_t *)nullptr, (light & 2) ? P.thist : (double *)nullptr, (light & 4) ? 1 : 0, pol };
     icp_iter_body(bid, P.blocks, P.src, P.n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, P.row_of, P.src_sorted, P.idx_sorted, P.ptgt_sorted,
                   P.idx_cur, P.d2_cur, max_d2, mode, k, P.pair, P.ring, tile_visits, fuse);
 }
@@ -1583,6 +1616,7 @@ __global__ __launch_bounds__(256) void icp_batch_init_kernel(IcpBatchArgs args, 
     if (threadIdx.x == 0) P.light_key[bid] = 0.0;
     if (bid == 0) {
         for (int e = threadIdx.x; e < 3 * kAccSet; e += 256) P.ring[e] = 0ull;
+        if (threadIdx.x >= 64 && threadIdx.x < 76) P.thist[threadIdx.x - 64] = T0.m[pi][threadIdx.x - 64];
         if (threadIdx.x < 32) {
             IcpState *st = P.pair + (threadIdx.x >> 4);
             st->T[threadIdx.x & 15] = T0.m[pi][threadIdx.x & 15];
@@ -1735,7 +1769,8 @@ struct NnBuffers {
     float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates of each row's last partner, same order
     unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
     double *light_key;                                  // per block of the iteration kernel (LightSkip)
-    float4 *cert_sorted;                                // per sorted row: certificate (icp_iter_body)
+    uint32_t *cert_sorted;                              // per sorted row: certificate (icp_iter_body)
+    double *thist;                                      // transforms of the iterations so far (certificates)
     float *tile_box, *group_box;
     SortScratch sort_t, sort_s;
 };
@@ -1777,7 +1812,8 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->ptgt_sorted = a.get<float>(nn * 3);
     b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * 2);      // ring of three sets (icp_iter_kernel, IcpFuse)
     b->light_key = a.get<double>((size_t)cdiv((int64_t)nn, kIRows));
-    b->cert_sorted = a.get<float4>(nn);
+    b->cert_sorted = a.get<uint32_t>(nn);
+    b->thist = a.get<double>((size_t)kCertHist * 12);
     sort_carve(a, n, &b->sort_s);
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
@@ -1832,7 +1868,7 @@ static void icp_fused_launch(const float *src, const float *tgt, const float *tn
                              int k, int max_iter, double rel_fit, double rel_rmse, double *d_result, hipStream_t st,
                              unsigned long long *progress, unsigned long long tag)
 {
-    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag, nullptr, nullptr, nullptr, nullptr, 0, CertPolicy{ 0.0f, 0.0f, 0.0f, 0.0f } };
+    const IcpFuse fuse{ b.state, b.acc_fixed, max_iter, rel_fit, rel_rmse, d_result, progress, tag, nullptr, nullptr, nullptr, nullptr, nullptr, 0, CertPolicy{ 0.0f, 0.0f, 0.0f, 0.0f } };
     const unsigned blocks = k > max_iter ? 1u : (unsigned)cdiv(p.n_src, kIRows);
     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, st);
     hipLaunchKernelGGL(icp_iter_kernel, dim3(blocks), dim3(kIThreads), 0, st, src, p.n_src, tgt, tn, b.Bs, b.orig_t, b.tile_box, b.group_box,
@@ -2299,7 +2335,7 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                 P.ptgt_sorted = bufs[i].ptgt_sorted; P.pair = bufs[i].state;
                 P.idx_cur = nullptr; P.d2_cur = nullptr;          // a batch reports transforms, not correspondence lists
                 P.ring = bufs[i].acc_fixed; P.result = d_results + 20 * i; P.progress = &h_progress[i]; P.n = h_n_src[i];
-                P.light_key = bufs[i].light_key; P.sbbox = bufs[i].sort_s.bbox; P.cert = bufs[i].cert_sorted;
+                P.light_key = bufs[i].light_key; P.sbbox = bufs[i].sort_s.bbox; P.cert = bufs[i].cert_sorted; P.thist = bufs[i].thist;
                 P.block0 = b0; P.blocks = (unsigned)cdiv(h_n_src[i], kIRows);
                 Ac[g].p[c] = P;
                 Ac[g].p[c].block0 = (unsigned)c; Ac[g].p[c].blocks = 1u;

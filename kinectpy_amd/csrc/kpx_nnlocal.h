@@ -294,6 +294,9 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
     const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int32_t *list = scr, *cand = scr + kLList, *surv = scr + kLList + 7 * kLCand;
+    // records of the lane's four rows q, q + 4, q + 8, q + 12: ONE base each, the rows at constant offsets (immediates of the ds instructions)
+    double *const rowq = w.rows + kRowStride * q;
+    float *const rowfq = w.rowsf + kRowFStride * q;
     constexpr double kRel = 1.0 + 9.31322574615478515625e-10;      // 1 + 2^-30
     double slo[3], shi[3];
     {
@@ -340,8 +343,8 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         if (j == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                w.rows[kRowStride * (q + 4 * r) + kRowBound] = rbv[r];
-                w.rowsf[kRowFStride * (q + 4 * r) + kRowFBound] = f32_up(rbv[r]);
+                rowq[4 * kRowStride * r + kRowBound] = rbv[r];
+                rowfq[4 * kRowFStride * r + kRowFBound] = f32_up(rbv[r]);
             }
         }
     };
@@ -418,12 +421,12 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         };
         if (updated) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gain |= next_bound(r) < kTightenGain * (double)w.rowsf[kRowFStride * (q + 4 * r) + kRowFBound];
+            for (int r = 0; r < 4; ++r) gain |= next_bound(r) < kTightenGain * (double)rowfq[4 * kRowFStride * r + kRowFBound];
         }
         if (updated && __builtin_amdgcn_ballot_w64(gain) != 0) {
             double nrb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) nrb[r] = fmin(w.rows[kRowStride * (q + 4 * r) + kRowBound], row16_all_min(next_bound(r)) * kRel + eps);
+            for (int r = 0; r < 4; ++r) nrb[r] = fmin(rowq[4 * kRowStride * r + kRowBound], row16_all_min(next_bound(r)) * kRel + eps);
             R2 = quad_uniform_max(fmax(fmax(nrb[0], nrb[1]), fmax(nrb[2], nrb[3])));
             wave_lds_fence();                                  // every lane has read the old bounds
             publish_bounds(nrb);
@@ -524,7 +527,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
                 gid = cand[7 * j + 6];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float *pr = w.rowsf + kRowFStride * (q + 4 * r);
+                    const float *pr = rowfq + 4 * kRowFStride * r;
                     float f[7];
 #pragma unroll
                     for (int e = 0; e < 7; ++e) f[e] = pr[e];
@@ -590,7 +593,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
     if (CERT) {
         wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w.rb_out[r] = w.rows[kRowStride * (q + 4 * r) + kRowBound];
+        for (int r = 0; r < 4; ++r) w.rb_out[r] = rowq[4 * kRowStride * r + kRowBound];
         w.eps_out = eps;
     }
 #undef KPX_NNL_ROWMIN

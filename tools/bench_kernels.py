@@ -82,8 +82,13 @@ def main():
     ms, out = timed(lambda: ops.transform(big, T, out=big))
     report("transform (a17)", ms, n_big * 24, points=n_big)
     idx = torch.randperm(n_big, device=dev)[: n_big // 2].to(torch.int32).sort().values
+    # (two rows: bench.py's roofline_targets times the gather alone -- an index list the caller vouches for, `trusted=True`; the default
+    # call first validates the list on the device, Open3D's SelectByIndex semantics for arbitrary lists: range check, duplicates, order --
+    # which is the 0.07-of-peak figure profiles/r03/kernels.json showed beside bench.py's 0.45)
+    ms, _ = timed(lambda: ops.select_by_index([big], idx, trusted=True))
+    report("select_by_index gather (trusted ascending list: what bench.py times)", ms, n_big // 2 * (12 + 12 + 4), points=n_big // 2)
     ms, _ = timed(lambda: ops.select_by_index([big], idx))
-    report("select_by_index gather", ms, n_big // 2 * (12 + 12 + 4), points=n_big // 2)
+    report("select_by_index with the list validated on the device (the default call)", ms, n_big // 2 * (12 + 12 + 4), points=n_big // 2)
     ms, hs = timed(lambda: ops.halfspace_select(big, [0.1, -0.9, 0.2, 300.0]))
     report("halfspace_select (a19)", ms, n_big * 12 + int(hs.shape[0]) * 4, points=n_big)
     ms, (lo_, up_) = timed(lambda: ops.slab_split(big, 200.0))

@@ -7,7 +7,7 @@ ROOT=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 Q="--no-targets --cpu-budget-s 0 --spread-blocks 0"
-timeout -k 10 400 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+timeout -k 10 500 python3 bench.py --workload reference-stream > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 KPX_NN_ENGINE=dense timeout -k 10 300 python3 bench.py $Q > "$OUT/bench_n1_dense_engine.json" 2>> "$OUT/bench_n1.err"
 timeout -k 10 300 python3 bench.py $Q --overlap 1 > "$OUT/bench_n1_overlap1.json" 2>> "$OUT/bench_n1.err"
 timeout -k 10 300 python3 tools/bench_kernels.py > "$OUT/kernels.json" 2>> "$OUT/bench_n1.err"
