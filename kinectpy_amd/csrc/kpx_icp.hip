@@ -58,7 +58,10 @@ constexpr int kCT = 32;                      // 16-column tiles per LDS stage (1
 constexpr int kChunk = KPX_NN_CHUNK;         // column tiles per fast-pass chunk of the dense sweep (nn_mfma_kernel)
 constexpr int kStageDoubles = kCT * 64;
 #ifndef KPX_SEED_STRIDE
-#define KPX_SEED_STRIDE 16                  // measured 100k x 100k, whole bare search (seed + main sweep): 64 -> 2.60 ms, 16 -> 2.48, 8 -> 2.66
+#define KPX_SEED_STRIDE 128                 // round 4, operands in curve order, seed = every n-th POINT of the curve: whole bare search 100k x 100k at
+                                            // 8 / 16 / 32 / 64 / 128 / 256 -> 0.42 / 0.47 / 0.49 / 0.51 / 0.515 / 0.52 of the fp64 matrix peak (the
+                                            // main sweep no longer cares how loose the bound is: a row reaches only the chunks around it).
+                                            // Until round 3 (operands in the caller's order, every n-th TILE): 64 -> 2.60 ms, 16 -> 2.48, 8 -> 2.66
 #endif
 constexpr int kSeedStride = KPX_SEED_STRIDE;  // the seed sweep visits every kSeedStride-th target tile
 constexpr double kSentinel = 1e300;
@@ -93,21 +96,29 @@ __device__ __forceinline__ unsigned hi32(double v) { return __builtin_bit_cast(u
 
 // ---- target preparation: B tiles, element (k, j) of tile t at B[t*64 + k*16 + j]; Bseed = every 64th tile --
 __global__ __launch_bounds__(256) void nn_prep_kernel(const float *__restrict__ tgt, int64_t m, int64_t tiles_pad, double *__restrict__ B,
-                                                      int64_t seed_tiles_pad, double *__restrict__ Bseed)
+                                                      int64_t seed_tiles_pad, double *__restrict__ Bseed, const int32_t *__restrict__ perm,
+                                                      int32_t *__restrict__ colB, int32_t *__restrict__ colSeed)
 {
+    // perm (round 4): the columns stand in the target's CURVE order (perm[slot] = the caller's index of the point in column `slot`), so
+    // that the 64 columns of a chunk are neighbours in space and a row's bound -- however loose -- reaches few chunks; colB / colSeed carry
+    // every column's ORIGINAL index (INT_MAX in the padding): the sweep reports, and breaks ties by, those.
     const int64_t total = (tiles_pad + seed_tiles_pad) * 16;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
         const bool seed = q >= tiles_pad * 16;
         const int64_t jj = seed ? q - tiles_pad * 16 : q;                 // column slot inside its operand array
-        const int64_t j = seed ? (jj >> 4) * kSeedStride * 16 + (jj & 15) : jj;   // target index it stands for
+        const int64_t j = seed ? jj * kSeedStride : jj;                    // (curve-ordered) target slot it stands for: the seed operand is every
+                                                                            // kSeedStride-th POINT of the curve, a spatially uniform sample
         double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = kSentinel;
+        int32_t oj = INT_MAX;
         if (j < m) {
-            double tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
+            oj = perm ? perm[j] : (int32_t)j;
+            double tx = tgt[3 * (int64_t)oj], ty = tgt[3 * (int64_t)oj + 1], tz = tgt[3 * (int64_t)oj + 2];
             b0 = -2.0 * tx; b1 = -2.0 * ty; b2 = -2.0 * tz;
             b3 = fma(tx, tx, fma(ty, ty, tz * tz));
         }
         double *o = (seed ? Bseed : B) + (jj >> 4) * 64 + (jj & 15);
         o[0] = b0; o[16] = b1; o[32] = b2; o[48] = b3;
+        (seed ? colSeed : colB)[jj] = oj;
     }
 }
 
@@ -345,21 +356,24 @@ __global__ __launch_bounds__(256) void nn_overflow_kernel(const float *__restric
 }
 
 // ---- the MFMA nearest-neighbour sweep ------------------------------------------------------------------
-// tile_stride: 1 for the full operand, kSeedStride for the seed operand (column = tile * tile_stride * 16 + lane&15)
+// colid: the ORIGINAL target index of every column of B (the full operand or the seed operand: every kSeedStride-th tile), staged in LDS beside the tiles
 // FAST: the rows arrive with TIGHT bounds (the previous partner under the new transform: every ICP iteration after the first) -- the
 // stage is swept in chunks whose hot loop is MFMAs + one v_min_u32 per result register, and a chunk is swept again the exact way
 // only when some row's smallest high word reaches its bound (measured 100k x 100k: 50.6 TFLOP/s for the hot loop alone = 0.64 of the
 // 78.6 vendor peak, the instruction's measured issue ceiling; the per-trip prefilter form runs at 31).  !FAST: loose bounds (seed
 // sweep, first search) -- nearly every chunk would be swept twice, so every trip is examined behind the prefilter as it comes.
 template <bool FAST>
-__global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double *__restrict__ B, int32_t tiles_per_split,
-                                                         int32_t tile_stride, const int32_t *__restrict__ done,
+__global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double *__restrict__ B, const int32_t *__restrict__ colid, int32_t tiles_per_split,
+                                                         const int32_t *__restrict__ done,
                                                          const double *__restrict__ A64, const double *__restrict__ K64,
                                                          const double *__restrict__ init_val, const int32_t *__restrict__ init_idx,
-                                                         double *__restrict__ part_val, int32_t *__restrict__ part_idx)
+                                                         double *__restrict__ part_val, int32_t *__restrict__ part_idx, const int32_t *__restrict__ rperm)
 {
+    // rperm (round 4): block row r is the caller's row rperm[r] -- the source's curve order, so that the 32 rows of a wave are neighbours
+    // in space and reach the SAME few chunks of the (curve-ordered) columns; operands and results stay indexed by the caller's row
     if (done && *done) return;
     __shared__ __align__(16) double lds[2][kStageDoubles];
+    __shared__ __align__(16) int32_t lds_col[2][kCT * 16];           // the stage's ORIGINAL column indices (the operand stands in curve order)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row_base = (int64_t)blockIdx.x * kRowsPerBlock + (int64_t)wave * (kRT * 16);
     const int split = blockIdx.y;
@@ -371,7 +385,7 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) {
         const int64_t row = row_base + rt * 16 + (lane & 15);
-        a[rt] = row < n ? A64[row * 4 + (lane >> 4)] : 0.0;
+        a[rt] = row < n ? A64[(int64_t)(rperm ? rperm[row] : row) * 4 + (lane >> 4)] : 0.0;
     }
     // C operands (row seeds K_i), running best and its column: D layout row = (lane>>4) + 4*reg
     d4 seed[kRT];
@@ -385,14 +399,16 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
             double kk = 1.0, bv = INFINITY;
             int32_t bj = INT_MAX;
             if (row < n) {
-                kk = K64[row];
-                if (init_val) { bv = init_val[row]; bj = init_idx[row]; }
+                const int64_t ri = rperm ? rperm[row] : row;
+                kk = K64[ri];
+                if (init_val) { bv = init_val[ri]; bj = init_idx[ri]; }
             }
             seed[rt][r] = kk; best[rt][r] = bv; bcol[rt][r] = bj;
         }
 
     // B stream: global -> LDS by LDS-DMA (1 KiB per wave-instruction, 16 pieces per 16 KiB stage)
     const double *gB = B + t0 * 64;
+    const int32_t *gC = colid + t0 * 16;
     auto stage_load = [&](int stage, int buf) {
         const double *g = gB + (int64_t)stage * kStageDoubles;
 #pragma unroll
@@ -401,6 +417,10 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + piece * 128 + lane * 2),
                                              (__attribute__((address_space(3))) void *)(&lds[buf][piece * 128]), 16, 0, 0);
         }
+        // 512 column ids = 2 KiB: waves 0 and 1, one 16-byte piece per lane
+        if (wave < 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gC + (int64_t)stage * (kCT * 16) + wave * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(&lds_col[buf][wave * 256]), 16, 0, 0);
     };
     stage_load(0, 0);
     __syncthreads();
@@ -409,7 +429,6 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
         const int buf = st & 1;
         if (st + 1 < nstages) stage_load(st + 1, buf ^ 1);
         const double *lb = lds[buf] + lane;
-        const int32_t tile0 = (int32_t)t0 + st * kCT;
         // One trip = two column tiles x two row tiles = four MFMAs; examine() looks at a trip's 16 result registers: prefilter on the
         // high words (D > 0: the unsigned order of the bit patterns is the numeric order), exact (value, column) update only when
         // some lane passes (wave-uniform, rare once the bound is tight).
@@ -421,8 +440,7 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
                 pass |= (bool)((int)(min(hi32(c00[r]), hi32(c01[r])) <= h0) | (int)(min(hi32(c10[r]), hi32(c11[r])) <= h1));
             }
             if (__builtin_amdgcn_ballot_w64(pass) == 0) return;
-            const int32_t col0 = (tile0 + ct) * tile_stride * 16 + (lane & 15);
-            const int32_t col1 = col0 + tile_stride * 16;
+            const int32_t col0 = lds_col[buf][ct * 16 + (lane & 15)], col1 = lds_col[buf][ct * 16 + 16 + (lane & 15)];
             bool anyeq = false;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -521,8 +539,9 @@ __global__ __launch_bounds__(256, 4) void nn_mfma_kernel(int64_t n, const double
             }
             int64_t row = row_base + rt * 16 + (lane >> 4) + 4 * r;
             if ((lane & 15) == 0 && row < n) {
-                part_val[(int64_t)split * n + row] = v;
-                part_idx[(int64_t)split * n + row] = c;
+                const int64_t ri = rperm ? rperm[row] : row;
+                part_val[(int64_t)split * n + ri] = v;
+                part_idx[(int64_t)split * n + ri] = c;
             }
         }
 }
@@ -1761,6 +1780,7 @@ struct NnBuffers {
     float *Bf, *A32, *thr32;
     NnAux *aux;
     int32_t *part_idx, *init_idx, *idx_cur, *cand_cnt, *cand, *overflow;
+    int32_t *colB, *colSeed;                            // dense engine: original index of every column of B / Bseed (curve-ordered operand)
     IcpState *state;
     double *T0;
     // culled sweep
@@ -1783,6 +1803,8 @@ static void nn_carve_target(Arena &a, const NnPlan &p, NnBuffers *b)
     sort_carve(a, p.n_tgt, &b->sort_t);
     b->B = a.get<double>((size_t)p.tiles_pad * 64);
     b->Bseed = a.get<double>((size_t)p.seed_tiles_pad * 64);
+    b->colB = a.get<int32_t>((size_t)p.tiles_pad * 16);
+    b->colSeed = a.get<int32_t>((size_t)p.seed_tiles_pad * 16);
     b->Bf = a.get<float>((size_t)p.f_tiles_pad * 64);
     b->aux = a.get<NnAux>(1);
     b->tbbox = a.get<double>((size_t)kBboxBlocks * 6 + 8);
@@ -1837,9 +1859,14 @@ static __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__
     out[3 * r] = src[3 * i]; out[3 * r + 1] = src[3 * i + 1]; out[3 * r + 2] = src[3 * i + 2];
 }
 // ordered: b.row_of already holds the Morton order (morton_order_batch)
+static bool dense_sort_on()
+{
+    static const bool on = [] { const char *e = getenv("KPX_NN_DENSE_SORT"); return !(e && e[0] == '0'); }();      // A/B switch: the all-pairs operands in curve order
+    return on;
+}
 static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b, hipStream_t st, bool ordered = false)
 {
-    if (!local_engine()) return KPX_OK;
+    if (!local_engine()) return dense_sort_on() ? morton_order(src, p.n_src, b.sort_s, b.row_of, st) : KPX_OK;
     KPX_HIP(hipMemsetAsync(b.acc_fixed, 0, (size_t)3 * kAccCopies * kAcc * 2 * sizeof(unsigned long long), st));
     int rc = ordered ? KPX_OK : morton_order(src, p.n_src, b.sort_s, b.row_of, st);
     if (rc) return rc;
@@ -1886,9 +1913,15 @@ static int nn_prep(const float *tgt, const NnPlan &p, const NnBuffers &b, hipStr
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
+    // the all-pairs operand in the target's curve order (KPX_NN_DENSE_SORT=0: in the caller's order, as until round 3)
+    const bool dense_sort = dense_sort_on();
+    if (dense_sort) {
+        int rc = morton_order(tgt, p.n_tgt, b.sort_t, b.orig_t, st);
+        if (rc) return rc;
+    }
     int64_t work = (p.tiles_pad + p.seed_tiles_pad) * 16;
     hipLaunchKernelGGL(nn_prep_kernel, dim3((unsigned)(cdiv(work, 256) > 2048 ? 2048 : cdiv(work, 256))), dim3(256), 0, st, tgt,
-                       p.n_tgt, p.tiles_pad, b.B, p.seed_tiles_pad, b.Bseed);
+                       p.n_tgt, p.tiles_pad, b.B, p.seed_tiles_pad, b.Bseed, dense_sort ? b.orig_t : (const int32_t *)nullptr, b.colB, b.colSeed);
     {   // float32 screening operand: centre + radius from the target's bounding box
         double *bbox = b.tbbox + (size_t)kBboxBlocks * 6;
         int rc = bbox_f32(tgt, p.n_tgt, bbox, b.tbbox, st);
@@ -1943,25 +1976,28 @@ static int nn_search_launch(const float *src, const float *tgt, const float *tn,
         KPX_LAUNCH_CHECK();
         return KPX_OK;
     }
+    const int32_t *rperm = dense_sort_on() ? b.row_of : (const int32_t *)nullptr;     // (nn_prep_source ordered the rows)
     {
     // (timed as ONE unit: a bare search's seed sweep + its merge belong to the all-pairs sweep they make cheaper -- with bounds from
     // every 16th tile the main sweep alone runs at 38 TFLOP/s, from every 64th at 33, but the seed sweep costs what it saves beyond that)
     ProfScope prof(KPX_PROF_NN_MFMA, 8.0 * (double)p.n_src * (double)p.n_tgt, st);     // 4 MAC per (source, target) pair
     if (!have_prev) {
-        hipLaunchKernelGGL(nn_mfma_kernel<false>, dim3(p.row_blocks, 1), thr, 0, st, n, b.Bseed, (int32_t)p.seed_tiles_pad, (int32_t)kSeedStride,
-                           done, b.A64, b.K64, (const double *)nullptr, (const int32_t *)nullptr, b.part_val, b.part_idx);
+        hipLaunchKernelGGL(nn_mfma_kernel<false>, dim3(p.row_blocks, 1), thr, 0, st, n, b.Bseed, b.colSeed, (int32_t)p.seed_tiles_pad,
+                           done, b.A64, b.K64, (const double *)nullptr, (const int32_t *)nullptr, b.part_val, b.part_idx, rperm);
         hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx, 1,
                            0.0, -2, b.init_idx, (double *)nullptr, b.init_val, b.part_acc, (const int32_t *)nullptr, (const int32_t *)nullptr,
                            ColorTerms{});
     }
     static const int fast_env = [] { const char *e = getenv("KPX_NN_FAST"); return e ? atoi(e) : -1; }();     // A/B switch: 0 / 1 force a form
-    const bool fast = fast_env >= 0 ? fast_env != 0 : have_prev;
+    // (with the operands in curve order the per-trip form wins in both cases: its prefilter rarely passes, and the chunked form's
+    // bookkeeping is then pure overhead -- 0.545 vs 0.532 of the matrix peak warm, 0.458 vs 0.453 cold)
+    const bool fast = fast_env >= 0 ? fast_env != 0 : (have_prev && !dense_sort_on());
     if (fast)
-        hipLaunchKernelGGL(nn_mfma_kernel<true>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
-                           b.init_val, b.init_idx, b.part_val, b.part_idx);
+        hipLaunchKernelGGL(nn_mfma_kernel<true>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, b.colB, p.tiles_per_split, done, b.A64, b.K64,
+                           b.init_val, b.init_idx, b.part_val, b.part_idx, rperm);
     else
-        hipLaunchKernelGGL(nn_mfma_kernel<false>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, p.tiles_per_split, 1, done, b.A64, b.K64,
-                           b.init_val, b.init_idx, b.part_val, b.part_idx);
+        hipLaunchKernelGGL(nn_mfma_kernel<false>, dim3(p.row_blocks, p.splits), thr, 0, st, n, b.B, b.colB, p.tiles_per_split, done, b.A64, b.K64,
+                           b.init_val, b.init_idx, b.part_val, b.part_idx, rperm);
     }
     hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)cdiv(n, kMergeThreads)), dim3(kMergeThreads), 0, st, src, n, tgt, tn, T, done, b.part_val, b.part_idx,
                        p.splits, max_d2, mode, b.idx_cur, b.d2_cur, (double *)nullptr, b.part_acc, (const int32_t *)nullptr,
@@ -2238,7 +2274,7 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
     }
     nn_carve_target(a, tplan, &bufs[0]);
     for (int i = 0; i < count; ++i) {
-        bufs[i].B = bufs[0].B; bufs[i].Bseed = bufs[0].Bseed; bufs[i].Bf = bufs[0].Bf; bufs[i].aux = bufs[0].aux;
+        bufs[i].B = bufs[0].B; bufs[i].Bseed = bufs[0].Bseed; bufs[i].colB = bufs[0].colB; bufs[i].colSeed = bufs[0].colSeed; bufs[i].Bf = bufs[0].Bf; bufs[i].aux = bufs[0].aux;
         bufs[i].tbbox = bufs[0].tbbox;
         bufs[i].Bs = bufs[0].Bs; bufs[i].orig_t = bufs[0].orig_t; bufs[i].tile_box = bufs[0].tile_box; bufs[i].group_box = bufs[0].group_box;
         bufs[i].sort_t = bufs[0].sort_t;
