@@ -107,6 +107,7 @@ SIGNATURES = {
     "kpx_prof_icp_phases": (C.c_int, [_vp]),
     "kpx_prof_icp_waves": (C.c_int, [_vp, C.c_int64, _vp]),
     "kpx_prof_icp_cert": (C.c_int, [_vp]),
+    "kpx_prof_icp_chain": (C.c_int, [_vp]),
     "kpx_prof_end": (C.c_int, [_vp, _vp, _vp]),
 }
 

@@ -22,6 +22,7 @@
 // and accumulates the sums the update needs.  The ICP loop runs on the device; a small kernel solves the
 // 3x3 (Kabsch) or 6x6 (point-to-plane) system, updates T and raises `done`.
 #include <chrono>
+#include <mutex>
 #include <limits.h>
 #include <stddef.h>
 #include <time.h>
@@ -888,6 +889,15 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
     }
 }
 
+// The same behind a CALL (icp_chain_kernel): inlined into that kernel's loop, the literal constants of cos / sin / sqrt are hoisted
+// out of the loop into registers the kernel does not have, and spilled around every sweep
+__device__ __attribute__((noinline)) void icp_finish_wave_call(const double *acc, int64_t n, int mode, int k, int max_iter, double rel_fit, double rel_rmse,
+                                                               IcpState *st, double *result, FinishScratch *fs, int lane, const double *sbbox, double max_d2,
+                                                               double t2max)
+{
+    icp_finish_wave(acc, n, mode, k, max_iter, rel_fit, rel_rmse, st, result, *fs, lane, LightSkip{ sbbox, max_d2, t2max });
+}
+
 // 1024 threads: thread (slot q = t & 63, slice = t >> 6) sums its slice of the per-block partials with eight
 // interleaved accumulators (lanes of a wave read consecutive slots of one partial row: coalesced; a row-per-thread
 // variant was 3x slower, the single CU's address path saturates), the sixteen slices are then added in order (a
@@ -1073,6 +1083,15 @@ constexpr int kIRows = kIWaves * kLRows;
 // (launch k reads set k-1, adds to set k, block 0 clears set k+1) and two state slots (launch k reads slot k-1, writes
 // slot k) keep the launches free of races.  pair == nullptr: two-kernel mode, icp_solve_fixed_kernel does the update.
 constexpr int kCertHist = 64;                 // iterations whose transforms are kept for the certificates (6 bits of the word)
+// The whole chain in ONE launch (icp_chain_kernel): the blocks of a registration stay resident and iterate; the hand-off between
+// iterations is a RECORD per iteration -- the registration's state as the update of iteration k - 1 left it -- whose 23 words the
+// winner (the block that drew the last ticket) writes with device-coherent stores and wave 0 of every block polls with
+// device-coherent loads, each lane ITS word, until none of them is the "empty" pattern any more (a NaN payload no computation
+// produces): every word validates itself, so there is no flag, no release and no second round trip.
+constexpr int kChainRec = 32;                 // doubles per record (23 used)
+constexpr int kChainRecords = 64;             // records 0 .. max_iteration + 1: the chain form serves max_iteration <= 62
+constexpr int kChainWords = 23;                // = sizeof(IcpState) / 8
+constexpr unsigned long long kChainEmpty = 0xFFF8C0DEC0DEC0DEull;
 struct CertPolicy {
     float calm, factor, smin, smax;      // KPX_CERT_CALM / _FACTOR / _SKIN_MIN / _SKIN_MAX (fractions of the correspondence distance)
 };
@@ -1091,6 +1110,8 @@ struct IcpFuse {
     double *thist;                     // with cert: the transforms of iterations 0 .. 63, 12 doubles each (the winner writes entry k + 1)
     int cert_check;                    // self-check mode: certified rows are searched anyway and compared (g_cert_check)
     CertPolicy pol;
+    double *chain_rec;                 // icp_iter_body<true> only: the registration's records (kChainRecords x kChainRec doubles)
+    unsigned long long *stamp;         // icp_iter_body<true>, KPX_ICP_CHAIN_STAMPS=1: this iteration's row of g_chain_stamp
 };
 constexpr int kAccSet = kAccCopies * kAcc * 2;
 // Phase clock of the iteration kernel (while the profiler is armed): thread 0 of every block stores 100 MHz wall-clock stamps in
@@ -1106,6 +1127,14 @@ __device__ unsigned long long g_icp_wave[kStampBlocks * 4][4];
 // partner the certificate kept.  [0] rows certified, [1] rows searched, [2] certified rows whose search disagreed, [3..7] the first
 // disagreement: iteration, sorted row, kept partner, found partner, key as float bits.  Read (and cleared) by kpx_prof_icp_cert.
 __device__ unsigned long long g_cert_check[8];
+// Clock of the one-launch chain (KPX_ICP_CHAIN_STAMPS=1, first registration of the launch; 100 MHz stamps, one row per iteration):
+// block 0: [0] record seen, [1] rows prepared, [2] sweep over, [3] sums added, [4] ticket drawn; over all blocks: [5] latest / [10]
+// earliest "record seen", [11] latest "sums added", [6] latest ticket; the winner: [7] totals read, [8] update done, [9] record published.
+__device__ unsigned long long g_chain_stamp[64][16];
+__device__ __forceinline__ void chain_tick(unsigned long long *row, int slot, bool on)
+{
+    if (row && on) row[slot] = wall_clock64();
+}
 __device__ __forceinline__ void phase_tick(unsigned long long *__restrict__ armed, int slot, unsigned bid)
 {
     if (!armed || threadIdx.x || bid >= kStampBlocks) return;
@@ -1127,6 +1156,7 @@ __device__ __forceinline__ void phase_tick(unsigned long long *__restrict__ arme
 // bit.  The policy is CertPolicy, above IcpFuse.  (KPX_ICP_CERT=0 switches the certificates off: test_icp_update_placements_and_light_skip_are_bit_identical; KPX_ICP_CERT_CHECK=1
 // searches the certified rows all the same and counts disagreements: test_icp_certificates_never_contradict_the_search).
 // bid / nblocks: this block's index among the blocks of ITS registration (one launch may carry several, see icp_iter_batch_kernel)
+template <bool PERSIST = false>
 __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned nblocks, const float *__restrict__ src, int64_t n, const float *__restrict__ tgt,
                                                        const float *__restrict__ tn, const double *__restrict__ Bs,
                                                        const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
@@ -1138,12 +1168,24 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                                                        int k, const IcpState *__restrict__ st, unsigned long long *acc,
                                                        unsigned long long *__restrict__ tile_visits, IcpFuse fuse)
 {
+    // (chain form: the thread number behind an opaque move, taken anew in every iteration -- otherwise everything derived from it,
+    // LDS addresses first of all, is hoisted out of the chain's loop and held in registers this kernel does not have)
+    const unsigned tix = PERSIST ? (unsigned)opaque_i((int)threadIdx.x) : threadIdx.x;
     __shared__ IcpState s_state;
     __shared__ double s_sums[kAcc];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    // PERSIST (icp_chain_kernel: this body runs once per iteration inside ONE launch, `st` is the block's LDS copy of the iteration's
+    // record): what a row carries from one iteration to the next -- its coordinates, its partner (index, coordinates, normal), its
+    // certificate, the block's LightSkip key -- stays in LDS; nothing but constants is read from memory after iteration 0.
+    __shared__ float rowk[kIWaves][16][8];           // what a row carries across the sweep (its previous partner: coordinates, normal, index),
+                                                     // parked here: a value in 16 lanes costs a whole register through the multiply loop
+    __shared__ float rowsrc[kIWaves][16][3];
+    __shared__ uint32_t rowc[kIWaves][16];
+    __shared__ int32_t rowi[kIWaves][16][2];         // partner (bound / result), original row
+    __shared__ double s_key;
+    const int wave = PERSIST ? __builtin_amdgcn_readfirstlane((int)(tix >> 6)) : (int)(tix >> 6), lane = tix & 63, q = lane >> 4, j = lane & 15;
     const int64_t row_base = ((int64_t)bid * kIWaves + wave) * kLRows;
     const int64_t last = n - 1;
-    const unsigned long long t_block_start = (tile_visits && threadIdx.x == 0) ? wall_clock64() : 0ull;
+    const unsigned long long t_block_start = (tile_visits && tix == 0) ? wall_clock64() : 0ull;
     const double t2max = target_t2max(tbbox);
     // An iteration is a chain of dependent memory round trips, so everything that does not depend on this iteration's
     // transform is requested FIRST -- the wave's rows, their previous partners (index AND coordinates, kept in sorted-row
@@ -1153,11 +1195,24 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     int32_t my_row = 0, my_prev = -1;
     uint32_t my_cert = 0u;
     const bool certs = fuse.ticket && fuse.light_key && fuse.cert;
-    if (lane < 16) {
+    if (PERSIST && k > 0) {
+        if (lane < 16) {
+            my_row = rowi[wave][lane][1];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { my_src[a] = rowsrc[wave][lane][a]; my_pt[a] = rowk[wave][lane][a]; my_nrm[a] = rowk[wave][lane][3 + a]; }
+            my_prev = __float_as_int(rowk[wave][lane][6]);
+            if (certs) my_cert = rowc[wave][lane];
+        }
+    } else if (lane < 16) {
         const int64_t r = row_base + lane < last ? row_base + lane : last;
         if (idx_cur || d2_cur) my_row = row_of[r];           // only the caller-order outputs need the original row number
 #pragma unroll
         for (int a = 0; a < 3; ++a) my_src[a] = src_sorted[3 * r + a];
+        if (PERSIST) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) rowsrc[wave][lane][a] = my_src[a];
+            rowc[wave][lane] = 0u;
+        }
         if (k > 0) {
             my_prev = idx_sorted[r];
 #pragma unroll
@@ -1167,11 +1222,13 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     }
     // (certificates) the transforms of the iterations so far: a certified row's position at its search is recomputed from them, exactly
     __shared__ double s_thist[kCertHist][12];
-    if (certs && k > 0)
-        for (int e = threadIdx.x; e < 12 * (k < kCertHist ? k : kCertHist); e += kIThreads) (&s_thist[0][0])[e] = fuse.thist[e];
+    if (PERSIST) {                                        // (the earlier entries are still there; a barrier follows before the rows use them)
+        if (certs && k < kCertHist && tix < 12) s_thist[k][tix] = st->T[tix];
+    } else if (certs && k > 0)
+        for (int e = tix; e < 12 * (k < kCertHist ? k : kCertHist); e += kIThreads) (&s_thist[0][0])[e] = fuse.thist[e];
     GroupPre gpre;
     group_pre_load(gpre, group_box, n_groups, lane);
-    if (mode == 1 && k > 0 && lane < 16) {
+    if (!PERSIST && mode == 1 && k > 0 && lane < 16) {
         // the previous partner's normal, requested through the index as soon as that has arrived (behind everything that does not
         // depend on anything): it is not needed before the pair epilogue, where an unchanged partner -- the rule in the late
         // iterations -- then costs no round trip at all
@@ -1184,18 +1241,18 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // update step on this copy -- fitness / rmse / T / motion were four dependent global round trips inside a step that every launch waits
     // for -- and writes the new state back in one burst
     static_assert(sizeof(IcpState) % sizeof(double) == 0, "IcpState is copied as doubles");
-    if (KPX_ICP_STATE_LDS && fuse.ticket && threadIdx.x < sizeof(IcpState) / sizeof(double))
-        reinterpret_cast<double *>(&s_state)[threadIdx.x] = reinterpret_cast<const double *>(st)[threadIdx.x];
+    if (KPX_ICP_STATE_LDS && fuse.ticket && tix < sizeof(IcpState) / sizeof(double))
+        reinterpret_cast<double *>(&s_state)[tix] = reinterpret_cast<const double *>(st)[tix];
     if (fuse.pair) {
         const IcpState *in = fuse.pair + ((k + 1) & 1);
         IcpState *out = fuse.pair + (k & 1);
         // state and accumulators are read in ONE round trip (the sums of a converged chain are simply not used)
         const unsigned long long *prev = fuse.ring + (int64_t)((k + 2) % 3) * kAccSet;
-        if (k > 0 && threadIdx.x < kAcc) s_sums[threadIdx.x] = (int)threadIdx.x < (mode == 1 ? kAcc : 17) ? fixed_total(prev, threadIdx.x) : 0.0;
-        if (threadIdx.x == 0) s_state = *in;
+        if (k > 0 && tix < kAcc) s_sums[tix] = (int)tix < (mode == 1 ? kAcc : 17) ? fixed_total(prev, tix) : 0.0;
+        if (tix == 0) s_state = *in;
         __syncthreads();
         if (s_state.done) {                               // converged earlier: hand the state on, nothing else to do
-            if (bid == 0 && threadIdx.x == 0) *out = s_state;
+            if (bid == 0 && tix == 0) *out = s_state;
             return;
         }
         __shared__ FinishScratch s_fs;
@@ -1205,8 +1262,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         __syncthreads();
         if (bid == 0) {
             unsigned long long *next = fuse.ring + (int64_t)((k + 1) % 3) * kAccSet;
-            for (int e = threadIdx.x; e < kAccSet; e += kIThreads) next[e] = 0ull;
-            if (threadIdx.x == 0) {
+            for (int e = tix; e < kAccSet; e += kIThreads) next[e] = 0ull;
+            if (tix == 0) {
                 *out = s_state;
                 if (k > 0 && fuse.progress)
                     __hip_atomic_store(fuse.progress, fuse.tag | ((unsigned long long)(s_state.done ? 1 : 0) << 32) | (unsigned long long)(unsigned)k,
@@ -1220,26 +1277,32 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // LightSkip: nothing of this block can have come within reach since it was last swept -> straight to the ticket
     bool skip = false;
     if (fuse.ticket && fuse.light_key) {
-        const double key = fuse.light_key[bid];
+        const double key = PERSIST ? (k > 0 ? s_key : 0.0) : fuse.light_key[bid];
         skip = key > 0.0 && (st->motion + st->reach) * (1.0 + 1e-6) + 1e-6 < key;
     }
     __shared__ double s_light[kIWaves];
     const int nacc = mode == 1 ? kAcc : 17;
-    if (tile_visits && threadIdx.x == 0 && bid < kStampBlocks) { g_icp_stamp[bid][7] = skip ? 1ull : 0ull; g_icp_stamp[bid][6] = (unsigned long long)nblocks; }
+    if (tile_visits && tix == 0 && bid < kStampBlocks) { g_icp_stamp[bid][7] = skip ? 1ull : 0ull; g_icp_stamp[bid][6] = (unsigned long long)nblocks; }
     do {
     if (skip) break;
     __shared__ int32_t lists[kIWaves][kLScratch];
     __shared__ double rowd[kIWaves][16][kRowStride]; // s_x, s_y, s_z, (the sweep's row bound), K, bound / result value
-    __shared__ int32_t rowi[kIWaves][16][2];         // partner (bound / result), original row
     __shared__ float rowf[kIWaves][16][kRowFStride]; // float32 mirror of the rows for the sweep's culling tests
-    __shared__ float rowk[kIWaves][16][8];           // what a row carries across the sweep (its previous partner: coordinates, normal, index),
-                                                     // parked here: a value in 16 lanes costs a whole register through the multiply loop
     __shared__ double sh[kAcc][kIRows + 1];
-    if (tile_visits && threadIdx.x == 0 && bid < kStampBlocks) {     // only launches that sweep stamp (not the converged / closing ones)
+    if (tile_visits && tix == 0 && bid < kStampBlocks) {     // only launches that sweep stamp (not the converged / closing ones)
         g_icp_stamp[bid][0] = t_block_start;
         g_icp_stamp[bid][6] = (unsigned long long)nblocks;
     }
     phase_tick(tile_visits, 1, bid);
+    // s_thist was staged by all threads of the block and is read by the rows of every wave (until this barrier was added the
+    // per-launch form relied on the waves of a block running in step: a row could read an entry before another wave had written it)
+    if (certs && (k > 0 || PERSIST)) __syncthreads();
+    if (PERSIST && fuse.stamp && tix == 0) {
+        const unsigned long long t = wall_clock64();
+        if (bid == 0) fuse.stamp[0] = t;
+        atomicMax(&fuse.stamp[5], t);
+        atomicMin(&fuse.stamp[10], t);
+    }
 
     // Row certificates (kpx_icp.hip, "Certificates" above icp_iter_body): how calm the registration is decides the skin
     const double c_reach = certs ? st->reach : 0.0;
@@ -1327,6 +1390,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     w.act_mask = act_mask;
     w.light_gap2 = -1.0;
     phase_tick(tile_visits, 2, bid);
+    if (PERSIST) chain_tick(fuse.stamp, 1, bid == 0 && tix == 0);
     const unsigned long long t_sweep = tile_visits ? wall_clock64() : 0ull;
     unsigned long long swept = 0ull;
     int lane_p = 0, wave_p = 0, q_p = 0, j_p = 0;
@@ -1337,7 +1401,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     };
     if (act_mask != 0u) {                                 // (a wave whose 16 rows are all certified keeps what it came with)
         wave_lds_fence();                                 // rowd[..][3] is the sweep's own slot from here on
-        swept = sweep_wave<true, true>(w, Bs, orig, tile_box, group_box, n_groups, t2max, lists[wave], &gpre);
+        swept = sweep_wave<true, true, PERSIST>(w, Bs, orig, tile_box, group_box, n_groups, t2max, lists[wave], &gpre);
         rederive();
         // new keys for the rows that were searched: L^2 = min(final culling bound, runner-up among the multiplied columns), both on d^2
         if (certs && fuse.cert_check && j_p == 0) {
@@ -1348,7 +1412,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                     if (atomicAdd(&g_cert_check[2], 1ull) == 0ull) {
                         g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = (unsigned long long)(row_base_p + rr);
                         g_cert_check[5] = (unsigned long long)(unsigned)rowi[wave_p][rr][0]; g_cert_check[6] = (unsigned long long)(unsigned)w.bcol[r];
-                        g_cert_check[7] = (unsigned long long)(fuse.cert[row_base_p + rr] & ~63u);
+                        g_cert_check[7] = (unsigned long long)((PERSIST ? rowc[wave_p][rr] : fuse.cert[row_base_p + rr]) & ~63u);
                     }
                 }
             }
@@ -1365,7 +1429,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                     // L rounded DOWN to a float with its low six mantissa bits cleared; those bits carry the iteration (k < 64: later iterations
                     // of a longer chain are searched every time)
                     const uint32_t lb = l2 > 0.0 && k < kCertHist ? (__float_as_uint(f32_down(sqrt(l2) * (1.0 - 1e-7))) & ~63u) : 0u;
-                    fuse.cert[row_base_p + rr] = lb > 63u ? (lb | (uint32_t)k) : 0u;
+                    const uint32_t cw = lb > 63u ? (lb | (uint32_t)k) : 0u;
+                    if (PERSIST) rowc[wave_p][rr] = cw; else fuse.cert[row_base_p + rr] = cw;
                 }
             }
         }
@@ -1390,6 +1455,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         o[0] = t_sweep; o[1] = wall_clock64(); o[2] = swept; o[3] = (unsigned long long)with;
     }
     phase_tick(tile_visits, 3, bid);
+    if (PERSIST) chain_tick(fuse.stamp, 2, bid == 0 && lane_p == 0 && wave_p == 0);
     if (tile_visits && lane_p == 0) atomicAdd(tile_visits + ((bid * kIWaves + wave_p) & (kVisitSlots - 1)), (unsigned long long)visited);
     wave_lds_fence();
     if (j_p == 0) {
@@ -1417,7 +1483,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
             const int32_t prev_j = __float_as_int(rowk[wave_e][lane_e][6]);
             const bool changed = k == 0 || out_j != prev_j;
             if (idx_cur) idx_cur[i] = out_j;
-            if (changed) idx_sorted[row_base_p + lane_e] = out_j;
+            if (PERSIST) rowk[wave_e][lane_e][6] = __int_as_float(out_j);
+            else if (changed) idx_sorted[row_base_p + lane_e] = out_j;
             if (none) {
                 if (d2_cur) d2_cur[i] = INFINITY;
             } else {
@@ -1437,7 +1504,10 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
                         for (int c = 0; c < 3; ++c) nf[c] = np_[c];
                     }
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) ptgt_sorted[3 * (row_base_p + lane_e) + c] = tf[c]; // the next launch bounds this row with it
+                    for (int c = 0; c < 3; ++c) {                                                   // the next iteration bounds this row with it
+                        if (PERSIST) { rowk[wave_e][lane_e][c] = tf[c]; rowk[wave_e][lane_e][3 + c] = nf[c]; }
+                        else ptgt_sorted[3 * (row_base_p + lane_e) + c] = tf[c];
+                    }
                 }
                 const double t[3] = { (double)tf[0], (double)tf[1], (double)tf[2] };
                 const double dx = s[0] - t[0], dy = s[1] - t[1], dz = s[2] - t[2];
@@ -1469,21 +1539,27 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     }
     __syncthreads();
     phase_tick(tile_visits, 4, bid);
-    if ((int)threadIdx.x < nacc) {
+    if ((int)tix < nacc) {
         double v = 0.0;
-        for (int l = 0; l < kIRows; ++l) v += sh[threadIdx.x][l];
-        unsigned long long *slot = acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + threadIdx.x) * 2);
+        for (int l = 0; l < kIRows; ++l) v += sh[tix][l];
+        unsigned long long *slot = acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + tix) * 2);
         if (fuse.ticket) fixed_add_performed(slot, v); else fixed_add(slot, v);
     }
-    if (fuse.light_key && threadIdx.x == kIThreads - 1) {      // (after the barrier above: s_light is complete)
+    if (fuse.light_key && tix == kIThreads - 1) {      // (after the barrier above: s_light is complete)
         double g2 = INFINITY;
         bool light = true;
 #pragma unroll
         for (int wv = 0; wv < kIWaves; ++wv) { light = light && s_light[wv] >= 0.0; g2 = fmin(g2, s_light[wv]); }
-        fuse.light_key[bid] = light ? st->motion + sqrt(g2) * (1.0 - 1e-9) : 0.0;
+        const double nk = light ? st->motion + sqrt(g2) * (1.0 - 1e-9) : 0.0;
+        if (PERSIST) s_key = nk; else fuse.light_key[bid] = nk;
     }
     phase_tick(tile_visits, 5, bid);
     } while (false);
+    if (PERSIST && fuse.stamp && tix == 0) {
+        const unsigned long long t = wall_clock64();
+        if (bid == 0) fuse.stamp[3] = t;
+        atomicMax(&fuse.stamp[11], t);
+    }
     if (!fuse.ticket) return;
     // "The last block finishes the job": every add above has RETURNED (it has been performed at the device's point of coherence),
     // the barrier orders the block's ticket behind them, and the block that draws the last ticket of its registration reads the
@@ -1500,23 +1576,53 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // The state is written with plain stores: its readers are the blocks of the NEXT launch, behind the kernel boundary.
     __shared__ unsigned s_ticket;
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = (unsigned)__hip_atomic_fetch_add(fuse.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tix == 0) s_ticket = (unsigned)__hip_atomic_fetch_add(fuse.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    if (PERSIST && fuse.stamp && tix == 0) {
+        const unsigned long long t = wall_clock64();
+        if (bid == 0) fuse.stamp[4] = t;
+        atomicMax(&fuse.stamp[6], t);
+    }
     if (s_ticket != nblocks - 1u) return;
 #if KPX_ICP_ACQ_FENCE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the winner only: one per registration and launch
 #endif
-    if (threadIdx.x < kAcc) s_sums[threadIdx.x] = (int)threadIdx.x < nacc ? fixed_total_coherent(acc, threadIdx.x) : 0.0;
+    if (tix < kAcc) s_sums[tix] = (int)tix < nacc ? fixed_total_coherent(acc, tix) : 0.0;
     __syncthreads();
-    for (int e = threadIdx.x; e < kAccSet; e += kIThreads) __hip_atomic_store(acc + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 0) __hip_atomic_store(fuse.ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wave != 0) return;
+    if (PERSIST) chain_tick(fuse.stamp, 7, tix == 0);
+    for (int e = tix; e < kAccSet; e += kIThreads) __hip_atomic_store(acc + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tix == 0) __hip_atomic_store(fuse.ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // PERSIST: the blocks that see the next record add to these accumulators at once, so every clearing store (and the ticket's) must
+    // have been performed before the record is published: each wave drains its stores, the block meets at a barrier (wave 0 after the
+    // update algebra, which hides the drain), then wave 0 publishes
+    if (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave != 0) {
+        if (PERSIST) __syncthreads();
+        return;
+    }
     __shared__ FinishScratch s_tail;
     IcpState *stw = const_cast<IcpState *>(st);
     IcpState *work = KPX_ICP_STATE_LDS ? &s_state : stw;
-    icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, fuse.result, s_tail, lane,
-                    LightSkip{ fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max });
+    if (PERSIST)
+        icp_finish_wave_call(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, fuse.result, &s_tail, lane,
+                             fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max);
+    else
+        icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, fuse.result, s_tail, lane,
+                        LightSkip{ fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max });
     wave_lds_fence();
+    if (PERSIST) chain_tick(fuse.stamp, 8, lane == 0);
+    if (PERSIST) {
+        static_assert(KPX_ICP_STATE_LDS, "the chain form updates the LDS copy of the state");
+        static_assert(sizeof(IcpState) == 23 * sizeof(double), "record layout");
+        __syncthreads();
+        if (lane < 23)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(fuse.chain_rec + (size_t)kChainRec * (k + 1)) + lane,
+                               reinterpret_cast<const unsigned long long *>(&s_state)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && fuse.progress && work->done)
+            __hip_atomic_store(fuse.progress, fuse.tag | (1ull << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        chain_tick(fuse.stamp, 9, lane == 0);
+        return;
+    }
     if (KPX_ICP_STATE_LDS && lane < (int)(sizeof(IcpState) / sizeof(double))) reinterpret_cast<double *>(stw)[lane] = reinterpret_cast<const double *>(&s_state)[lane];
     if (fuse.cert && fuse.thist && k + 1 < kCertHist && lane < 12) fuse.thist[12 * (k + 1) + lane] = work->T[lane];     // what iteration k + 1 transforms with
     if (lane == 0 && fuse.progress)
@@ -1562,6 +1668,7 @@ struct IcpProblem {
     const double *sbbox;
     uint32_t *cert;
     double *thist;
+    double *chain_rec;
     int64_t n;
     uint32_t block0, blocks;
 };
@@ -1589,9 +1696,71 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_I
     // second accumulator set, which only the one-launch form uses)
     const IcpFuse fuse{ split ? (IcpState *)nullptr : P.pair, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag,
                         split == 2 ? P.ring + kAccSet : (unsigned long long *)nullptr, (light & 1) ? P.light_key : (double *)nullptr, P.sbbox,
-                        (light & 2) ? P.cert : (uint32_t *)nullptr, (light & 2) ? P.thist : (double *)nullptr, (light & 4) ? 1 : 0, pol };
+                        (light & 2) ? P.cert : (uint32_t *)nullptr, (light & 2) ? P.thist : (double *)nullptr, (light & 4) ? 1 : 0, pol, nullptr, nullptr };
     icp_iter_body(bid, P.blocks, P.src, P.n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, P.row_of, P.src_sorted, P.idx_sorted, P.ptgt_sorted,
                   P.idx_cur, P.d2_cur, max_d2, mode, k, P.pair, P.ring, tile_visits, fuse);
+}
+
+// The whole chain of a group of registrations in ONE launch: block b iterates over k on the rows it owns (icp_iter_body<true>), the
+// block that draws the last ticket of iteration k performs the update and publishes record k + 1, everybody else waits for it (see
+// kChainRec).  No kernel boundary, no host poll, no re-read of the rows: an iteration costs the ticket, the update algebra and one
+// coherent round trip instead of a launch.
+// REQUIRES every block of the launch to be resident at the same time (a block that is not can never deliver its sums): the host
+// launches this form only when the grid fits the device beside every other chain kernel it has in flight (chain_reserve), and every
+// wait is bounded -- a block that has waited `limit_ticks` (100 MHz wall clock, counted from ITS start) raises *abort_word (pinned
+// host memory), poisons its registration's result and leaves; the others follow on their own clocks.  The library reports a raised
+// word at the next call (KPX_ERR_HIP); KPX_ICP_CHAIN=0 selects the launch-per-iteration form.
+__global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE, KPX_ICP_WPE))) void icp_chain_kernel(IcpBatchArgs args, const float *__restrict__ tgt,
+                                                       const float *__restrict__ tn, const double *__restrict__ Bs,
+                                                       const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
+                                                       const float *__restrict__ group_box, int32_t n_groups,
+                                                       const double *__restrict__ tbbox, double max_d2, int mode, int max_iter, double rel_fit,
+                                                       double rel_rmse, unsigned long long tag, unsigned long long *__restrict__ tile_visits, int light,
+                                                       CertPolicy pol, unsigned long long limit_ticks, unsigned long long *abort_word)
+{
+    int pi = 0;
+#pragma unroll
+    for (int c = 1; c < kIcpBatchMax; ++c) pi += (c < args.count && blockIdx.x >= args.p[c].block0) ? 1 : 0;
+    const IcpProblem &P = args.p[pi];
+    const unsigned bid = blockIdx.x - P.block0;
+    __shared__ IcpState s_cur;
+    __shared__ int s_abort;
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+    for (int k = 0; k <= max_iter; ++k) {
+        // (the operands' addresses behind opaque moves, per iteration: their loop-invariant loads -- the first group boxes, the problem's
+        // descriptor -- would otherwise be hoisted out of the loop and live in registers across it)
+        asm volatile("" : "+s"(tgt), "+s"(tn), "+s"(Bs), "+s"(orig), "+s"(tile_box), "+s"(group_box), "+s"(tbbox));
+        asm volatile("" : "+s"(max_d2), "+s"(mode), "+s"(n_groups), "+s"(pol.calm), "+s"(pol.factor), "+s"(pol.smin), "+s"(pol.smax));
+        const IcpFuse fuse{ (IcpState *)nullptr, P.ring, max_iter, rel_fit, rel_rmse, P.result, P.progress, tag, P.ring + kAccSet,
+                            (light & 1) ? P.light_key : (double *)nullptr, P.sbbox, (light & 2) ? P.cert : (uint32_t *)nullptr,
+                            (light & 2) ? P.thist : (double *)nullptr, (light & 4) ? 1 : 0, pol, P.chain_rec,
+                            ((light & 8) && pi == 0 && k < 64) ? &g_chain_stamp[k][0] : (unsigned long long *)nullptr };
+        if (threadIdx.x < kChainWords) {
+            const unsigned long long *w = reinterpret_cast<const unsigned long long *>(P.chain_rec + (size_t)kChainRec * k) + threadIdx.x;
+            unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (v == kChainEmpty) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 255u) == 0u && wall_clock64() - t0 > limit_ticks) { s_abort = 1; break; }
+                v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            reinterpret_cast<unsigned long long *>(&s_cur)[threadIdx.x] = v;
+        }
+        __syncthreads();
+        if (s_abort) {
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(abort_word, tag | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (P.result) P.result[16] = __builtin_nan("");
+            }
+            return;
+        }
+        if (s_cur.done) break;
+        icp_iter_body<true>(bid, P.blocks, P.src, P.n, tgt, tn, Bs, orig, tile_box, group_box, n_groups, tbbox, P.row_of, P.src_sorted, P.idx_sorted, P.ptgt_sorted,
+                            P.idx_cur, P.d2_cur, max_d2, mode, k, &s_cur, P.ring, tile_visits, fuse);
+        __syncthreads();                                     // (the body's early returns meet here before s_cur is written again)
+    }
 }
 
 // The update step of every registration of a batch, one block each (split mode: see icp_iter_batch_kernel)
@@ -1636,6 +1805,13 @@ __global__ __launch_bounds__(256) void icp_batch_init_kernel(IcpBatchArgs args, 
     if (bid == 0) {
         for (int e = threadIdx.x; e < 3 * kAccSet; e += 256) P.ring[e] = 0ull;
         if (threadIdx.x >= 64 && threadIdx.x < 76) P.thist[threadIdx.x - 64] = T0.m[pi][threadIdx.x - 64];
+        if (P.chain_rec) {                                  // the chain form: record 0 = the initial state (below), every other record empty
+            unsigned long long *rw = reinterpret_cast<unsigned long long *>(P.chain_rec);
+            for (int e = kChainRec + threadIdx.x; e < kChainRecords * kChainRec; e += 256) rw[e] = kChainEmpty;
+            IcpState *r0 = reinterpret_cast<IcpState *>(P.chain_rec);
+            if (threadIdx.x >= 128 && threadIdx.x < 144) r0->T[threadIdx.x - 128] = T0.m[pi][threadIdx.x - 128];
+            if (threadIdx.x == 144) { r0->fitness = 0.0; r0->rmse = 0.0; r0->count = 0.0; r0->iter = 0; r0->done = 0; r0->motion = 0.0; r0->reach = INFINITY; r0->last_motion = INFINITY; }
+        }
         if (threadIdx.x < 32) {
             IcpState *st = P.pair + (threadIdx.x >> 4);
             st->T[threadIdx.x & 15] = T0.m[pi][threadIdx.x & 15];
@@ -1791,6 +1967,7 @@ struct NnBuffers {
     double *light_key;                                  // per block of the iteration kernel (LightSkip)
     uint32_t *cert_sorted;                              // per sorted row: certificate (icp_iter_body)
     double *thist;                                      // transforms of the iterations so far (certificates)
+    double *chain_rec;                                  // records of the one-launch chain (kChainRecords x kChainRec)
     float *tile_box, *group_box;
     SortScratch sort_t, sort_s;
 };
@@ -1836,6 +2013,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->light_key = a.get<double>((size_t)cdiv((int64_t)nn, kIRows));
     b->cert_sorted = a.get<uint32_t>(nn);
     b->thist = a.get<double>((size_t)kCertHist * 12);
+    b->chain_rec = a.get<double>((size_t)kChainRecords * kChainRec);
     sort_carve(a, n, &b->sort_s);
 }
 static void nn_carve(Arena &a, int64_t n, int64_t m, const NnPlan &p, NnBuffers *b)
@@ -2025,6 +2203,18 @@ KPX_EXPORT int kpx_prof_icp_cert(uint64_t *h_out8)
     KPX_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_cert_check)));
     KPX_HIP(hipMemcpy(h_out8, p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     KPX_HIP(hipMemcpy(p, zero, sizeof(zero), hipMemcpyHostToDevice));
+    return KPX_OK;
+}
+// The chain clock (g_chain_stamp): 64 x 16 words, read and reset ([10], the earliest-block slot, to all ones)
+KPX_EXPORT int kpx_prof_icp_chain(uint64_t *h_out1024)
+{
+    KPX_REQUIRE(h_out1024, "kpx_prof_icp_chain: null pointer");
+    unsigned long long *p = nullptr;
+    static unsigned long long init[64 * 16];
+    for (int i = 0; i < 64 * 16; ++i) init[i] = (i & 15) == 10 ? ~0ull : 0ull;
+    KPX_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_chain_stamp)));
+    KPX_HIP(hipMemcpy(h_out1024, p, sizeof(init), hipMemcpyDeviceToHost));
+    KPX_HIP(hipMemcpy(p, init, sizeof(init), hipMemcpyHostToDevice));
     return KPX_OK;
 }
 KPX_EXPORT int kpx_prof_icp_phases(double *h_out8)
@@ -2240,6 +2430,79 @@ KPX_EXPORT int kpx_icp_batch(int32_t count, const float *const *h_src, const int
     return kpx::icp_batch_ordered(count, h_src, h_n_src, tgt, tgt_normals, n_tgt, max_dist, h_init, mode, max_iteration, relative_fitness, relative_rmse,
                                   d_results, ws, ws_bytes, stream, false);
 }
+// ---- the one-launch chain: who may be resident ---------------------------------------------------------------------------
+// icp_chain_kernel needs all its blocks resident together, so the host admits a chain only while the blocks of every chain kernel it
+// has in flight on the device (this process: the deployment is one process per GPU) plus the new ones fit a budget below what the
+// device holds (blocks per CU by the occupancy API minus one -- MI355X_MICROARCH.md, "Correctness boundaries": the API can be one
+// block per CU high -- times the CUs).  A chain that does not fit runs in the launch-per-iteration form: nothing ever waits for
+// another chain.  Finished chains are retired by querying the event recorded behind them.
+namespace {
+struct ChainSlot {
+    hipEvent_t ev;
+    unsigned blocks;
+    bool busy, made;
+};
+struct ChainBook {
+    std::mutex mu;
+    ChainSlot slot[16] = {};
+    long budget = -1;                                    // blocks; -1 = not asked yet
+};
+ChainBook g_chain_book[16];
+unsigned long long *g_chain_abort = nullptr;             // pinned: raised by a chain block that gave up waiting
+std::once_flag g_chain_abort_once;
+unsigned long long *chain_abort_word()
+{
+    std::call_once(g_chain_abort_once, [] {
+        if (hipHostMalloc((void **)&g_chain_abort, 64, hipHostMallocDefault) != hipSuccess) g_chain_abort = nullptr;
+        else *g_chain_abort = 0ull;
+    });
+    return g_chain_abort;
+}
+template <class F> bool chain_launch_if_fits(unsigned blocks, hipStream_t st, F &&launch)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    ChainBook &bk = g_chain_book[dev];
+    std::lock_guard<std::mutex> lock(bk.mu);
+    if (bk.budget < 0) {
+        int per_cu = 0, cus = 0;
+        static const long forced = [] { const char *e = getenv("KPX_ICP_CHAIN_BUDGET"); return e ? atol(e) : -1L; }();
+        if (forced >= 0) bk.budget = forced;
+        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)icp_chain_kernel, kIThreads, 0) == hipSuccess &&
+                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 1)
+            bk.budget = (long)(per_cu - 1) * cus;
+        else bk.budget = 0;
+    }
+    long used = 0;
+    int free_slot = -1;
+    for (int i = 0; i < 16; ++i) {
+        ChainSlot &c = bk.slot[i];
+        if (c.busy && hipEventQuery(c.ev) == hipSuccess) c.busy = false;
+        if (c.busy) used += c.blocks;
+        else if (free_slot < 0) free_slot = i;
+    }
+    if (free_slot < 0 || used + (long)blocks > bk.budget) return false;
+    ChainSlot &c = bk.slot[free_slot];
+    if (!c.made) {
+        if (hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) return false;
+        c.made = true;
+    }
+    launch();
+    if (hipEventRecord(c.ev, st) != hipSuccess) return true;     // launched all the same; the slot just is not booked
+    c.blocks = blocks;
+    c.busy = true;
+    return true;
+}
+}  // namespace
+// A chain kernel gave up waiting since the last call (see icp_chain_kernel): 1 once, then cleared
+int kpx::icp_chain_abort_take()
+{
+    unsigned long long *w = chain_abort_word();
+    if (!w) return 0;
+    const unsigned long long v = __atomic_exchange_n(w, 0ull, __ATOMIC_ACQ_REL);
+    return v ? 1 : 0;
+}
+
 int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
                            double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness, double relative_rmse,
                            double *d_results, void *ws, size_t ws_bytes, void *stream, bool presorted)
@@ -2254,6 +2517,9 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
     for (int i = 0; i < count; ++i)
         KPX_REQUIRE(h_src[i] && h_n_src[i] >= 1 && h_n_src[i] < ((int64_t)1 << 31), "kpx_icp_batch: bad source cloud %d", i);
     hipStream_t st = (hipStream_t)stream;
+    if (icp_chain_abort_take())
+        return fail(KPX_ERR_HIP, "kpx_icp_batch: an earlier one-launch ICP chain gave up waiting for its blocks to become resident (another process on this "
+                                 "GPU?); its result is NaN.  KPX_ICP_CHAIN=0 selects the launch-per-iteration form");
     // the problems of a batch are independent chains of short, latency-bound kernels: they run side by side on the
     // library's internal lanes (kpx_internal.h), forked from / joined to the caller's stream by events
     LaneSet *ln = nullptr;
@@ -2355,6 +2621,35 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
         generation = (generation + 1) & 0xFFFFFFull;
         const unsigned long long tag = generation << 40;
         constexpr int window = 6;
+        static const double stall_limit = [] { const char *e = getenv("KPX_ICP_STALL_SECONDS"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 60.0; }();
+        auto t_last = std::chrono::steady_clock::now();
+        // split (default): the update of every registration runs in icp_solve_batch_kernel between the sweeps; KPX_ICP_SPLIT=0: in the
+        // prologue of the next sweep's blocks (one launch per iteration).  Same-run A/B with four frames in flight: 1830-1930 vs
+        // 1730-1830 Mpoints/s -- the redundant prologue holds every block's wave slots 4 us longer, and slots are what frames compete for.
+        // KPX_ICP_SPLIT=2: in the LAST block of the sweep itself (no update kernel, no redundant prologue).
+        static const int split = [] { const char *e = getenv("KPX_ICP_SPLIT"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : KPX_ICP_SPLIT_DEFAULT; }();
+        const int last_k = split ? max_iteration : max_iteration + 1;     // the fused chain ends with an update-only launch
+        // A/B switches: bit 0 LightSkip, bit 1 row certificates (they rest on LightSkip's motion bookkeeping)
+        static const int light = [] {
+            const char *e = getenv("KPX_ICP_LIGHT_SKIP"), *c = getenv("KPX_ICP_CERT");
+            const char *ck = getenv("KPX_ICP_CERT_CHECK");
+            const int l = (e && e[0] == '0') ? 0 : 1;
+            const char *cs = getenv("KPX_ICP_CHAIN_STAMPS");
+            return l | ((l && !(c && c[0] == '0')) ? 2 : 0) | ((ck && ck[0] == '1') ? 4 : 0) | ((cs && cs[0] == '1') ? 8 : 0);
+        }();
+        static const CertPolicy cert_policy = [] {
+            auto f = [](const char *name, float dflt) { const char *e = getenv(name); return e ? (float)atof(e) : dflt; };
+            return CertPolicy{ f("KPX_CERT_CALM", 0.15f), f("KPX_CERT_FACTOR", 3.0f), f("KPX_CERT_SKIN_MIN", 0.02f), f("KPX_CERT_SKIN_MAX", 0.2f) };
+        }();
+        // The one-launch chain (icp_chain_kernel) when the update is the last block's (split 2), the records hold the iterations and the
+        // group's blocks fit the device beside the chains already in flight; KPX_ICP_CHAIN=0: always a launch per iteration.
+        static const bool chain_env = [] { const char *e = getenv("KPX_ICP_CHAIN"); return !(e && e[0] == '0'); }();
+        static const unsigned long long chain_limit = [] {
+            const char *e = getenv("KPX_ICP_CHAIN_WAIT_SECONDS");
+            const double v = e ? atof(e) : 0.0;
+            return (unsigned long long)((v > 0.0 ? v : 2.0) * 1e8);
+        }();
+        const bool chain_ok = chain_env && split == 2 && max_iteration <= kChainRecords - 2 && chain_abort_word() != nullptr;
         IcpBatchArgs A[8], Ac[8];                              // count <= 64: at most 8 groups
         int gk[8];
         bool gfin[8];
@@ -2372,6 +2667,7 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                 P.idx_cur = nullptr; P.d2_cur = nullptr;          // a batch reports transforms, not correspondence lists
                 P.ring = bufs[i].acc_fixed; P.result = d_results + 20 * i; P.progress = &h_progress[i]; P.n = h_n_src[i];
                 P.light_key = bufs[i].light_key; P.sbbox = bufs[i].sort_s.bbox; P.cert = bufs[i].cert_sorted; P.thist = bufs[i].thist;
+                P.chain_rec = chain_ok ? bufs[i].chain_rec : nullptr;
                 P.block0 = b0; P.blocks = (unsigned)cdiv(h_n_src[i], kIRows);
                 Ac[g].p[c] = P;
                 Ac[g].p[c].block0 = (unsigned)c; Ac[g].p[c].blocks = 1u;
@@ -2382,26 +2678,16 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
             gblocks[g] = b0;
             gk[g] = 0; gfin[g] = false;
             hipLaunchKernelGGL(icp_batch_init_kernel, dim3(b0), dim3(256), 0, ls, A[g], T0);
+            if (chain_ok) {
+                const bool launched = chain_launch_if_fits(b0, ls, [&] {
+                    ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, ls);
+                    hipLaunchKernelGGL(icp_chain_kernel, dim3(b0), dim3(kIThreads), 0, ls, A[g], tgt, tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box,
+                                       bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2, mode, max_iteration, relative_fitness, relative_rmse, tag,
+                                       prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, light, cert_policy, chain_limit, chain_abort_word());
+                });
+                if (launched) gfin[g] = true;
+            }
         }
-        static const double stall_limit = [] { const char *e = getenv("KPX_ICP_STALL_SECONDS"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 60.0; }();
-        auto t_last = std::chrono::steady_clock::now();
-        // split (default): the update of every registration runs in icp_solve_batch_kernel between the sweeps; KPX_ICP_SPLIT=0: in the
-        // prologue of the next sweep's blocks (one launch per iteration).  Same-run A/B with four frames in flight: 1830-1930 vs
-        // 1730-1830 Mpoints/s -- the redundant prologue holds every block's wave slots 4 us longer, and slots are what frames compete for.
-        // KPX_ICP_SPLIT=2: in the LAST block of the sweep itself (no update kernel, no redundant prologue).
-        static const int split = [] { const char *e = getenv("KPX_ICP_SPLIT"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : KPX_ICP_SPLIT_DEFAULT; }();
-        const int last_k = split ? max_iteration : max_iteration + 1;     // the fused chain ends with an update-only launch
-        // A/B switches: bit 0 LightSkip, bit 1 row certificates (they rest on LightSkip's motion bookkeeping)
-        static const int light = [] {
-            const char *e = getenv("KPX_ICP_LIGHT_SKIP"), *c = getenv("KPX_ICP_CERT");
-            const char *ck = getenv("KPX_ICP_CERT_CHECK");
-            const int l = (e && e[0] == '0') ? 0 : 1;
-            return l | ((l && !(c && c[0] == '0')) ? 2 : 0) | ((ck && ck[0] == '1') ? 4 : 0);
-        }();
-        static const CertPolicy cert_policy = [] {
-            auto f = [](const char *name, float dflt) { const char *e = getenv(name); return e ? (float)atof(e) : dflt; };
-            return CertPolicy{ f("KPX_CERT_CALM", 0.15f), f("KPX_CERT_FACTOR", 3.0f), f("KPX_CERT_SKIN_MIN", 0.02f), f("KPX_CERT_SKIN_MAX", 0.2f) };
-        }();
         for (bool pending = true; pending && !rc;) {
             pending = false;
             bool advanced = false;

@@ -63,6 +63,7 @@ int fuse_voxel_downsample_dev(int32_t count, const float *const *h_pts, const fl
 
 // kpx_icp_batch for clouds that already lie along a space-filling curve (presorted = true: no Morton sort inside; the culled
 // search's tiles are then 16 consecutive points of the caller's order).  presorted = false: the exported behaviour.
+int icp_chain_abort_take();   // 1 if a one-launch ICP chain gave up waiting since the last call (kpx_icp.hip, icp_chain_kernel)
 int icp_batch_ordered(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
                       double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness, double relative_rmse,
                       double *d_results, void *ws, size_t ws_bytes, void *stream, bool presorted);

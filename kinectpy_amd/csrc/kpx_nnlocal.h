@@ -286,12 +286,14 @@ __device__ __forceinline__ double wave_uniform_min(double v)
 //      loads are issued together); a tile is tested against the rows of its group's mask only;
 //   M  ONE round trip per kMulBatch listed tiles: B operands and original column ids requested together, then the fp64 MFMAs
 //      behind the 32-bit high-word prefilter; the row bounds tighten afterwards (registers and LDS).
-template <bool PRE, bool CERT = false>
+template <bool PRE, bool CERT = false, bool LOOPED = false>
 __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const double *__restrict__ Bs, const int32_t *__restrict__ orig,
                                                          const float *__restrict__ tile_box, const float *__restrict__ group_box,
                                                          int32_t n_groups, const double t2max, int32_t *scr, const GroupPre *pre)
 {
-    const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    // (LOOPED = called inside a loop, icp_chain_kernel: the lane number behind an opaque move keeps what is derived from it from being
+    // hoisted out of that loop)
+    const int lane = LOOPED ? opaque_i((int)(threadIdx.x & 63)) : (int)(threadIdx.x & 63), q = lane >> 4, j = lane & 15;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int32_t *list = scr, *cand = scr + kLList, *surv = scr + kLList + 7 * kLCand;
     // records of the lane's four rows q, q + 4, q + 8, q + 12: ONE base each, the rows at constant offsets (immediates of the ds instructions)
