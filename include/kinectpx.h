@@ -467,9 +467,9 @@ int kpx_prof_icp_waves(uint64_t *h_out, int64_t cap_waves, int64_t *h_count);
  * the same and compared).  h_out8 (8 x uint64, cleared by the call): [0] rows certified, [1] rows searched, [2] certified rows whose
  * search found another partner (must be 0), [3..7] the first such row: iteration, sorted row, kept and found partner, key bits. */
 int kpx_prof_icp_cert(uint64_t *h_out8);
-/* Clock of the one-launch ICP chain (KPX_ICP_CHAIN_STAMPS=1): 64 iterations x 16 stamps of the 100 MHz wall clock, first registration of
+/* Clock of the one-launch ICP chain (KPX_ICP_CHAIN_STAMPS=1): 64 iterations x 32 stamps of the 100 MHz wall clock, first registration of
    the last chain launch (slots: kpx_icp.hip, g_chain_stamp); read and reset.  A development aid like the other kpx_prof_* entries. */
-int kpx_prof_icp_chain(uint64_t *h_out1024);
+int kpx_prof_icp_chain(uint64_t *h_out2048);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,8 @@
 #include <mutex>
 #include <limits.h>
 #include <stddef.h>
+#include <string.h>
+#include <stdio.h>
 #include <time.h>
 #include <stdlib.h>
 
@@ -1003,30 +1005,28 @@ __global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restric
 constexpr int kAccCopies = 8;
 __device__ __forceinline__ double fixed_total(const unsigned long long *acc, int slot)
 {
-    unsigned long long lo = 0ull, hi = 0ull;
+    unsigned long long w[3] = { 0ull, 0ull, 0ull }, lo, hi;
 #pragma unroll
-    for (int c = 0; c < kAccCopies; ++c) {
-        const unsigned long long l = acc[((int64_t)c * kAcc + slot) * 2], h = acc[((int64_t)c * kAcc + slot) * 2 + 1];
-        lo += l;
-        hi += h + (lo < l ? 1ull : 0ull);
-    }
+    for (int c = 0; c < kAccCopies; ++c)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) w[e] += acc[((int64_t)c * kAcc + slot) * kFixedWords + e];
+    fixed_fold(w[0], w[1], w[2], lo, hi);
     return fixed_value(lo, hi);
 }
 // the same through device-coherent loads (for a reader inside the launch that did the adds: the XCDs' L2s are not coherent)
 __device__ __forceinline__ double fixed_total_coherent(unsigned long long *acc, int slot)
 {
-    unsigned long long l[kAccCopies], h[kAccCopies];
+    unsigned long long v[kAccCopies][3];
 #pragma unroll
-    for (int c = 0; c < kAccCopies; ++c) {
-        l[c] = __hip_atomic_load(acc + ((int64_t)c * kAcc + slot) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        h[c] = __hip_atomic_load(acc + ((int64_t)c * kAcc + slot) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    unsigned long long lo = 0ull, hi = 0ull;
+    for (int c = 0; c < kAccCopies; ++c)
 #pragma unroll
-    for (int c = 0; c < kAccCopies; ++c) {
-        lo += l[c];
-        hi += h[c] + (lo < l[c] ? 1ull : 0ull);
-    }
+        for (int e = 0; e < 3; ++e) v[c][e] = __hip_atomic_load(acc + ((int64_t)c * kAcc + slot) * kFixedWords + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long w[3] = { 0ull, 0ull, 0ull }, lo, hi;
+#pragma unroll
+    for (int c = 0; c < kAccCopies; ++c)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) w[e] += v[c][e];
+    fixed_fold(w[0], w[1], w[2], lo, hi);
     return fixed_value(lo, hi);
 }
 // sums -> update step; clears the accumulators for the next iteration (single block: no race)
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(256) void icp_solve_fixed_kernel(unsigned long long
     const int nacc = mode == 1 ? kAcc : 17;
     if (threadIdx.x < kAcc) sums[threadIdx.x] = (int)threadIdx.x < nacc ? fixed_total(acc, threadIdx.x) : 0.0;
     __syncthreads();
-    for (int e = threadIdx.x; e < kAccCopies * kAcc * 2; e += 256) acc[e] = 0ull;
+    for (int e = threadIdx.x; e < kAccCopies * kAcc * kFixedWords; e += 256) acc[e] = 0ull;
     __shared__ FinishScratch fs;
     if (threadIdx.x >= 64) return;
     icp_finish_wave(sums, n, mode, k, max_iter, rel_fit, rel_rmse, st, result, fs, (int)threadIdx.x);
@@ -1113,7 +1113,7 @@ struct IcpFuse {
     double *chain_rec;                 // icp_iter_body<true> only: the registration's records (kChainRecords x kChainRec doubles)
     unsigned long long *stamp;         // icp_iter_body<true>, KPX_ICP_CHAIN_STAMPS=1: this iteration's row of g_chain_stamp
 };
-constexpr int kAccSet = kAccCopies * kAcc * 2;
+constexpr int kAccSet = kAccCopies * kAcc * kFixedWords;
 // Phase clock of the iteration kernel (while the profiler is armed): thread 0 of every block stores 100 MHz wall-clock stamps in
 // its own row of g_icp_stamp -- [0] block start, [1] after the update prologue, [2] after row preparation, [3] after the culled
 // sweep, [4] after the pair epilogue, [5] block end.  Plain stores to private slots: the clock does not disturb what it times.
@@ -1130,7 +1130,7 @@ __device__ unsigned long long g_cert_check[8];
 // Clock of the one-launch chain (KPX_ICP_CHAIN_STAMPS=1, first registration of the launch; 100 MHz stamps, one row per iteration):
 // block 0: [0] record seen, [1] rows prepared, [2] sweep over, [3] sums added, [4] ticket drawn; over all blocks: [5] latest / [10]
 // earliest "record seen", [11] latest "sums added", [6] latest ticket; the winner: [7] totals read, [8] update done, [9] record published.
-__device__ unsigned long long g_chain_stamp[64][16];
+__device__ unsigned long long g_chain_stamp[64][32];    // [16 ..]: block 0 wave 0's sweep (sweep_wave, dbg_tick)
 __device__ __forceinline__ void chain_tick(unsigned long long *row, int slot, bool on)
 {
     if (row && on) row[slot] = wall_clock64();
@@ -1389,6 +1389,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     w.skin = c_skin;
     w.act_mask = act_mask;
     w.light_gap2 = -1.0;
+    w.dbg = (PERSIST && fuse.stamp && bid == 0 && wave == 0) ? fuse.stamp + 16 : (unsigned long long *)nullptr;
     phase_tick(tile_visits, 2, bid);
     if (PERSIST) chain_tick(fuse.stamp, 1, bid == 0 && tix == 0);
     const unsigned long long t_sweep = tile_visits ? wall_clock64() : 0ull;
@@ -1456,6 +1457,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     }
     phase_tick(tile_visits, 3, bid);
     if (PERSIST) chain_tick(fuse.stamp, 2, bid == 0 && lane_p == 0 && wave_p == 0);
+    if (PERSIST && fuse.stamp && bid == 0 && lane_p == 0 && wave_p == 0) { fuse.stamp[13] = swept; fuse.stamp[14] = (unsigned long long)act_mask | ((unsigned long long)certd_mask << 16); }
     if (tile_visits && lane_p == 0) atomicAdd(tile_visits + ((bid * kIWaves + wave_p) & (kVisitSlots - 1)), (unsigned long long)visited);
     wave_lds_fence();
     if (j_p == 0) {
@@ -1542,7 +1544,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     if ((int)tix < nacc) {
         double v = 0.0;
         for (int l = 0; l < kIRows; ++l) v += sh[tix][l];
-        unsigned long long *slot = acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + tix) * 2);
+        unsigned long long *slot = acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + tix) * kFixedWords);
         if (fuse.ticket) fixed_add_performed(slot, v); else fixed_add(slot, v);
     }
     if (fuse.light_key && tix == kIThreads - 1) {      // (after the barrier above: s_light is complete)
@@ -1604,7 +1606,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     IcpState *stw = const_cast<IcpState *>(st);
     IcpState *work = KPX_ICP_STATE_LDS ? &s_state : stw;
     if (PERSIST)
-        icp_finish_wave_call(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, fuse.result, &s_tail, lane,
+        icp_finish_wave_call(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, (double *)nullptr, &s_tail, lane,
                              fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max);
     else
         icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, fuse.result, s_tail, lane,
@@ -1618,9 +1620,16 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         if (lane < 23)
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(fuse.chain_rec + (size_t)kChainRec * (k + 1)) + lane,
                                reinterpret_cast<const unsigned long long *>(&s_state)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the result is written ONCE, by the winner of the last iteration: the winners of a chain sit on different XCDs, and plain stores of
+        // several of them to the same words would reach memory in whatever order their L2s are written back at the end of the kernel
+        if (work->done && fuse.result) {
+            if (lane < 16) fuse.result[lane] = work->T[lane];
+            if (lane == 0) { fuse.result[16] = work->fitness; fuse.result[17] = work->rmse; fuse.result[18] = (double)k; fuse.result[19] = work->count; }
+        }
         if (lane == 0 && fuse.progress && work->done)
             __hip_atomic_store(fuse.progress, fuse.tag | (1ull << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         chain_tick(fuse.stamp, 9, lane == 0);
+        if (fuse.stamp && lane == 0) fuse.stamp[12] = __builtin_amdgcn_s_memtime();      // shader clock (against [9]: the clock the chip runs the chain at)
         return;
     }
     if (KPX_ICP_STATE_LDS && lane < (int)(sizeof(IcpState) / sizeof(double))) reinterpret_cast<double *>(stw)[lane] = reinterpret_cast<const double *>(&s_state)[lane];
@@ -1776,7 +1785,7 @@ __global__ __launch_bounds__(256) void icp_solve_batch_kernel(IcpBatchArgs args,
     const int nacc = mode == 1 ? kAcc : 17;
     if (threadIdx.x < kAcc) sums[threadIdx.x] = (int)threadIdx.x < nacc ? fixed_total(acc, threadIdx.x) : 0.0;
     __syncthreads();
-    for (int e = threadIdx.x; e < kAccCopies * kAcc * 2; e += 256) acc[e] = 0ull;
+    for (int e = threadIdx.x; e < kAccCopies * kAcc * kFixedWords; e += 256) acc[e] = 0ull;
     if (threadIdx.x >= 64) return;
     icp_finish_wave(sums, P.n, mode, k, max_iter, rel_fit, rel_rmse, st, P.result, fs, (int)threadIdx.x);
     if (threadIdx.x == 0 && P.progress)
@@ -1963,7 +1972,7 @@ struct NnBuffers {
     double *Bs;
     int32_t *orig_t, *row_of, *idx_sorted;
     float *src_sorted, *ptgt_sorted;                    // rows in Morton order; coordinates of each row's last partner, same order
-    unsigned long long *acc_fixed;                      // [kAccCopies][kAcc][2] exact accumulators
+    unsigned long long *acc_fixed;                      // [3][kAccCopies][kAcc][kFixedWords] exact accumulators
     double *light_key;                                  // per block of the iteration kernel (LightSkip)
     uint32_t *cert_sorted;                              // per sorted row: certificate (icp_iter_body)
     double *thist;                                      // transforms of the iterations so far (certificates)
@@ -2009,7 +2018,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->idx_sorted = a.get<int32_t>(nn);
     b->src_sorted = a.get<float>(nn * 3);
     b->ptgt_sorted = a.get<float>(nn * 3);
-    b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * 2);      // ring of three sets (icp_iter_kernel, IcpFuse)
+    b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * kFixedWords + 8);      // ring of three sets (icp_iter_kernel, IcpFuse)
     b->light_key = a.get<double>((size_t)cdiv((int64_t)nn, kIRows));
     b->cert_sorted = a.get<uint32_t>(nn);
     b->thist = a.get<double>((size_t)kCertHist * 12);
@@ -2045,7 +2054,7 @@ static bool dense_sort_on()
 static int nn_prep_source(const float *src, const NnPlan &p, const NnBuffers &b, hipStream_t st, bool ordered = false)
 {
     if (!local_engine()) return dense_sort_on() ? morton_order(src, p.n_src, b.sort_s, b.row_of, st) : KPX_OK;
-    KPX_HIP(hipMemsetAsync(b.acc_fixed, 0, (size_t)3 * kAccCopies * kAcc * 2 * sizeof(unsigned long long), st));
+    KPX_HIP(hipMemsetAsync(b.acc_fixed, 0, ((size_t)3 * kAccCopies * kAcc * kFixedWords + 8) * sizeof(unsigned long long), st));
     int rc = ordered ? KPX_OK : morton_order(src, p.n_src, b.sort_s, b.row_of, st);
     if (rc) return rc;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(p.n_src, 256)), dim3(256), 0, st, src, p.n_src, b.row_of, b.src_sorted);
@@ -2206,14 +2215,14 @@ KPX_EXPORT int kpx_prof_icp_cert(uint64_t *h_out8)
     return KPX_OK;
 }
 // The chain clock (g_chain_stamp): 64 x 16 words, read and reset ([10], the earliest-block slot, to all ones)
-KPX_EXPORT int kpx_prof_icp_chain(uint64_t *h_out1024)
+KPX_EXPORT int kpx_prof_icp_chain(uint64_t *h_out2048)
 {
-    KPX_REQUIRE(h_out1024, "kpx_prof_icp_chain: null pointer");
+    KPX_REQUIRE(h_out2048, "kpx_prof_icp_chain: null pointer");
     unsigned long long *p = nullptr;
-    static unsigned long long init[64 * 16];
-    for (int i = 0; i < 64 * 16; ++i) init[i] = (i & 15) == 10 ? ~0ull : 0ull;
+    static unsigned long long init[64 * 32];
+    for (int i = 0; i < 64 * 32; ++i) init[i] = (i & 31) == 10 ? ~0ull : 0ull;
     KPX_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_chain_stamp)));
-    KPX_HIP(hipMemcpy(h_out1024, p, sizeof(init), hipMemcpyDeviceToHost));
+    KPX_HIP(hipMemcpy(h_out2048, p, sizeof(init), hipMemcpyDeviceToHost));
     KPX_HIP(hipMemcpy(p, init, sizeof(init), hipMemcpyHostToDevice));
     return KPX_OK;
 }
@@ -2686,6 +2695,22 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                                        prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, light, cert_policy, chain_limit, chain_abort_word());
                 });
                 if (launched) gfin[g] = true;
+                static const bool chain_dump = [] { const char *e = getenv("KPX_ICP_CHAIN_DUMP"); return e && e[0] == '1'; }();
+                if (launched && chain_dump) {                // development aid: the records of every registration of the group, per iteration
+                    (void)hipStreamSynchronize(ls);
+                    static double rec[kChainRecords * kChainRec];
+                    for (int c = 0; c < A[g].count; ++c) {
+                        (void)hipMemcpy(rec, A[g].p[c].chain_rec, sizeof(rec), hipMemcpyDeviceToHost);
+                        for (int k = 0; k < kChainRecords; ++k) {
+                            const IcpState *r = reinterpret_cast<const IcpState *>(rec + (size_t)kChainRec * k);
+                            unsigned long long w0;
+                            memcpy(&w0, r, 8);
+                            if (w0 == kChainEmpty) { fprintf(stderr, "chain problem %d record %d: empty\n", c, k); break; }
+                            fprintf(stderr, "chain problem %d record %d: iter %d done %d fitness %.9f rmse %.9f count %.0f T03 %.6f motion %.4f last %.4f reach %.3f\n", c, k, r->iter,
+                                    r->done, r->fitness, r->rmse, r->count, r->T[3], r->motion, r->last_motion, r->reach);
+                        }
+                    }
+                }
             }
         }
         for (bool pending = true; pending && !rc;) {

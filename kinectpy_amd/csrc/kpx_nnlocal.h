@@ -211,6 +211,7 @@ struct WaveRows {
     unsigned sec[4];           // out (all 16 lanes of a row): high word of a LOWER bound of the smallest D among the multiplied columns other than
                                //     the row's winner (0xFFFFFFFF: none was multiplied)
     double rb_out[4], eps_out; // out: the rows' final culling bounds (every culled column has d^2 > rb_out) and the metric's rounding margin
+    unsigned long long *dbg;   // LOOPED sweeps only (KPX_ICP_CHAIN_STAMPS): 100 MHz stamps of this wave's sweep, or nullptr
 };
 constexpr int kRowStride = 6, kRowBound = 3;
 constexpr int kRowFStride = 8, kRowFBound = 6;
@@ -295,6 +296,8 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
     // hoisted out of that loop)
     const int lane = LOOPED ? opaque_i((int)(threadIdx.x & 63)) : (int)(threadIdx.x & 63), q = lane >> 4, j = lane & 15;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    auto dbg_tick = [&](int slot) { if (LOOPED && w.dbg && lane == 0) w.dbg[slot] = wall_clock64(); };
+    dbg_tick(0);
     int32_t *list = scr, *cand = scr + kLList, *surv = scr + kLList + 7 * kLCand;
     // records of the lane's four rows q, q + 4, q + 8, q + 12: ONE base each, the rows at constant offsets (immediates of the ds instructions)
     double *const rowq = w.rows + kRowStride * q;
@@ -355,6 +358,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         w.rowsf[kRowFStride * j + 3 + q] = f32_up(w.a);
     }
     publish_bounds(rb);
+    dbg_tick(1);
 
     const double bpad = q == 3 ? kSentinel : 0.0;
     int nlist = 0, ns = 0;
@@ -374,6 +378,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
                 oc[h] = t >= 0 ? orig[(int64_t)t * 16 + j] : INT_MAX;
             }
             ++mul_trips;
+            if (mul_trips == 1) dbg_tick(5);
 #pragma unroll
             for (int h0 = 0; h0 < kMulBatch; h0 += 4) {
                 if (e0 + h0 >= nlist) break;
@@ -404,6 +409,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
 #undef KPX_NNL_TILE
             }
         }
+        if (mul_trips <= 2) dbg_tick(6);
         visited += (unsigned)nlist;
         nlist = 0;
         // tighten the row bounds with the best value any of the row's 16 lanes holds -- when that pays: the reductions below cost
@@ -434,6 +440,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
             publish_bounds(nrb);
         }
         wave_lds_fence();
+        dbg_tick(7);
     };
 
     // T: the tile boxes of the surviving groups surv[0 .. ns) -> tile list
@@ -455,6 +462,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
             }
         }
         ++box_trips;
+        if (box_trips == 1) dbg_tick(3);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (4 * p >= ns) break;
@@ -480,6 +488,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
             nlist += __builtin_popcountll(hm);
         }
         ns = 0;
+        if (box_trips == 1) dbg_tick(4);
     };
 
     // G: lane holds the box of group gbase + lane; gmask = groups the wave's box can reach
@@ -555,11 +564,13 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
             wave_lds_fence();                              // the candidate slots are reused by the next pass
         }
         const bool last = gmask == 0ull && g_next >= n_groups;
+        if (box_trips == 0) dbg_tick(2);
         if (ns) tiles_of_survivors();
         if (nlist > kLList - 16 * kLSurv || (last && nlist)) multiply();
         if (last) break;
     }
 
+    dbg_tick(8);
     w.light_gap2 = reached ? -1.0 : wave_uniform_min(gap_min);
     // reduce over the 16 lanes that hold the same rows (lexicographic (value, original column) minimum)
 #define KPX_NNL_ROWMIN(CTRL)                                               \
@@ -598,6 +609,7 @@ __device__ __forceinline__ unsigned long long sweep_wave(WaveRows &w, const doub
         for (int r = 0; r < 4; ++r) w.rb_out[r] = rowq[4 * kRowStride * r + kRowBound];
         w.eps_out = eps;
     }
+    dbg_tick(9);
 #undef KPX_NNL_ROWMIN
     return (unsigned long long)(visited & 0xFFFFu) | ((unsigned long long)(box_trips & 0xFFFFu) << 16) | ((unsigned long long)(mul_trips & 0xFFFFu) << 32) |
            ((unsigned long long)(groups_kept & 0xFFFFu) << 48);

@@ -17,10 +17,11 @@ for mode, nrm in (("p2p", None), ("p2plane", tn)):
         one = ops.icp(s, tgt, 100.0, i0, mode, nrm, 12)
         solo = ops.icp_batch([s], tgt, 100.0, [i0], mode, nrm, 12)[0]
         rT, rf, _, rit = O.registration_icp(s, tgt, 100.0, i0, mode, nrm, 12)
-        print(os.environ.get("KPX_ICP_CERT", "1"), mode, i, "it", b["iterations"], one["iterations"], rit, "fit", b["fitness"] == one["fitness"], rf == b["fitness"],
+        print(os.environ.get("KPX_ICP_CERT", "1"), os.environ.get("KPX_ICP_CHAIN", "1"), mode, i, "it", b["iterations"], solo["iterations"], one["iterations"], rit, "fit", b["fitness"] == one["fitness"], rf == b["fitness"],
               "batch-one %.3e  batch-oracle %.3e  one-oracle %.3e  solo-batch %.3e" % (np.abs(b["transformation"] - one["transformation"]).max(),
               np.abs(b["transformation"] - rT).max(), np.abs(one["transformation"] - rT).max(), np.abs(solo["transformation"] - b["transformation"]).max()))
 '''
+VAR = os.environ.get("DBG_VAR", "KPX_ICP_CERT")
 for cert in ("1", "0"):
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "KPX_ICP_CERT": cert}, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, VAR: cert}, capture_output=True, text=True)
     print(r.stdout, r.stderr[-1500:] if r.returncode else "")

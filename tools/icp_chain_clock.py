@@ -32,4 +32,11 @@ for k in range(31):
     f = lambda v: (v - base) / 100.0
     print(f"k {k:2d}  first seen {f(r[10]):6.2f}  last seen {f(r[5]):6.2f} | b0: seen {f(r[0]):6.2f} prepared {f(r[1]):6.2f} swept {f(r[2]):6.2f} added {f(r[3]):6.2f} ticket {f(r[4]):6.2f} | "
           f"last added {f(r[11]):6.2f}  last ticket {f(r[6]):6.2f} | winner: totals {f(r[7]):6.2f} update {f(r[8]):6.2f} published {f(r[9]):6.2f}")
+    sw = int(r[13])
+    print(f"       b0 wave 0: rows searched {bin(int(r[14]) & 0xFFFF).count('1'):2d} certified {bin((int(r[14]) >> 16) & 0xFFFF).count('1'):2d}  tiles multiplied {sw & 0xFFFF}  "
+          f"tile-box trips {(sw >> 16) & 0xFFFF}  operand trips {(sw >> 32) & 0xFFFF}  groups kept {(sw >> 48) & 0xFFFF}")
+    if r[16]:
+        t0 = int(r[16]); g = lambda i: (int(r[16 + i]) - t0) / 100.0 if r[16 + i] else float("nan")
+        print(f"       its sweep (us from entry): bounds published {g(1):5.2f}  groups tested {g(2):5.2f}  tile boxes asked {g(3):5.2f}  tiles listed {g(4):5.2f}  "
+              f"operands asked {g(5):5.2f}  multiplied {g(6):5.2f}  bounds tightened {g(7):5.2f}  loop left {g(8):5.2f}  exit {g(9):5.2f}")
     prev_pub = r[9]
