@@ -364,6 +364,9 @@ def launch_ranks(n):
         ndev = 0
     if ndev < n:
         env.setdefault("KPX_DIST_BACKEND", "gloo")
+        # processes that share a GPU must not run one-launch ICP chains side by side: each admits its chain against the whole device
+        # (kpx_icp.hip, chain_launch_if_fits), and blocks of two chains waiting for each other's wave slots would only end at the timeout
+        env.setdefault("KPX_ICP_CHAIN", "0")
         print(f"bench: {n} ranks on {ndev} visible GPU(s): the ranks share the device(s), rendezvous and collectives over gloo (rehearsal, not a "
               f"scaling measurement)", file=sys.stderr, flush=True)
     with socket.socket() as sk:

@@ -23,6 +23,9 @@
 // 3x3 (Kabsch) or 6x6 (point-to-plane) system, updates T and raises `done`.
 #include <chrono>
 #include <mutex>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include <limits.h>
 #include <stddef.h>
 #include <string.h>
@@ -1371,6 +1374,16 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         for (int a = 0; a < 3; ++a) { rowk[wave][lane][a] = my_pt[a]; rowk[wave][lane][3 + a] = my_nrm[a]; }
         rowk[wave][lane][6] = __int_as_float(my_prev);
     }
+    if (PERSIST && fuse.stamp) {          // who is searched, and why (chain clock: [26] waves, [27] rows, [28] rows without partner, [29] rows without certificate)
+        const bool searched = lane < 16 && my_active && !my_certd;
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(searched);
+        const unsigned long long np = __builtin_amdgcn_ballot_w64(searched && my_prev < 0);
+        const unsigned long long nc = __builtin_amdgcn_ballot_w64(searched && (my_cert & ~63u) == 0u);
+        if (lane == 0 && sm) {
+            atomicAdd(&fuse.stamp[26], 1ull); atomicAdd(&fuse.stamp[27], (unsigned long long)__builtin_popcountll(sm));
+            atomicAdd(&fuse.stamp[28], (unsigned long long)__builtin_popcountll(np)); atomicAdd(&fuse.stamp[29], (unsigned long long)__builtin_popcountll(nc));
+        }
+    }
     const unsigned act_mask = (unsigned)(__builtin_amdgcn_ballot_w64(lane < 16 && my_active) & 0xFFFFull);
     const unsigned certd_mask = (unsigned)(__builtin_amdgcn_ballot_w64(lane < 16 && my_certd) & 0xFFFFull);
     wave_lds_fence();
@@ -2476,7 +2489,24 @@ template <class F> bool chain_launch_if_fits(unsigned blocks, hipStream_t st, F 
     if (bk.budget < 0) {
         int per_cu = 0, cus = 0;
         static const long forced = [] { const char *e = getenv("KPX_ICP_CHAIN_BUDGET"); return e ? atol(e) : -1L; }();
-        if (forced >= 0) bk.budget = forced;
+        // ONE process per GPU may run chains: two processes each admitting chains against the whole device could leave blocks of both
+        // waiting for wave slots the other holds (ended only by the timeout).  The first process to take the device's lock file keeps
+        // it for its lifetime; the others (ranks sharing a GPU in a rehearsal, a second service on the same card) run a launch per
+        // iteration.  No lock (no writable /tmp, no bus id) = no chains.
+        bool mine = false;
+        char bus[64] = { 0 };
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) == hipSuccess) {
+            char path[128];
+            for (char *c = bus; *c; ++c) if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'f') || (*c >= 'A' && *c <= 'F'))) *c = '_';
+            snprintf(path, sizeof(path), "/tmp/kpx_chain_%s.lock", bus);
+            const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+            if (fd >= 0) {
+                if (flock(fd, LOCK_EX | LOCK_NB) == 0) mine = true;        // (kept open: the lock lives as long as the process)
+                else close(fd);
+            }
+        }
+        if (!mine) bk.budget = 0;
+        else if (forced >= 0) bk.budget = forced;
         else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)icp_chain_kernel, kIThreads, 0) == hipSuccess &&
                  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 1)
             bk.budget = (long)(per_cu - 1) * cus;

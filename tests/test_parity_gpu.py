@@ -1765,6 +1765,11 @@ for mode in ("p2plane", "p2p"):
     r = ops.icp_batch(downs[1:], downs[0], P.icp_max_dist, inits, mode, tn, P.icp_max_iteration)
     out[mode + "_T"] = np.stack([x["transformation"] for x in r])
     out[mode + "_s"] = np.array([[x["fitness"], x["inlier_rmse"], x["iterations"], x["count"]] for x in r])
+    # a batch small enough for the one-launch chain (its blocks must all be resident: <= 512), ragged sizes, and one registration alone
+    for tag, srcs, ini in (("small", [downs[1][:9000], downs[2][:7001], downs[3][:12000]], inits), ("alone", [downs[3][:20001]], inits[2:3])):
+        r = ops.icp_batch(srcs, downs[0], P.icp_max_dist, ini, mode, tn, P.icp_max_iteration)
+        out[mode + "_" + tag + "_T"] = np.stack([x["transformation"] for x in r])
+        out[mode + "_" + tag + "_s"] = np.array([[x["fitness"], x["inlier_rmse"], x["iterations"], x["count"]] for x in r])
 np.savez(sys.argv[1], **out)
 """
 
@@ -1772,20 +1777,22 @@ np.savez(sys.argv[1], **out)
 def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
     """The update step in its own kernel (KPX_ICP_SPLIT=1), in the last block of the sweep (2, the default) and with the blocks
     that provably cannot find a partner left out of the sweeps (KPX_ICP_LIGHT_SKIP, default on) and the rows whose partner provably
-    cannot change left out of the search (KPX_ICP_CERT, default on): the exact fixed-point sums do not depend on which blocks add to
-    them or when, and a certified row keeps exactly the partner a search would return, so transforms, fitness, rmse, iterations and
-    counts agree to the last bit."""
+    cannot change left out of the search (KPX_ICP_CERT, default on), and the whole chain in one launch (icp_chain_kernel, the default
+    where a batch's blocks fit the device: the "small" and "alone" batches) against a launch per iteration (KPX_ICP_CHAIN=0): the
+    exact fixed-point sums do not depend on which blocks add to them or when, and a certified row keeps exactly the partner a search
+    would return, so transforms, fitness, rmse, iterations and counts agree to the last bit."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for name, env in (("tail+skip", {}), ("nocert", {"KPX_ICP_CERT": "0"}), ("tail", {"KPX_ICP_LIGHT_SKIP": "0"}), ("kernel", {"KPX_ICP_SPLIT": "1"})):
-        f = str(tmp_path / (name.replace("+", "_") + ".npz"))
+    for name, env in (("tail+skip", {}), ("nocert", {"KPX_ICP_CERT": "0"}), ("tail", {"KPX_ICP_LIGHT_SKIP": "0"}), ("kernel", {"KPX_ICP_SPLIT": "1"}),
+                      ("launches", {"KPX_ICP_CHAIN": "0"}), ("chain nocert", {"KPX_ICP_CERT": "0", "KPX_ICP_CHAIN": "1"})):
+        f = str(tmp_path / (name.replace("+", "_").replace(" ", "_") + ".npz"))
         r = subprocess.run([sys.executable, "-c", _ICP_UPDATE_MODES, f], cwd=root, capture_output=True, text=True, timeout=300,
                            env={**os.environ, **env})
         assert r.returncode == 0, r.stderr[-2000:]
         got[name] = dict(np.load(f))
-    for name in ("nocert", "tail", "kernel"):
+    for name in ("nocert", "tail", "kernel", "launches", "chain nocert"):
         for key, v in got["tail+skip"].items():
             assert np.array_equal(v, got[name][key]), (name, key)
     its = got["tail+skip"]["p2plane_s"][:, 2]

@@ -39,4 +39,5 @@ for k in range(31):
         t0 = int(r[16]); g = lambda i: (int(r[16 + i]) - t0) / 100.0 if r[16 + i] else float("nan")
         print(f"       its sweep (us from entry): bounds published {g(1):5.2f}  groups tested {g(2):5.2f}  tile boxes asked {g(3):5.2f}  tiles listed {g(4):5.2f}  "
               f"operands asked {g(5):5.2f}  multiplied {g(6):5.2f}  bounds tightened {g(7):5.2f}  loop left {g(8):5.2f}  exit {g(9):5.2f}")
+    print(f"       searched: {int(r[26])} waves, {int(r[27])} rows ({int(r[28])} without a partner, {int(r[29])} without a certificate)")
     prev_pub = r[9]
