@@ -138,9 +138,24 @@ def quiet_kernel_roofline(torch, ops, xy, pair_depth, init, P):
     fk = ops._count(fcnt)
     downs = [d[0] for d in ops.voxel_downsample_batch([fp[i, :fk[i]] for i in range(S)], P.reg_voxel)]
     tn = ops.estimate_normals(downs[0], 2.0 * P.reg_voxel, P.normals_nn) if P.icp_mode == "p2plane" else None
-    for _ in range(3):
-        ops.icp_batch([downs[1]], downs[0], P.icp_max_dist, [init], P.icp_mode, tn, P.icp_max_iteration)
-    torch.cuda.synchronize()
+    # The roofline row is the launch-per-iteration form (the form the frame's three registrations run in: their blocks do not fit the
+    # device at once); the one-launch form of the same registration (icp_chain_kernel, the default for a batch this size) is timed
+    # beside it as `chain_form`: host wall of the whole chain, per registration and per iteration.
+    import time as _t
+    chain = {}
+    was = ops.icp_chain(-1)
+    for form in ((1, 0) if was else (0,)):
+        ops.icp_chain(form)
+        for _ in range(3):
+            r = ops.icp_batch([downs[1]], downs[0], P.icp_max_dist, [init], P.icp_mode, tn, P.icp_max_iteration)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for _ in range(20):
+            r = ops.icp_batch([downs[1]], downs[0], P.icp_max_dist, [init], P.icp_mode, tn, P.icp_max_iteration)
+        torch.cuda.synchronize()
+        us = (_t.perf_counter() - t0) / 20 * 1e6
+        its = int(r[0]["iterations"]) + 1
+        chain["one_launch" if form else "launch_per_iteration"] = {"us_per_registration": round(us, 1), "searches": its, "us_per_search": round(us / its, 2)}
     ops.prof_stride(1)
     ops.prof_begin(1 << 14)
     reps = 10
@@ -148,6 +163,7 @@ def quiet_kernel_roofline(torch, ops, xy, pair_depth, init, P):
         ops.icp_batch([downs[1]], downs[0], P.icp_max_dist, [init], P.icp_mode, tn, P.icp_max_iteration)
     torch.cuda.synchronize()
     prof = ops.prof_end()
+    ops.icp_chain(was)
     kname = max(KERNEL_OF, key=lambda k: prof[k][0])
     ms, launches, flops = prof[kname]
     if not launches:
@@ -164,6 +180,10 @@ def quiet_kernel_roofline(torch, ops, xy, pair_depth, init, P):
             "algorithmic_flop_per_launch": round(dense), "algorithmic_TFLOPs": round(dense / dur / 1e12, 2),
             "culled_to": round(issued / dense, 6), "algorithmic_bytes": 12 * (n + m),
             "timing": "one registration alone on the device, HIP event pair around every launch on its launch stream"}
+    if chain:
+        chain["note"] = ("host wall of kpx_icp_batch on this one registration (sort, preparation and the whole chain), same process, same clouds; "
+                         "one_launch = icp_chain_kernel (resident blocks iterate; no kernel boundary, no host poll)")
+        roof["chain_form"] = chain
     rec = pmc_recorded(KERNEL_OF[kname])
     roof.update(rec)
     if rec.get("traffic"):

@@ -466,6 +466,10 @@ int kpx_prof_icp_waves(uint64_t *h_out, int64_t cap_waves, int64_t *h_count);
  * partner is certified unchanged -- registration_icp's correspondence step, preprocessing/registration.py:78-84 -- are searched all
  * the same and compared).  h_out8 (8 x uint64, cleared by the call): [0] rows certified, [1] rows searched, [2] certified rows whose
  * search found another partner (must be 0), [3..7] the first such row: iteration, sorted row, kept and found partner, key bits. */
+/* The one-launch form of the culled ICP chain (kpx_icp_batch groups whose blocks fit the device; kpx_icp.hip, icp_chain_kernel): on = 1 / 0
+   switches it for the calling process, on = -1 only asks; returns the previous setting (on = -2: the number of chains this process has launched).  Default: on unless KPX_ICP_CHAIN=0.  Results do
+   not depend on it (tests/test_parity_gpu.py, test_icp_update_placements_and_light_skip_are_bit_identical). */
+int kpx_icp_chain(int32_t on);
 int kpx_prof_icp_cert(uint64_t *h_out8);
 /* Clock of the one-launch ICP chain (KPX_ICP_CHAIN_STAMPS=1): 64 iterations x 32 stamps of the 100 MHz wall clock, first registration of
    the last chain launch (slots: kpx_icp.hip, g_chain_stamp); read and reset.  A development aid like the other kpx_prof_* entries. */

@@ -106,6 +106,7 @@ SIGNATURES = {
     "kpx_sort_pairs_u32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "kpx_prof_icp_phases": (C.c_int, [_vp]),
     "kpx_prof_icp_waves": (C.c_int, [_vp, C.c_int64, _vp]),
+    "kpx_icp_chain": (C.c_int, [C.c_int32]),
     "kpx_prof_icp_cert": (C.c_int, [_vp]),
     "kpx_prof_icp_chain": (C.c_int, [_vp]),
     "kpx_prof_end": (C.c_int, [_vp, _vp, _vp]),

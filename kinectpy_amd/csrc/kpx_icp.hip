@@ -1912,6 +1912,14 @@ double nn_local_take_visits()
     return sum;
 }
 
+// the one-launch chain: on unless KPX_ICP_CHAIN=0; kpx_icp_chain() switches it at run time (A/B measurements inside one process)
+static int g_chain_form = -1;
+static int g_chain_launches = 0;                // chains launched by this process (kpx_icp_chain(-2): tests check that the form they test ran)
+static bool chain_form_on()
+{
+    if (g_chain_form < 0) { const char *e = getenv("KPX_ICP_CHAIN"); g_chain_form = (e && e[0] == '0') ? 0 : 1; }
+    return g_chain_form != 0;
+}
 static int g_nn_engine = -1;          // KPX_NN_ENGINE_*; -1 = not chosen yet (environment decides at first use)
 static bool g_nn_fp64_only = false;   // KPX_NN_ENGINE_DENSE_FP64: the all-pairs engine without its float32 screening sweep
 static bool local_engine()
@@ -2227,6 +2235,13 @@ KPX_EXPORT int kpx_prof_icp_cert(uint64_t *h_out8)
     KPX_HIP(hipMemcpy(p, zero, sizeof(zero), hipMemcpyHostToDevice));
     return KPX_OK;
 }
+KPX_EXPORT int kpx_icp_chain(int32_t on)
+{
+    if (on == -2) return __atomic_load_n(&g_chain_launches, __ATOMIC_RELAXED);
+    const int cur = chain_form_on() ? 1 : 0;
+    if (on >= 0) g_chain_form = on ? 1 : 0;
+    return cur;
+}
 // The chain clock (g_chain_stamp): 64 x 16 words, read and reset ([10], the earliest-block slot, to all ones)
 KPX_EXPORT int kpx_prof_icp_chain(uint64_t *h_out2048)
 {
@@ -2493,9 +2508,10 @@ template <class F> bool chain_launch_if_fits(unsigned blocks, hipStream_t st, F 
         // waiting for wave slots the other holds (ended only by the timeout).  The first process to take the device's lock file keeps
         // it for its lifetime; the others (ranks sharing a GPU in a rehearsal, a second service on the same card) run a launch per
         // iteration.  No lock (no writable /tmp, no bus id) = no chains.
-        bool mine = false;
+        static const bool no_lock = [] { const char *e = getenv("KPX_ICP_CHAIN_LOCK"); return e && e[0] == '0'; }();   // the caller vouches for being alone
+        bool mine = no_lock;
         char bus[64] = { 0 };
-        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) == hipSuccess) {
+        if (!mine && hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) == hipSuccess) {
             char path[128];
             for (char *c = bus; *c; ++c) if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'f') || (*c >= 'A' && *c <= 'F'))) *c = '_';
             snprintf(path, sizeof(path), "/tmp/kpx_chain_%s.lock", bus);
@@ -2527,6 +2543,7 @@ template <class F> bool chain_launch_if_fits(unsigned blocks, hipStream_t st, F 
         c.made = true;
     }
     launch();
+    __atomic_fetch_add(&g_chain_launches, 1, __ATOMIC_RELAXED);
     if (hipEventRecord(c.ev, st) != hipSuccess) return true;     // launched all the same; the slot just is not booked
     c.blocks = blocks;
     c.busy = true;
@@ -2682,13 +2699,12 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
         }();
         // The one-launch chain (icp_chain_kernel) when the update is the last block's (split 2), the records hold the iterations and the
         // group's blocks fit the device beside the chains already in flight; KPX_ICP_CHAIN=0: always a launch per iteration.
-        static const bool chain_env = [] { const char *e = getenv("KPX_ICP_CHAIN"); return !(e && e[0] == '0'); }();
         static const unsigned long long chain_limit = [] {
             const char *e = getenv("KPX_ICP_CHAIN_WAIT_SECONDS");
             const double v = e ? atof(e) : 0.0;
             return (unsigned long long)((v > 0.0 ? v : 2.0) * 1e8);
         }();
-        const bool chain_ok = chain_env && split == 2 && max_iteration <= kChainRecords - 2 && chain_abort_word() != nullptr;
+        const bool chain_ok = chain_form_on() && split == 2 && max_iteration <= kChainRecords - 2 && chain_abort_word() != nullptr;
         IcpBatchArgs A[8], Ac[8];                              // count <= 64: at most 8 groups
         int gk[8];
         bool gfin[8];

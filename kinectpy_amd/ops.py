@@ -627,6 +627,11 @@ def sort_pairs_u32(keys, vals, end_bit=32):
     return ko, vo
 
 
+def icp_chain(on=-1):
+    """the one-launch form of the culled ICP chain on (1) / off (0) for this process; -1 only asks.  -> the previous setting (-2: -> chains launched by this process so far)"""
+    return int(L.load().kpx_icp_chain(int(on)))
+
+
 def prof_icp_chain():
     """-> (64, 32) uint64: the one-launch ICP chain's clock (KPX_ICP_CHAIN_STAMPS=1; slots in kpx_icp.hip, g_chain_stamp), reset by the call"""
     out = np.zeros((64, 32), dtype=np.uint64)

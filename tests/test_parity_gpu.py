@@ -1770,6 +1770,7 @@ for mode in ("p2plane", "p2p"):
         r = ops.icp_batch(srcs, downs[0], P.icp_max_dist, ini, mode, tn, P.icp_max_iteration)
         out[mode + "_" + tag + "_T"] = np.stack([x["transformation"] for x in r])
         out[mode + "_" + tag + "_s"] = np.array([[x["fitness"], x["inlier_rmse"], x["iterations"], x["count"]] for x in r])
+out["chains"] = np.array([ops.icp_chain(-2)])
 np.savez(sys.argv[1], **out)
 """
 
@@ -1789,14 +1790,66 @@ def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
                       ("launches", {"KPX_ICP_CHAIN": "0"}), ("chain nocert", {"KPX_ICP_CERT": "0", "KPX_ICP_CHAIN": "1"})):
         f = str(tmp_path / (name.replace("+", "_").replace(" ", "_") + ".npz"))
         r = subprocess.run([sys.executable, "-c", _ICP_UPDATE_MODES, f], cwd=root, capture_output=True, text=True, timeout=300,
-                           env={**os.environ, **env})
+                           env={**os.environ, "KPX_ICP_CHAIN_LOCK": "0", **env})    # (this process may hold the device's chain lock; it is idle meanwhile)
         assert r.returncode == 0, r.stderr[-2000:]
         got[name] = dict(np.load(f))
+    # the forms that were to be compared did run: four chains (two modes x two small batches) by default, none with KPX_ICP_CHAIN=0 or a split update
+    assert got["tail+skip"]["chains"][0] == 4 and got["chain nocert"]["chains"][0] == 4 and got["launches"]["chains"][0] == 0 and got["kernel"]["chains"][0] == 0
     for name in ("nocert", "tail", "kernel", "launches", "chain nocert"):
         for key, v in got["tail+skip"].items():
-            assert np.array_equal(v, got[name][key]), (name, key)
+            if key != "chains":
+                assert np.array_equal(v, got[name][key]), (name, key)
     its = got["tail+skip"]["p2plane_s"][:, 2]
     assert its.max() >= 10, its                                        # a chain long enough for blocks to be skipped
+
+
+_ICP_CHAIN_ABORT = r"""
+import os, sys, json, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from kinectpy_amd import ops
+from kinectpy_amd.pipeline import PipelineParams
+from kinectpy_amd.utils import synth
+P = PipelineParams()
+xy, depth, rgb, inits, _ = synth.sensor_ring(4, 1)
+d = torch.as_tensor(depth[0]).cuda()
+fp, _, _, cnt = ops.depth_to_cloud(d, xy, None, 4, False, False, sync=False)
+k = ops._count(cnt)
+downs = [x[0] for x in ops.voxel_downsample_batch([fp[i, :k[i]] for i in range(4)], P.reg_voxel)]
+tn = ops.estimate_normals(downs[0], 2.0 * P.reg_voxel, P.normals_nn)
+big = torch.cat(downs[1:])                            # ONE registration of ~94k rows: ~1470 blocks (several problems of a batch could
+                                                      # still drain one after the other; one problem larger than the device cannot)
+r = ops.icp_batch([big], downs[0], P.icp_max_dist, inits[:1], "p2plane", tn, 8)
+torch.cuda.synchronize()
+first = float(r[0]["fitness"])
+err = ""
+try:
+    ops.icp_batch(downs[1:2], downs[0], P.icp_max_dist, inits[:1], "p2plane", tn, 8)
+except Exception as e:                                  # noqa: BLE001
+    err = str(e)
+ops.icp_chain(0)
+again = ops.icp_batch([big], downs[0], P.icp_max_dist, inits[:1], "p2plane", tn, 8)
+print(json.dumps(dict(first=None if np.isnan(first) else first, err=err, chains=ops.icp_chain(-2), again=float(again[0]["fitness"]), iterations=int(again[0]["iterations"]),
+                      blocks=int((big.shape[0] + 63) // 64))))
+"""
+
+
+def test_icp_chain_that_cannot_be_resident_fails_loudly():
+    """The one-launch chain needs all its blocks resident; the host only admits chains that fit (chain_launch_if_fits).  Forced past
+    that check (KPX_ICP_CHAIN_BUDGET far above what the device holds, a short KPX_ICP_CHAIN_WAIT_SECONDS), a chain whose blocks cannot
+    all be resident must END -- every block's wait is bounded -- poison its results and make the next call fail with a message that
+    names the cause; the launch-per-iteration form then still works in the same process."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ICP_CHAIN_ABORT], cwd=root, capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "KPX_ICP_CHAIN_LOCK": "0", "KPX_ICP_CHAIN_BUDGET": "1000000", "KPX_ICP_CHAIN_WAIT_SECONDS": "0.05"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["blocks"] > 1024, out["blocks"]                          # more blocks than an MI355X holds at 3 per CU: the chain cannot be resident
+    assert out["chains"] == 1 and out["first"] is None, out
+    assert "gave up waiting" in out["err"], out
+    assert 0.0 < out["again"] <= 1.0 and out["iterations"] >= 1, out
 
 
 _ICP_CERT_CHECK = r"""
