@@ -2807,8 +2807,20 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
             }
             if (advanced) t_last = std::chrono::steady_clock::now();
             else if (pending) {
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > stall_limit)
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count();
+                if (waited > stall_limit)
                     rc = fail(KPX_ERR_HIP, "kpx_icp_batch: no progress for %.0f s (KPX_ICP_STALL_SECONDS)", stall_limit);
+                static const bool trace = [] { const char *e = getenv("KPX_ICP_TRACE_STALL"); return e && e[0] == '1'; }();
+                static thread_local double told = 0.0;
+                if (trace && waited > 0.003 && waited > told + 0.003) {
+                    told = waited;
+                    fprintf(stderr, "icp_batch waiting %.1f ms: generation %llu gk %d", waited * 1e3, generation, gk[0]);
+                    for (int c = 0; c < A[0].count; ++c) {
+                        const unsigned long long w = __atomic_load_n(&h_progress[c], __ATOMIC_ACQUIRE);
+                        fprintf(stderr, " | p%d gen %llu done %llu k %llu", c, w >> 40, (w >> 32) & 1ull, w & 0xFFFFFFFFull);
+                    }
+                    fprintf(stderr, " query %d\n", (int)hipStreamQuery(on_caller ? st : lanes[0]));
+                } else if (waited < 0.001) told = 0.0;
                 __builtin_ia32_pause();
             }
         }
