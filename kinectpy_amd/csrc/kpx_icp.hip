@@ -2676,7 +2676,12 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
         if (!h_progress) KPX_HIP(hipHostMalloc((void **)&h_progress, 64 * sizeof(unsigned long long), hipHostMallocDefault));
         generation = (generation + 1) & 0xFFFFFFull;
         const unsigned long long tag = generation << 40;
-        constexpr int window = 6;
+        // Launches kept queued ahead of the newest progress word the host has seen.  Every launch queued beyond the one that turns out to
+        // be the last still runs (its blocks read "done" and return: ~4 us each) IN FRONT of whatever the caller queues next, and with
+        // several frames in flight those empty launches take dispatch slots from the other frames' chains: 3 instead of round 2's 6,
+        // same box, four frames in flight 2556-2600 vs 2441-2448 Mpoints/s, one frame at a time equal (a launch lasts >= 20 us, the
+        // progress word reaches the host in a few; 2 starts to starve: profiles/r04/exp_icp_window.txt).  KPX_ICP_WINDOW: A/B switch.
+        static const int window = [] { const char *e = getenv("KPX_ICP_WINDOW"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 3; }();
         static const double stall_limit = [] { const char *e = getenv("KPX_ICP_STALL_SECONDS"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 60.0; }();
         auto t_last = std::chrono::steady_clock::now();
         // split (default): the update of every registration runs in icp_solve_batch_kernel between the sweeps; KPX_ICP_SPLIT=0: in the
