@@ -471,9 +471,9 @@ int kpx_prof_icp_waves(uint64_t *h_out, int64_t cap_waves, int64_t *h_count);
    not depend on it (tests/test_parity_gpu.py, test_icp_update_placements_and_light_skip_are_bit_identical). */
 int kpx_icp_chain(int32_t on);
 int kpx_prof_icp_cert(uint64_t *h_out8);
-/* Clock of the one-launch ICP chain (KPX_ICP_CHAIN_STAMPS=1): 64 iterations x 32 stamps of the 100 MHz wall clock, first registration of
+/* Clock of the one-launch ICP chain (KPX_ICP_CHAIN_STAMPS=1): 64 iterations x 48 stamps of the 100 MHz wall clock, first registration of
    the last chain launch (slots: kpx_icp.hip, g_chain_stamp); read and reset.  A development aid like the other kpx_prof_* entries. */
-int kpx_prof_icp_chain(uint64_t *h_out2048);
+int kpx_prof_icp_chain(uint64_t *h_out3072);
 
 #ifdef __cplusplus
 }

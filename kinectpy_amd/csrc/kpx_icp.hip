@@ -85,6 +85,7 @@ struct IcpState {
     int32_t iter, done;
     double motion, reach;      // see LightSkip: accumulated bound on how far any source point has moved; reach of a row's search
     double last_motion;        // what the latest update added to `motion` (row certificates: how calm the registration is)
+    double smax;               // largest |T p| over the source's bounding box under the CURRENT T (the next update's lever arm); < 0: not known yet
 };
 
 __device__ __forceinline__ void xform_row(const double *__restrict__ T, const float *__restrict__ p, double s[3])
@@ -779,18 +780,22 @@ struct FinishScratch {
     int flag;
 };
 __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, int mode, int k, int max_iter, double rel_fit, double rel_rmse,
-                                                IcpState *st, double *__restrict__ result, FinishScratch &fs, int lane, const LightSkip ls = LightSkip{ nullptr, 0.0, 0.0 })
+                                                IcpState *st, double *__restrict__ result, FinishScratch &fs, int lane, const LightSkip ls = LightSkip{ nullptr, 0.0, 0.0 },
+                                                unsigned long long *dbg = nullptr)
 {
+    auto tick = [&](int slot) { if (dbg && lane == 0) dbg[slot] = wall_clock64(); };
+    tick(0);
     // largest |T p| over the source: |.| is convex, so it is attained at a corner of the source's bounding box (any affine T)
+    // (every lane of the wave calls it: lane c & 7 takes corner c, the maximum -- exact, order-free -- is folded over the lanes)
     auto reach_of_source = [&](const double *T) {
-        double m2 = 0.0;
-        for (int c = 0; c < 8; ++c) {
-            const double x = ls.sbbox[(c & 1) ? 3 : 0], y = ls.sbbox[(c & 2) ? 4 : 1], z = ls.sbbox[(c & 4) ? 5 : 2];
-            double n2 = 0.0;
+        const int c = lane & 7;
+        const double x = ls.sbbox[(c & 1) ? 3 : 0], y = ls.sbbox[(c & 2) ? 4 : 1], z = ls.sbbox[(c & 4) ? 5 : 2];
+        double n2 = 0.0;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { const double v = T[4 * r] * x + T[4 * r + 1] * y + T[4 * r + 2] * z + T[4 * r + 3]; n2 += v * v; }
-            m2 = fmax(m2, n2);
-        }
+        for (int r = 0; r < 3; ++r) { const double v = T[4 * r] * x + T[4 * r + 1] * y + T[4 * r + 2] * z + T[4 * r + 3]; n2 += v * v; }
+        double m2 = fmax(0.0, n2);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) m2 = fmax(m2, __shfl_xor(m2, o, 64));
         return sqrt(m2) * (1.0 + 1e-9);
     };
     if (lane == 0) {
@@ -805,6 +810,7 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
         fs.flag = done ? 1 : (cnt < 1.0 ? 2 : 0);              // 2: no correspondence -> identity update
     }
     wave_lds_fence();
+    tick(1);
     const int flag = fs.flag;
     if (flag == 0) {
         if (lane < 16) fs.U[lane] = (lane % 5 == 0) ? 1.0 : 0.0;
@@ -821,6 +827,7 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
                 fs.M[i][c] = v;
             }
             wave_lds_fence();
+            tick(2);
             bool ok = true;
 #pragma unroll
             for (int jj = 0; jj < 6; ++jj) {
@@ -836,6 +843,7 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
                 if (mine && ok) fs.M[i][c] = v;
                 wave_lds_fence();
             }
+            tick(3);
             if (ok) {
                 if (lane < 3) {
                     const double a = fs.M[lane][6] / fs.M[lane][lane];
@@ -860,6 +868,11 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
             for (int e = 0; e < 16; ++e) fs.U[e] = U[e];
         }
         wave_lds_fence();
+        tick(4);
+        // the lever arm of this update = the reach of the source under the transform it is applied to: what the previous update left in
+        // `smax` (the same function of the same T, bit for bit); the first update of a registration computes it
+        double lever = 0.0;
+        if (ls.sbbox) lever = st->smax >= 0.0 ? st->smax : reach_of_source(st->T);      // (wave-uniform branch: smax is one LDS / memory word)
         if (ls.sbbox && lane == 0) {                       // bound on the displacement this update gives any source point
             double rot = 0.0;
 #pragma unroll
@@ -867,10 +880,11 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { const double d = fs.U[4 * r + c] - (r == c ? 1.0 : 0.0); rot += d * d; }
             const double tu = sqrt(fs.U[3] * fs.U[3] + fs.U[7] * fs.U[7] + fs.U[11] * fs.U[11]);
-            const double moved = (sqrt(rot) * reach_of_source(st->T) + tu) * (1.0 + 1e-9) + 1e-9;
+            const double moved = (sqrt(rot) * lever + tu) * (1.0 + 1e-9) + 1e-9;
             st->motion += moved;
             st->last_motion = moved;
         }
+        tick(5);
         if (lane < 16) {
             const int r = lane >> 2, c = lane & 3;
             double v = 0.0;
@@ -882,12 +896,16 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
         if (lane < 16) st->T[lane] = fs.Tn[lane];
     }
     wave_lds_fence();
+    tick(6);
+    double smax = 0.0;
+    if (ls.sbbox) smax = reach_of_source(st->T);
     if (ls.sbbox && lane == 0) {                           // reach of a row's search under the transform the next sweep uses
-        const double smax = reach_of_source(st->T);
+        st->smax = smax;
         // upper bound of nn_local's row bound rb = (clamp - 1)(1 + 2^-30) + eps with clamp, eps as in icp_iter_body / sweep_wave
         const double r2 = ls.max_d2 * (1.0 + 3.7252902984619140625e-9) + 3.7252902984619140625e-9 + 1.4551915228366851806640625e-11 * (smax * smax + ls.t2max + 2.0);
         st->reach = sqrt(r2) * (1.0 + 1e-9);
     }
+    tick(7);
     if (result) {
         if (lane < 16) result[lane] = st->T[lane];
         if (lane == 0) { result[16] = st->fitness; result[17] = st->rmse; result[18] = (double)k; result[19] = st->count; }
@@ -898,9 +916,9 @@ __device__ __forceinline__ void icp_finish_wave(const double *acc, int64_t n, in
 // out of the loop into registers the kernel does not have, and spilled around every sweep
 __device__ __attribute__((noinline)) void icp_finish_wave_call(const double *acc, int64_t n, int mode, int k, int max_iter, double rel_fit, double rel_rmse,
                                                                IcpState *st, double *result, FinishScratch *fs, int lane, const double *sbbox, double max_d2,
-                                                               double t2max)
+                                                               double t2max, unsigned long long *dbg)
 {
-    icp_finish_wave(acc, n, mode, k, max_iter, rel_fit, rel_rmse, st, result, *fs, lane, LightSkip{ sbbox, max_d2, t2max });
+    icp_finish_wave(acc, n, mode, k, max_iter, rel_fit, rel_rmse, st, result, *fs, lane, LightSkip{ sbbox, max_d2, t2max }, dbg);
 }
 
 // 1024 threads: thread (slot q = t & 63, slice = t >> 6) sums its slice of the per-block partials with eight
@@ -954,7 +972,7 @@ __global__ void icp_init_kernel(IcpState *st, Mat16 T0)
     for (int slot = 0; slot < 2; ++slot) {               // both slots (see IcpFuse)
         for (int q = 0; q < 16; ++q) st[slot].T[q] = T0.m[q];
         st[slot].fitness = 0.0; st[slot].rmse = 0.0; st[slot].count = 0.0; st[slot].iter = 0; st[slot].done = 0;
-        st[slot].motion = 0.0; st[slot].reach = INFINITY; st[slot].last_motion = INFINITY;
+        st[slot].motion = 0.0; st[slot].reach = INFINITY; st[slot].last_motion = INFINITY; st[slot].smax = -1.0;
     }
 }
 static Mat16 mat16_from(const double *h)
@@ -1093,7 +1111,7 @@ constexpr int kCertHist = 64;                 // iterations whose transforms are
 // produces): every word validates itself, so there is no flag, no release and no second round trip.
 constexpr int kChainRec = 32;                 // doubles per record (23 used)
 constexpr int kChainRecords = 64;             // records 0 .. max_iteration + 1: the chain form serves max_iteration <= 62
-constexpr int kChainWords = 23;                // = sizeof(IcpState) / 8
+constexpr int kChainWords = 24;                // = sizeof(IcpState) / 8
 constexpr unsigned long long kChainEmpty = 0xFFF8C0DEC0DEC0DEull;
 struct CertPolicy {
     float calm, factor, smin, smax;      // KPX_CERT_CALM / _FACTOR / _SKIN_MIN / _SKIN_MAX (fractions of the correspondence distance)
@@ -1133,7 +1151,7 @@ __device__ unsigned long long g_cert_check[8];
 // Clock of the one-launch chain (KPX_ICP_CHAIN_STAMPS=1, first registration of the launch; 100 MHz stamps, one row per iteration):
 // block 0: [0] record seen, [1] rows prepared, [2] sweep over, [3] sums added, [4] ticket drawn; over all blocks: [5] latest / [10]
 // earliest "record seen", [11] latest "sums added", [6] latest ticket; the winner: [7] totals read, [8] update done, [9] record published.
-__device__ unsigned long long g_chain_stamp[64][32];    // [16 ..]: block 0 wave 0's sweep (sweep_wave, dbg_tick)
+__device__ unsigned long long g_chain_stamp[64][48];    // [32 ..]: the winner's update step from inside (icp_finish_wave, tick)    // [16 ..]: block 0 wave 0's sweep (sweep_wave, dbg_tick)
 __device__ __forceinline__ void chain_tick(unsigned long long *row, int slot, bool on)
 {
     if (row && on) row[slot] = wall_clock64();
@@ -1620,7 +1638,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     IcpState *work = KPX_ICP_STATE_LDS ? &s_state : stw;
     if (PERSIST)
         icp_finish_wave_call(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, (double *)nullptr, &s_tail, lane,
-                             fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max);
+                             fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max, fuse.stamp ? fuse.stamp + 32 : (unsigned long long *)nullptr);
     else
         icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, fuse.result, s_tail, lane,
                         LightSkip{ fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max });
@@ -1628,9 +1646,9 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     if (PERSIST) chain_tick(fuse.stamp, 8, lane == 0);
     if (PERSIST) {
         static_assert(KPX_ICP_STATE_LDS, "the chain form updates the LDS copy of the state");
-        static_assert(sizeof(IcpState) == 23 * sizeof(double), "record layout");
+        static_assert(sizeof(IcpState) == kChainWords * sizeof(double), "record layout");
         __syncthreads();
-        if (lane < 23)
+        if (lane < kChainWords)
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(fuse.chain_rec + (size_t)kChainRec * (k + 1)) + lane,
                                reinterpret_cast<const unsigned long long *>(&s_state)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the result is written ONCE, by the winner of the last iteration: the winners of a chain sit on different XCDs, and plain stores of
@@ -1832,12 +1850,12 @@ __global__ __launch_bounds__(256) void icp_batch_init_kernel(IcpBatchArgs args, 
             for (int e = kChainRec + threadIdx.x; e < kChainRecords * kChainRec; e += 256) rw[e] = kChainEmpty;
             IcpState *r0 = reinterpret_cast<IcpState *>(P.chain_rec);
             if (threadIdx.x >= 128 && threadIdx.x < 144) r0->T[threadIdx.x - 128] = T0.m[pi][threadIdx.x - 128];
-            if (threadIdx.x == 144) { r0->fitness = 0.0; r0->rmse = 0.0; r0->count = 0.0; r0->iter = 0; r0->done = 0; r0->motion = 0.0; r0->reach = INFINITY; r0->last_motion = INFINITY; }
+            if (threadIdx.x == 144) { r0->fitness = 0.0; r0->rmse = 0.0; r0->count = 0.0; r0->iter = 0; r0->done = 0; r0->motion = 0.0; r0->reach = INFINITY; r0->last_motion = INFINITY; r0->smax = -1.0; }
         }
         if (threadIdx.x < 32) {
             IcpState *st = P.pair + (threadIdx.x >> 4);
             st->T[threadIdx.x & 15] = T0.m[pi][threadIdx.x & 15];
-            if ((threadIdx.x & 15) == 0) { st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0; st->motion = 0.0; st->reach = INFINITY; st->last_motion = INFINITY; }
+            if ((threadIdx.x & 15) == 0) { st->fitness = 0.0; st->rmse = 0.0; st->count = 0.0; st->iter = 0; st->done = 0; st->motion = 0.0; st->reach = INFINITY; st->last_motion = INFINITY; st->smax = -1.0; }
         }
     }
 }
@@ -2243,14 +2261,14 @@ KPX_EXPORT int kpx_icp_chain(int32_t on)
     return cur;
 }
 // The chain clock (g_chain_stamp): 64 x 16 words, read and reset ([10], the earliest-block slot, to all ones)
-KPX_EXPORT int kpx_prof_icp_chain(uint64_t *h_out2048)
+KPX_EXPORT int kpx_prof_icp_chain(uint64_t *h_out3072)
 {
-    KPX_REQUIRE(h_out2048, "kpx_prof_icp_chain: null pointer");
+    KPX_REQUIRE(h_out3072, "kpx_prof_icp_chain: null pointer");
     unsigned long long *p = nullptr;
-    static unsigned long long init[64 * 32];
-    for (int i = 0; i < 64 * 32; ++i) init[i] = (i & 31) == 10 ? ~0ull : 0ull;
+    static unsigned long long init[64 * 48];
+    for (int i = 0; i < 64 * 48; ++i) init[i] = (i % 48) == 10 ? ~0ull : 0ull;
     KPX_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_chain_stamp)));
-    KPX_HIP(hipMemcpy(h_out2048, p, sizeof(init), hipMemcpyDeviceToHost));
+    KPX_HIP(hipMemcpy(h_out3072, p, sizeof(init), hipMemcpyDeviceToHost));
     KPX_HIP(hipMemcpy(p, init, sizeof(init), hipMemcpyHostToDevice));
     return KPX_OK;
 }

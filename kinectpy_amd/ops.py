@@ -633,8 +633,8 @@ def icp_chain(on=-1):
 
 
 def prof_icp_chain():
-    """-> (64, 32) uint64: the one-launch ICP chain's clock (KPX_ICP_CHAIN_STAMPS=1; slots in kpx_icp.hip, g_chain_stamp), reset by the call"""
-    out = np.zeros((64, 32), dtype=np.uint64)
+    """-> (64, 48) uint64: the one-launch ICP chain's clock (KPX_ICP_CHAIN_STAMPS=1; slots in kpx_icp.hip, g_chain_stamp), reset by the call"""
+    out = np.zeros((64, 48), dtype=np.uint64)
     L.check(L.load().kpx_prof_icp_chain(out.ctypes.data_as(C.c_void_p)))
     return out
 

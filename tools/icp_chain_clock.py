@@ -39,5 +39,9 @@ for k in range(31):
         t0 = int(r[16]); g = lambda i: (int(r[16 + i]) - t0) / 100.0 if r[16 + i] else float("nan")
         print(f"       its sweep (us from entry): bounds published {g(1):5.2f}  groups tested {g(2):5.2f}  tile boxes asked {g(3):5.2f}  tiles listed {g(4):5.2f}  "
               f"operands asked {g(5):5.2f}  multiplied {g(6):5.2f}  bounds tightened {g(7):5.2f}  loop left {g(8):5.2f}  exit {g(9):5.2f}")
+    if r[32]:
+        t0 = int(r[32]); g = lambda i: (int(r[32 + i]) - t0) / 100.0 if r[32 + i] else float("nan")
+        print(f"       the update (us from entry): fitness / rmse / test {g(1):5.2f}  system set up {g(2):5.2f}  eliminated {g(3):5.2f}  angles, U {g(4):5.2f}  "
+              f"motion bound {g(5):5.2f}  T = U T {g(6):5.2f}  reach {g(7):5.2f}")
     print(f"       searched: {int(r[26])} waves, {int(r[27])} rows ({int(r[28])} without a partner, {int(r[29])} without a certificate)")
     prev_pub = r[9]
