@@ -1026,28 +1026,30 @@ __global__ __launch_bounds__(64) void pairs_solve_kernel(const double *__restric
 constexpr int kAccCopies = 8;
 __device__ __forceinline__ double fixed_total(const unsigned long long *acc, int slot)
 {
-    unsigned long long w[3] = { 0ull, 0ull, 0ull }, lo, hi;
+    unsigned long long lo = 0ull, hi = 0ull;
 #pragma unroll
-    for (int c = 0; c < kAccCopies; ++c)
-#pragma unroll
-        for (int e = 0; e < 3; ++e) w[e] += acc[((int64_t)c * kAcc + slot) * kFixedWords + e];
-    fixed_fold(w[0], w[1], w[2], lo, hi);
+    for (int c = 0; c < kAccCopies; ++c) {
+        const unsigned long long l = acc[((int64_t)c * kAcc + slot) * 2], h = acc[((int64_t)c * kAcc + slot) * 2 + 1];
+        lo += l;
+        hi += h + (lo < l ? 1ull : 0ull);
+    }
     return fixed_value(lo, hi);
 }
 // the same through device-coherent loads (for a reader inside the launch that did the adds: the XCDs' L2s are not coherent)
 __device__ __forceinline__ double fixed_total_coherent(unsigned long long *acc, int slot)
 {
-    unsigned long long v[kAccCopies][3];
+    unsigned long long l[kAccCopies], h[kAccCopies];
 #pragma unroll
-    for (int c = 0; c < kAccCopies; ++c)
+    for (int c = 0; c < kAccCopies; ++c) {
+        l[c] = __hip_atomic_load(acc + ((int64_t)c * kAcc + slot) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h[c] = __hip_atomic_load(acc + ((int64_t)c * kAcc + slot) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned long long lo = 0ull, hi = 0ull;
 #pragma unroll
-        for (int e = 0; e < 3; ++e) v[c][e] = __hip_atomic_load(acc + ((int64_t)c * kAcc + slot) * kFixedWords + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long w[3] = { 0ull, 0ull, 0ull }, lo, hi;
-#pragma unroll
-    for (int c = 0; c < kAccCopies; ++c)
-#pragma unroll
-        for (int e = 0; e < 3; ++e) w[e] += v[c][e];
-    fixed_fold(w[0], w[1], w[2], lo, hi);
+    for (int c = 0; c < kAccCopies; ++c) {
+        lo += l[c];
+        hi += h[c] + (lo < l[c] ? 1ull : 0ull);
+    }
     return fixed_value(lo, hi);
 }
 // sums -> update step; clears the accumulators for the next iteration (single block: no race)
@@ -1572,10 +1574,14 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     }
     __syncthreads();
     phase_tick(tile_visits, 4, bid);
-    if ((int)tix < nacc) {
+    // (the thread number re-derived behind the sweep, like the lane state of the pair epilogue: the accumulator slot's address, a 64-bit
+    // value per lane known from the kernel's first instruction, was otherwise computed there and carried -- spilled -- across the sweep;
+    // every spilled dword is 256 B of scratch per wave written back to HBM at the end of the launch: 0.5 MB per launch at 31k rows)
+    const int tix_e = wave_e * 64 + lane_e;
+    if (tix_e < nacc) {
         double v = 0.0;
-        for (int l = 0; l < kIRows; ++l) v += sh[tix][l];
-        unsigned long long *slot = acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + tix) * kFixedWords);
+        for (int l = 0; l < kIRows; ++l) v += sh[tix_e][l];
+        unsigned long long *slot = acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + tix_e) * kFixedWords);
         if (fuse.ticket) fixed_add_performed(slot, v); else fixed_add(slot, v);
     }
     if (fuse.light_key && tix == kIThreads - 1) {      // (after the barrier above: s_light is complete)
@@ -1620,10 +1626,12 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
 #if KPX_ICP_ACQ_FENCE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the winner only: one per registration and launch
 #endif
-    if (tix < kAcc) s_sums[tix] = (int)tix < nacc ? fixed_total_coherent(acc, tix) : 0.0;
+    // (the winner's thread number behind an opaque move as well: addresses derived from it are then formed here, not in front of the sweep)
+    const int tix_w = opaque_i((int)threadIdx.x);
+    if (tix_w < kAcc) s_sums[tix_w] = tix_w < nacc ? fixed_total_coherent(acc, tix_w) : 0.0;
     __syncthreads();
     if (PERSIST) chain_tick(fuse.stamp, 7, tix == 0);
-    for (int e = tix; e < kAccSet; e += kIThreads) __hip_atomic_store(acc + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int e = tix_w; e < kAccSet; e += kIThreads) __hip_atomic_store(acc + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tix == 0) __hip_atomic_store(fuse.ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // PERSIST: the blocks that see the next record add to these accumulators at once, so every clearing store (and the ticket's) must
     // have been performed before the record is published: each wave drains its stores, the block meets at a barrier (wave 0 after the
@@ -1634,14 +1642,18 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         return;
     }
     __shared__ FinishScratch s_tail;
+    // (t2max again from the target's box, behind an opaque move of its address: a double every lane would otherwise carry across the sweep)
+    const double *tbbox_w = tbbox;
+    asm volatile("" : "+s"(tbbox_w));
+    const double t2max_w = target_t2max(tbbox_w);
     IcpState *stw = const_cast<IcpState *>(st);
     IcpState *work = KPX_ICP_STATE_LDS ? &s_state : stw;
     if (PERSIST)
         icp_finish_wave_call(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, (double *)nullptr, &s_tail, lane,
-                             fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max, fuse.stamp ? fuse.stamp + 32 : (unsigned long long *)nullptr);
+                             fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max_w, fuse.stamp ? fuse.stamp + 32 : (unsigned long long *)nullptr);
     else
         icp_finish_wave(s_sums, n, mode, k, fuse.max_iter, fuse.rel_fit, fuse.rel_rmse, work, fuse.result, s_tail, lane,
-                        LightSkip{ fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max });
+                        LightSkip{ fuse.light_key ? fuse.sbbox : (const double *)nullptr, max_d2, t2max_w });
     wave_lds_fence();
     if (PERSIST) chain_tick(fuse.stamp, 8, lane == 0);
     if (PERSIST) {

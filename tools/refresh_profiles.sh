@@ -11,14 +11,15 @@ timeout -k 10 500 python3 bench.py --workload reference-stream > "$OUT/bench_n1.
 KPX_NN_ENGINE=dense timeout -k 10 300 python3 bench.py $Q > "$OUT/bench_n1_dense_engine.json" 2>> "$OUT/bench_n1.err"
 timeout -k 10 300 python3 bench.py $Q --overlap 1 > "$OUT/bench_n1_overlap1.json" 2>> "$OUT/bench_n1.err"
 timeout -k 10 300 python3 tools/bench_kernels.py > "$OUT/kernels.json" 2>> "$OUT/bench_n1.err"
-timeout -k 10 120 python3 tools/icp_probe.py 20 --waves > "$OUT/icp_probe.txt" 2>> "$OUT/bench_n1.err"
+KPX_ICP_CHAIN=0 timeout -k 10 120 python3 tools/icp_probe.py 20 --waves > "$OUT/icp_probe.txt" 2>> "$OUT/bench_n1.err"
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$ROOT/bench.py" --steps 40 --warmup 5 $Q > "$OUT/bench_n1_under_rocprof.json" 2>> "$OUT/bench_n1.err"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o b -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 $Q --overlap 1 > /dev/null 2>> "$OUT/bench_n1.err"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o b -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 $Q --overlap 1 > /dev/null 2>> "$OUT/bench_n1.err"
 # the dominant kernel with ONE registration per launch (what bench.py's quiet timing measures): traffic per launch
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch1" -o b -- python3 "$ROOT/tools/icp_probe.py" 3 --noprof --single > /dev/null 2>> "$OUT/bench_n1.err"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write1" -o b -- python3 "$ROOT/tools/icp_probe.py" 3 --noprof --single > /dev/null 2>> "$OUT/bench_n1.err"
+# (KPX_ICP_CHAIN=0: the launch-per-iteration form, the one the roofline row is about; a single registration would otherwise run as one chain)
+KPX_ICP_CHAIN=0 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch1" -o b -- python3 "$ROOT/tools/icp_probe.py" 3 --noprof --single > /dev/null 2>> "$OUT/bench_n1.err"
+KPX_ICP_CHAIN=0 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write1" -o b -- python3 "$ROOT/tools/icp_probe.py" 3 --noprof --single > /dev/null 2>> "$OUT/bench_n1.err"
 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o m -- python3 "$ROOT/tools/mfma_probe.py" > /dev/null 2>> "$OUT/bench_n1.err"
 cd "$ROOT"
 python3 tools/pmc_mfma.py "$OUT/pmc_mfma.csv" "$OUT/pmc_mfma"
