@@ -77,6 +77,7 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     KPX_REQUIRE(prm->icp_mode == KPX_ICP_POINT_TO_POINT || prm->icp_mode == KPX_ICP_POINT_TO_PLANE, "kpx_frame_step: bad icp_mode");
     const int S = sensors;
     hipStream_t st = (hipStream_t)stream;
+    BusyScope busy;                                        // (a frame in flight: see kpx_internal.h)
     Arena a(ws, ws_bytes);
     FrameLayout L;
     frame_carve(a, S, n_px, &L);
@@ -344,6 +345,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     KPX_REQUIRE(prm->icp_mode == KPX_ICP_POINT_TO_POINT || prm->icp_mode == KPX_ICP_POINT_TO_PLANE, "kpx_frame_step_sharded: bad icp_mode");
     KPX_REQUIRE(fused_filter == 0 || fused_filter == 1, "kpx_frame_step_sharded: fused_filter is 0 (sharded) or 1 (rank 0)");
     hipStream_t st = (hipStream_t)stream;
+    BusyScope busy;
     const int g0 = shard_first(S, rank, world), S_l = shard_count(S, rank, world);
     const bool owns_master = g0 == 0, plane = prm->icp_mode == KPX_ICP_POINT_TO_PLANE;
     Arena a(ws, ws_bytes);

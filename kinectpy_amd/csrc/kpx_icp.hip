@@ -2580,6 +2580,11 @@ template <class F> bool chain_launch_if_fits(unsigned blocks, hipStream_t st, F 
     return true;
 }
 }  // namespace
+static int g_busy_threads = 0;
+static thread_local int t_busy_depth = 0;
+kpx::BusyScope::BusyScope() : counted(t_busy_depth++ == 0) { if (counted) __atomic_fetch_add(&g_busy_threads, 1, __ATOMIC_RELAXED); }
+kpx::BusyScope::~BusyScope() { --t_busy_depth; if (counted) __atomic_fetch_sub(&g_busy_threads, 1, __ATOMIC_RELAXED); }
+int kpx::busy_threads() { return __atomic_load_n(&g_busy_threads, __ATOMIC_RELAXED); }
 // A chain kernel gave up waiting since the last call (see icp_chain_kernel): 1 once, then cleared
 int kpx::icp_chain_abort_take()
 {
@@ -2603,6 +2608,7 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
     for (int i = 0; i < count; ++i)
         KPX_REQUIRE(h_src[i] && h_n_src[i] >= 1 && h_n_src[i] < ((int64_t)1 << 31), "kpx_icp_batch: bad source cloud %d", i);
     hipStream_t st = (hipStream_t)stream;
+    BusyScope busy;
     if (icp_chain_abort_take())
         return fail(KPX_ERR_HIP, "kpx_icp_batch: an earlier one-launch ICP chain gave up waiting for its blocks to become resident (another process on this "
                                  "GPU?); its result is NaN.  KPX_ICP_CHAIN=0 selects the launch-per-iteration form");
@@ -2739,7 +2745,9 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
             const double v = e ? atof(e) : 0.0;
             return (unsigned long long)((v > 0.0 ? v : 2.0) * 1e8);
         }();
-        const bool chain_ok = chain_form_on() && split == 2 && max_iteration <= kChainRecords - 2 && chain_abort_word() != nullptr;
+        static const bool chain_alone = [] { const char *e = getenv("KPX_ICP_CHAIN_ALONE"); return !(e && e[0] == '0'); }();     // A/B: 0 = also with other frames in flight
+        const bool chain_ok = chain_form_on() && split == 2 && max_iteration <= kChainRecords - 2 && chain_abort_word() != nullptr &&
+                              (!chain_alone || busy_threads() <= 1);
         IcpBatchArgs A[8], Ac[8];                              // count <= 64: at most 8 groups
         int gk[8];
         bool gfin[8];

@@ -63,6 +63,18 @@ int fuse_voxel_downsample_dev(int32_t count, const float *const *h_pts, const fl
 
 // kpx_icp_batch for clouds that already lie along a space-filling curve (presorted = true: no Morton sort inside; the culled
 // search's tiles are then 16 consecutive points of the caller's order).  presorted = false: the exported behaviour.
+// Host threads of this process that are inside a frame step or an ICP batch right now (each thread counted once).  The one-launch ICP
+// chain is a LATENCY form: its resident blocks hold wave slots for the whole chain, most of the time waiting; with other frames in
+// flight those slots are worth more to the other frames' kernels (two-sensor rig, four frames in flight: 1320 vs 1570-1620 Mpoints/s
+// with the chain, profiles/r04/exp_icp_chain_two_sensors.txt), so a chain is admitted only while the calling thread is alone.
+struct BusyScope {
+    BusyScope();
+    ~BusyScope();
+    BusyScope(const BusyScope &) = delete;
+    BusyScope &operator=(const BusyScope &) = delete;
+    bool counted;
+};
+int busy_threads();
 int icp_chain_abort_take();   // 1 if a one-launch ICP chain gave up waiting since the last call (kpx_icp.hip, icp_chain_kernel)
 int icp_batch_ordered(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
                       double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness, double relative_rmse,
