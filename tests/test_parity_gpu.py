@@ -1803,6 +1803,35 @@ def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
     assert its.max() >= 10, its                                        # a chain long enough for blocks to be skipped
 
 
+def test_icp_chain_edge_sizes_equal_launch_per_iteration(ops, base_cloud):
+    """the one-launch chain (kpx_icp_chain(1)) against a launch per iteration (0) in ONE process, at the edges: sources of 1, 17, 64 and
+    65 rows (partial waves, partial blocks, a block boundary), seven registrations in one group (with the target: all the batch sort takes), max_iteration 0, 1, 62 (the last the
+    chain's records hold) and 63 (one more: must fall back by itself), both estimation modes -- every output bit for bit"""
+    if ops.icp_chain(-1) == 0:
+        pytest.skip("KPX_ICP_CHAIN=0")
+    src, tgt, T = synth.icp_pair(4000, base_cloud)
+    tn = ops.estimate_normals(torch.as_tensor(tgt).cuda(), 70.0, 40)
+    cases = [([src[:1]], 5), ([src[:17], src[:64], src[:65]], 5), ([src[i * 300:(i + 1) * 300 + 7 * i] for i in range(7)], 6),
+             ([src[:2000]], 0), ([src[:2000]], 1), ([src[:1500], src[1500:2600]], 62), ([src[:1500]], 63)]
+    before = ops.icp_chain(-2)
+    try:
+        for srcs, iters in cases:
+            for mode, nrm in (("p2p", None), ("p2plane", tn)):
+                inits = [np.eye(4)] * len(srcs)
+                got = {}
+                for form in (1, 0):
+                    ops.icp_chain(form)
+                    got[form] = ops.icp_batch(srcs, tgt, 100.0, inits, mode, nrm, iters)
+                for a, b in zip(got[1], got[0]):
+                    assert a["iterations"] == b["iterations"] and a["fitness"] == b["fitness"] and a["inlier_rmse"] == b["inlier_rmse"], (len(srcs), iters, mode)
+                    assert np.array_equal(a["transformation"], b["transformation"]), (len(srcs), iters, mode)
+    finally:
+        ops.icp_chain(1)
+    # the chain form ran for every case but max_iteration 63 (two modes each); with another process holding the card's chain lock nothing is compared
+    ran = ops.icp_chain(-2) - before
+    assert ran in (0, 12), ran
+
+
 _ICP_CHAIN_ABORT = r"""
 import os, sys, json, numpy as np, torch
 sys.path.insert(0, os.getcwd())
