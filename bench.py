@@ -337,9 +337,10 @@ def roofline_targets(torch, ops, quick=False):
     fused = synth.frame_cloud()                              # a fused 4-sensor person cloud, millimetres: filter_outliers' defaults on it
     fv = ops.voxel_downsample(torch.as_tensor(fused).to(dev), 10.0)[0]
     ms, (keep, _, _) = ev_timed(torch, lambda: ops.sor(fv, 200, 3.0), reps=3, warm=1)
-    hbm(f"remove_statistical_outlier(200, 3.0) (filter_outliers' defaults, filtering.py:12), {fv.shape[0]} points", "sor_knn_kernel (k > 40: thread per query)", ms,
+    hbm(f"remove_statistical_outlier(200, 3.0) (filter_outliers' defaults, filtering.py:12), {fv.shape[0]} points", "sor_cell_kernel<64, 32, 1> (k > 64: a cell's queries together) + sor_wave_kernel passes for what it leaves + grid build + statistics", ms,
         12 * fv.shape[0] + 16 * int(keep.shape[0]), points=int(fv.shape[0]), kept=int(keep.shape[0]),
-        Mqueries_per_s=round(fv.shape[0] / ms / 1e3, 2), binds="LDS / VALU / latency, not HBM")
+        Mqueries_per_s=round(fv.shape[0] / ms / 1e3, 2),
+        binds="vector ALU on LDS-resident candidates (distances + bisection on the high words: ~1500 wave-instructions per query at k = 200), not HBM")
     del keeps, vb
 
     # segment_plane: the (point, hypothesis) distances are a K = 4 fp64 GEMM on the matrix cores (8 flop per pair); the row
