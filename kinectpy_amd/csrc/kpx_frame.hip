@@ -160,6 +160,9 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     KPX_HIP(hipMemcpyAsync(h_d, L.icp_res, ((size_t)S * 20 + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
     KPX_HIP(hipStreamSynchronize(st));
     h_i[48] = *reinterpret_cast<const int32_t *>(h_d + (size_t)S * 20);
+    if (S > 1 && icp_chain_abort_take())                   // (a one-launch ICP chain that lost its race for residency: its transform is NaN)
+        return fail(KPX_ERR_HIP, "kpx_frame_step: the frame's one-launch ICP chain gave up waiting for its blocks to become resident; KPX_ICP_CHAIN=0 "
+                                 "selects the launch-per-iteration form");
     for (int i = 1; i < S; ++i) {
         for (int q = 0; q < 16; ++q) h_T[16 * i + q] = h_d[20 * (i - 1) + q];
         if (h_info) h_info[32 + i] = (int32_t)h_d[20 * (i - 1) + 18];
