@@ -14,6 +14,8 @@ Each function cites the reference call site it stands behind:
   estimate_normals     preprocessing/registration.py:9-13       [O3D] estimate_normals(KDTreeSearchParamHybrid)
   compute_fpfh         preprocessing/registration.py:15-20      [O3D] compute_fpfh_feature
   feature_correspondences   preprocessing/registration.py:50-57 [O3D] registration_ransac_based_on_feature_matching (matching step)
+  voxel_down_sample    preprocessing/filtering.py:23, registration.py:8,100-101   [O3D] PointCloud.voxel_down_sample
+  remove_statistical_outlier   preprocessing/filtering.py:24, floor_removal.py:73   [O3D] PointCloud.remove_statistical_outlier
 Clouds arrive as float32 (the storage contract of DESIGN.md section 3); all arithmetic is float64 on the promoted values.
 """
 import numpy as np
@@ -267,3 +269,49 @@ def feature_correspondences(fs, ft, mutual_filter=True, ransac_n=3):
         return one_way, gap_st, gap_ts
     mutual = one_way[i1[j1] == np.arange(len(fs))]
     return (mutual if len(mutual) >= 3 * ransac_n else one_way), gap_st, gap_ts
+
+
+# ------------------------------------------------------------------------------------------------ the filter pair (a7, a8)
+def voxel_down_sample(pts, voxel_size, colours=None):
+    """[O3D] PointCloud.voxel_down_sample (filtering.py:23, registration.py:8, 100-101), SURVEY Appendix A: origin = min_bound - v / 2,
+    index = floor((p - origin) / v) per axis, per voxel the MEAN of its points (and colours), accumulated in float64 in ascending
+    point order; output in ascending (ix, iy, iz) (the build's documented order).  -> points f32 (M, 3), colours f32 (M, 3) | None,
+    counts (M,)"""
+    if not voxel_size > 0.0:
+        raise RuntimeError("voxel_size <= 0")
+    p = np.asarray(pts, dtype=np.float32).reshape(-1, 3).astype(np.float64)
+    origin = p.min(axis=0) - 0.5 * voxel_size
+    idx = np.floor((p - origin) / voxel_size).astype(np.int64)
+    uniq, inv = np.unique(idx, axis=0, return_inverse=True)            # rows sorted lexicographically = ascending (ix, iy, iz)
+    inv = inv.reshape(-1)
+    sums = np.zeros((len(uniq), 3), dtype=np.float64)
+    np.add.at(sums, inv, p)                                            # unbuffered: one add after the other, in point order
+    cnt = np.bincount(inv, minlength=len(uniq))
+    out_c = None
+    if colours is not None:
+        c = np.asarray(colours, dtype=np.float32).reshape(-1, 3).astype(np.float64)
+        cs = np.zeros((len(uniq), 3), dtype=np.float64)
+        np.add.at(cs, inv, c)
+        out_c = (cs / cnt[:, None]).astype(np.float32)
+    return (sums / cnt[:, None]).astype(np.float32), out_c, cnt
+
+
+def remove_statistical_outlier(pts, nb_neighbors, std_ratio):
+    """[O3D] PointCloud.remove_statistical_outlier (filtering.py:24, floor_removal.py:73), SURVEY row a8: k nearest neighbours with
+    the point itself among them (distance 0), avg_i = mean of the distances over the min(k, N) neighbours returned, mu and the
+    Bessel-corrected sigma over the points with avg > 0... here: over all points that have neighbours, keep avg_i > 0 and
+    avg_i < mu + r sigma, indices ascending.  -> keep indices, (mu, sigma, threshold), avg"""
+    if nb_neighbors < 1 or not std_ratio > 0.0:
+        raise RuntimeError("invalid nb_neighbors / std_ratio")
+    p = np.asarray(pts, dtype=np.float32).reshape(-1, 3).astype(np.float64)
+    n = len(p)
+    k = min(int(nb_neighbors), n)
+    d, _ = cKDTree(p).query(p, k=k)
+    d = d.reshape(n, k)
+    avg = d.sum(axis=1) / k
+    valid = np.ones(n, dtype=bool)                                     # every point has itself as a neighbour
+    mu = avg[valid].sum() / valid.sum()
+    sigma = np.sqrt(((avg[valid] - mu) ** 2).sum() / (valid.sum() - 1)) if valid.sum() > 1 else 0.0
+    thr = mu + std_ratio * sigma
+    keep = np.nonzero((avg > 0.0) & (avg < thr))[0]
+    return keep.astype(np.int64), (mu, sigma, thr), avg

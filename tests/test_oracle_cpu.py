@@ -357,6 +357,30 @@ def test_second_lineage_segment_plane(oracle, ransac_n, iters, prob, thr):
             assert evaluated < iters                      # the early exit did cut the loop
 
 
+def test_second_lineage_voxel_and_statistical_outlier(oracle, base_cloud):
+    """filtering.py:23-24, floor_removal.py:73 -- the filter pair restated with numpy / a k-d tree (oracle/lineage2.py): voxel means
+    (points, colours, counts) equal to the last bit for four voxel sizes, the statistical filter's per-point mean distances within 1e-12
+    relative, its mean / deviation / threshold within 1e-10, and the SAME keep list -- (20, 2.0), (50, 0.30), (200, 3.0) and k > N"""
+    from oracle import lineage2
+    rng = np.random.default_rng(11)
+    pts = np.ascontiguousarray(base_cloud[rng.choice(len(base_cloud), 20000, replace=False)], dtype=np.float32)
+    col = rng.random((len(pts), 3)).astype(np.float32)
+    for v in (10.0, 35.0, 20.0, 137.5):
+        op, oc, _, cnt = oracle.voxel_downsample(pts, v, col=col, return_counts=True)
+        lp, lc, lcnt = lineage2.voxel_down_sample(pts, v, col)
+        assert len(op) == len(lp) and np.array_equal(cnt, lcnt), (v, len(op), len(lp))
+        assert np.array_equal(op, lp) and np.array_equal(oc, lc), v
+    small = pts[:7000]
+    for k, r, cloud in ((20, 2.0, small), (50, 0.30, small), (200, 3.0, small[:3000]), (40, 1.0, small[:25])):
+        keep, (mu, sd, thr), avg = oracle.sor(cloud, k, r)
+        k2, (mu2, sd2, thr2), avg2 = lineage2.remove_statistical_outlier(cloud, k, r)
+        assert np.allclose(avg, avg2, rtol=1e-12, atol=1e-12), (k, r)
+        assert abs(mu - mu2) < 1e-10 * mu and abs(sd - sd2) < 1e-10 * max(sd, 1.0) and abs(thr - thr2) < 1e-10 * thr
+        border = np.abs(avg - thr) < 1e-9 * thr                        # a point exactly on the threshold may fall either way
+        assert np.array_equal(np.setdiff1d(keep, np.nonzero(border)[0]), np.setdiff1d(k2, np.nonzero(border)[0])), (k, r)
+        assert 0 < len(keep) < len(cloud) or k >= len(cloud)
+
+
 @pytest.mark.parametrize("mode", ["p2p", "p2plane"])
 def test_second_lineage_registration_icp(oracle, base_cloud, mode):
     """registration.py:78-84 / manual_pointcloud_registration.py:96-98 -- cKDTree correspondences, SVD (Umeyama without scale) or a
