@@ -315,3 +315,29 @@ def remove_statistical_outlier(pts, nb_neighbors, std_ratio):
     thr = mu + std_ratio * sigma
     keep = np.nonzero((avg > 0.0) & (avg < thr))[0]
     return keep.astype(np.int64), (mu, sigma, thr), avg
+
+
+def fuse_voxel_down_sample(clouds, colours, transforms, voxel_size):
+    """data.py:44-61: every sensor's cloud moved by its 4x4 (`pcd.transform(T)`: float64 points), the moved clouds stacked in order
+    (`np.vstack`), `voxel_down_sample` of the stack.  The stack is float64 in the reference, so the voxel index and the means are taken
+    from the float64 values of the moved points (never rounded to float32 in between).  -> points f32, colours f32 | None, counts"""
+    moved = []
+    for p, T in zip(clouds, transforms):
+        p = np.asarray(p, dtype=np.float32).reshape(-1, 3).astype(np.float64)
+        T = np.asarray(T, dtype=np.float64).reshape(4, 4)
+        moved.append(p @ T[:3, :3].T + T[:3, 3])
+    q = np.vstack(moved)
+    origin = q.min(axis=0) - 0.5 * voxel_size
+    idx = np.floor((q - origin) / voxel_size).astype(np.int64)
+    uniq, inv = np.unique(idx, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    cnt = np.bincount(inv, minlength=len(uniq))
+    sums = np.zeros((len(uniq), 3), dtype=np.float64)
+    np.add.at(sums, inv, q)
+    out_c = None
+    if colours is not None:
+        c = np.vstack([np.asarray(x, dtype=np.float32).reshape(-1, 3).astype(np.float64) for x in colours])
+        cs = np.zeros((len(uniq), 3), dtype=np.float64)
+        np.add.at(cs, inv, c)
+        out_c = (cs / cnt[:, None]).astype(np.float32)
+    return (sums / cnt[:, None]).astype(np.float32), out_c, cnt

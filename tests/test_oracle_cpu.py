@@ -370,6 +370,17 @@ def test_second_lineage_voxel_and_statistical_outlier(oracle, base_cloud):
         lp, lc, lcnt = lineage2.voxel_down_sample(pts, v, col)
         assert len(op) == len(lp) and np.array_equal(cnt, lcnt), (v, len(op), len(lp))
         assert np.array_equal(op, lp) and np.array_equal(oc, lc), v
+    # data.py:44-61: transform + stack + voxel on the float64 moved points.  numpy's matrix product rounds differently from the oracle's
+    # fma chains (1 ulp of a double), so a point within ~1e-13 of a voxel face could change sides: the voxel sets are compared through
+    # the counts, the means to one float32 ulp
+    Ts = [np.eye(4), synth.t_star(), np.linalg.inv(synth.t_star())]
+    parts = [pts[:8000], pts[8000:15000], pts[15000:]]
+    cols = [col[:8000], col[8000:15000], col[15000:]]
+    for v in (10.0, 35.0):
+        fp, fc, fcnt = oracle.fuse_voxel_downsample(parts, cols, Ts, v, return_counts=True)
+        lp, lc, lcnt = lineage2.fuse_voxel_down_sample(parts, cols, Ts, v)
+        assert len(fp) == len(lp) and np.array_equal(fcnt, lcnt), (v, len(fp), len(lp))
+        assert np.abs(fp - lp).max() <= np.spacing(np.abs(fp).max().astype(np.float32)) and np.abs(fc - lc).max() <= 2.0 ** -23
     small = pts[:7000]
     for k, r, cloud in ((20, 2.0, small), (50, 0.30, small), (200, 3.0, small[:3000]), (40, 1.0, small[:25])):
         keep, (mu, sd, thr), avg = oracle.sor(cloud, k, r)
