@@ -14,6 +14,7 @@ Each function cites the reference call site it stands behind:
   estimate_normals     preprocessing/registration.py:9-13       [O3D] estimate_normals(KDTreeSearchParamHybrid)
   compute_fpfh         preprocessing/registration.py:15-20      [O3D] compute_fpfh_feature
   feature_correspondences   preprocessing/registration.py:50-57 [O3D] registration_ransac_based_on_feature_matching (matching step)
+  evaluate_registration   preprocessing/registration.py:50-61   [O3D] the scoring of a candidate transform (fitness, inlier_rmse)
   voxel_down_sample    preprocessing/filtering.py:23, registration.py:8,100-101   [O3D] PointCloud.voxel_down_sample
   remove_statistical_outlier   preprocessing/filtering.py:24, floor_removal.py:73   [O3D] PointCloud.remove_statistical_outlier
 Clouds arrive as float32 (the storage contract of DESIGN.md section 3); all arithmetic is float64 on the promoted values.
@@ -341,3 +342,17 @@ def fuse_voxel_down_sample(clouds, colours, transforms, voxel_size):
         np.add.at(cs, inv, c)
         out_c = (cs / cnt[:, None]).astype(np.float32)
     return (sums / cnt[:, None]).astype(np.float32), out_c, cnt
+
+
+def evaluate_registration(src, tgt, max_dist, T):
+    """[O3D] evaluate_registration / the scoring step of registration_ransac_based_on_feature_matching (registration.py:50-61 keeps the
+    trial of the highest `fitness`): every source point moved by T, its nearest target point from a k-d tree, inliers = distance below
+    max_dist.  -> fitness (inliers / source points), inlier_rmse, inlier count"""
+    s = np.asarray(src, dtype=np.float32).reshape(-1, 3).astype(np.float64)
+    t = np.asarray(tgt, dtype=np.float32).reshape(-1, 3).astype(np.float64)
+    T = np.asarray(T, dtype=np.float64).reshape(4, 4)
+    p = s @ T[:3, :3].T + T[:3, 3]
+    d, _ = cKDTree(t).query(p, k=1)
+    ok = d < max_dist
+    k = int(ok.sum())
+    return (k / len(s) if len(s) else 0.0), (float(np.sqrt((d[ok] ** 2).sum() / k)) if k else 0.0), k

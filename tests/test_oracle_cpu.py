@@ -449,3 +449,13 @@ def test_second_lineage_normals_fpfh_and_matching(oracle, base_cloud):
         amb = set(np.nonzero(~uniq)[0].tolist()) | {int(i) for i in np.nonzero(gap_ts <= 1e-9)[0]}
         assert all((i in amb or j in amb) for i, j in (s1 ^ s2)) or len(s1 ^ s2) <= 2 * (len(uniq) - int(uniq.sum()) + int((gap_ts <= 1e-9).sum()))
     assert len(c1) >= 9
+    # the RANSAC on those correspondences (registration.py:50-57): the oracle's result scored AGAIN by the second lineage -- every source
+    # point moved by the returned T, nearest target from a k-d tree, inliers within the threshold -- must give the fitness and rmse the
+    # oracle reports; T must be a rigid motion; and the ICP refinement that follows in the reference must not lose inliers
+    thr = 1.5 * 35.0
+    for seed in (0, 1):
+        T, st = oracle.ransac_corres(a, b, c1, thr, 3, 0.95, 20000, 0.999, seed)
+        fit, rmse, k = lineage2.evaluate_registration(a, b, thr, T)
+        assert st["fitness"] > 0.2 and abs(fit - st["fitness"]) < 1e-12 and abs(rmse - st["rmse"]) < 1e-9 * max(1.0, rmse), (seed, st, fit, rmse)
+        R = T[:3, :3]
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(R) - 1.0) < 1e-9 and np.array_equal(T[3], [0.0, 0.0, 0.0, 1.0])
