@@ -1832,6 +1832,19 @@ def test_icp_chain_edge_sizes_equal_launch_per_iteration(ops, base_cloud):
     assert ran in (0, 12), ran
 
 
+def test_icp_chain_fuzz_against_launches_and_oracle():
+    """tools/fuzz_icp_chain.py: 40 random batches (1-7 registrations of 1-3000 rows, both modes, 0-40 iterations, three correspondence
+    distances, random initial transforms) through the one-launch chain and through a launch per iteration -- bit-identical -- and every
+    fifth against the CPU oracle where the update is well posed"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_icp_chain.py"), "40", "3"], cwd=root, capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "KPX_ICP_CHAIN_LOCK": "0"})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+    assert "chains launched 40 mismatches 0" in r.stdout, r.stdout[-500:]
+
+
 _ICP_CHAIN_ABORT = r"""
 import os, sys, json, numpy as np, torch
 sys.path.insert(0, os.getcwd())
