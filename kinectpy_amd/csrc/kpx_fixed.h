@@ -13,17 +13,27 @@ namespace kpx {
 // interval measured) and +50 % atomic traffic (WRITE_SIZE 0.48 -> 0.83 MB per launch); not kept.)
 constexpr int kFixedWords = 2;
 
-__device__ __forceinline__ void fixed_add(unsigned long long *acc2, double v)
+// v -> its 128-bit two's complement fixed-point words (exact under the conditions above)
+__device__ __forceinline__ void fixed_split(double v, unsigned long long &lo, unsigned long long &hi)
 {
     const bool neg = v < 0.0;
     const double m = fabs(v);
     const double ip = floor(m);
-    unsigned long long hi = (unsigned long long)ip;
-    unsigned long long lo = (unsigned long long)((m - ip) * 18446744073709551616.0);     // frac * 2^64, exact
+    hi = (unsigned long long)ip;
+    lo = (unsigned long long)((m - ip) * 18446744073709551616.0);     // frac * 2^64, exact
     if (neg) {                                              // two's complement of the 128-bit magnitude
         lo = ~lo + 1ull;
         hi = ~hi + (lo == 0ull ? 1ull : 0ull);
     }
+}
+// (lo, hi) += (l, h) in registers: integer addition, exact and order-independent like the atomics below
+__device__ __forceinline__ void fixed_accumulate(unsigned long long &lo, unsigned long long &hi, unsigned long long l, unsigned long long h)
+{
+    lo += l;
+    hi += h + (lo < l ? 1ull : 0ull);
+}
+__device__ __forceinline__ void fixed_add_words(unsigned long long *acc2, unsigned long long lo, unsigned long long hi)
+{
     if (hi == 0ull && lo == 0ull) return;
     const unsigned long long old = atomicAdd(acc2, lo);
     const unsigned long long carry = (old + lo) < old ? 1ull : 0ull;
@@ -31,17 +41,8 @@ __device__ __forceinline__ void fixed_add(unsigned long long *acc2, double v)
 }
 // The same add with both atomics RETURNING: when the call returns, the add has been performed at the device's point of
 // coherence (what a later ticket of the same block may be ordered behind without a release fence).
-__device__ __forceinline__ void fixed_add_performed(unsigned long long *acc2, double v)
+__device__ __forceinline__ void fixed_add_words_performed(unsigned long long *acc2, unsigned long long lo, unsigned long long hi)
 {
-    const bool neg = v < 0.0;
-    const double m = fabs(v);
-    const double ip = floor(m);
-    unsigned long long hi = (unsigned long long)ip;
-    unsigned long long lo = (unsigned long long)((m - ip) * 18446744073709551616.0);
-    if (neg) {
-        lo = ~lo + 1ull;
-        hi = ~hi + (lo == 0ull ? 1ull : 0ull);
-    }
     if (hi == 0ull && lo == 0ull) return;
     const unsigned long long old = __hip_atomic_fetch_add(acc2, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long carry = (old + lo) < old ? 1ull : 0ull;
@@ -49,6 +50,18 @@ __device__ __forceinline__ void fixed_add_performed(unsigned long long *acc2, do
         const unsigned long long back = __hip_atomic_fetch_add(acc2 + 1, hi + carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("" ::"v"(back));                       // the value is waited for
     }
+}
+__device__ __forceinline__ void fixed_add(unsigned long long *acc2, double v)
+{
+    unsigned long long lo, hi;
+    fixed_split(v, lo, hi);
+    fixed_add_words(acc2, lo, hi);
+}
+__device__ __forceinline__ void fixed_add_performed(unsigned long long *acc2, double v)
+{
+    unsigned long long lo, hi;
+    fixed_split(v, lo, hi);
+    fixed_add_words_performed(acc2, lo, hi);
 }
 // (lo, hi) two's complement -> double: (double)hi + (double)lo * 2^-64 on the magnitude
 __device__ __forceinline__ double fixed_value(unsigned long long lo, unsigned long long hi)

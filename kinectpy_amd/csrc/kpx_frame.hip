@@ -3,6 +3,7 @@
 // C ABI.  The Python mirror of the same loop (kinectpy_amd/pipeline.py) issues ~12 library calls per frame with interpreter
 // work, tensor allocations and the GIL in between; with several frames in flight on host threads that interpreter time is
 // serialised.  Here a frame is a single call with the GIL released throughout; everything lives in the caller's workspace.
+#include <chrono>
 #include <vector>
 
 #include "kpx_internal.h"
@@ -12,6 +13,50 @@ namespace kpx {
 // measurement hook: KPX_FRAME_EXTRA_DISPATCHES=n queues n empty kernels behind the extraction of every frame (how much of the frame
 // rate is the dispatch count itself?)
 __global__ void frame_empty_kernel() {}
+
+// A frame's read-backs without the runtime's wait: a one-thread kernel behind everything queued so far stores a sequence number in
+// pinned host memory (system scope) and the host thread spins on that word.  hipStreamSynchronize costs 40-80 us per call with four
+// frame threads inside the runtime at once (profiles/r05/overlap_timeline_*.txt: ~7 idle gaps of ~80 us per frame and stream, every
+// one behind a read-back); the word arrives a few microseconds after the kernel has run.  Stream order makes everything queued before
+// the flag kernel (kernels' stores to pinned memory, device-to-host copies) complete, and visible, before its store.  A fault or a
+// hang still surfaces: the wait falls back to hipStreamQuery every millisecond and to the runtime's error.  KPX_FRAME_SPIN=0: A/B switch.
+__global__ void frame_flag_kernel(unsigned long long *flag, unsigned long long seq)
+{
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static int frame_wait(hipStream_t st)
+{
+    static const bool spin = [] { const char *e = getenv("KPX_FRAME_SPIN"); return !(e && e[0] == '0'); }();
+    if (!spin) {
+        KPX_HIP(hipStreamSynchronize(st));
+        return KPX_OK;
+    }
+    static thread_local unsigned long long *flag = nullptr;
+    static thread_local unsigned long long seq = 0;
+    if (!flag) {
+        KPX_HIP(hipHostMalloc((void **)&flag, 64, hipHostMallocDefault));
+        *flag = 0ull;
+    }
+    ++seq;
+    hipLaunchKernelGGL(frame_flag_kernel, dim3(1), dim3(1), 0, st, flag, seq);
+    KPX_LAUNCH_CHECK();
+    auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return KPX_OK;
+        __builtin_ia32_pause();
+        if ((spins & 4095u) == 4095u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {                          // drained: the word is there (or the launch itself was lost)
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return KPX_OK;
+                KPX_HIP(hipStreamSynchronize(st));
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return KPX_OK;
+                return fail(KPX_ERR_HIP, "kpx_frame_step: the frame's completion word never arrived");
+            }
+            if (q != hipErrorNotReady) return fail(KPX_ERR_HIP, "kpx_frame_step: %s while waiting for a read-back", hipGetErrorString(q));
+            t0 = std::chrono::steady_clock::now();
+        }
+    }
+}
 
 struct FrameLayout {
     float *full_pts, *mask_pts, *mask_col, *down_pts, *normals, *vox_pts, *vox_col;
@@ -110,7 +155,7 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     std::vector<const float *> p_in((size_t)S), c_in((size_t)S);
     std::vector<float *> p_out((size_t)S);
     for (int i = 0; i < S; ++i) { p_in[(size_t)i] = L.full_pts + (size_t)i * n_px * 3; p_out[(size_t)i] = L.down_pts + (size_t)i * n_px * 3; }
-    KPX_HIP(hipStreamSynchronize(st));                     // read-back 1: both extractions' counts
+    KPX_SUB(frame_wait(st));                     // read-back 1: both extractions' counts
     for (int i = 0; i < S; ++i) { fk[(size_t)i] = h_i[i]; mk[(size_t)i] = h_i[16 + i]; }
     if (negative(h_i, S) || negative(h_i + 16, S)) return fail(KPX_ERR_RANGE, "kpx_frame_step: extraction reported %d", negative(h_i, S) | negative(h_i + 16, S));
     // The sort-key width of the registration voxel grid is speculated from the last frame of this thread (the scene's extent in
@@ -127,7 +172,7 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     for (int attempt = 0; attempt < 2; ++attempt) {
         KPX_SUB(voxel_downsample_batch_spec(S, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, h_i + 32, L.op_ws, L.op_bytes, st,
                                             attempt == 0 ? spec_bits : 0, h_i + 50, zorder));
-        KPX_HIP(hipStreamSynchronize(st));
+        KPX_SUB(frame_wait(st));
         const int need = h_i[50];
         const bool narrow = attempt == 0 && spec_bits > 0 && need > spec_bits;
         spec_bits = need > 0 && need <= 32 ? (need + 7) / 8 * 8 : 0;      // whole 8-bit passes; wide keys are not speculated
@@ -158,7 +203,7 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     KPX_SUB(fuse_voxel_downsample_dev(S, p_in.data(), c_in.data(), mk.data(), h_T, dT.data(), prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws,
                                       L.op_bytes, st));
     KPX_HIP(hipMemcpyAsync(h_d, L.icp_res, ((size_t)S * 20 + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
-    KPX_HIP(hipStreamSynchronize(st));
+    KPX_SUB(frame_wait(st));
     h_i[48] = *reinterpret_cast<const int32_t *>(h_d + (size_t)S * 20);
     if (S > 1 && icp_chain_abort_take())                   // (a one-launch ICP chain that lost its race for residency: its transform is NaN)
         return fail(KPX_ERR_HIP, "kpx_frame_step: the frame's one-launch ICP chain gave up waiting for its blocks to become resident; KPX_ICP_CHAIN=0 "
@@ -174,7 +219,7 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     if (M == 0) return KPX_OK;
     // filter + selection in one pass (no count read-back between them)
     KPX_SUB(kpx_sor_select(L.vox_pts, L.vox_col, M, prm->filt_k, prm->filt_ratio, out_pts, out_col, L.keep_idx, h_i + 49, L.sor_stats, L.op_ws, L.op_bytes, st));
-    KPX_HIP(hipStreamSynchronize(st));
+    KPX_SUB(frame_wait(st));
     *h_count = h_i[49];
     return KPX_OK;
 }
@@ -379,7 +424,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     std::vector<const float *> p_in((size_t)S_l);
     std::vector<float *> p_out((size_t)S_l);
     for (int i = 0; i < S_l; ++i) { p_in[(size_t)i] = L.full_pts + (size_t)i * n_px * 3; p_out[(size_t)i] = L.down_pts + (size_t)i * n_px * 3; }
-    KPX_HIP(hipStreamSynchronize(st));
+    KPX_SUB(frame_wait(st));
     for (int i = 0; i < S_l; ++i) { fk[(size_t)i] = h_i[i]; mk[(size_t)i] = h_i[16 + i]; }
     // A data-dependent failure on ONE rank (an occluded camera, a voxel size too small for its cloud) must not leave its peers
     // spinning inside a collective it never enters: the rank keeps its place in the frame's collectives with an empty payload and a
@@ -393,7 +438,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     for (int attempt = 0; attempt < 2 && !lerr; ++attempt) {
         KPX_SUB(voxel_downsample_batch_spec(S_l, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, h_i + 32, L.op_ws, L.op_bytes, st,
                                             attempt == 0 ? spec_bits : 0, h_i + 50, zorder));
-        KPX_HIP(hipStreamSynchronize(st));
+        KPX_SUB(frame_wait(st));
         const int need = h_i[50];
         const bool narrow = attempt == 0 && spec_bits > 0 && need > spec_bits;
         spec_bits = need > 0 && need <= 32 ? (need + 7) / 8 * 8 : 0;
@@ -434,7 +479,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     int64_t m = owns_master ? dk[0] : 0;
     if (!owns_master) {
         KPX_HIP(hipMemcpyAsync(h_d, m_hdr, sizeof(double), hipMemcpyDeviceToHost, st));
-        KPX_HIP(hipStreamSynchronize(st));
+        KPX_SUB(frame_wait(st));
         m = (int64_t)h_d[0];
         if (!(m >= 1 && m <= n_px)) {
             kpx_order_finish(order, frame);
@@ -493,7 +538,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     if (rc) return rc;
     const size_t hrow = (size_t)K * kHdrDoubles * sizeof(double);
     KPX_HIP(hipMemcpy2DAsync(h_hdr, hrow, L.xchg_recv + (size_t)capc * 24, xbytes, hrow, (size_t)world, hipMemcpyDeviceToHost, st));
-    KPX_HIP(hipStreamSynchronize(st));
+    KPX_SUB(frame_wait(st));
     std::vector<const float *> f_p((size_t)S), f_c((size_t)S);
     std::vector<int64_t> f_n((size_t)S);
     int64_t need = 0;
@@ -531,7 +576,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     KPX_SUB(fuse_voxel_downsample_dev(S, f_p.data(), f_c.data(), f_n.data(), h_T, nullptr, prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws,
                                       L.op_bytes, st));
     KPX_HIP(hipMemcpyAsync(h_i + 48, L.vox_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    KPX_HIP(hipStreamSynchronize(st));
+    KPX_SUB(frame_wait(st));
     if (h_i[48] < 0) return fail(KPX_ERR_RANGE, "voxel_size is too small");
     const int64_t M = h_i[48];
     if (h_info) h_info[48] = (int32_t)M;
@@ -542,7 +587,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     if (fused_filter == 1) {                                   // rank 0, alone: the one-GPU filter + selection
         kpx_order_skip(order, frame, 2);
         KPX_SUB(kpx_sor_select(L.vox_pts, L.vox_col, M, prm->filt_k, prm->filt_ratio, out_pts, out_col, L.keep_idx, h_i + 49, L.sor_stats, L.op_ws, L.op_bytes, st));
-        KPX_HIP(hipStreamSynchronize(st));
+        KPX_SUB(frame_wait(st));
         *h_count = h_i[49];
         return KPX_OK;
     }
@@ -556,7 +601,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     if (rc) return rc;
     KPX_SUB(kpx_sor_finish(L.avg_all, L.order_idx, M, prm->filt_ratio, L.keep_idx, L.keep_cnt, L.sor_stats, nullptr, L.op_ws, L.op_bytes, st));
     KPX_HIP(hipMemcpyAsync(h_i + 49, L.keep_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    KPX_HIP(hipStreamSynchronize(st));
+    KPX_SUB(frame_wait(st));
     const int64_t kept = h_i[49];
     if (kept > 0)
         KPX_SUB(kpx_select_by_index(L.vox_pts, L.vox_col, nullptr, M, L.keep_idx, kept, KPX_SELECT_GATHER, out_pts, out_col, nullptr, nullptr, L.op_ws,

@@ -96,6 +96,43 @@ __device__ __forceinline__ void xform_row(const double *__restrict__ T, const fl
 }
 __device__ __forceinline__ double row_seed(const double s[3]) { return fma(s[0], s[0], fma(s[1], s[1], s[2] * s[2])) + 1.0; }
 __device__ __forceinline__ int opaque_i(int v) { asm volatile("" : "+v"(v)); return v; }
+// bits 33..39 of a progress word: the share of the registration's rows the iteration searched, in 1/127ths rounded up (0 = none)
+__host__ __device__ __forceinline__ unsigned long long progress_searched(unsigned long long searched, int64_t n)
+{
+    const unsigned long long cls = n > 0 ? (searched * 127ull + (unsigned long long)n - 1ull) / (unsigned long long)n : 0ull;
+    return (cls > 127ull ? 127ull : cls) << 33;
+}
+// the searched-row counts of a registration: eight words behind its ticket, read (device-coherent) and cleared by the block that drew the
+// last ticket; every lane < 8 of the calling wave takes one word, the total comes back in every lane of that wave's first 8-lane group
+constexpr int kSearchedWord = 8;
+__device__ __forceinline__ unsigned long long searched_take(unsigned long long *ticket, int lane_in_block)
+{
+    unsigned long long v = 0ull;
+    if (lane_in_block < 8) {
+        v = __hip_atomic_load(ticket + kSearchedWord + lane_in_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket + kSearchedWord + lane_in_block, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane_in_block < 64) {                              // (wave 0: an 8-lane butterfly; the other waves of a block do not publish)
+        unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const unsigned ol = (unsigned)__shfl_xor((int)lo, o, 64), oh = (unsigned)__shfl_xor((int)hi, o, 64);
+            const unsigned long long sum = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)oh << 32) | ol);
+            lo = (unsigned)sum; hi = (unsigned)(sum >> 32);
+        }
+        v = ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+// balanced tree over 16 adjacent values: (((x0+x1)+(x2+x3))+((x4+x5)+(x6+x7))) + (the same over x8..x15) -- the order in which four
+// butterfly steps (lane ^ 1, lane ^ 2, half-row mirror, row mirror) add the 16 lanes of a DPP row (row16_tree_sum, kpx_icprows.h)
+__device__ __forceinline__ double tile_tree16(const double *x)
+{
+    double a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = x[2 * i] + x[2 * i + 1];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 // high word of the IEEE pattern as a 32-bit register reference (a shift of the 64-bit pattern makes hipcc
 // compare zero-extended 64-bit values, i.e. the slow v_cmp_*_u64 this prefilter exists to avoid)
@@ -1470,6 +1507,11 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
         }
     }
     if (act_mask == 0u) rederive();
+    // how much of the registration is still searched: what the host picks the next launches' form by (icp_rows_kernel once most rows
+    // carry a certificate).  One returning add per BLOCK into one of eight words behind the ticket (kSearchedWord: same-address atomics
+    // serialise at ~12 ns each -- one word per registration cost 20 us per launch), waited for like the sums' adds.
+    __shared__ int s_cnt[kIWaves];
+    if (lane_p == 0) s_cnt[wave_p] = __builtin_popcount(act_mask & ~certd_mask);
     const unsigned visited = (unsigned)(swept & 0xFFFFu);
     if (certs && fuse.cert_check && lane_p == 0) {
         if (bid == 0 && wave_p == 0 && g_cert_check[2] == 0ull) {       // no disagreement so far: [3..7] report the chain's state at its last launch
@@ -1579,10 +1621,26 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // every spilled dword is 256 B of scratch per wave written back to HBM at the end of the launch: 0.5 MB per launch at 31k rows)
     const int tix_e = wave_e * 64 + lane_e;
     if (tix_e < nacc) {
-        double v = 0.0;
-        for (int l = 0; l < kIRows; ++l) v += sh[tix_e][l];
+        // The sums' contract (round 5): per 16-row TILE a balanced tree over adjacent rows (tile_tree16: what four DPP steps give a
+        // wave that holds one row per lane, icp_rows_kernel), the tiles' partials then added EXACTLY in 128-bit fixed point -- so the
+        // totals do not depend on how tiles are dealt out to waves, blocks or launches, and every form of the iteration agrees bit for bit.
+        unsigned long long lo = 0ull, hi = 0ull;
+#pragma unroll
+        for (int t = 0; t < kIWaves; ++t) {
+            unsigned long long l, h;
+            fixed_split(tile_tree16(&sh[tix_e][16 * t]), l, h);
+            fixed_accumulate(lo, hi, l, h);
+        }
         unsigned long long *slot = acc + (((int64_t)(bid & (kAccCopies - 1)) * kAcc + tix_e) * kFixedWords);
-        if (fuse.ticket) fixed_add_performed(slot, v); else fixed_add(slot, v);
+        if (fuse.ticket) fixed_add_words_performed(slot, lo, hi); else fixed_add_words(slot, lo, hi);
+    } else if (!PERSIST && fuse.ticket && tix_e == nacc) {
+        int cnt = 0;
+#pragma unroll
+        for (int wv = 0; wv < kIWaves; ++wv) cnt += s_cnt[wv];
+        if (cnt) {
+            const unsigned long long back = __hip_atomic_fetch_add(fuse.ticket + kSearchedWord + (bid & 7u), (unsigned long long)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(back));
+        }
     }
     if (fuse.light_key && tix == kIThreads - 1) {      // (after the barrier above: s_light is complete)
         double g2 = INFINITY;
@@ -1629,6 +1687,7 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     // (the winner's thread number behind an opaque move as well: addresses derived from it are then formed here, not in front of the sweep)
     const int tix_w = opaque_i((int)threadIdx.x);
     if (tix_w < kAcc) s_sums[tix_w] = tix_w < nacc ? fixed_total_coherent(acc, tix_w) : 0.0;
+    const unsigned long long n_searched = PERSIST ? 0ull : searched_take(fuse.ticket, tix_w);
     __syncthreads();
     if (PERSIST) chain_tick(fuse.stamp, 7, tix == 0);
     for (int e = tix_w; e < kAccSet; e += kIThreads) __hip_atomic_store(acc + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1678,8 +1737,8 @@ __device__ __forceinline__ void icp_iter_body(const unsigned bid, const unsigned
     if (KPX_ICP_STATE_LDS && lane < (int)(sizeof(IcpState) / sizeof(double))) reinterpret_cast<double *>(stw)[lane] = reinterpret_cast<const double *>(&s_state)[lane];
     if (fuse.cert && fuse.thist && k + 1 < kCertHist && lane < 12) fuse.thist[12 * (k + 1) + lane] = work->T[lane];     // what iteration k + 1 transforms with
     if (lane == 0 && fuse.progress)
-        __hip_atomic_store(fuse.progress, fuse.tag | ((unsigned long long)(work->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fuse.progress, fuse.tag | progress_searched(n_searched, n) | ((unsigned long long)(work->done ? 1 : 0) << 32) | (unsigned long long)(unsigned)(k + 1),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 
@@ -1871,6 +1930,10 @@ __global__ __launch_bounds__(256) void icp_batch_init_kernel(IcpBatchArgs args, 
         }
     }
 }
+
+}  // namespace kpx
+#include "kpx_icprows.h"
+namespace kpx {
 
 // tiles multiplied by nn_local_kernel while the profiler is armed (one atomic per wave, spread over kVisitSlots
 // addresses: same-address atomics from thousands of waves serialise in L2); read by kpx_prof_end
@@ -2748,6 +2811,15 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
         static const bool chain_alone = [] { const char *e = getenv("KPX_ICP_CHAIN_ALONE"); return !(e && e[0] == '0'); }();     // A/B: 0 = also with other frames in flight
         const bool chain_ok = chain_form_on() && split == 2 && max_iteration <= kChainRecords - 2 && chain_abort_word() != nullptr &&
                               (!chain_alone || busy_threads() <= 1);
+        // KPX_ICP_ROWS=0: the iterations through icp_iter_batch_kernel (a wave per 16-row tile, blocks of four) -- the A/B switch of
+        // icp_rows_kernel (a wave per 64 rows), which serves the update in the last block (split 2) with LightSkip's bookkeeping
+        // (1, the default: per launch, by how much of the registrations the last reported iteration still searched -- the progress word's
+        // bits 33..39: a wave per tile while most rows are searched, a wave per 64 rows once most are certified (KPX_ICP_ROWS_SHARE: the
+        // largest searched share, in 1/127ths, at which the rows form is taken); 2: always the rows form.  The forms agree bit for bit,
+        // so the choice -- which follows the host's timing -- never shows in a result.)
+        static const int rows_env = [] { const char *e = getenv("KPX_ICP_ROWS"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+        static const int rows_share = [] { const char *e = getenv("KPX_ICP_ROWS_SHARE"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 127 ? v : 3; }();
+        const int rows_mode = split == 2 ? rows_env : 0;
         IcpBatchArgs A[8], Ac[8];                              // count <= 64: at most 8 groups
         int gk[8];
         bool gfin[8];
@@ -2807,7 +2879,7 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
             bool advanced = false;
             for (int g = 0; g < n_chain; ++g) {
                 if (gfin[g]) continue;
-                int seen = INT_MAX;
+                int seen = INT_MAX, share = 0;
                 bool all_done = true;
                 // the launches still to be queued carry only the registrations that have not converged yet (as far as the host
                 // knows: the progress words lag by up to `window` launches); a converged problem's blocks in an already queued
@@ -2822,6 +2894,8 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                     all_done = false;
                     const int sc = mine ? (int)(w & 0xFFFFFFFFull) : 0;
                     seen = sc < seen ? sc : seen;
+                    const int sh_c = mine && sc >= 1 ? (int)((w >> 33) & 127ull) : 127;
+                    share = sh_c > share ? sh_c : share;
                     act.p[act.count] = A[g].p[c];
                     act.p[act.count].block0 = ab;
                     ab += A[g].p[c].blocks;
@@ -2836,6 +2910,29 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                     advanced = true;
                     const bool closing = gk[g] > max_iteration;
                     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, ls);
+                    if (rows_mode == 2 || (rows_mode == 1 && share <= rows_share)) {
+                        // one wave per 64 rows (kpx_icprows.h): every problem with its own operands and iteration number
+                        RowsArgs ra;
+                        ra.count = act.count;
+                        for (int c = 0; c < kRowsBatchMax; ++c) {
+                            const IcpProblem &Q = act.p[c < act.count ? c : act.count - 1];
+                            RowsProblem &R = ra.p[c];
+                            R.src_sorted = Q.src_sorted; R.idx_sorted = Q.idx_sorted; R.ptgt_sorted = Q.ptgt_sorted; R.cert = Q.cert; R.thist = Q.thist;
+                            R.light_key = Q.light_key; R.sbbox = Q.sbbox; R.state = Q.pair; R.ring = Q.ring; R.result = Q.result; R.progress = Q.progress;
+                            R.tag = tag; R.tgt = tgt; R.tn = tgt_normals; R.Bs = bufs[0].Bs; R.orig = bufs[0].orig_t; R.tile_box = bufs[0].tile_box;
+                            R.group_box = bufs[0].group_box; R.tbbox = bufs[0].sort_t.bbox; R.n = Q.n; R.n_groups = tplan.l_groups; R.k = gk[g];
+                            R.block0 = Q.block0; R.blocks = Q.blocks;
+                        }
+                        unsigned long long *visits = prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr;
+                        if (mode == 1)
+                            hipLaunchKernelGGL(icp_rows_kernel<1>, dim3(ab), dim3(kRowsBlock), 0, ls, ra, md2, max_iteration, relative_fitness, relative_rmse, visits,
+                                               light, cert_policy);
+                        else
+                            hipLaunchKernelGGL(icp_rows_kernel<0>, dim3(ab), dim3(kRowsBlock), 0, ls, ra, md2, max_iteration, relative_fitness, relative_rmse, visits,
+                                               light, cert_policy);
+                        ++gk[g];
+                        continue;
+                    }
                     hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)act.count : ab), dim3(kIThreads), 0, ls, closing ? actc : act, tgt,
                                        tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box, bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2,
                                        mode, gk[g], max_iteration, relative_fitness, relative_rmse, tag,

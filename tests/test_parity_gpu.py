@@ -1781,13 +1781,19 @@ def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
     cannot change left out of the search (KPX_ICP_CERT, default on), and the whole chain in one launch (icp_chain_kernel, the default
     where a batch's blocks fit the device: the "small" and "alone" batches) against a launch per iteration (KPX_ICP_CHAIN=0): the
     exact fixed-point sums do not depend on which blocks add to them or when, and a certified row keeps exactly the partner a search
-    would return, so transforms, fitness, rmse, iterations and counts agree to the last bit."""
+    would return, so transforms, fitness, rmse, iterations and counts agree to the last bit.  Round 5: the default iteration kernel is
+    icp_rows_kernel (a wave per 64 rows) once most rows carry a certificate and icp_iter_batch_kernel (a wave per 16-row tile, blocks
+    of four) before, chosen per launch from the progress words (KPX_ICP_ROWS=0: never, 2: always, KPX_ICP_ROWS_SHARE: the threshold) --
+    the sums' contract (a tree per tile, tiles added exactly) makes the forms agree bit for bit as well."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
     for name, env in (("tail+skip", {}), ("nocert", {"KPX_ICP_CERT": "0"}), ("tail", {"KPX_ICP_LIGHT_SKIP": "0"}), ("kernel", {"KPX_ICP_SPLIT": "1"}),
-                      ("launches", {"KPX_ICP_CHAIN": "0"}), ("chain nocert", {"KPX_ICP_CERT": "0", "KPX_ICP_CHAIN": "1"})):
+                      ("launches", {"KPX_ICP_CHAIN": "0"}), ("chain nocert", {"KPX_ICP_CERT": "0", "KPX_ICP_CHAIN": "1"}),
+                      ("blocks of four", {"KPX_ICP_ROWS": "0"}), ("blocks of four nocert", {"KPX_ICP_ROWS": "0", "KPX_ICP_CERT": "0", "KPX_ICP_CHAIN": "0"}),
+                      ("rows", {"KPX_ICP_ROWS": "2", "KPX_ICP_CHAIN": "0"}), ("rows nocert", {"KPX_ICP_ROWS": "2", "KPX_ICP_CERT": "0", "KPX_ICP_CHAIN": "0"}),
+                      ("rows early", {"KPX_ICP_ROWS_SHARE": "100", "KPX_ICP_CHAIN": "0"})):
         f = str(tmp_path / (name.replace("+", "_").replace(" ", "_") + ".npz"))
         r = subprocess.run([sys.executable, "-c", _ICP_UPDATE_MODES, f], cwd=root, capture_output=True, text=True, timeout=300,
                            env={**os.environ, "KPX_ICP_CHAIN_LOCK": "0", **env})    # (this process may hold the device's chain lock; it is idle meanwhile)
@@ -1795,7 +1801,7 @@ def test_icp_update_placements_and_light_skip_are_bit_identical(tmp_path):
         got[name] = dict(np.load(f))
     # the forms that were to be compared did run: four chains (two modes x two small batches) by default, none with KPX_ICP_CHAIN=0 or a split update
     assert got["tail+skip"]["chains"][0] == 4 and got["chain nocert"]["chains"][0] == 4 and got["launches"]["chains"][0] == 0 and got["kernel"]["chains"][0] == 0
-    for name in ("nocert", "tail", "kernel", "launches", "chain nocert"):
+    for name in ("nocert", "tail", "kernel", "launches", "chain nocert", "blocks of four", "blocks of four nocert", "rows", "rows nocert", "rows early"):
         for key, v in got["tail+skip"].items():
             if key != "chains":
                 assert np.array_equal(v, got[name][key]), (name, key)
@@ -1948,13 +1954,14 @@ def test_update_placements_agree_with_four_frames_in_flight(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for mode in ("2", "1", "0"):
+    for mode in ("2", "1", "0", "blocks", "rows"):
         f = str(tmp_path / f"split{mode}.npz")
+        env = {"KPX_ICP_SPLIT": "2", "KPX_ICP_ROWS": "0" if mode == "blocks" else "2"} if mode in ("blocks", "rows") else {"KPX_ICP_SPLIT": mode}
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_frames.py"), f, "4", "3"], cwd=root, capture_output=True, text=True,
-                           timeout=600, env={**os.environ, "KPX_ICP_SPLIT": mode, "GPU_MAX_HW_QUEUES": "8"})
+                           timeout=600, env={**os.environ, **env, "GPU_MAX_HW_QUEUES": "8"})
         assert r.returncode == 0, r.stderr[-2000:]
         got[mode] = dict(np.load(f))
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "blocks", "rows"):
         for key, v in got["2"].items():
             assert np.array_equal(v, got[mode][key]), (mode, key)
     for k in range(8):
