@@ -562,8 +562,8 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     from kinectpy_amd import ops, parallel
-    from kinectpy_amd.pipeline import (FrameStream, NativeFramePipeline, NativeShardPipeline, PipelineParams, SensorGroupPipeline,
-                                       SensorShardPipeline)
+    from kinectpy_amd.pipeline import (FrameStream, NativeFramePipeline, NativeFrameStream, NativeShardPipeline, PipelineParams,
+                                       SensorGroupPipeline, SensorShardPipeline)
     from kinectpy_amd.utils import synth
 
     rank, world, local = parallel.init_distributed()
@@ -626,8 +626,16 @@ def main():
             return out_p, out_c, Ts
         return out
 
-    frames = FrameStream(pipes if pipes is not None else pipe, overlap) if overlap > 1 else None
     native_loop = isinstance(pipe, (NativeFramePipeline, NativeShardPipeline))
+    # frames in flight: scheduled inside the library (kpx_stream: C++ worker threads) for the native loops; KPX_BENCH_PY_STREAM=1 keeps
+    # rounds 2-4's Python FrameStream (a thread pool and futures) for same-box A/B runs
+    py_stream = os.environ.get("KPX_BENCH_PY_STREAM", "0") == "1" or not native_loop
+    if overlap <= 1:
+        frames = None
+    elif py_stream:
+        frames = FrameStream(pipes if pipes is not None else pipe, overlap)
+    else:
+        frames = NativeFrameStream(pipes if isinstance(pipe, NativeShardPipeline) else pipe, overlap)
 
     def run_steps(first, count, d=None, c=None):
         """`count` steps, all finished on return; with --overlap > 1 up to that many frames are in flight"""
@@ -694,7 +702,7 @@ def main():
         blocks.append(px_per_step * 20 / timed(k0, 20) / 1e6)
         blocks_pin.append(px_per_step * 20 / timed(k0 + 20, 20, depth_pin, rgb_pin) / 1e6)
         k0 += 40
-    last = dict(pipe.last)
+    last = dict(frames.last if frames is not None else pipe.last)
 
     if rank != 0:
         if frames is not None:
@@ -793,6 +801,8 @@ def main():
                "partition": "group", "sensors_per_gpu": args.sensors_per_gpu}
     cfg.update(pixels_per_step=px_per_step, icp=f"{P.icp_mode}, voxel {P.reg_voxel}, max_dist {P.icp_max_dist}, <= {P.icp_max_iteration} it",
                filter=f"voxel {P.filt_voxel} + SOR({P.filt_k}, {P.filt_ratio})", frames_in_flight=overlap, hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
+               frame_scheduler=("none (one frame at a time)" if frames is None else "python (pipeline.FrameStream: thread pool)" if py_stream
+                                else "native (kpx_stream: C++ worker threads, one HIP stream + workspace slice per slot)"),
                distinct_frames=F, priming_steps=k_prime,
                last_step=last)
     # The pinned-host figure: a window of fewer than 100 steps is ~12 ms of wall time, and ONE host hiccup halves it (seen: 1272 in a

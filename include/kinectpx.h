@@ -434,6 +434,30 @@ int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t frame, cons
                            int32_t fused_filter, float *out_pts, float *out_col, int32_t *h_count, double *h_T, int32_t *h_info, void *ws,
                            size_t ws_bytes, void *stream);
 
+/* ---- frames in flight, scheduled natively (round 5) -------------------------------------------------
+ * The reference's frame loop is sequential (preprocessing/data.py:35-61); consecutive frames are independent, and one frame is a
+ * chain of ~100 short dispatches with four read-backs, so `depth` frames run side by side: kpx_stream owns `depth` worker threads
+ * (C++, inside the library: no interpreter between a frame's end and the next one's start), each with its own HIP stream and its
+ * own slice of the caller's workspace (kpx_stream_workspace_bytes).  kpx_stream_submit hands a frame over and returns at once
+ * (KPX_ERR_INVALID when kpx_stream_capacity frames are queued); kpx_stream_pop blocks until the OLDEST frame in flight is done and returns
+ * its status, its point count (out_pts / out_col given at submit: rows [0, *h_count) are valid when pop returns, on any stream),
+ * transforms (f64 [sensors][16]) and info words (int32 [64], as kpx_frame_step).  depth / rgb of a frame: device memory, or pinned
+ * host memory with host_input != 0 (the copy then runs on the slot's stream, inside the frame); they must stay valid until the
+ * frame has been popped.  submit / pop / destroy: one calling thread.
+ * comms == NULL: one GPU (kpx_frame_step / kpx_frame_step_host per frame).  comms = `depth` communicators, one per slot: the
+ * rank's share of the rig through kpx_frame_step_sharded, the collectives of the frames in flight in ONE issue order on every rank
+ * (a kpx_order owned by the stream); a frame that outgrew its messages on every rank alike is run again inside kpx_stream_pop. */
+typedef struct kpx_stream kpx_stream;
+size_t kpx_stream_workspace_bytes(int32_t sensors, int32_t rank, int32_t world, int64_t n_px, int32_t depth);
+int kpx_stream_create(const float *xy_table, int64_t n_px, int32_t sensors, const double *h_init, const kpx_frame_params *params,
+                      int32_t depth, kpx_comm *const *comms, int32_t fused_filter, void *ws, size_t ws_bytes, kpx_stream **out);
+int kpx_stream_submit(kpx_stream *stream, const void *depth, const void *rgb, int32_t host_input, float *out_pts, float *out_col);
+int kpx_stream_pop(kpx_stream *stream, int32_t *h_count, double *h_T, int32_t *h_info);
+int kpx_stream_pending(const kpx_stream *stream);
+int kpx_stream_capacity(const kpx_stream *stream);    /* frames kpx_stream_submit takes before a pop: 2 x depth on one GPU (one queue, any free worker
+                                                         takes the oldest frame), depth with communicators (frame j runs on slot j % depth on every rank) */
+int kpx_stream_destroy(kpx_stream *stream);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it
  * (capacity = max launches recorded); every launch of a tagged kernel is bracketed by an event pair;

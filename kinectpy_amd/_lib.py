@@ -101,6 +101,13 @@ SIGNATURES = {
     "kpx_order_log": (C.c_int, [_vp, _vp, _i64, _vp]),
     "kpx_frame_step_sharded_workspace_bytes": (_sz, [_i32, _i32, _i32, _i64, _i32]),
     "kpx_frame_step_sharded": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_stream_workspace_bytes": (_sz, [_i32, _i32, _i32, _i64, _i32]),
+    "kpx_stream_create": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "kpx_stream_submit": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "kpx_stream_pop": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "kpx_stream_pending": (C.c_int, [_vp]),
+    "kpx_stream_capacity": (C.c_int, [_vp]),
+    "kpx_stream_destroy": (C.c_int, [_vp]),
     "kpx_sor_select": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "kpx_sort_pairs_u32_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "kpx_sort_pairs_u32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),

@@ -421,3 +421,108 @@ class FrameStream:
         from . import _lib
         for s_ in self.streams:                  # the slots' scratch (hundreds of MB per frame workspace) goes with the stream
             _lib.release_workspace(s_.cuda_stream, self.device)
+
+
+class NativeFrameStream:
+    """Several frames in flight, scheduled inside the library (kpx_stream: C++ worker threads, one HIP stream and one slice of one
+    workspace per slot; the interpreter only hands frames over and takes results).  Same interface as FrameStream -- submit / pop /
+    full / pending / close / last -- over a NativeFramePipeline (one GPU) or a list of NativeShardPipelines, one per slot (several
+    GPUs: every slot needs its own communicator).  `depth` frames run side by side; on one GPU up to 2 x depth may be queued (a free
+    worker takes the oldest).  Results are written into a ring of capacity + depth output buffers owned by the stream: a result stays
+    valid until `depth` more frames have been submitted after its pop -- clone what has to live longer."""
+
+    def __init__(self, pipe, depth: int = 4):
+        import ctypes as C
+        from . import _lib as L
+        self.pipes = list(pipe) if isinstance(pipe, (list, tuple)) else None
+        self.depth = len(self.pipes) if self.pipes else max(1, int(depth))
+        self.pipe = self.pipes[0] if self.pipes else pipe
+        p0 = self.pipe
+        if not isinstance(p0, (NativeFramePipeline, NativeShardPipeline)):
+            raise TypeError("NativeFrameStream runs the native frame loops (NativeFramePipeline / NativeShardPipeline)")
+        self.sharded = isinstance(p0, NativeShardPipeline)
+        if self.sharded and self.pipes is None:
+            raise ValueError("several ranks: one NativeShardPipeline (one communicator) per frame slot")
+        lib = L.load()
+        self._lib, self._L, self._C = lib, L, C
+        self.S = p0.n_sensors
+        self.S_local = len(p0.sensors) if self.sharded else self.S
+        self.n_px = int(p0.xy.numel() // 2)
+        self.dev = p0.xy.device
+        rank, world = (p0.comm.rank, p0.comm.world) if self.sharded else (0, 1)
+        nbytes = int(lib.kpx_stream_workspace_bytes(self.S, rank, world, self.n_px, self.depth))
+        if nbytes <= 0:
+            raise ValueError("kpx_stream_workspace_bytes: bad shape")
+        self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        init = np.ascontiguousarray(np.stack([ops._T(T) for T in p0.init])) if self.S > 1 else np.zeros((1, 4, 4))
+        comms = None
+        if self.sharded:
+            comms = (C.c_void_p * self.depth)(*[getattr(p_.comm.handle, "value", p_.comm.handle) for p_ in self.pipes])
+        fused = 1 if (self.sharded and p0.fused_filter == "rank0") else 0
+        h = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            torch.cuda.synchronize()                  # the table and the workspace exist before a worker's stream touches them
+            L.check(lib.kpx_stream_create(L.ptr(p0.xy), self.n_px, self.S, L.hptr(init), C.byref(p0._c), self.depth, comms, fused,
+                                          C.c_void_p(self._ws.data_ptr()), nbytes, C.byref(h)))
+        self.handle = h
+        rows = self.S * self.n_px
+        self.capacity = int(lib.kpx_stream_capacity(h))      # frames submit() takes before a pop(): 2 x depth on one GPU
+        self._ring = [tuple(torch.empty((rows, 3), dtype=torch.float32, device=self.dev) for _ in range(2)) for _ in range(self.capacity + self.depth)]
+        self.pending = deque()
+        self.submitted = 0
+        self._h_count = np.zeros(1, dtype=np.int32)
+        self.last = {}
+
+    def full(self) -> bool:
+        return len(self.pending) >= self.capacity
+
+    def submit(self, depth: torch.Tensor, rgb: torch.Tensor):
+        """queue one frame (call pop() first when full()): depth (S_local, n_px) u16, rgb (S_local, n_px, 3) u8, device tensors or
+        pinned host tensors; they are kept alive until the frame has been popped"""
+        assert not self.full()
+        L, C = self._L, self._C
+        host = not depth.is_cuda
+        if depth.dtype != torch.uint16 or rgb.dtype != torch.uint8 or not (depth.is_contiguous() and rgb.is_contiguous()):
+            raise ValueError("NativeFrameStream.submit: contiguous uint16 depth / uint8 rgb tensors")
+        if int(depth.numel()) != self.S_local * self.n_px or int(rgb.numel()) != 3 * self.S_local * self.n_px:
+            raise ValueError("NativeFrameStream.submit: a frame is (sensors, n_px) depth + (sensors, n_px, 3) rgb")
+        out = self._ring[self.submitted % len(self._ring)]
+        L.check(self._lib.kpx_stream_submit(self.handle, C.c_void_p(depth.data_ptr()), C.c_void_p(rgb.data_ptr()), 1 if host else 0, L.ptr(out[0]), L.ptr(out[1])))
+        self.submitted += 1
+        self.pending.append((depth, rgb, out))
+
+    def pop(self):
+        """-> (points, colours, transforms) of the oldest frame in flight; the rows are complete when this returns"""
+        L = self._L
+        _, _, out = self.pending[0]
+        h_T = np.zeros((self.S, 4, 4))
+        h_info = np.zeros(64, dtype=np.int32)
+        rc = self._lib.kpx_stream_pop(self.handle, self._h_count.ctypes.data_as(self._C.c_void_p), L.hptr(h_T), h_info.ctypes.data_as(self._C.c_void_p))
+        self.pending.popleft()
+        if self.sharded:
+            for p_ in self.pipes:
+                if p_.comm.error is not None:
+                    e, p_.comm.error = p_.comm.error, None
+                    raise e
+        L.check(rc)
+        k, S = int(self._h_count[0]), self.S
+        self.last = {"icp": [(int(h_info[32 + i]), None, None) for i in range(1, S)], "n_down": [int(v) for v in h_info[:S]],
+                     "n_masked": [int(v) for v in h_info[16:16 + S]], "n_fused": int(h_info[16:16 + S].sum()), "n_voxel": int(h_info[48]), "n_out": k}
+        return out[0][:k], out[1][:k], h_T
+
+    def close(self):
+        if self.handle is not None:
+            while self.pending:
+                try:
+                    self.pop()
+                except Exception:                      # noqa: BLE001 -- closing: the frames' errors were the caller's to collect
+                    pass
+            self._lib.kpx_stream_destroy(self.handle)
+            self.handle = None
+            self._ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                              # noqa: BLE001
+            pass

@@ -2035,6 +2035,48 @@ def test_native_frame_step_from_pinned_host_memory(four_sensor_oracle):
         nat.step(torch.as_tensor(depth[0].astype(np.int32)), torch.as_tensor(rgb[0]))
 
 
+def test_native_frame_stream_equals_serial_steps_and_oracle(four_sensor_oracle):
+    """kpx_stream (pipeline.NativeFrameStream: the frames in flight scheduled by C++ worker threads inside the library): 14 frames with
+    four in flight, from device memory and from pinned host memory in turn, come back in submission order and equal the serial native
+    step bit for bit (clouds, colours, transforms) and the oracle step (clouds identical, transforms within TOL_T); submit beyond the
+    depth is refused; an error inside a frame surfaces in pop() with its message, and the stream goes on."""
+    from kinectpy_amd.pipeline import NativeFramePipeline, NativeFrameStream, PipelineParams
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    dh, ch = torch.as_tensor(depth).pin_memory(), torch.as_tensor(rgb).pin_memory()
+    dd, cd = torch.as_tensor(depth).cuda(), torch.as_tensor(rgb).cuda()
+    nat = NativeFramePipeline(xy, 4, inits, PipelineParams())
+    serial = []
+    for f in range(2):
+        gp, gc, gT = nat.step(dd[f], cd[f])
+        serial.append((npy(gp), npy(gc), gT.copy()))
+        assert np.array_equal(serial[f][0], ref[f][0]) and np.array_equal(serial[f][1], ref[f][1]) and np.abs(gT - np.stack(ref[f][2])).max() < TOL_T
+    fs = NativeFrameStream(nat, 4)
+    got = []
+    for k in range(14):
+        if fs.full():
+            with pytest.raises(AssertionError):
+                fs.submit(dd[0], cd[0])
+            got.append([npy(t) if isinstance(t, torch.Tensor) else t.copy() for t in fs.pop()])
+        fs.submit(dh[k % 2], ch[k % 2]) if k % 3 == 1 else fs.submit(dd[k % 2], cd[k % 2])
+    while fs.pending:
+        got.append([npy(t) if isinstance(t, torch.Tensor) else t.copy() for t in fs.pop()])
+    assert len(got) == 14 and fs.last["n_out"] == got[-1][0].shape[0]
+    for k, (gp, gc, gT) in enumerate(got):
+        assert np.array_equal(gp, serial[k % 2][0]) and np.array_equal(gc, serial[k % 2][1]) and np.array_equal(gT, serial[k % 2][2]), k
+    # a frame that fails (a voxel size far too small for the cloud's extent) reports in ITS pop; the frames around it are unaffected
+    bad = NativeFramePipeline(xy, 4, inits, PipelineParams(filt_voxel=1e-6))
+    fb = NativeFrameStream(bad, 2)
+    fb.submit(dd[0], cd[0])
+    with pytest.raises(Exception) as ei:
+        fb.pop()
+    assert "voxel_size is too small" in str(ei.value)
+    fb.close()
+    fs.submit(dd[1], cd[1])
+    gp, gc, gT = fs.pop()
+    assert np.array_equal(npy(gp), serial[1][0])
+    fs.close()
+
+
 def test_native_frame_step_ten_sensors_equals_oracle(oracle):
     """ten sensors: nine registrations = two launch chains side by side on the library's lanes (each with its own update-in-the-
     last-block tickets and skip keys), the voxel batch in two groups (row-major clouds: the ICP batch sorts them itself)"""
