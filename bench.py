@@ -676,7 +676,9 @@ def main():
         if blk >= 3 and flat >= 2:                  # at least 100 steps; two blocks in a row without a 3 % gain on the best so far
             break
     run_steps(k_prime, args.warmup)
+    st0 = frames.stats() if hasattr(frames, "stats") else None
     dt = timed(k_prime + args.warmup, args.steps)                        # THE timed region: exactly --steps steps, frames resident in HBM
+    st1 = frames.stats() if hasattr(frames, "stats") else None
     k0 = k_prime + args.warmup + args.steps
     # SURVEY 8(d)'s interval -- "depth frame resident in host pinned memory -> fused cloud on the GPU": the same loop, every frame
     # handed over in pinned host memory (native loop: staged through the slot's workspace on the frame's stream by
@@ -803,6 +805,9 @@ def main():
                filter=f"voxel {P.filt_voxel} + SOR({P.filt_k}, {P.filt_ratio})", frames_in_flight=overlap, hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
                frame_scheduler=("none (one frame at a time)" if frames is None else "python (pipeline.FrameStream: thread pool)" if py_stream
                                 else "native (kpx_stream: C++ worker threads, one HIP stream + workspace slice per slot)"),
+               icp_engine=None if st1 is None else {"on": st1["icp_engine"], "iteration_launches_per_step": round((st1["engine_launches"] - st0["engine_launches"]) / max(1, args.steps), 2),
+                                                    "ticks_per_step": round((st1["engine_ticks"] - st0["engine_ticks"]) / max(1, args.steps), 2),
+                                                    "note": "the registrations of all frames in flight in one launch chain (kpx_icp.hip, IcpEngine)"},
                distinct_frames=F, priming_steps=k_prime,
                last_step=last)
     # The pinned-host figure: a window of fewer than 100 steps is ~12 ms of wall time, and ONE host hiccup halves it (seen: 1272 in a

@@ -457,6 +457,11 @@ int kpx_stream_pending(const kpx_stream *stream);
 int kpx_stream_capacity(const kpx_stream *stream);    /* frames kpx_stream_submit takes before a pop: 2 x depth on one GPU (one queue, any free worker
                                                          takes the oldest frame), depth with communicators (frame j runs on slot j % depth on every rank) */
 int kpx_stream_destroy(kpx_stream *stream);
+/* h_out4: [0] frames finished by the stream's workers, [1] 1 = the frames' registrations run through the device's ICP engine (one host
+ * thread and one HIP stream carry the point-to-plane / point-to-point iterations of EVERY frame in flight in one launch per tick --
+ * preprocessing/registration.py:78-84 as called from data.py:144-161, for all frames at once; KPX_STREAM_ENGINE=1 -- measured slower
+ * than a chain of launches per frame, the default: DESIGN.md), [2] iteration launches and [3] ticks of that engine since it started (process-wide per device). */
+int kpx_stream_stats(const kpx_stream *stream, uint64_t *h_out4);
 
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------- */
 /* HIP-event timing of the hot kernels on the stream they are launched on.  kpx_prof_begin arms it
@@ -486,14 +491,14 @@ int kpx_prof_icp_phases(double *h_out8);
  * tile-box fetches << 16 | operand fetches << 32 | groups kept << 48; sampled rows with a partner).  *h_count = the number of
  * waves written (<= cap_waves). */
 int kpx_prof_icp_waves(uint64_t *h_out, int64_t cap_waves, int64_t *h_count);
-/* Self-check of the row certificates of the culled ICP sweep (kpx_icp_batch with KPX_ICP_CERT_CHECK=1 in the environment: rows whose
- * partner is certified unchanged -- registration_icp's correspondence step, preprocessing/registration.py:78-84 -- are searched all
- * the same and compared).  h_out8 (8 x uint64, cleared by the call): [0] rows certified, [1] rows searched, [2] certified rows whose
- * search found another partner (must be 0), [3..7] the first such row: iteration, sorted row, kept and found partner, key bits. */
 /* The one-launch form of the culled ICP chain (kpx_icp_batch groups whose blocks fit the device; kpx_icp.hip, icp_chain_kernel): on = 1 / 0
    switches it for the calling process, on = -1 only asks; returns the previous setting (on = -2: the number of chains this process has launched).  Default: on unless KPX_ICP_CHAIN=0.  Results do
    not depend on it (tests/test_parity_gpu.py, test_icp_update_placements_and_light_skip_are_bit_identical). */
 int kpx_icp_chain(int32_t on);
+/* Self-check of the row certificates of the culled ICP sweep (kpx_icp_batch with KPX_ICP_CERT_CHECK=1 in the environment: rows whose
+ * partner is certified unchanged -- registration_icp's correspondence step, preprocessing/registration.py:78-84 -- are searched all
+ * the same and compared).  h_out8 (8 x uint64, cleared by the call): [0] rows certified, [1] rows searched, [2] certified rows whose
+ * search found another partner (must be 0), [3..7] the first such row: iteration, sorted row, kept and found partner, key bits. */
 int kpx_prof_icp_cert(uint64_t *h_out8);
 /* Clock of the one-launch ICP chain (KPX_ICP_CHAIN_STAMPS=1): 64 iterations x 48 stamps of the 100 MHz wall clock, first registration of
    the last chain launch (slots: kpx_icp.hip, g_chain_stamp); read and reset.  A development aid like the other kpx_prof_* entries. */

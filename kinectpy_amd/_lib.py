@@ -108,6 +108,7 @@ SIGNATURES = {
     "kpx_stream_pending": (C.c_int, [_vp]),
     "kpx_stream_capacity": (C.c_int, [_vp]),
     "kpx_stream_destroy": (C.c_int, [_vp]),
+    "kpx_stream_stats": (C.c_int, [_vp, _vp]),
     "kpx_sor_select": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "kpx_sort_pairs_u32_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "kpx_sort_pairs_u32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),

@@ -200,14 +200,28 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
         p_in[(size_t)i] = L.mask_pts + (size_t)i * n_px * 3; c_in[(size_t)i] = L.mask_col + (size_t)i * n_px * 3;
         if (i > 0) dT[(size_t)i] = L.icp_res + 20 * (size_t)(i - 1);
     }
-    KPX_SUB(fuse_voxel_downsample_dev(S, p_in.data(), c_in.data(), mk.data(), h_T, dT.data(), prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws,
-                                      L.op_bytes, st));
-    KPX_HIP(hipMemcpyAsync(h_d, L.icp_res, ((size_t)S * 20 + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
-    KPX_SUB(frame_wait(st));
+    // The fused cloud's sort-key width is speculated from this thread's previous frame, like the registration grids' above: <= 32 bits,
+    // the library's own radix sort; a frame that needs more is seen at the read-back below and fused again the careful way.
+    static thread_local int fuse_spec = 0;
+    if (!speculate) fuse_spec = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        h_i[51] = 0;
+        KPX_SUB(fuse_voxel_downsample_dev(S, p_in.data(), c_in.data(), mk.data(), h_T, dT.data(), prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws,
+                                          L.op_bytes, st, attempt == 0 ? fuse_spec : 0, h_i + 51));
+        KPX_HIP(hipMemcpyAsync(h_d, L.icp_res, ((size_t)S * 20 + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+        KPX_SUB(frame_wait(st));
+        const int need = h_i[51];
+        const bool narrow = attempt == 0 && fuse_spec > 0 && need > fuse_spec;
+        fuse_spec = (speculate && need > 0 && need <= 32) ? (need + 7) / 8 * 8 : 0;      // whole 8-bit passes; wide keys are not speculated
+        if (!narrow) break;
+    }
     h_i[48] = *reinterpret_cast<const int32_t *>(h_d + (size_t)S * 20);
-    if (S > 1 && icp_chain_abort_take())                   // (a one-launch ICP chain that lost its race for residency: its transform is NaN)
-        return fail(KPX_ERR_HIP, "kpx_frame_step: the frame's one-launch ICP chain gave up waiting for its blocks to become resident; KPX_ICP_CHAIN=0 "
-                                 "selects the launch-per-iteration form");
+    for (int i = 1; i < S; ++i)                            // (a one-launch ICP chain that lost its race for residency: its results are NaN)
+        if (h_d[20 * (i - 1) + 16] != h_d[20 * (i - 1) + 16]) {
+            (void)icp_chain_abort_take();
+            return fail(KPX_ERR_HIP, "kpx_frame_step: the one-launch ICP chain of sensor %d gave up waiting for its blocks to become resident; KPX_ICP_CHAIN=0 "
+                                     "selects the launch-per-iteration form", i);
+        }
     for (int i = 1; i < S; ++i) {
         for (int q = 0; q < 16; ++q) h_T[16 * i + q] = h_d[20 * (i - 1) + q];
         if (h_info) h_info[32 + i] = (int32_t)h_d[20 * (i - 1) + 18];
@@ -503,10 +517,13 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
             ns[(size_t)j] = dk[(size_t)i];
         }
         const float *tgt = owns_master ? L.down_pts : m_xyz, *tn = plane ? L.normals : nullptr;
-        if (plane) KPX_SUB(kpx_estimate_normals(tgt, m, 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st));
+        // (a failure here is this rank's alone: it keeps its place in collective 1 with a negative count -- `lerr` -- and every rank
+        // returns together; returning from here would leave the peers spinning in the all-gather)
+        if (plane) lerr = kpx_estimate_normals(tgt, m, 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st);
         const int first_sub = g0 + (owns_master ? 1 : 0);      // global sensor number of subs[0]; h_init[g - 1] belongs to sensor g
-        KPX_SUB(icp_batch_ordered(n_sub, subs.data(), ns.data(), tgt, tn, m, prm->icp_max_dist, h_init + 16 * (size_t)(first_sub - 1), prm->icp_mode,
-                                  prm->icp_max_iteration, 1e-6, 1e-6, L.icp_res, L.op_ws, L.op_bytes, st, zorder));
+        if (!lerr)
+            lerr = icp_batch_ordered(n_sub, subs.data(), ns.data(), tgt, tn, m, prm->icp_max_dist, h_init + 16 * (size_t)(first_sub - 1), prm->icp_mode,
+                                     prm->icp_max_iteration, 1e-6, 1e-6, L.icp_res, L.op_ws, L.op_bytes, st, zorder);
     }
     // -- collective 1: the masked clouds, unmoved, planar (xyz rows, then rgb rows), + header rows
     int64_t &cap_c = comm_cap_clouds(comm);
@@ -553,6 +570,12 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
                 if (lerr) return lerr;
                 return n < 0 ? fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: rank %d failed on its own sensors (see its error)", r)
                              : fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: bad exchange header (rank %d)", r);
+            }
+            if (row[2 + 16] != row[2 + 16]) {                      // NaN fitness: that rank's one-launch ICP chain gave up its residency wait (icp_chain_kernel);
+                kpx_order_finish(order, frame);                    // the same rows on every rank: everyone returns here, behind the same collective
+                (void)icp_chain_abort_take();
+                return fail(KPX_ERR_HIP, "kpx_frame_step_sharded: the one-launch ICP chain of sensor %d (rank %d) gave up waiting for its blocks to become "
+                                         "resident; KPX_ICP_CHAIN=0 selects the launch-per-iteration form", g, r);
             }
             f_p[(size_t)g] = reinterpret_cast<const float *>(L.xchg_recv + (size_t)r * xbytes + (size_t)off * 12);
             f_c[(size_t)g] = reinterpret_cast<const float *>(L.xchg_recv + (size_t)r * xbytes + (size_t)(capc + off) * 12);

@@ -24,6 +24,10 @@
 #include <chrono>
 #include <mutex>
 #include <fcntl.h>
+#include <memory>
+#include <condition_variable>
+#include <thread>
+#include <atomic>
 #include <sys/file.h>
 #include <unistd.h>
 #include <limits.h>
@@ -1782,17 +1786,23 @@ struct IcpProblem {
     double *chain_rec;
     int64_t n;
     uint32_t block0, blocks;
+    // round 5: every problem carries its own target operands, iteration number and progress tag, so that one launch can hold the
+    // registrations of SEVERAL frames in flight, each at the iteration it has reached (IcpEngine below; icp_chain_kernel, which iterates
+    // by itself over one shared target, takes these as kernel arguments instead)
+    const float *tgt, *tn;
+    const double *Bs;
+    const int32_t *orig;
+    const float *tile_box, *group_box;
+    const double *tbbox;
+    int32_t n_groups, k;
+    unsigned long long tag;
 };
 struct IcpBatchArgs {
     IcpProblem p[kIcpBatchMax];
     int32_t count;
 };
-__global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE, KPX_ICP_WPE))) void icp_iter_batch_kernel(IcpBatchArgs args, const float *__restrict__ tgt,
-                                                       const float *__restrict__ tn, const double *__restrict__ Bs,
-                                                       const int32_t *__restrict__ orig, const float *__restrict__ tile_box,
-                                                       const float *__restrict__ group_box, int32_t n_groups,
-                                                       const double *__restrict__ tbbox, double max_d2, int mode, int k, int max_iter, double rel_fit,
-                                                       double rel_rmse, unsigned long long tag, unsigned long long *__restrict__ tile_visits, int split, int light,
+__global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE, KPX_ICP_WPE))) void icp_iter_batch_kernel(IcpBatchArgs args, double max_d2, int mode, int max_iter, double rel_fit,
+                                                       double rel_rmse, unsigned long long *__restrict__ tile_visits, int split, int light,
                                                        CertPolicy pol)
 {
     int pi = 0;
@@ -1800,6 +1810,12 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_I
     for (int c = 1; c < kIcpBatchMax; ++c) pi += (c < args.count && blockIdx.x >= args.p[c].block0) ? 1 : 0;
     const IcpProblem &P = args.p[pi];
     const unsigned bid = blockIdx.x - P.block0;
+    const float *__restrict__ tgt = P.tgt, *__restrict__ tn = P.tn, *__restrict__ tile_box = P.tile_box, *__restrict__ group_box = P.group_box;
+    const double *__restrict__ Bs = P.Bs, *__restrict__ tbbox = P.tbbox;
+    const int32_t *__restrict__ orig = P.orig;
+    const int32_t n_groups = P.n_groups;
+    const int k = P.k;
+    const unsigned long long tag = P.tag;
     if (k > max_iter && bid != 0) return;                   // the closing launch only performs the last update (one block per problem)
     // split: the update runs in icp_solve_batch_kernel between the sweeps (state slot 0, first accumulator set): the sweep's blocks
     // then live 8 us instead of 12 -- under load (several frames in flight) the device's wave slots are what the sweeps compete for
@@ -1861,10 +1877,11 @@ __global__ __launch_bounds__(kIThreads) __attribute__((amdgpu_waves_per_eu(KPX_I
         }
         __syncthreads();
         if (s_abort) {
-            if (threadIdx.x == 0) {
-                __hip_atomic_store(abort_word, tag | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (P.result) P.result[16] = __builtin_nan("");
-            }
+            // the abort is reported PER CALL: every result word of the registration is NaN (nothing stale leaks out, and whoever reads the
+            // result -- ops.icp_batch, kpx_frame_step*, the exchange header of the sharded step -- sees it for THIS call); the pinned word is
+            // the process-wide diagnostic behind it
+            if (threadIdx.x == 0) __hip_atomic_store(abort_word, tag | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (P.result && threadIdx.x < 20) P.result[threadIdx.x] = __builtin_nan("");
             return;
         }
         if (s_cur.done) break;
@@ -1912,7 +1929,13 @@ __global__ __launch_bounds__(256) void icp_batch_init_kernel(IcpBatchArgs args, 
         const int64_t r = (int64_t)bid * kIRows + rr;
         if (r < P.n && c < 3) P.src_sorted[3 * r + c] = P.src[3 * (int64_t)P.row_of[r] + c];
     }
-    if (threadIdx.x == 0) P.light_key[bid] = 0.0;
+    if (threadIdx.x < 7) {                                  // the block's LightSkip keys at every granularity: 1 x 64 rows, 2 x 32, 4 x 16
+        const int64_t n64 = (P.n + 63) / 64, n32 = (P.n + 31) / 32, n16 = (P.n + 15) / 16;
+        const int t = threadIdx.x;
+        const int64_t e = t == 0 ? (int64_t)bid : t < 3 ? n64 + 2 * (int64_t)bid + (t - 1) : n64 + n32 + 4 * (int64_t)bid + (t - 3);
+        const int64_t lim = t == 0 ? n64 : t < 3 ? n64 + n32 : n64 + n32 + n16;
+        if (e < lim) P.light_key[e] = 0.0;
+    }
     if (bid == 0) {
         for (int e = threadIdx.x; e < 3 * kAccSet; e += 256) P.ring[e] = 0ull;
         if (threadIdx.x >= 64 && threadIdx.x < 76) P.thist[threadIdx.x - 64] = T0.m[pi][threadIdx.x - 64];
@@ -2133,7 +2156,7 @@ static void nn_carve_source(Arena &a, int64_t n, const NnPlan &p, NnBuffers *b)
     b->src_sorted = a.get<float>(nn * 3);
     b->ptgt_sorted = a.get<float>(nn * 3);
     b->acc_fixed = a.get<unsigned long long>((size_t)3 * kAccCopies * kAcc * kFixedWords + 8);      // ring of three sets (icp_iter_kernel, IcpFuse)
-    b->light_key = a.get<double>((size_t)cdiv((int64_t)nn, kIRows));
+    b->light_key = a.get<double>((size_t)(cdiv((int64_t)nn, 64) + cdiv((int64_t)nn, 32) + cdiv((int64_t)nn, 16)));   // per 64 rows (both forms), then per 32 and per 16 (icp_rows_kernel<., R>)
     b->cert_sorted = a.get<uint32_t>(nn);
     b->thist = a.get<double>((size_t)kCertHist * 12);
     b->chain_rec = a.get<double>((size_t)kChainRecords * kChainRec);
@@ -2607,8 +2630,10 @@ template <class F> bool chain_launch_if_fits(unsigned blocks, hipStream_t st, F 
         if (!mine && hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) == hipSuccess) {
             char path[128];
             for (char *c = bus; *c; ++c) if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'f') || (*c >= 'A' && *c <= 'F'))) *c = '_';
-            snprintf(path, sizeof(path), "/tmp/kpx_chain_%s.lock", bus);
-            const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+            // (per user, never through a planted symlink, not inherited across exec; containers that share a GPU but not /dev/shm each
+            // believe they are alone: such deployments set KPX_ICP_CHAIN=0 -- INTEGRATION.md)
+            snprintf(path, sizeof(path), "/dev/shm/kpx_chain_%u_%s.lock", (unsigned)getuid(), bus);
+            const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
             if (fd >= 0) {
                 if (flock(fd, LOCK_EX | LOCK_NB) == 0) mine = true;        // (kept open: the lock lives as long as the process)
                 else close(fd);
@@ -2657,6 +2682,330 @@ int kpx::icp_chain_abort_take()
     return v ? 1 : 0;
 }
 
+namespace kpx {
+
+// icp_rows_kernel with R rows per wave (KPX_ICP_ROWS_R: 64 / 32 / 16): problems given as IcpProblems, each at its own iteration k[c]
+static int rows_per_wave()
+{
+    static const int r = [] { const char *e = getenv("KPX_ICP_ROWS_R"); const int v = e ? atoi(e) : 0; return v == 16 || v == 32 || v == 64 ? v : 64; }();
+    return r;
+}
+static void rows_launch(const IcpProblem *const *probs, const int *ks, int cnt, double md2, int mode, int max_iter, double rel_fit, double rel_rmse,
+                        unsigned long long *visits, int light, CertPolicy pol, hipStream_t st)
+{
+    const int R = rows_per_wave();
+    RowsArgs ra;
+    ra.count = cnt;
+    unsigned b0 = 0;
+    for (int c = 0; c < kRowsBatchMax; ++c) {
+        const int cc = c < cnt ? c : cnt - 1;
+        const IcpProblem &Q = *probs[cc];
+        RowsProblem &Rp = ra.p[c];
+        const int64_t n64 = cdiv(Q.n, 64), n32 = cdiv(Q.n, 32);
+        Rp.src_sorted = Q.src_sorted; Rp.idx_sorted = Q.idx_sorted; Rp.ptgt_sorted = Q.ptgt_sorted; Rp.cert = Q.cert; Rp.thist = Q.thist;
+        Rp.light_key = Q.light_key + (R == 64 ? 0 : R == 32 ? n64 : n64 + n32); Rp.sbbox = Q.sbbox; Rp.state = Q.pair; Rp.ring = Q.ring; Rp.result = Q.result;
+        Rp.progress = Q.progress; Rp.tag = Q.tag; Rp.tgt = Q.tgt; Rp.tn = Q.tn; Rp.Bs = Q.Bs; Rp.orig = Q.orig; Rp.tile_box = Q.tile_box; Rp.group_box = Q.group_box;
+        Rp.tbbox = Q.tbbox; Rp.n = Q.n; Rp.n_groups = Q.n_groups; Rp.k = ks[cc];
+        Rp.block0 = b0; Rp.blocks = (unsigned)cdiv(Q.n, R);
+        if (c < cnt) b0 += Rp.blocks;
+    }
+#define KPX_ROWS_LAUNCH(M, RR) hipLaunchKernelGGL((icp_rows_kernel<M, RR>), dim3(b0), dim3(64), 0, st, ra, md2, max_iter, rel_fit, rel_rmse, visits, light, pol)
+    if (mode == 1) { if (R == 64) KPX_ROWS_LAUNCH(1, 64); else if (R == 32) KPX_ROWS_LAUNCH(1, 32); else KPX_ROWS_LAUNCH(1, 16); }
+    else { if (R == 64) KPX_ROWS_LAUNCH(0, 64); else if (R == 32) KPX_ROWS_LAUNCH(0, 32); else KPX_ROWS_LAUNCH(0, 16); }
+#undef KPX_ROWS_LAUNCH
+}
+
+// ---- IcpEngine: the registrations of ALL frames in flight in one chain of launches (round 5) ------------------------------------
+// With several frames in flight every frame used to drive its own chain of ~31 launches from its own host thread: four chains, four
+// poll loops, ~120 launches per four frames competing for the command processor.  A kpx_stream attaches its worker threads to the
+// device's engine instead: icp_batch_ordered prepares its registrations as before (curve order, boxes, operands, the init kernel: on
+// the frame's own stream), records an event, and hands the group over; the engine thread -- ONE host thread, ONE stream -- carries the
+// registrations of every frame that is in its registration phase in one launch per tick, each at the iteration it has reached
+// (IcpProblem::k), the calm ones in icp_rows_kernel (<= 16 per launch), those still searching most rows in icp_iter_batch_kernel
+// (<= 8 per launch).  A group joins at the first tick after its preparation has finished on the device (its event is polled: the
+// engine's stream never waits for a frame that is still preparing), leaves when its last registration has converged or run out of
+// iterations, and the frame's stream waits for the event recorded behind the group's last launch.  Results do not depend on who
+// launches what when: partners are exact, the sums order-free (test_native_frame_stream_equals_serial_steps_and_oracle runs with and
+// without the engine).  MEASURED (profiles/r05/exp_icp_engine_one_chain.txt, exp_icp_engine_two_chains.txt): 1550 Mpoints/s with one chain,
+// 1720 with two (below), against 2740-2800 with a chain of launches per frame on the same box -- lockstep ticks advance every frame at the pace
+// of the slowest launch, and a launch's tail (it lasts as long as its slowest block) is filled by nobody, where four independent chains fill
+// each other's.  So the engine is OFF by default (KPX_STREAM_ENGINE=1 switches it on); results are identical either way.
+struct EngJob;
+struct EngProblem {
+    IcpProblem P;
+    unsigned long long gen;
+    int next_k, seen, share;
+    int lane;                              // the chain (0 / 1) its last launch ran in; -1: none yet
+    bool done;
+    EngJob *job;
+};
+constexpr int kEngEvents = 32;
+struct EngJob {
+    int count = 0;
+    EngProblem p[kIcpBatchMax];
+    double md2 = 0.0, rel_fit = 0.0, rel_rmse = 0.0;
+    int mode = 0, max_iter = 0, light = 0, rows_mode = 0, rows_share = 0, window = 3;
+    CertPolicy pol = { 0.0f, 0.0f, 0.0f, 0.0f };
+    hipEvent_t ready = nullptr, done_ev[2] = { nullptr, nullptr };
+    int used = 0;                          // bit f: the group ran launches in chain f (done_ev[f] is recorded when it leaves)
+    std::atomic<int> state{ 0 };          // 0 handed over, 1 active, 2 finished (done events recorded, rc set)
+    int rc = KPX_OK;
+    bool same_launch(const EngJob &o) const
+    {
+        return md2 == o.md2 && rel_fit == o.rel_fit && rel_rmse == o.rel_rmse && mode == o.mode && max_iter == o.max_iter && light == o.light &&
+               pol.calm == o.pol.calm && pol.factor == o.pol.factor && pol.smin == o.pol.smin && pol.smax == o.pol.smax;
+    }
+};
+struct IcpEngine {
+    int dev = 0, refs = 0;
+    hipStream_t st[2] = { nullptr, nullptr };
+    hipEvent_t mig[kEngEvents] = { nullptr };
+    unsigned mig_next = 0;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<EngJob *> inbox;
+    std::atomic<int> inbox_n{ 0 };
+    std::atomic<bool> quit{ false };
+    std::atomic<unsigned long long> launches{ 0 }, ticks{ 0 };
+};
+static std::mutex g_engine_mu;
+static IcpEngine *g_engine[16] = { nullptr };
+static thread_local IcpEngine *t_engine = nullptr;
+
+static void engine_fail(std::vector<EngJob *> &jobs, int rc)
+{
+    for (EngJob *j : jobs) { j->rc = rc; j->state.store(2, std::memory_order_release); }
+    jobs.clear();
+}
+static void engine_run(IcpEngine *E)
+{
+    (void)hipSetDevice(E->dev);
+    static const double stall_limit = [] { const char *e = getenv("KPX_ICP_STALL_SECONDS"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 60.0; }();
+    std::vector<EngJob *> pending, active;
+    auto t_last = std::chrono::steady_clock::now();
+    for (;;) {
+        if (E->inbox_n.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> lock(E->mu);
+            for (EngJob *j : E->inbox) pending.push_back(j);
+            E->inbox.clear();
+            E->inbox_n.store(0, std::memory_order_release);
+        }
+        if (E->quit.load(std::memory_order_acquire)) {
+            engine_fail(pending, KPX_ERR_HIP);
+            engine_fail(active, KPX_ERR_HIP);
+            return;
+        }
+        if (pending.empty() && active.empty()) {             // idle: a short spin, then sleep until a group arrives
+            const auto t0 = std::chrono::steady_clock::now();
+            bool woke = false;
+            for (unsigned spins = 0; !woke; ++spins) {
+                if (E->inbox_n.load(std::memory_order_acquire) > 0 || E->quit.load(std::memory_order_acquire)) woke = true;
+                else if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+                else __builtin_ia32_pause();
+            }
+            if (!woke) {
+                std::unique_lock<std::mutex> lock(E->mu);
+                E->cv.wait(lock, [&] { return E->inbox_n.load(std::memory_order_acquire) > 0 || E->quit.load(std::memory_order_acquire); });
+            }
+            t_last = std::chrono::steady_clock::now();
+            continue;
+        }
+        bool advanced = false;
+        // groups whose preparation has finished on the device join (the engine's stream never waits for one that has not)
+        for (size_t i = 0; i < pending.size();) {
+            const hipError_t q = hipEventQuery(pending[i]->ready);
+            if (q == hipErrorNotReady) { ++i; continue; }
+            EngJob *j = pending[i];
+            pending.erase(pending.begin() + (long)i);
+            if (q != hipSuccess || hipStreamWaitEvent(E->st[0], j->ready, 0) != hipSuccess || hipStreamWaitEvent(E->st[1], j->ready, 0) != hipSuccess) {
+                j->rc = fail(KPX_ERR_HIP, "kpx_icp_batch (engine): the group's preparation failed: %s", hipGetErrorString(q));
+                j->state.store(2, std::memory_order_release);
+                continue;
+            }
+            j->state.store(1, std::memory_order_release);
+            active.push_back(j);
+            advanced = true;
+        }
+        // progress words -> what every registration has finished, whether it converged, how much of it is still searched
+        for (EngJob *j : active)
+            for (int c = 0; c < j->count; ++c) {
+                EngProblem &q = j->p[c];
+                if (q.done) continue;
+                const unsigned long long w = __atomic_load_n(q.P.progress, __ATOMIC_ACQUIRE);
+                if ((w >> 40) != q.gen) continue;
+                q.seen = (int)(w & 0xFFFFFFFFull);
+                q.share = q.seen >= 1 ? (int)((w >> 33) & 127ull) : 127;
+                if ((w >> 32) & 1ull) q.done = true;
+            }
+        // Ticks.  Two chains of launches, each on its own stream: [0] the registrations that still search most of their rows
+        // (icp_iter_batch_kernel: long, slot-bound launches), [1] the calm ones (icp_rows_kernel: short, latency-bound) -- in ONE chain the
+        // calm registrations of three frames advanced at the pace of the fourth frame's first sweeps (measured: 1550 vs 2800 Mpoints/s,
+        // profiles/r05/exp_icp_engine_one_chain.txt).  A chain ticks when every registration it would carry has room in its window; a
+        // registration that changes chains takes an event along (its next launch waits for its previous one).
+        std::vector<char> ticked(active.size(), 0);
+        for (size_t a = 0; a < active.size(); ++a) {
+            if (ticked[a]) continue;
+            EngJob *lead = active[a];
+            const int last_k = lead->max_iter;                      // (update in the last block: no closing launch)
+            std::vector<EngProblem *> form[2];
+            bool room[2] = { true, true };
+            for (size_t b = a; b < active.size(); ++b) {
+                if (ticked[b] || !active[b]->same_launch(*lead)) continue;
+                ticked[b] = 1;
+                for (int c = 0; c < active[b]->count; ++c) {
+                    EngProblem &q = active[b]->p[c];
+                    if (q.done || q.next_k > last_k) continue;
+                    const int f = (lead->rows_mode == 2 || (lead->rows_mode == 1 && q.share <= lead->rows_share)) ? 1 : 0;
+                    if (q.next_k - q.seen >= lead->window) room[f] = false;
+                    form[f].push_back(&q);
+                    q.job = active[b];
+                }
+            }
+            unsigned long long *visits = prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr;
+            for (int f = 0; f < 2; ++f) {
+                if (form[f].empty() || !room[f]) continue;
+                advanced = true;
+                E->ticks.fetch_add(1, std::memory_order_relaxed);
+                hipStream_t fs = E->st[f];
+                for (EngProblem *q : form[f]) {
+                    if (q->lane >= 0 && q->lane != f) {                 // its previous launch ran in the other chain
+                        hipEvent_t ev = E->mig[E->mig_next++ % kEngEvents];
+                        (void)hipEventRecord(ev, E->st[q->lane]);
+                        (void)hipStreamWaitEvent(fs, ev, 0);
+                    }
+                    q->lane = f;
+                    q->job->used |= 1 << f;
+                }
+                if (f == 1) {
+                    for (size_t i0 = 0; i0 < form[1].size(); i0 += kRowsBatchMax) {
+                        const int cnt = (int)(form[1].size() - i0 < (size_t)kRowsBatchMax ? form[1].size() - i0 : (size_t)kRowsBatchMax);
+                        const IcpProblem *pp[kRowsBatchMax];
+                        int ks[kRowsBatchMax];
+                        for (int c = 0; c < cnt; ++c) { pp[c] = &form[1][i0 + (size_t)c]->P; ks[c] = form[1][i0 + (size_t)c]->next_k; }
+                        rows_launch(pp, ks, cnt, lead->md2, lead->mode, lead->max_iter, lead->rel_fit, lead->rel_rmse, visits, lead->light, lead->pol, fs);
+                        E->launches.fetch_add(1, std::memory_order_relaxed);
+                    }
+                } else {
+                    for (size_t i0 = 0; i0 < form[0].size(); i0 += kIcpBatchMax) {
+                        IcpBatchArgs ba;
+                        const int cnt = (int)(form[0].size() - i0 < (size_t)kIcpBatchMax ? form[0].size() - i0 : (size_t)kIcpBatchMax);
+                        ba.count = cnt;
+                        unsigned b0 = 0;
+                        for (int c = 0; c < kIcpBatchMax; ++c) {
+                            const EngProblem *q = form[0][i0 + (size_t)(c < cnt ? c : cnt - 1)];
+                            ba.p[c] = q->P;
+                            ba.p[c].k = q->next_k;
+                            ba.p[c].block0 = b0;
+                            if (c < cnt) b0 += q->P.blocks;
+                        }
+                        hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(b0), dim3(kIThreads), 0, fs, ba, lead->md2, lead->mode, lead->max_iter, lead->rel_fit, lead->rel_rmse, visits,
+                                           2, lead->light, lead->pol);
+                        E->launches.fetch_add(1, std::memory_order_relaxed);
+                    }
+                }
+                for (EngProblem *q : form[f]) ++q->next_k;
+            }
+            if (hipGetLastError() != hipSuccess) {
+                const int rc = fail(KPX_ERR_HIP, "kpx_icp_batch (engine): launch failed");
+                engine_fail(active, rc);
+                break;
+            }
+        }
+        // groups whose registrations have all converged or run out of iterations leave: the frame waits for the events behind their last
+        // launches (one per chain the group used)
+        for (size_t i = 0; i < active.size();) {
+            EngJob *j = active[i];
+            bool fin = true;
+            for (int c = 0; c < j->count; ++c) fin = fin && (j->p[c].done || j->p[c].next_k > j->max_iter);
+            if (!fin) { ++i; continue; }
+            for (int f = 0; f < 2; ++f)
+                if (((j->used >> f) & 1) && hipEventRecord(j->done_ev[f], E->st[f]) != hipSuccess) j->rc = fail(KPX_ERR_HIP, "kpx_icp_batch (engine): hipEventRecord failed");
+            j->state.store(2, std::memory_order_release);
+            active.erase(active.begin() + (long)i);
+            advanced = true;
+        }
+        if (advanced) t_last = std::chrono::steady_clock::now();
+        else {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > stall_limit) {
+                const int rc = fail(KPX_ERR_HIP, "kpx_icp_batch (engine): no progress for %.0f s (KPX_ICP_STALL_SECONDS)", stall_limit);
+                engine_fail(active, rc);
+                engine_fail(pending, rc);
+                t_last = std::chrono::steady_clock::now();
+            }
+            __builtin_ia32_pause();
+        }
+    }
+}
+
+IcpEngine *icp_engine_acquire()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_engine_mu);
+    IcpEngine *E = g_engine[dev];
+    if (!E) {
+        E = new IcpEngine();
+        E->dev = dev;
+        bool ok = hipStreamCreateWithFlags(&E->st[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&E->st[1], hipStreamNonBlocking) == hipSuccess;
+        for (int e = 0; e < kEngEvents && ok; ++e) ok = hipEventCreateWithFlags(&E->mig[e], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { delete E; return nullptr; }
+        E->th = std::thread(engine_run, E);
+        g_engine[dev] = E;
+    }
+    ++E->refs;
+    return E;
+}
+void icp_engine_release(IcpEngine *E)
+{
+    if (!E) return;
+    {
+        std::lock_guard<std::mutex> lock(g_engine_mu);
+        if (--E->refs > 0) return;
+        g_engine[E->dev] = nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> lock(E->mu);
+        E->quit.store(true, std::memory_order_release);
+    }
+    E->cv.notify_all();
+    if (E->th.joinable()) E->th.join();
+    for (int f = 0; f < 2; ++f) { (void)hipStreamSynchronize(E->st[f]); (void)hipStreamDestroy(E->st[f]); }
+    for (int e = 0; e < kEngEvents; ++e) if (E->mig[e]) (void)hipEventDestroy(E->mig[e]);
+    delete E;
+}
+void icp_engine_attach(IcpEngine *E) { t_engine = E; }
+void icp_engine_counters(IcpEngine *E, unsigned long long *launches, unsigned long long *ticks)
+{
+    if (launches) *launches = E ? E->launches.load() : 0ull;
+    if (ticks) *ticks = E ? E->ticks.load() : 0ull;
+}
+// hands one prepared group over and waits (host) until its last launch has been queued; `ls` then waits for that launch on the device
+static int engine_run_group(IcpEngine *E, EngJob &job, hipStream_t ls)
+{
+    static thread_local hipEvent_t ev[kIcpBatchMax][3] = { { nullptr } };
+    static thread_local int ev_next = 0;
+    const int slot = ev_next++ % kIcpBatchMax;
+    for (int e = 0; e < 3; ++e)
+        if (!ev[slot][e]) KPX_HIP(hipEventCreateWithFlags(&ev[slot][e], hipEventDisableTiming));
+    job.ready = ev[slot][0];
+    job.done_ev[0] = ev[slot][1];
+    job.done_ev[1] = ev[slot][2];
+    KPX_HIP(hipEventRecord(job.ready, ls));
+    {
+        std::lock_guard<std::mutex> lock(E->mu);
+        E->inbox.push_back(&job);
+        E->inbox_n.fetch_add(1, std::memory_order_release);
+    }
+    E->cv.notify_all();
+    while (job.state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+    if (job.rc) return job.rc;
+    for (int f = 0; f < 2; ++f)
+        if ((job.used >> f) & 1) KPX_HIP(hipStreamWaitEvent(ls, job.done_ev[f], 0));
+    return KPX_OK;
+}
+}  // namespace kpx
+
 int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
                            double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness, double relative_rmse,
                            double *d_results, void *ws, size_t ws_bytes, void *stream, bool presorted)
@@ -2672,9 +3021,9 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
         KPX_REQUIRE(h_src[i] && h_n_src[i] >= 1 && h_n_src[i] < ((int64_t)1 << 31), "kpx_icp_batch: bad source cloud %d", i);
     hipStream_t st = (hipStream_t)stream;
     BusyScope busy;
-    if (icp_chain_abort_take())
-        return fail(KPX_ERR_HIP, "kpx_icp_batch: an earlier one-launch ICP chain gave up waiting for its blocks to become resident (another process on this "
-                                 "GPU?); its result is NaN.  KPX_ICP_CHAIN=0 selects the launch-per-iteration form");
+    // (a one-launch chain that gave up its residency wait poisons ITS OWN results with NaN -- icp_chain_kernel -- and the callers that read
+    // results report it for that call; an abort left over from an earlier call is not this call's error)
+    (void)icp_chain_abort_take();
     // the problems of a batch are independent chains of short, latency-bound kernels: they run side by side on the
     // library's internal lanes (kpx_internal.h), forked from / joined to the caller's stream by events
     LaneSet *ln = nullptr;
@@ -2839,6 +3188,8 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                 P.light_key = bufs[i].light_key; P.sbbox = bufs[i].sort_s.bbox; P.cert = bufs[i].cert_sorted; P.thist = bufs[i].thist;
                 P.chain_rec = chain_ok ? bufs[i].chain_rec : nullptr;
                 P.block0 = b0; P.blocks = (unsigned)cdiv(h_n_src[i], kIRows);
+                P.tgt = tgt; P.tn = tgt_normals; P.Bs = bufs[0].Bs; P.orig = bufs[0].orig_t; P.tile_box = bufs[0].tile_box; P.group_box = bufs[0].group_box;
+                P.tbbox = bufs[0].sort_t.bbox; P.n_groups = tplan.l_groups; P.k = 0; P.tag = tag;
                 Ac[g].p[c] = P;
                 Ac[g].p[c].block0 = (unsigned)c; Ac[g].p[c].blocks = 1u;
                 for (int e = 0; e < 16; ++e) T0.m[c][e] = h_init[16 * i + e];
@@ -2872,6 +3223,24 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                         }
                     }
                 }
+            }
+        }
+        // a kpx_stream worker: the device's engine carries this group's iterations together with the other frames' (IcpEngine above)
+        if (t_engine && split == 2 && !rc) {
+            std::vector<std::unique_ptr<EngJob>> jobs;
+            for (int g = 0; g < n_chain && !rc; ++g) {
+                if (gfin[g]) continue;                       // (ran as a one-launch chain)
+                jobs.emplace_back(new EngJob());
+                EngJob &J = *jobs.back();
+                J.count = A[g].count;
+                for (int c = 0; c < J.count; ++c) {
+                    J.p[c].P = A[g].p[c];
+                    J.p[c].gen = generation; J.p[c].next_k = 0; J.p[c].seen = 0; J.p[c].share = 127; J.p[c].done = false; J.p[c].lane = -1; J.p[c].job = nullptr;
+                }
+                J.md2 = md2; J.rel_fit = relative_fitness; J.rel_rmse = relative_rmse; J.mode = mode; J.max_iter = max_iteration; J.light = light;
+                J.rows_mode = rows_mode; J.rows_share = rows_share; J.window = window; J.pol = cert_policy;
+                rc = engine_run_group(t_engine, J, on_caller ? st : lanes[g % kBatchLanes]);
+                gfin[g] = true;
             }
         }
         for (bool pending = true; pending && !rc;) {
@@ -2912,30 +3281,17 @@ int kpx::icp_batch_ordered(int32_t count, const float *const *h_src, const int64
                     ProfScope prof(KPX_PROF_NN_LOCAL, 0.0, ls);
                     if (rows_mode == 2 || (rows_mode == 1 && share <= rows_share)) {
                         // one wave per 64 rows (kpx_icprows.h): every problem with its own operands and iteration number
-                        RowsArgs ra;
-                        ra.count = act.count;
-                        for (int c = 0; c < kRowsBatchMax; ++c) {
-                            const IcpProblem &Q = act.p[c < act.count ? c : act.count - 1];
-                            RowsProblem &R = ra.p[c];
-                            R.src_sorted = Q.src_sorted; R.idx_sorted = Q.idx_sorted; R.ptgt_sorted = Q.ptgt_sorted; R.cert = Q.cert; R.thist = Q.thist;
-                            R.light_key = Q.light_key; R.sbbox = Q.sbbox; R.state = Q.pair; R.ring = Q.ring; R.result = Q.result; R.progress = Q.progress;
-                            R.tag = tag; R.tgt = tgt; R.tn = tgt_normals; R.Bs = bufs[0].Bs; R.orig = bufs[0].orig_t; R.tile_box = bufs[0].tile_box;
-                            R.group_box = bufs[0].group_box; R.tbbox = bufs[0].sort_t.bbox; R.n = Q.n; R.n_groups = tplan.l_groups; R.k = gk[g];
-                            R.block0 = Q.block0; R.blocks = Q.blocks;
-                        }
-                        unsigned long long *visits = prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr;
-                        if (mode == 1)
-                            hipLaunchKernelGGL(icp_rows_kernel<1>, dim3(ab), dim3(kRowsBlock), 0, ls, ra, md2, max_iteration, relative_fitness, relative_rmse, visits,
-                                               light, cert_policy);
-                        else
-                            hipLaunchKernelGGL(icp_rows_kernel<0>, dim3(ab), dim3(kRowsBlock), 0, ls, ra, md2, max_iteration, relative_fitness, relative_rmse, visits,
-                                               light, cert_policy);
+                        const IcpProblem *pp[kRowsBatchMax];
+                        int ks[kRowsBatchMax];
+                        for (int c = 0; c < act.count; ++c) { pp[c] = &act.p[c]; ks[c] = gk[g]; }
+                        rows_launch(pp, ks, act.count, md2, mode, max_iteration, relative_fitness, relative_rmse,
+                                    prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, light, cert_policy, ls);
                         ++gk[g];
                         continue;
                     }
-                    hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)act.count : ab), dim3(kIThreads), 0, ls, closing ? actc : act, tgt,
-                                       tgt_normals, bufs[0].Bs, bufs[0].orig_t, bufs[0].tile_box, bufs[0].group_box, tplan.l_groups, bufs[0].sort_t.bbox, md2,
-                                       mode, gk[g], max_iteration, relative_fitness, relative_rmse, tag,
+                    for (int c = 0; c < kIcpBatchMax; ++c) { act.p[c].k = gk[g]; actc.p[c].k = gk[g]; }
+                    hipLaunchKernelGGL(icp_iter_batch_kernel, dim3(closing ? (unsigned)act.count : ab), dim3(kIThreads), 0, ls, closing ? actc : act, md2,
+                                       mode, max_iteration, relative_fitness, relative_rmse,
                                        prof_armed() ? nn_visits_ptr() : (unsigned long long *)nullptr, split, split == 2 ? light : 0, cert_policy);
                     if (split == 1)
                         hipLaunchKernelGGL(icp_solve_batch_kernel, dim3((unsigned)act.count), dim3(256), 0, ls, act, mode, gk[g], max_iteration,

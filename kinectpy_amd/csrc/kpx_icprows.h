@@ -61,12 +61,13 @@ __device__ __forceinline__ double row16_tree_sum(double v)
     return v;
 }
 
-template <int MODE>
+template <int MODE, int R>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE, KPX_ICP_WPE))) void icp_rows_kernel(RowsArgs args, double max_d2, int max_iter, double rel_fit,
                                                                                                                      double rel_rmse, unsigned long long *__restrict__ tile_visits,
                                                                                                                      int light, CertPolicy pol)
 {
     constexpr int NACC = MODE == 1 ? kAcc : 17;
+    static_assert(R == 16 || R == 32 || R == 64, "rows per wave");
     int pi = 0;
 #pragma unroll
     for (int c = 1; c < kRowsBatchMax; ++c) pi += (c < args.count && blockIdx.x >= args.p[c].block0) ? 1 : 0;
@@ -94,8 +95,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE,
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int64_t last = P.n - 1;
-    const int64_t row = (int64_t)bid * kRowsBlock + lane;
-    const bool valid = row <= last;
+    const int64_t row = (int64_t)bid * R + lane;
+    const bool valid = lane < R && row <= last;
     const int64_t r = valid ? row : last;
     const bool certs = (light & 2) != 0, use_light = (light & 1) != 0, cert_check = (light & 4) != 0;
     const double t2max = target_t2max(P.tbbox);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE,
         wave_lds_fence();
 
         // the rows to be searched, 16 at a time (a block whose 64 rows all are: its four tiles as they stand)
-        bool light_blk = n_act == kRowsBlock;                 // (LightSkip speaks for ALL rows of the block)
+        bool light_blk = n_act == R;                 // (LightSkip speaks for ALL rows of the block)
         double gap2_blk = INFINITY;
 #pragma unroll 1
         for (int v0 = 0; v0 < n_act; v0 += kLRows) {
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE,
                     const int rr = q_p + 4 * rr4;
                     if (((act_mask >> rr) & 1u) != 0u && rowm[v0 + rr] != 0 && w.bcol[rr4] != rowi[v0 + rr]) {
                         if (atomicAdd(&g_cert_check[2], 1ull) == 0ull) {
-                            g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = (unsigned long long)((int64_t)bid * kRowsBlock + v0 + rr);
+                            g_cert_check[3] = (unsigned long long)k; g_cert_check[4] = (unsigned long long)((int64_t)bid * R + v0 + rr);
                             g_cert_check[5] = (unsigned long long)(unsigned)rowi[v0 + rr]; g_cert_check[6] = (unsigned long long)(unsigned)w.bcol[rr4];
                             g_cert_check[7] = (unsigned long long)(rowc[v0 + rr] & ~63u);
                         }
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPX_ICP_WPE,
         double c[NACC];
 #pragma unroll
         for (int a = 0; a < NACC; ++a) c[a] = 0.0;
-        const int64_t row_e = (int64_t)bid * kRowsBlock + lane_e;
-        if (row_e <= last) {
+        const int64_t row_e = (int64_t)bid * R + lane_e;
+        if (lane_e < R && row_e <= last) {
             const bool was_act = ((act64 >> lane_e) & 1ull) != 0ull;
             const int slot_e = __builtin_popcountll(act64 & lt_e);
             const int32_t prev_j = __float_as_int(rowk[lane_e][6]);

@@ -59,7 +59,9 @@ int voxel_downsample_batch_spec(int32_t count, const float *const *h_pts, const 
 // (h_T[16 i ..] is then ignored); h_dT == NULL: the exported behaviour.
 int fuse_voxel_downsample_dev(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n, const double *h_T,
                               const double *const *h_dT, double voxel, float *opts, float *ocol, int32_t *d_count, void *ws, size_t ws_bytes,
-                              void *stream);
+                              void *stream, int spec_bits = 0, int32_t *d_bits = nullptr);
+// (spec_bits > 0: the keys are taken to fit that many (<= 32) bits and sorted by the library's own radix sort; *d_bits -- pinned host
+// memory -- receives the width the cloud really needs: larger than spec_bits = the outputs are garbage, call again with spec_bits = 0)
 
 // kpx_icp_batch for clouds that already lie along a space-filling curve (presorted = true: no Morton sort inside; the culled
 // search's tiles are then 16 consecutive points of the caller's order).  presorted = false: the exported behaviour.
@@ -79,6 +81,15 @@ int icp_chain_abort_take();   // 1 if a one-launch ICP chain gave up waiting sin
 int icp_batch_ordered(int32_t count, const float *const *h_src, const int64_t *h_n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
                       double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness, double relative_rmse,
                       double *d_results, void *ws, size_t ws_bytes, void *stream, bool presorted);
+
+// The device's ICP engine (kpx_icp.hip, IcpEngine): one host thread + one stream that carry the registrations of every frame in flight
+// in one launch per tick.  acquire / release: reference-counted per device (kpx_stream_create / destroy); attach: the CALLING thread's
+// icp_batch_ordered hands its groups to the engine from now on (nullptr: drives its own chain of launches).
+struct IcpEngine;
+IcpEngine *icp_engine_acquire();
+void icp_engine_release(IcpEngine *e);
+void icp_engine_attach(IcpEngine *e);
+void icp_engine_counters(IcpEngine *e, unsigned long long *launches, unsigned long long *ticks);
 
 // Column tiles (16 rows x 16 columns, 2048 flops each) the culled nearest-neighbour sweep has multiplied since the
 // last call; resets the device counter (kpx_icp.hip).

@@ -130,13 +130,39 @@ __global__ __launch_bounds__(256) void grid_rank_kernel(const float *__restrict_
     }
 }
 
+// Exclusive prefix sums of the cell counts in ONE launch (decoupled look-back over tiles of 2048 counters, kpx_common.h) instead of
+// the vendor scan's two launches and its host-side set-up: with four frames in flight the frame's stream sat idle 50-65 us in front
+// of that scan (profiles/r05/overlap_timeline_native_stream.txt).  states: one cleared 64-bit word per tile.
+constexpr int kGridScanItems = 8, kGridScanTile = 256 * kGridScanItems;
+constexpr int kGridScanWords = 2 * ((kGridMaxCells + 1 + kGridScanTile - 1) / kGridScanTile) + 2;
+__global__ __launch_bounds__(256) void grid_scan_kernel(const uint32_t *__restrict__ counts, int64_t len, uint32_t *__restrict__ out,
+                                                        unsigned long long *__restrict__ states)
+{
+    __shared__ int sh[256 / 64 + 2];
+    const int64_t base = (int64_t)blockIdx.x * kGridScanTile + (int64_t)threadIdx.x * kGridScanItems;
+    uint32_t v[kGridScanItems];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kGridScanItems; ++k) { v[k] = base + k < len ? counts[base + k] : 0u; c += (int)v[k]; }
+    int tot;
+    const int ex = block_excl_scan(c, sh, &tot);
+    __syncthreads();
+    const int before = lookback_exclusive(states, blockIdx.x, tot, sh + 256 / 64 + 1);
+    uint32_t run = (uint32_t)(before + ex);
+#pragma unroll
+    for (int k = 0; k < kGridScanItems; ++k) {
+        if (base + k < len) out[base + k] = run;
+        run += v[k];
+    }
+}
+
 int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Grid *g, hipStream_t st)
 {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     g->params = a.get<GridParams>(1);
     // ONE cleared region per build: [16 spare words for the caller's counters | sum of squares | counts of the first binning |
     // counts of the definitive binning] (each binning has its own counters so that nothing is cleared in between)
-    uint32_t *zero = a.get<uint32_t>(3 * ((size_t)kGridMaxCells + 1) + 32 + kGridExtraWords);
+    uint32_t *zero = a.get<uint32_t>(3 * ((size_t)kGridMaxCells + 1) + 32 + kGridExtraWords + kGridScanWords);
     g->cell_start = a.get<uint32_t>((size_t)kGridMaxCells + 1);
     g->sorted_pts = a.get<float>(nn * 3);
     g->sorted_idx = a.get<int32_t>(nn);
@@ -166,8 +192,9 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     g->spare = reinterpret_cast<int32_t *>(zero);
     unsigned long long *sumsq = reinterpret_cast<unsigned long long *>(zero + 16);
     g->extra = reinterpret_cast<int32_t *>(zero + 32);
-    uint32_t *count1 = zero + 32 + kGridExtraWords, *count2 = count1 + (size_t)cell_cap + 1, *cursor = count2 + (size_t)cell_cap + 1;
-    KPX_HIP(hipMemsetAsync(zero, 0, (32 + kGridExtraWords + 3 * ((size_t)cell_cap + 1)) * sizeof(uint32_t), st));
+    unsigned long long *scan_states = reinterpret_cast<unsigned long long *>(zero + 32 + kGridExtraWords);
+    uint32_t *count1 = zero + 32 + kGridExtraWords + kGridScanWords, *count2 = count1 + (size_t)cell_cap + 1, *cursor = count2 + (size_t)cell_cap + 1;
+    KPX_HIP(hipMemsetAsync(zero, 0, (32 + kGridExtraWords + kGridScanWords + 3 * ((size_t)cell_cap + 1)) * sizeof(uint32_t), st));
     int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
     // first binning from the bounding-box heuristic, one round of occupancy feedback, then the definitive binning
     hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, bbox, target_per_cell, cell_cap, (const unsigned long long *)nullptr, g->params,
@@ -175,7 +202,11 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     hipLaunchKernelGGL(grid_occupancy_kernel, dim3(1024), dim3(256), 0, st, count1, g->params, sumsq);
     hipLaunchKernelGGL(grid_cell_kernel, dim3(nb), dim3(256), 0, st, pts, n, bbox, target_per_cell, cell_cap, (const unsigned long long *)sumsq, g->params,
                        keys_in, vals_in, count2);
-    KPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, count2, g->cell_start, cell_cap + 1, st));
+    static const bool vendor_scan = [] { const char *e = getenv("KPX_GRID_SCAN"); return e && e[0] == '0'; }();      // A/B switch
+    if (vendor_scan) KPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, count2, g->cell_start, cell_cap + 1, st));
+    else
+        hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)cdiv((int64_t)cell_cap + 1, kGridScanTile)), dim3(256), 0, st, count2, (int64_t)cell_cap + 1, g->cell_start,
+                           scan_states);
     // The rank pass reads a cell's whole range per point: quadratic in the cell's population.  Cells are sized for 6-96 points, but
     // exact duplicates cannot be split by any grid, so the counting build is kept to frame-sized clouds (where the launch count is
     // what matters and an all-duplicates input costs at most 65536^2 range reads, ~1 s); larger clouds take the radix sort, whose

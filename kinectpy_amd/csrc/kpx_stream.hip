@@ -71,6 +71,8 @@ struct kpx_stream {
     std::atomic<bool> quit{ false };
     kpx_order *order = nullptr;
     bool sharded = false;
+    kpx::IcpEngine *engine = nullptr;      // the device's ICP engine (kpx_icp.hip): the frames' registrations in one chain of launches
+    std::atomic<uint64_t> frames_done{ 0 };
 };
 
 namespace kpx {
@@ -91,6 +93,7 @@ template <class Pred> static void spin_then_wait(std::mutex &mu, std::condition_
 static void stream_worker(kpx_stream *S, StreamSlot *s)
 {
     (void)hipSetDevice(S->dev);
+    icp_engine_attach(S->engine);
     uint64_t mine = (uint64_t)s->index;                       // (several GPUs) the next job of this slot
     for (;;) {
         StreamJob *j = nullptr;
@@ -130,6 +133,7 @@ static void stream_worker(kpx_stream *S, StreamSlot *s)
         }
         if (S->sharded) kpx_order_finish(S->order, j->frame);      // stages the frame did not use (or did not reach) are passed
         j->rc = rc;
+        S->frames_done.fetch_add(1, std::memory_order_relaxed);
         if (S->sharded && rc != KPX_RETRY) mine += (uint64_t)S->depth;      // (a frame to be run again stays this slot's next job)
         {
             std::lock_guard<std::mutex> lock(S->mu);
@@ -187,6 +191,12 @@ KPX_EXPORT int kpx_stream_create(const float *xy_table, int64_t n_px, int32_t se
         const int rc = kpx_order_create(depth, &S->order);
         if (rc) return rc;
     }
+    // KPX_STREAM_ENGINE=1: the device's ICP engine carries the registrations of all frames in flight in one launch per tick (kpx_icp.hip,
+    // IcpEngine).  Built and measured in round 5: 1550 (one chain) / 1720 (two chains) against 2740-2800 Mpoints/s with a chain of launches per
+    // frame, same box (profiles/r05/exp_icp_engine_*.txt) -- one chain advances every frame at the pace of the slowest launch and leaves
+    // the tail of every launch unfilled, where four independent chains fill each other's tails.  Default: off.
+    static const bool engine_on = [] { const char *e = getenv("KPX_STREAM_ENGINE"); return e && e[0] == '1'; }();
+    S->engine = engine_on ? icp_engine_acquire() : nullptr;
     for (int i = 0; i < S->cap; ++i) S->jobs.emplace_back(new StreamJob());
     const size_t per = need / (size_t)depth;
     for (int i = 0; i < depth; ++i) {
@@ -198,6 +208,7 @@ KPX_EXPORT int kpx_stream_create(const float *xy_table, int64_t n_px, int32_t se
         if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
             for (auto &p : S->slots) (void)hipStreamDestroy(p->st);
             if (S->order) kpx_order_destroy(S->order);
+            icp_engine_release(S->engine);
             return fail(KPX_ERR_HIP, "kpx_stream_create: hipStreamCreateWithFlags failed");
         }
         S->slots.push_back(std::move(s));
@@ -265,6 +276,19 @@ KPX_EXPORT int kpx_stream_destroy(kpx_stream *S)
         (void)hipStreamDestroy(p->st);
     }
     if (S->order) kpx_order_destroy(S->order);
+    icp_engine_release(S->engine);
     delete S;
+    return KPX_OK;
+}
+
+KPX_EXPORT int kpx_stream_stats(const kpx_stream *S, uint64_t *h_out4)
+{
+    KPX_REQUIRE(S && h_out4, "kpx_stream_stats: null pointer");
+    unsigned long long launches = 0ull, ticks = 0ull;
+    icp_engine_counters(S->engine, &launches, &ticks);
+    h_out4[0] = S->frames_done.load();
+    h_out4[1] = S->engine ? 1u : 0u;
+    h_out4[2] = launches;
+    h_out4[3] = ticks;
     return KPX_OK;
 }

@@ -600,6 +600,53 @@ __global__ __launch_bounds__(256) void fuse_key_kernel(FuseBatch b, const double
         vals[i] = (int32_t)i;
     }
 }
+// The same keys as 32-bit mixed-radix words (ix DY + iy) DZ + iz over the grid's own extent -- the SAME order (ascending ix, iy, iz)
+// in as few bits as the fused cloud needs (a person at 10 mm voxels: ~23), for the library's own radix sort: three 8-bit passes of two
+// launches each where the vendor's merge sort of the 63-bit keys took seven launches with host work between them (~150 us of a frame
+// under load, profiles/r05/overlap_timeline_native_stream.txt).  bits_out: the width this cloud needs (> 32: the keys written here
+// are useless and the caller takes the 63-bit path).
+__device__ __forceinline__ int fuse_key_bits(const double *__restrict__ bbox, double voxel, double d[3], bool *sane_out)
+{
+    const double o[3] = { bbox[0] - voxel * 0.5, bbox[1] - voxel * 0.5, bbox[2] - voxel * 0.5 };
+#pragma unroll
+    for (int a = 0; a < 3; ++a) d[a] = floor((bbox[3 + a] - o[a]) / voxel) + 1.0;
+    const bool sane = d[0] >= 1.0 && d[1] >= 1.0 && d[2] >= 1.0 && d[0] < 2097152.0 && d[1] < 2097152.0 && d[2] < 2097152.0;      // (NaN / empty boxes: not sane)
+    int bits = 64;
+    if (sane && d[0] * d[1] * d[2] < 18446744073709551616.0) {
+        const unsigned long long range = (unsigned long long)d[0] * (unsigned long long)d[1] * (unsigned long long)d[2];
+        bits = 1;
+        while (bits < 64 && (range >> bits) != 0ull) ++bits;
+    }
+    *sane_out = sane;
+    return bits;
+}
+__global__ void fuse_bits_kernel(const double *__restrict__ bbox, double voxel, int32_t *__restrict__ bits_out)
+{
+    double d[3];
+    bool sane;
+    *bits_out = fuse_key_bits(bbox, voxel, d, &sane);
+}
+__global__ __launch_bounds__(256) void fuse_key32_kernel(FuseBatch b, const double *__restrict__ bbox, double voxel, uint32_t *__restrict__ keys,
+                                                         int32_t *__restrict__ vals, int32_t *__restrict__ bits_out)
+{
+    const double ox = bbox[0] - voxel * 0.5, oy = bbox[1] - voxel * 0.5, oz = bbox[2] - voxel * 0.5;
+    double dd[3];
+    bool sane;
+    const int bits = fuse_key_bits(bbox, voxel, dd, &sane);
+    const double dx = dd[0], dy = dd[1], dz = dd[2];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *bits_out = bits;
+    const unsigned long long DY = sane ? (unsigned long long)dy : 1ull, DZ = sane ? (unsigned long long)dz : 1ull;
+    const int64_t total = b.off[b.count];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = fuse_cloud(b, i);
+        double q[3];
+        fuse_point(b, c, i - b.off[c], q);
+        double fx = floor((q[0] - ox) / voxel), fy = floor((q[1] - oy) / voxel), fz = floor((q[2] - oz) / voxel);
+        if (!(fx >= 0.0) || !(fy >= 0.0) || !(fz >= 0.0) || !(fx < dx) || !(fy < dy) || !(fz < dz)) fx = fy = fz = 0.0;      // (only with bits = 64: caller redoes)
+        keys[i] = (uint32_t)(((unsigned long long)fx * DY + (unsigned long long)fy) * DZ + (unsigned long long)fz);
+        vals[i] = (int32_t)i;
+    }
+}
 __global__ __launch_bounds__(256) void fuse_mean_kernel(FuseBatch b, const int32_t *__restrict__ vals, const int32_t *__restrict__ seg_start,
                                                         int32_t *__restrict__ d_count, const int32_t *__restrict__ err, float *__restrict__ opts,
                                                         float *__restrict__ ocol)
@@ -651,6 +698,8 @@ struct FuseScratch {
     double *part, *bbox;
     char *sort_tmp;
     size_t sort_bytes;
+    RadixScratch rx;            // the library's own sort (32-bit keys, total <= kRadixMaxPairs): the speculative path of the frame loop
+    char *counts_end;
 };
 static void fuse_carve(Arena &a, int64_t total, FuseScratch *s)
 {
@@ -658,7 +707,9 @@ static void fuse_carve(Arena &a, int64_t total, FuseScratch *s)
     s->keys_in = a.get<uint64_t>(nn); s->keys_out = a.get<uint64_t>(nn);
     s->vals_in = a.get<int32_t>(nn); s->vals_out = a.get<int32_t>(nn);
     s->seg_start = a.get<int32_t>(nn);
-    s->counts = a.get<int32_t>((size_t)compact_ws_ints(total));
+    radix_carve(a, total <= kRadixMaxPairs ? total : kRadixMaxPairs, &s->rx);
+    s->counts = a.get<int32_t>((size_t)compact_ws_ints(total));          // right behind the sort's cleared histograms: one memset for both
+    s->counts_end = reinterpret_cast<char *>(s->counts + (size_t)compact_ws_ints(total));
     s->err = a.get<int32_t>(1);
     s->part = a.get<double>((size_t)kFuseMax * kFuseBboxBlocks * 6);
     s->bbox = a.get<double>(8);
@@ -667,7 +718,12 @@ static void fuse_carve(Arena &a, int64_t total, FuseScratch *s)
                                              (hipStream_t) nullptr);
     s->sort_tmp = a.get<char>(s->sort_bytes);
 }
-static int fuse_voxel_impl(const FuseBatch &b, double voxel, float *opts, float *ocol, int32_t *d_count, Arena &a, hipStream_t st)
+// spec_bits > 0 (frame loop): the fused cloud's keys are taken to fit `spec_bits` <= 32 bits -- the width its slot's previous frame
+// needed -- and sorted as 32-bit words by the library's own radix sort; *d_bits (pinned host memory, written by the key kernel) receives
+// the width this frame really needs, and the caller repeats the call with spec_bits = 0 when that is larger (the outputs of the
+// speculative call are then garbage).  spec_bits = 0: 63-bit keys and the vendor sort, as exported.
+static int fuse_voxel_impl(const FuseBatch &b, double voxel, float *opts, float *ocol, int32_t *d_count, Arena &a, hipStream_t st, int spec_bits = 0,
+                           int32_t *d_bits = nullptr)
 {
     const int64_t total = b.off[b.count];
     FuseScratch s;
@@ -676,6 +732,18 @@ static int fuse_voxel_impl(const FuseBatch &b, double voxel, float *opts, float 
     hipLaunchKernelGGL(fuse_bbox_partial_kernel, dim3(kFuseBboxBlocks, b.count), dim3(256), 0, st, b, s.part);
     hipLaunchKernelGGL(fuse_bbox_final_kernel, dim3(1), dim3(64), 0, st, s.part, b.count * kFuseBboxBlocks, s.bbox, s.err);
     const int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+    if (spec_bits > 0 && spec_bits <= 32 && d_bits && total <= kRadixMaxPairs) {
+        uint32_t *k_in = reinterpret_cast<uint32_t *>(s.keys_in), *k_out = reinterpret_cast<uint32_t *>(s.keys_out);
+        hipLaunchKernelGGL(fuse_key32_kernel, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, k_in, s.vals_in, d_bits);
+        int rc = radix_sort_pairs_u32(s.rx, k_in, k_out, s.vals_in, s.vals_out, total, spec_bits, st, s.counts_end);
+        if (rc) return rc;
+        rc = compact(HeadPredT<uint32_t>{ k_out }, HeadEmit{ s.seg_start }, total, 1, s.counts, d_count, st, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fuse_mean_kernel, dim3(nb), dim3(256), 0, st, b, s.vals_out, s.seg_start, d_count, s.err, opts, ocol);
+        KPX_LAUNCH_CHECK();
+        return KPX_OK;
+    }
+    if (d_bits) hipLaunchKernelGGL(fuse_bits_kernel, dim3(1), dim3(1), 0, st, s.bbox, voxel, d_bits);      // for the caller's next speculation
     hipLaunchKernelGGL(fuse_key_kernel, dim3(nb), dim3(256), 0, st, b, s.bbox, voxel, s.keys_in, s.vals_in, s.err);
     size_t bytes = s.sort_bytes;
     KPX_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, bytes, s.keys_in, s.keys_out, s.vals_in, s.vals_out, (int)total, 0, 63, st));
@@ -701,11 +769,11 @@ KPX_EXPORT int kpx_fuse_voxel_downsample(int32_t count, const float *const *h_pt
                                          const double *h_T, double voxel, float *opts, float *ocol, int32_t *d_count, void *ws,
                                          size_t ws_bytes, void *stream)
 {
-    return kpx::fuse_voxel_downsample_dev(count, h_pts, h_col, h_n, h_T, nullptr, voxel, opts, ocol, d_count, ws, ws_bytes, stream);
+    return kpx::fuse_voxel_downsample_dev(count, h_pts, h_col, h_n, h_T, nullptr, voxel, opts, ocol, d_count, ws, ws_bytes, stream, 0, nullptr);
 }
 int kpx::fuse_voxel_downsample_dev(int32_t count, const float *const *h_pts, const float *const *h_col, const int64_t *h_n, const double *h_T,
                                    const double *const *h_dT, double voxel, float *opts, float *ocol, int32_t *d_count, void *ws, size_t ws_bytes,
-                                   void *stream)
+                                   void *stream, int spec_bits, int32_t *d_bits)
 {
     KPX_REQUIRE(voxel > 0.0, "voxel_size <= 0");
     KPX_REQUIRE(count >= 1 && count <= kFuseMax, "kpx_fuse_voxel_downsample: 1 .. %d clouds", kFuseMax);
@@ -734,7 +802,7 @@ int kpx::fuse_voxel_downsample_dev(int32_t count, const float *const *h_pts, con
     if (total == 0) { KPX_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return KPX_OK; }
     KPX_REQUIRE(opts, "kpx_fuse_voxel_downsample: null pointer");
     Arena a(ws, ws_bytes);
-    return fuse_voxel_impl(b, voxel, opts, (any_col && all_col) ? ocol : nullptr, d_count, a, st);
+    return fuse_voxel_impl(b, voxel, opts, (any_col && all_col) ? ocol : nullptr, d_count, a, st, spec_bits, d_bits);
 }
 
 KPX_EXPORT size_t kpx_voxel_workspace_bytes(int64_t n)

@@ -479,6 +479,9 @@ def icp_batch(srcs, tgt, max_dist, inits, mode="p2p", tgt_normals=None, max_iter
                               float(max_dist), L.hptr(init), md, int(max_iteration), float(relative_fitness),
                               float(relative_rmse), L.ptr(res), ws, wsz, L.stream_ptr()))
     r = res.cpu().numpy()
+    if np.isnan(r[:, 16]).any():      # icp_chain_kernel poisons the results of a chain that gave up its residency wait: THIS call's error
+        raise L.KinectPxError("kpx_icp_batch: the one-launch ICP chain of registration(s) %s gave up waiting for its blocks to become resident "
+                              "(another process on this GPU?); KPX_ICP_CHAIN=0 selects the launch-per-iteration form" % np.flatnonzero(np.isnan(r[:, 16])).tolist())
     return [{"transformation": r[i, :16].reshape(4, 4).copy(), "fitness": float(r[i, 16]), "inlier_rmse": float(r[i, 17]),
              "iterations": int(r[i, 18]), "count": int(r[i, 19])} for i in range(cnt)]
 

@@ -195,7 +195,9 @@ class NativeComm:
 
         def agree(err, what):
             """raises on EVERY rank when any rank failed at this step"""
-            bad = allreduce_max(0.0 if err is None else 1.0, dev) if together else (0.0 if err is None else 1.0)
+            # (over `group` itself: the id is broadcast over it and its size is the communicator's -- a strict subgroup must not wait for
+            # ranks outside it)
+            bad = allreduce_max(0.0 if err is None else 1.0, dev, group) if together else (0.0 if err is None else 1.0)
             if bad > 0.0:
                 raise RuntimeError(f"NativeComm.rccl: {what} failed on {'this rank: ' + repr(err) if err is not None else 'another rank'}")
 
@@ -596,9 +598,9 @@ def barrier():
         dist.barrier()
 
 
-def allreduce_max(value: float, device) -> float:
+def allreduce_max(value: float, device, group=None) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend(group) == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())

@@ -510,6 +510,12 @@ class NativeFrameStream:
                      "n_masked": [int(v) for v in h_info[16:16 + S]], "n_fused": int(h_info[16:16 + S].sum()), "n_voxel": int(h_info[48]), "n_out": k}
         return out[0][:k], out[1][:k], h_T
 
+    def stats(self):
+        """frames finished, whether the registrations run through the device's ICP engine, its iteration launches and ticks so far"""
+        out = np.zeros(4, dtype=np.uint64)
+        self._L.check(self._lib.kpx_stream_stats(self.handle, out.ctypes.data_as(self._C.c_void_p)))
+        return {"frames": int(out[0]), "icp_engine": bool(out[1]), "engine_launches": int(out[2]), "engine_ticks": int(out[3])}
+
     def close(self):
         if self.handle is not None:
             while self.pending:

@@ -1866,17 +1866,16 @@ downs = [x[0] for x in ops.voxel_downsample_batch([fp[i, :k[i]] for i in range(4
 tn = ops.estimate_normals(downs[0], 2.0 * P.reg_voxel, P.normals_nn)
 big = torch.cat(downs[1:])                            # ONE registration of ~94k rows: ~1470 blocks (several problems of a batch could
                                                       # still drain one after the other; one problem larger than the device cannot)
-r = ops.icp_batch([big], downs[0], P.icp_max_dist, inits[:1], "p2plane", tn, 8)
-torch.cuda.synchronize()
-first = float(r[0]["fitness"])
-err = ""
+err, first = "", None
 try:
-    ops.icp_batch(downs[1:2], downs[0], P.icp_max_dist, inits[:1], "p2plane", tn, 8)
-except Exception as e:                                  # noqa: BLE001
+    r = ops.icp_batch([big], downs[0], P.icp_max_dist, inits[:1], "p2plane", tn, 8)
+    first = float(r[0]["fitness"])
+except Exception as e:                                  # noqa: BLE001 -- the abort is THIS call's error
     err = str(e)
+small = ops.icp_batch(downs[1:2], downs[0], P.icp_max_dist, inits[:1], "p2plane", tn, 8)      # an unrelated, healthy call right behind it: no error of its own
 ops.icp_chain(0)
 again = ops.icp_batch([big], downs[0], P.icp_max_dist, inits[:1], "p2plane", tn, 8)
-print(json.dumps(dict(first=None if np.isnan(first) else first, err=err, chains=ops.icp_chain(-2), again=float(again[0]["fitness"]), iterations=int(again[0]["iterations"]),
+print(json.dumps(dict(first=first, err=err, chains=ops.icp_chain(-2), small=float(small[0]["fitness"]), again=float(again[0]["fitness"]), iterations=int(again[0]["iterations"]),
                       blocks=int((big.shape[0] + 63) // 64))))
 """
 
@@ -1884,8 +1883,8 @@ print(json.dumps(dict(first=None if np.isnan(first) else first, err=err, chains=
 def test_icp_chain_that_cannot_be_resident_fails_loudly():
     """The one-launch chain needs all its blocks resident; the host only admits chains that fit (chain_launch_if_fits).  Forced past
     that check (KPX_ICP_CHAIN_BUDGET far above what the device holds, a short KPX_ICP_CHAIN_WAIT_SECONDS), a chain whose blocks cannot
-    all be resident must END -- every block's wait is bounded -- poison its results and make the next call fail with a message that
-    names the cause; the launch-per-iteration form then still works in the same process."""
+    all be resident must END -- every block's wait is bounded -- poison its results, and THAT call fails with a message that names the
+    cause (round 5: per call, not at the next call); a healthy call right behind it and the launch-per-iteration form work in the same process."""
     import json
     import subprocess
     import sys
@@ -1895,8 +1894,9 @@ def test_icp_chain_that_cannot_be_resident_fails_loudly():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["blocks"] > 1024, out["blocks"]                          # more blocks than an MI355X holds at 3 per CU: the chain cannot be resident
-    assert out["chains"] == 1 and out["first"] is None, out
-    assert "gave up waiting" in out["err"], out
+    assert out["chains"] >= 1 and out["first"] is None, out
+    assert "gave up waiting" in out["err"], out                          # reported by the call whose chain aborted, not by a later one
+    assert 0.0 < out["small"] <= 1.0, out
     assert 0.0 < out["again"] <= 1.0 and out["iterations"] >= 1, out
 
 
