@@ -158,8 +158,10 @@ int kpx_fuse_voxel_downsample(int32_t count, const float *const *h_pts, const fl
 /* a8: PointCloud.remove_statistical_outlier(nb_neighbors, std_ratio) (filtering.py:24,
  * floor_removal.py:73, utils/processing.py:309).  keep_idx ascending, d_count = kept,
  * d_stats f64 [3] = (mean, std, threshold), d_avg f64 [n] (optional) = per-point mean kNN distance.
- * nb_neighbors <= KPX_SOR_MAX_K. */
-#define KPX_SOR_MAX_K 288
+ * nb_neighbors <= KPX_SOR_MAX_K.  Up to KPX_SOR_LDS_K the neighbour heaps of the queries the wave passes leave over live in LDS;
+ * beyond, in the workspace (global memory: slower, the same result) -- the reference takes any value (preprocessing/filtering.py:12-17). */
+#define KPX_SOR_MAX_K 4096
+#define KPX_SOR_LDS_K 288
 size_t kpx_sor_workspace_bytes(int64_t n, int32_t nb_neighbors);
 int kpx_sor(const float *pts, int64_t n, int32_t nb_neighbors, double std_ratio, int32_t *keep_idx,
             int32_t *d_count, double *d_stats, double *d_avg, void *ws, size_t ws_bytes, void *stream);
@@ -185,8 +187,10 @@ int kpx_sor_finish(const double *d_avg_sorted, const int32_t *d_order, int64_t n
 
 /* estimate_normals(KDTreeSearchParamHybrid(radius, max_nn)) (preprocessing/registration.py:9-13):
  * neighbours = up to max_nn nearest with d2 < radius^2; < 3 neighbours -> (0,0,1); else the
- * eigenvector of the smallest eigenvalue of the neighbourhood covariance.  max_nn <= 128. */
-#define KPX_NORMALS_MAX_NN 128
+ * eigenvector of the smallest eigenvalue of the neighbourhood covariance.  max_nn <= KPX_NORMALS_MAX_NN (beyond KPX_NORMALS_LDS_NN the
+ * fall-back heaps live in the workspace instead of LDS; preprocessing/registration.py:7-21 takes any value). */
+#define KPX_NORMALS_MAX_NN 4096
+#define KPX_NORMALS_LDS_NN 128
 size_t kpx_normals_workspace_bytes(int64_t n, int32_t max_nn);
 int kpx_estimate_normals(const float *pts, int64_t n, double radius, int32_t max_nn, float *normals,
                          void *ws, size_t ws_bytes, void *stream);
@@ -237,7 +241,7 @@ int kpx_icp(const float *src, int64_t n_src, const float *tgt, const float *tgt_
 /* ---- global registration (rows a11-a13) ------------------------------------------------- */
 
 /* compute_fpfh_feature(pcd, KDTreeSearchParamHybrid(radius, max_nn)) (preprocessing/registration.py:15-20).
- * fpfh: f64 [n][33] (Open3D's Feature.data is the transpose, (33, n)).  Needs normals.  max_nn <= 128. */
+ * fpfh: f64 [n][33] (Open3D's Feature.data is the transpose, (33, n)).  Needs normals.  max_nn <= KPX_NORMALS_MAX_NN. */
 size_t kpx_fpfh_workspace_bytes(int64_t n, int32_t max_nn);
 int kpx_fpfh(const float *pts, const float *normals, int64_t n, double radius, int32_t max_nn, double *fpfh, void *ws,
              size_t ws_bytes, void *stream);

@@ -85,15 +85,17 @@ __global__ __launch_bounds__(WAVES * 64) void nbr_list_wave_kernel(const GridPar
 __global__ void nbr_list_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
                                 const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t n, int k, double r2,
                                 int32_t *__restrict__ nbr, double *__restrict__ d2, int32_t *__restrict__ cnt,
-                                const int32_t *__restrict__ list, const int32_t *__restrict__ list_count)
+                                const int32_t *__restrict__ list, const int32_t *__restrict__ list_count, double *__restrict__ gheap, int32_t *__restrict__ gix)
 {
+    // gheap / gix != NULL (max_nn beyond what LDS holds): the thread's (d^2, index) heap lives in the workspace
     extern __shared__ __align__(16) double lds[];
     const int64_t total = list ? (int64_t)*list_count : n;
     const GridParams g = *gp;
     int32_t *ilds = reinterpret_cast<int32_t *>(lds + (size_t)k * blockDim.x);
+    const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = list ? (int64_t)list[e] : e;
-        HeapDI heap{ lds + threadIdx.x, ilds + threadIdx.x, (int)blockDim.x, k, 0 };
+        HeapDI heap{ gheap ? gheap + gt : lds + threadIdx.x, gheap ? gix + gt : ilds + threadIdx.x, gheap ? (int)(gridDim.x * blockDim.x) : (int)blockDim.x, k, 0 };
         grid_knn_scan(g, cell_start, spts, sidx, (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2], r2, heap);
         const int64_t me = sidx[s];
         const int m = heap.sz;
@@ -489,11 +491,16 @@ static int knn_lists(const float *pts, int64_t n, double radius, int k, Arena &a
     *d2 = a.get<double>(nn * k);
     *cnt = a.get<int32_t>(nn);
     int32_t *fb_list = a.get<int32_t>(nn + 1);
+    const bool global_heap = k > KPX_NORMALS_LDS_NN;              // the fall-back heaps in the workspace (<= 256 MB of distances)
+    int heap_blocks = 256;
+    while (global_heap && heap_blocks > 8 && (size_t)heap_blocks * 64 * (size_t)k * sizeof(double) > ((size_t)256 << 20)) heap_blocks >>= 1;
+    double *gheap = global_heap ? a.get<double>((size_t)heap_blocks * 64 * (size_t)k) : nullptr;
+    int32_t *gix = global_heap ? a.get<int32_t>((size_t)heap_blocks * 64 * (size_t)k) : nullptr;
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     int32_t *fb_count = fb_list + nn;
-    const int threads = k <= 48 ? 128 : 64;
-    const size_t lds = (size_t)k * threads * (sizeof(double) + sizeof(int32_t));
+    const int threads = global_heap ? 64 : (k <= 48 ? 128 : 64);
+    const size_t lds = global_heap ? 0 : (size_t)k * threads * (sizeof(double) + sizeof(int32_t));
     static bool attr_set = false;
     if (!attr_set) {
         KPX_HIP(hipFuncSetAttribute((const void *)nbr_list_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -503,11 +510,13 @@ static int knn_lists(const float *pts, int64_t n, double radius, int k, Arena &a
     KPX_HIP(hipMemsetAsync(fb_count, 0, sizeof(int32_t), st));
     // pass 1: one wave per query, 512- or 1024-candidate buffer; pass 2: the queries that did not fit, thread-per-query heap walk
     const int cap = k <= 48 ? 512 : 1024;
-    hipLaunchKernelGGL(nbr_list_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256),
-                       (size_t)4 * cap * (sizeof(double) + sizeof(uint32_t)), st, g->params, g->cell_start, g->sorted_pts, g->sorted_idx, n, k, cap,
-                       radius * radius, *nbr, *d2, *cnt, fb_list, fb_count);
-    hipLaunchKernelGGL(nbr_list_kernel, dim3(256), dim3(threads), lds, st, g->params, g->cell_start, g->sorted_pts, g->sorted_idx, n, k,
-                       radius * radius, *nbr, *d2, *cnt, fb_list, fb_count);
+    const bool wave_pass = k <= 512;                               // (beyond, the 1024-candidate buffer cannot hold a neighbourhood: every query takes the heap walk)
+    if (wave_pass)
+        hipLaunchKernelGGL(nbr_list_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256),
+                           (size_t)4 * cap * (sizeof(double) + sizeof(uint32_t)), st, g->params, g->cell_start, g->sorted_pts, g->sorted_idx, n, k, cap,
+                           radius * radius, *nbr, *d2, *cnt, fb_list, fb_count);
+    hipLaunchKernelGGL(nbr_list_kernel, dim3(global_heap ? heap_blocks : 256), dim3(threads), lds, st, g->params, g->cell_start, g->sorted_pts, g->sorted_idx, n, k,
+                       radius * radius, *nbr, *d2, *cnt, wave_pass ? fb_list : (const int32_t *)nullptr, wave_pass ? fb_count : (const int32_t *)nullptr, gheap, gix);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }
@@ -622,7 +631,7 @@ KPX_EXPORT int kpx_color_gradient(const float *pts, const float *normals, const 
                                   double *grad, void *ws, size_t ws_bytes, void *stream)
 {
     KPX_REQUIRE(radius > 0.0 && max_nn >= 1 && max_nn <= KPX_NORMALS_MAX_NN, "kpx_color_gradient: radius / max_nn out of range");
-    KPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) / 128, "kpx_color_gradient: bad size");
+    KPX_REQUIRE(n >= 0 && n * (int64_t)max_nn < ((int64_t)1 << 31), "kpx_color_gradient: n x max_nn must stay below 2^31");
     if (n == 0) return KPX_OK;
     KPX_REQUIRE(pts && normals && colors && grad && ws, "kpx_color_gradient: null pointer");
     Arena a(ws, ws_bytes);
@@ -640,7 +649,7 @@ KPX_EXPORT int kpx_fpfh(const float *pts, const float *normals, int64_t n, doubl
 {
     KPX_REQUIRE(radius > 0.0 && max_nn >= 1, "compute_fpfh_feature: radius and max_nn must be positive");
     KPX_REQUIRE(max_nn <= KPX_NORMALS_MAX_NN, "compute_fpfh_feature: max_nn > %d is not supported", KPX_NORMALS_MAX_NN);
-    KPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) / 128, "kpx_fpfh: bad size");
+    KPX_REQUIRE(n >= 0 && n * (int64_t)max_nn < ((int64_t)1 << 31), "kpx_fpfh: n x max_nn must stay below 2^31");
     if (n == 0) return KPX_OK;
     KPX_REQUIRE(pts && fpfh && ws, "kpx_fpfh: null pointer");
     KPX_REQUIRE(normals, "Failed because input point cloud has no normal.");      // [O3D]

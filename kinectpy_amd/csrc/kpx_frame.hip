@@ -84,10 +84,10 @@ static void frame_carve(Arena &a, int32_t S, int64_t n_px, FrameLayout *L)
     std::vector<int64_t> worst((size_t)S, n_px);
     size_t w = kpx_depth_to_cloud_workspace_bytes(n_px, S);
     w = max_sz(w, kpx_voxel_batch_workspace_bytes(S, worst.data()));
-    w = max_sz(w, kpx_normals_workspace_bytes(n_px, KPX_NORMALS_MAX_NN));
+    w = max_sz(w, kpx_normals_workspace_bytes(n_px, KPX_NORMALS_LDS_NN));
     w = max_sz(w, kpx_icp_batch_workspace_bytes(S > 1 ? S - 1 : 1, worst.data(), n_px));
     w = max_sz(w, kpx_fuse_voxel_workspace_bytes((int64_t)all));
-    w = max_sz(w, kpx_sor_workspace_bytes((int64_t)all, KPX_SOR_MAX_K));
+    w = max_sz(w, kpx_sor_workspace_bytes((int64_t)all, KPX_SOR_LDS_K));
     w = max_sz(w, kpx_select_workspace_bytes((int64_t)all));
     L->op_bytes = w;
     L->op_ws = a.get<char>(w);
@@ -120,6 +120,8 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     KPX_REQUIRE(depth && rgb && xy_table && prm && out_pts && out_col && h_count && h_T && ws, "kpx_frame_step: null pointer");
     KPX_REQUIRE(sensors == 1 || h_init, "kpx_frame_step: initial transforms missing");
     KPX_REQUIRE(prm->icp_mode == KPX_ICP_POINT_TO_POINT || prm->icp_mode == KPX_ICP_POINT_TO_PLANE, "kpx_frame_step: bad icp_mode");
+    KPX_REQUIRE(prm->filt_k <= KPX_SOR_LDS_K && prm->normals_nn <= KPX_NORMALS_LDS_NN, "kpx_frame_step: filt_k <= %d and normals_nn <= %d (the frame's scratch is "
+                "sized for the LDS forms; kpx_sor / kpx_estimate_normals take larger values)", KPX_SOR_LDS_K, KPX_NORMALS_LDS_NN);
     const int S = sensors;
     hipStream_t st = (hipStream_t)stream;
     BusyScope busy;                                        // (a frame in flight: see kpx_internal.h)
@@ -360,10 +362,10 @@ static void shard_carve(Arena &a, int S, int S_l, int world, int64_t n_px, bool 
     std::vector<int64_t> worst((size_t)(S_l > 0 ? S_l : 1), n_px);
     size_t w = kpx_depth_to_cloud_workspace_bytes(n_px, S_l);
     w = max_sz(w, kpx_voxel_batch_workspace_bytes(S_l, worst.data()));
-    w = max_sz(w, kpx_normals_workspace_bytes(n_px, KPX_NORMALS_MAX_NN));
+    w = max_sz(w, kpx_normals_workspace_bytes(n_px, KPX_NORMALS_LDS_NN));
     w = max_sz(w, kpx_icp_batch_workspace_bytes(S_l > 0 ? S_l : 1, worst.data(), n_px));
     w = max_sz(w, kpx_fuse_voxel_workspace_bytes((int64_t)all));
-    w = max_sz(w, kpx_sor_workspace_bytes((int64_t)all, KPX_SOR_MAX_K));
+    w = max_sz(w, kpx_sor_workspace_bytes((int64_t)all, KPX_SOR_LDS_K));
     w = max_sz(w, kpx_sor_finish_workspace_bytes((int64_t)all));
     w = max_sz(w, kpx_select_workspace_bytes((int64_t)all));
     L->op_bytes = w;
@@ -406,6 +408,8 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     KPX_REQUIRE(S == 1 || h_init, "kpx_frame_step_sharded: initial transforms missing");
     KPX_REQUIRE(prm->icp_mode == KPX_ICP_POINT_TO_POINT || prm->icp_mode == KPX_ICP_POINT_TO_PLANE, "kpx_frame_step_sharded: bad icp_mode");
     KPX_REQUIRE(fused_filter == 0 || fused_filter == 1, "kpx_frame_step_sharded: fused_filter is 0 (sharded) or 1 (rank 0)");
+    KPX_REQUIRE(prm->filt_k <= KPX_SOR_LDS_K && prm->normals_nn <= KPX_NORMALS_LDS_NN, "kpx_frame_step_sharded: filt_k <= %d and normals_nn <= %d", KPX_SOR_LDS_K,
+                KPX_NORMALS_LDS_NN);
     hipStream_t st = (hipStream_t)stream;
     BusyScope busy;
     const int g0 = shard_first(S, rank, world), S_l = shard_count(S, rank, world);

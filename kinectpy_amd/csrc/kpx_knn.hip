@@ -578,14 +578,16 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
 // list != NULL: only the queries list[0 .. *list_count) (the wave kernel's overflow list).
 __global__ void sor_knn_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
                                const float *__restrict__ spts, const int32_t *__restrict__ sidx, int64_t q0, int64_t q1, int k,
-                               double *__restrict__ avg, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count)
+                               double *__restrict__ avg, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count,
+                               double *__restrict__ gheap)
 {
+    // gheap != NULL (k beyond what LDS holds): the thread's heap lives in the workspace, strided by the grid's thread count
     extern __shared__ __align__(16) double lds[];
     const GridParams g = *gp;
     const int64_t total = list ? (int64_t)*list_count : q1 - q0;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = list ? (int64_t)list[t] : q0 + t;
-        HeapD heap{ lds + threadIdx.x, (int)blockDim.x, k, 0 };
+        HeapD heap{ gheap ? gheap + (size_t)blockIdx.x * blockDim.x + threadIdx.x : lds + threadIdx.x, gheap ? (int)(gridDim.x * blockDim.x) : (int)blockDim.x, k, 0 };
         grid_knn_scan(g, cell_start, spts, (const int32_t *)nullptr, (double)spts[3 * s], (double)spts[3 * s + 1],
                       (double)spts[3 * s + 2], -1.0, heap);
         double sum = 0.0;
@@ -749,6 +751,11 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     int32_t *fb_list = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
     int32_t *fb_list2 = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
     int32_t *fb_list0 = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
+    // k beyond the LDS heaps (KPX_SOR_LDS_K): the last pass's per-thread heaps live here (fewer blocks as k grows: <= 256 MB)
+    const bool global_heap = kk > KPX_SOR_LDS_K;
+    int heap_blocks = 256;
+    while (global_heap && heap_blocks > 8 && (size_t)heap_blocks * 64 * (size_t)kk * sizeof(double) > ((size_t)256 << 20)) heap_blocks >>= 1;
+    double *gheap = global_heap ? a.get<double>((size_t)heap_blocks * 64 * (size_t)kk) : nullptr;
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     if (d_avg) avg = d_avg;
@@ -756,7 +763,7 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
     const int64_t nq = q1 - q0;
     int32_t *fb_count = g.spare, *fb_count2 = g.spare + 1, *fb_count0 = g.spare + 2;       // cleared by the grid build
     const int threads = sor_block_threads(kk);
-    const size_t lds = (size_t)kk * threads * sizeof(double);
+    const size_t lds = global_heap ? 0 : (size_t)kk * threads * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         KPX_HIP(hipFuncSetAttribute((const void *)sor_knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -775,7 +782,7 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
         // space (their k-th neighbour lies many cells away: the wave-per-query passes' re-gathers), and the selection itself is
         // instruction-bound either way.  So: KPX_SOR_CELL unset = the cell kernel from k > 64 on, 1 = always, 0 = never.
         static const int cell_mode = [] { const char *e = getenv("KPX_SOR_CELL"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();
-        const bool cell_on = cell_mode == 2 || (cell_mode == 1 && kk > 64);
+        const bool cell_on = (cell_mode == 2 || (cell_mode == 1 && kk > 64)) && kk <= 1024;       // (its largest block holds 2048 candidates)
         const int32_t *list0 = nullptr, *count0 = nullptr;
         if (cell_on && nq > 0) {
             const int kbuf = kk + kCellTieRoom;
@@ -793,17 +800,24 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
 #undef KPX_SOR_CELL_LAUNCH
             list0 = fb_list0; count0 = fb_count0;
         }
-        // pass 1: one wave per query, 1024-candidate buffer (k <= KPX_SOR_MAX_K = 288 < 1024; many waves per CU)
+        // pass 1: one wave per query, 1024-candidate buffer (many waves per CU)
+        // (round 5: k beyond half a buffer skips the pass whose buffer cannot hold k candidates plus their surroundings -- the queries
+        // go on to the next one through the same lists)
         const int cap1 = kk <= 32 ? 512 : 1024;               // small k: smaller buffers, more waves per CU
-        if (nq > 0)
+        const bool pass1 = kk <= 512, pass2 = kk <= 4096;
+        if (nq > 0 && pass1)
             hipLaunchKernelGGL(sor_wave_kernel<4>, dim3((unsigned)(cdiv(nq, 4) > (list0 ? 2048 : 8192) ? (list0 ? 2048 : 8192) : cdiv(nq, 4))), dim3(256), (size_t)4 * cap1 * 8, st,
                                g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk, cap1, avg, list0, count0, fb_list, fb_count);
         // pass 2: the queries whose block did not fit (isolated points next to a dense sheet), 8192-candidate buffer
-        hipLaunchKernelGGL(sor_wave_kernel<1>, dim3(2048), dim3(64), (size_t)8192 * 8, st, g.params, g.cell_start, g.sorted_pts,
-                           out_idx, q0, q1, kk, 8192, avg, fb_list, fb_count, fb_list2, fb_count2);
-        // pass 3: whatever is left: thread-per-query ring walk with a k-heap
-        hipLaunchKernelGGL(sor_knn_kernel, dim3(256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk,
-                           avg, fb_list2, fb_count2);
+        const int32_t *list1 = pass1 ? fb_list : list0, *count1 = pass1 ? fb_count : count0;      // what pass 2 searches: pass 1's leftovers, or its input
+        if (nq > 0 && pass2)
+            hipLaunchKernelGGL(sor_wave_kernel<1>, dim3(2048), dim3(64), (size_t)8192 * 8, st, g.params, g.cell_start, g.sorted_pts,
+                               out_idx, q0, q1, kk, 8192, avg, list1, count1, fb_list2, fb_count2);
+        // pass 3: whatever is left: thread-per-query ring walk with a k-heap (in LDS; in the workspace for k > KPX_SOR_LDS_K)
+        const int32_t *list2 = pass2 ? fb_list2 : list1, *count2 = pass2 ? fb_count2 : count1;
+        if (nq > 0)
+            hipLaunchKernelGGL(sor_knn_kernel, dim3(global_heap ? heap_blocks : 256), dim3(global_heap ? 64 : threads), lds, st, g.params, g.cell_start, g.sorted_pts,
+                               out_idx, q0, q1, kk, avg, list2, count2, gheap);
         (void)none;
     }
     if (!full) {
@@ -820,16 +834,19 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
 __global__ void normals_kernel(const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start,
                                const float *__restrict__ spts, const int32_t *__restrict__ sidx, const float *__restrict__ pts,
                                int64_t n, int k, double r2, float *__restrict__ normals, const int32_t *__restrict__ list,
-                               const int32_t *__restrict__ list_count)
+                               const int32_t *__restrict__ list_count, double *__restrict__ gheap, int32_t *__restrict__ gix)
 {
+    // gheap / gix != NULL (max_nn beyond what LDS holds): the thread's (d^2, index) heap lives in the workspace
     extern __shared__ __align__(16) double lds[];
     const int64_t total = list ? (int64_t)*list_count : n;
     const GridParams g = *gp;
     int32_t *ilds = reinterpret_cast<int32_t *>(lds + (size_t)k * blockDim.x);
+    const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gstride = (int)(gridDim.x * blockDim.x);
     // one query per thread; list != NULL: only the queries list[0 .. *list_count) (the wave kernel's leftovers)
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = list ? (int64_t)list[t] : t;
-        HeapDI heap{ lds + threadIdx.x, ilds + threadIdx.x, (int)blockDim.x, k, 0 };
+        HeapDI heap{ gheap ? gheap + gt : lds + threadIdx.x, gheap ? gix + gt : ilds + threadIdx.x, gheap ? gstride : (int)blockDim.x, k, 0 };
         grid_knn_scan(g, cell_start, spts, sidx, (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2], r2, heap);
         const int64_t me = sidx[s];
         double nx = 0.0, ny = 0.0, nz = 1.0;
@@ -937,11 +954,16 @@ static int normals_impl(const float *pts, int64_t n, double radius, int max_nn, 
     if (rc) return rc;
     int32_t *fb_list = a.get<int32_t>((size_t)(n > 0 ? n : 1) + 1);
     double *covbuf = a.get<double>((size_t)(n > 0 ? n : 1) * 10);
+    const bool global_heap = kk > KPX_NORMALS_LDS_NN;            // the fall-back heaps in the workspace (<= 256 MB of distances)
+    int heap_blocks = 256;
+    while (global_heap && heap_blocks > 8 && (size_t)heap_blocks * 64 * (size_t)kk * sizeof(double) > ((size_t)256 << 20)) heap_blocks >>= 1;
+    double *gheap = global_heap ? a.get<double>((size_t)heap_blocks * 64 * (size_t)kk) : nullptr;
+    int32_t *gix = global_heap ? a.get<int32_t>((size_t)heap_blocks * 64 * (size_t)kk) : nullptr;
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
     int32_t *fb_count = g.spare;                                  // cleared by the grid build
-    const int threads = kk <= 48 ? 128 : 64;
-    const size_t lds = (size_t)kk * threads * (sizeof(double) + sizeof(int32_t));
+    const int threads = global_heap ? 64 : (kk <= 48 ? 128 : 64);
+    const size_t lds = global_heap ? 0 : (size_t)kk * threads * (sizeof(double) + sizeof(int32_t));
     static bool attr_set = false;
     if (!attr_set) {
         KPX_HIP(hipFuncSetAttribute((const void *)normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -949,13 +971,17 @@ static int normals_impl(const float *pts, int64_t n, double radius, int max_nn, 
         attr_set = true;
     }
     // pass 1: one wave per query, 512- or 1024-candidate buffer; pass 2: the few queries that did not fit, thread-per-query heap walk
+    // (max_nn > 512: the wave kernel's 1024-candidate buffer cannot hold a neighbourhood and its surroundings -- every query takes the heap walk)
     const int cap = kk <= 48 ? 512 : 1024;
-    hipLaunchKernelGGL(normals_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256),
-                       (size_t)4 * cap * (sizeof(double) + sizeof(uint32_t)), st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk,
-                       cap, radius * radius, covbuf, fb_list, fb_count);
-    hipLaunchKernelGGL(normals_eigen_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, covbuf, g.sorted_idx, n, normals);
-    hipLaunchKernelGGL(normals_kernel, dim3(256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, pts, n, kk,
-                       radius * radius, normals, fb_list, fb_count);
+    const bool wave_pass = kk <= 512;
+    if (wave_pass) {
+        hipLaunchKernelGGL(normals_wave_kernel<4>, dim3((unsigned)(cdiv(n, 4) > 8192 ? 8192 : cdiv(n, 4))), dim3(256),
+                           (size_t)4 * cap * (sizeof(double) + sizeof(uint32_t)), st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, n, kk,
+                           cap, radius * radius, covbuf, fb_list, fb_count);
+        hipLaunchKernelGGL(normals_eigen_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, covbuf, g.sorted_idx, n, normals);
+    }
+    hipLaunchKernelGGL(normals_kernel, dim3(global_heap ? heap_blocks : 256), dim3(threads), lds, st, g.params, g.cell_start, g.sorted_pts, g.sorted_idx, pts, n, kk,
+                       radius * radius, normals, wave_pass ? fb_list : (const int32_t *)nullptr, wave_pass ? fb_count : (const int32_t *)nullptr, gheap, gix);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
 }

@@ -217,7 +217,7 @@ class PointCloud:
     def estimate_normals(self, search_param=None, fast_normal_computation=True):
         sp = search_param if search_param is not None else KDTreeSearchParamKNN()
         if self.has_points():
-            self._nrm = ops.estimate_normals(self._pts, sp.radius, sp.max_nn)       # max_nn > 128: the library raises
+            self._nrm = ops.estimate_normals(self._pts, sp.radius, sp.max_nn)       # any max_nn up to KPX_NORMALS_MAX_NN (beyond 128 the fall-back heaps live in the workspace)
         return self
 
     def get_oriented_bounding_box(self, robust=False):

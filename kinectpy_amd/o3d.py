@@ -125,7 +125,7 @@ def compute_fpfh_feature(input, search_param):
     """preprocessing/registration.py:15-20"""
     if not input.has_normals():
         raise RuntimeError("Failed because input point cloud has no normal.")
-    return Feature(ops.fpfh(input._pts, input._nrm, search_param.radius, search_param.max_nn))    # max_nn > 128: the library raises
+    return Feature(ops.fpfh(input._pts, input._nrm, search_param.radius, search_param.max_nn))
 
 
 def registration_ransac_based_on_feature_matching(source, target, source_feature, target_feature, mutual_filter,

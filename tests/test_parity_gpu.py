@@ -273,7 +273,7 @@ def test_voxel_edge_cases(ops, oracle):
 
 
 @pytest.mark.parametrize("n,k,ratio", [(5000, 20, 2.0), (60000, 20, 2.0), (20000, 50, 0.3), (20000, 200, 3.0),
-                                       (17, 20, 1.0), (2, 5, 1.0), (300, 288, 1.5)])
+                                       (17, 20, 1.0), (2, 5, 1.0), (300, 288, 1.5), (12000, 500, 2.0), (3000, 1500, 1.0)])
 def test_sor_indices_bit_exact(ops, oracle, base_cloud, n, k, ratio):
     rng = np.random.default_rng(n + k)
     p = base_cloud[rng.choice(len(base_cloud), n, replace=False)]
@@ -293,7 +293,7 @@ def test_sor_duplicates_and_errors(ops, oracle):
     gi, _, ga = ops.sor(p, 20, 2.0, want_avg=True)
     ri, _, ra = oracle.sor(p, 20, 2.0)
     assert np.array_equal(npy(gi), ri) and (npy(ga)[:40] == 0).all() and not np.isin(np.arange(40), ri).any()
-    for bad in [(0, 1.0), (5, 0.0), (5, -1.0), (289, 1.0)]:
+    for bad in [(0, 1.0), (5, 0.0), (5, -1.0), (4097, 1.0)]:
         with pytest.raises(KinectPxError):
             ops.sor(p, *bad)
 
@@ -390,6 +390,34 @@ def test_normals_up_to_sign(ops, oracle, base_cloud):
     assert well.mean() > 0.95
     assert (np.abs((gn * rn).sum(1))[well] > 1 - 1e-6).all()          # float32 storage of a unit vector
     assert np.allclose(gn[cnt < 3], [0, 0, 1])
+
+
+def test_large_neighbourhoods_beyond_the_lds_forms(ops, oracle, base_cloud):
+    """The reference takes any nb_neighbors / max_nn (preprocessing/filtering.py:12-17, registration.py:7-21).  Up to 288 / 128 the
+    neighbour heaps of the fall-back passes live in LDS; beyond, in the workspace (round 5): remove_statistical_outlier(500, 2.0),
+    estimate_normals(Hybrid(r, 300)) and compute_fpfh_feature(Hybrid(r, 200)) against the oracle."""
+    rng = np.random.default_rng(5)
+    p = base_cloud[rng.choice(len(base_cloud), 8000, replace=False)]
+    gi, gs, ga = ops.sor(p, 500, 2.0, want_avg=True)
+    ri, rs, ra = oracle.sor(p, 500, 2.0)
+    assert np.array_equal(npy(gi), ri) and np.allclose(npy(ga), ra, rtol=1e-14, atol=0)
+    gn = npy(ops.estimate_normals(p, 400.0, 300)).astype(np.float64)
+    rn, cov, cnt = oracle.estimate_normals(p, 400.0, 300)
+    assert cnt.max() == 300                                            # the cap binds: neighbourhoods are cut at max_nn
+    A = np.zeros((len(p), 3, 3))
+    A[:, 0, 0], A[:, 1, 1], A[:, 2, 2] = cov[:, 0], cov[:, 3], cov[:, 5]
+    A[:, 0, 1] = A[:, 1, 0] = cov[:, 1]
+    A[:, 0, 2] = A[:, 2, 0] = cov[:, 2]
+    A[:, 1, 2] = A[:, 2, 1] = cov[:, 4]
+    w = np.linalg.eigvalsh(A)
+    well = (cnt >= 3) & ((w[:, 1] - w[:, 0]) > 1e-3 * np.maximum(w[:, 2], 1e-30))
+    assert well.mean() > 0.9 and (np.abs((gn * rn).sum(1))[well] > 1 - 1e-6).all()
+    q = p[:3000]
+    nrm = npy(ops.estimate_normals(q, 150.0, 40))
+    got = npy(ops.fpfh(q, nrm, 600.0, 200))
+    want, _ = oracle.fpfh(q, nrm, 600.0, 200)
+    bad = np.abs(got - want).max(1) > 1e-6                              # (a libm atan2 ulp can move one pair across a bin edge)
+    assert bad.mean() < 2e-3 and np.allclose(got[~bad], want[~bad], rtol=1e-9, atol=1e-9)
 
 
 @pytest.mark.parametrize("n,rn,iters,prob,seed", [(50000, 30, 2000, 0.99999999, 7), (50000, 3, 500, 0.99999999, 1),
