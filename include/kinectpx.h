@@ -398,6 +398,13 @@ int kpx_rccl_load(const char *path);
 int kpx_rccl_unique_id(void *id128);
 int kpx_comm_create_rccl(const void *id128, int32_t rank, int32_t world, kpx_comm **out);
 int kpx_comm_create_callbacks(int32_t rank, int32_t world, kpx_bcast_fn bcast, kpx_allgather_fn allgather, void *user, kpx_comm **out);
+/* Replay transport (measurement aid of bench.py --emulate-world): ONE rank of a `world`-rank job on one GPU, the peers' messages taken
+ * from recordings of a real world-rank run.  d_payloads / bytes: [frames][3][world] device pointers / sizes of what rank r sent in
+ * collective c (0 master broadcast -- root's entry only --, 1 cloud exchange, 2 slab all-gather) of recorded frame f.  Call n of the
+ * communicator is collective n % 3 of frame (first_frame + stride * (n / 3)) % frames.  Message sizes must be the recording's (both
+ * runs with KPX_SHARD_FIXED_CAP=1).  Replaces nothing of the reference: it prices a rank's share of preprocessing/data.py:35-61. */
+int kpx_comm_create_replay(int32_t rank, int32_t world, int32_t frames, int32_t first_frame, int32_t stride, const void *const *d_payloads,
+                           const size_t *bytes, kpx_comm **out);
 int kpx_comm_destroy(kpx_comm *comm);
 int kpx_comm_rank(const kpx_comm *comm);
 int kpx_comm_world(const kpx_comm *comm);

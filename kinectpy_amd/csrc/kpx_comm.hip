@@ -58,9 +58,14 @@ struct kpx_comm {
     kpx_bcast_fn bcast = nullptr;               // callback transport
     kpx_allgather_fn allgather = nullptr;
     void *user = nullptr;
+    // replay transport (kpx_comm_create_replay): what every rank SENT in every collective of `frames` recorded frames
+    std::vector<const void *> rp_ptr;
+    std::vector<size_t> rp_bytes;
+    int rp_frames = 0, rp_first = 0, rp_stride = 1;
+    long long rp_calls = 0;
     // slot memory (kpx_frame_step_sharded): rows of the master broadcast / the cloud exchange, 0 = not seen a frame yet
     int64_t cap_master = 0, cap_clouds = 0;
-    int spec_bits = 0;
+    int spec_bits = 0, fuse_bits = 0;
 };
 
 KPX_EXPORT int kpx_rccl_load(const char *path)
@@ -121,6 +126,37 @@ KPX_EXPORT int kpx_comm_create_callbacks(int32_t rank, int32_t world, kpx_bcast_
     return KPX_OK;
 }
 
+// Replay transport -- a MEASUREMENT aid (bench.py --emulate-world): the collectives of ONE rank of a `world`-rank job on one GPU, the
+// peers' contributions taken from recordings of a real `world`-rank run (in-process ranks) over `frames` frames: entry
+// [(f * 3 + c) * world + r] = what rank r sent in collective c (0 master broadcast: root's entry only, 1 cloud exchange, 2 slab
+// all-gather) of frame f, in device memory.  The communicator counts its calls: call n is collective n % 3 of frame
+// (first_frame + stride * (n / 3)) % frames -- the frames a slot of a kpx_stream sees (slot s of depth d: first_frame = s,
+// stride = d).  The message sizes must be those of the recording: both runs use fixed worst-case capacities (KPX_SHARD_FIXED_CAP=1).
+KPX_EXPORT int kpx_comm_create_replay(int32_t rank, int32_t world, int32_t frames, int32_t first_frame, int32_t stride, const void *const *d_payloads,
+                                      const size_t *bytes, kpx_comm **out)
+{
+    KPX_REQUIRE(out && d_payloads && bytes && world >= 1 && rank >= 0 && rank < world && frames >= 1 && first_frame >= 0 && stride >= 1,
+                "kpx_comm_create_replay: bad arguments");
+    kpx_comm *k = new kpx_comm();
+    k->rank = rank;
+    k->world = world;
+    k->rp_frames = frames; k->rp_first = first_frame; k->rp_stride = stride;
+    const size_t n = (size_t)frames * 3 * (size_t)world;
+    k->rp_ptr.assign(d_payloads, d_payloads + n);
+    k->rp_bytes.assign(bytes, bytes + n);
+    *out = k;
+    return KPX_OK;
+}
+static int replay_entry(kpx_comm *c, int want_c, size_t *base)
+{
+    const long long n = c->rp_calls++;
+    const int col = (int)(n % 3);
+    if (col != want_c) return fail(KPX_ERR_INVALID, "replay transport: call %lld is collective %d of its frame, the recording has %d there", n, want_c, col);
+    const long long f = ((long long)c->rp_first + (long long)c->rp_stride * (n / 3)) % c->rp_frames;
+    *base = ((size_t)f * 3 + (size_t)col) * (size_t)c->world;
+    return KPX_OK;
+}
+
 KPX_EXPORT int kpx_comm_destroy(kpx_comm *c)
 {
     if (!c) return KPX_OK;
@@ -142,6 +178,17 @@ KPX_EXPORT int kpx_comm_broadcast(kpx_comm *c, void *d_buf, size_t bytes, int32_
         const int rc = g_rccl.broadcast(d_buf, d_buf, bytes, /*ncclInt8*/ 0, root, c->nccl, (hipStream_t)stream);
         return rc ? rccl_fail("ncclBroadcast", rc) : KPX_OK;
     }
+    if (c->rp_frames) {
+        size_t base;
+        const int rc = replay_entry(c, 0, &base);
+        if (rc) return rc;
+        if (c->rank != root) {
+            KPX_REQUIRE(c->rp_bytes[base + (size_t)root] == bytes && c->rp_ptr[base + (size_t)root], "replay transport: the recorded broadcast has %zu bytes, this one %zu",
+                        c->rp_bytes[base + (size_t)root], bytes);
+            KPX_HIP(hipMemcpyAsync(d_buf, c->rp_ptr[base + (size_t)root], bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        }
+        return KPX_OK;
+    }
     if (c->bcast) {
         const int rc = c->bcast(c->user, d_buf, bytes, root, stream);
         return rc ? fail(KPX_ERR_HIP, "kpx_comm_broadcast: the transport callback failed (%d)", rc) : KPX_OK;
@@ -158,6 +205,23 @@ KPX_EXPORT int kpx_comm_allgather(kpx_comm *c, const void *d_send, void *d_recv,
     if (c->nccl) {
         const int rc = g_rccl.all_gather(d_send, d_recv, bytes_per_rank, /*ncclInt8*/ 0, c->nccl, (hipStream_t)stream);
         return rc ? rccl_fail("ncclAllGather", rc) : KPX_OK;
+    }
+    if (c->rp_frames) {
+        size_t base;
+        const int col = (int)(c->rp_calls % 3);
+        const int rc = replay_entry(c, col == 0 ? 1 : col, &base);
+        if (rc) return rc;
+        for (int r = 0; r < c->world; ++r) {
+            char *dst = static_cast<char *>(d_recv) + (size_t)r * bytes_per_rank;
+            if (r == c->rank) {
+                if (dst != d_send) KPX_HIP(hipMemcpyAsync(dst, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+                continue;
+            }
+            KPX_REQUIRE(c->rp_bytes[base + (size_t)r] == bytes_per_rank && c->rp_ptr[base + (size_t)r], "replay transport: rank %d's recorded message has %zu bytes, this one %zu",
+                        r, c->rp_bytes[base + (size_t)r], bytes_per_rank);
+            KPX_HIP(hipMemcpyAsync(dst, c->rp_ptr[base + (size_t)r], bytes_per_rank, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        }
+        return KPX_OK;
     }
     if (c->allgather) {
         const int rc = c->allgather(c->user, d_send, d_recv, bytes_per_rank, stream);
@@ -184,6 +248,7 @@ namespace kpx {
 int64_t &comm_cap_master(kpx_comm *c) { return c->cap_master; }
 int64_t &comm_cap_clouds(kpx_comm *c) { return c->cap_clouds; }
 int &comm_spec_bits(kpx_comm *c) { return c->spec_bits; }
+int &comm_fuse_bits(kpx_comm *c) { return c->fuse_bits; }
 }  // namespace kpx
 
 // ---- the collectives' issue order ---------------------------------------------------------------------------------------

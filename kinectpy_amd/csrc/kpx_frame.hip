@@ -286,6 +286,7 @@ namespace kpx {
 int64_t &comm_cap_master(kpx_comm *c);
 int64_t &comm_cap_clouds(kpx_comm *c);
 int &comm_spec_bits(kpx_comm *c);
+int &comm_fuse_bits(kpx_comm *c);
 
 constexpr int kHdrDoubles = 24;        // per sensor: [0] masked points, [1] down-sampled points, [2..21] registration (T, fitness, rmse, iterations, pairs)
 
@@ -472,8 +473,11 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     // them as the message's second half.  Every rank now estimates them itself from the broadcast points, beside the others: the same
     // kernels on the same array give the same normals bit for bit, the message is half as long, and nothing serial is left between
     // rank 0's voxel grid and everyone's registrations (registration.py:9-13 is a function of the master cloud alone).
+    // KPX_SHARD_FIXED_CAP=1: the worst-case capacities in every frame (no adaptation, no retry) -- message sizes then do not depend on
+    // the slot's history, which the replay transport of bench.py --emulate-world needs (kpx_comm_create_replay)
+    static const bool fixed_cap = [] { const char *e = getenv("KPX_SHARD_FIXED_CAP"); return e && e[0] == '1'; }();
     int64_t &cap_m = comm_cap_master(comm);
-    if (cap_m <= 0) cap_m = n_px;
+    if (cap_m <= 0 || fixed_cap) cap_m = n_px;
     const int64_t capm = cap_m;
     char *msg = L.msg_master;
     float *m_xyz = reinterpret_cast<float *>(msg);
@@ -505,7 +509,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
                          : fail(KPX_ERR_RANGE, "kpx_frame_step_sharded: bad master header (%lld points)", (long long)m);
         }
     }
-    cap_m = round_cap(m, n_px);
+    cap_m = fixed_cap ? n_px : round_cap(m, n_px);
     if (m > capm) {                                            // every rank reads the same m: all retry, none goes on
         kpx_order_finish(order, frame);
         return KPX_RETRY;
@@ -532,7 +536,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     // -- collective 1: the masked clouds, unmoved, planar (xyz rows, then rgb rows), + header rows
     int64_t &cap_c = comm_cap_clouds(comm);
     const int64_t worst_c = (int64_t)K * n_px;
-    if (cap_c <= 0) cap_c = worst_c;
+    if (cap_c <= 0 || fixed_cap) cap_c = worst_c;
     const int64_t capc = cap_c;
     const size_t xbytes = (size_t)capc * 24 + L.hdr_bytes;
     {
@@ -590,7 +594,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
         }
         need = off > need ? off : need;
     }
-    cap_c = round_cap(need, worst_c);
+    cap_c = fixed_cap ? worst_c : round_cap(need, worst_c);
     if (need > capc) {
         kpx_order_finish(order, frame);
         return KPX_RETRY;
@@ -600,10 +604,22 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
         return KPX_OK;
     }
     // -- fuse: pcd.transform(T_i) + np.vstack + voxel_down_sample in one fp64 pass (every rank that filters: identical everywhere)
-    KPX_SUB(fuse_voxel_downsample_dev(S, f_p.data(), f_c.data(), f_n.data(), h_T, nullptr, prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws,
-                                      L.op_bytes, st));
-    KPX_HIP(hipMemcpyAsync(h_i + 48, L.vox_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    KPX_SUB(frame_wait(st));
+    // (the fused cloud's key width speculated from the slot's previous frame, as in kpx_frame_step: the library's own radix sort instead
+    // of the vendor's merge sort; every rank fuses the same cloud, so every rank speculates and -- rarely -- repeats alike)
+    int &fuse_spec = comm_fuse_bits(comm);
+    static const bool speculate_fuse = [] { const char *e = getenv("KPX_FRAME_SPECULATE"); return !(e && e[0] == '0'); }();
+    if (!speculate_fuse) fuse_spec = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        h_i[51] = 0;
+        KPX_SUB(fuse_voxel_downsample_dev(S, f_p.data(), f_c.data(), f_n.data(), h_T, nullptr, prm->filt_voxel, L.vox_pts, L.vox_col, L.vox_cnt, L.op_ws,
+                                          L.op_bytes, st, attempt == 0 ? fuse_spec : 0, h_i + 51));
+        KPX_HIP(hipMemcpyAsync(h_i + 48, L.vox_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KPX_SUB(frame_wait(st));
+        const int need_bits = h_i[51];
+        const bool narrow = attempt == 0 && fuse_spec > 0 && need_bits > fuse_spec;
+        fuse_spec = (speculate_fuse && need_bits > 0 && need_bits <= 32) ? (need_bits + 7) / 8 * 8 : 0;
+        if (!narrow) break;
+    }
     if (h_i[48] < 0) return fail(KPX_ERR_RANGE, "voxel_size is too small");
     const int64_t M = h_i[48];
     if (h_info) h_info[48] = (int32_t)M;
@@ -630,9 +646,13 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     KPX_HIP(hipMemcpyAsync(h_i + 49, L.keep_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     KPX_SUB(frame_wait(st));
     const int64_t kept = h_i[49];
-    if (kept > 0)
+    if (kept > 0) {
         KPX_SUB(kpx_select_by_index(L.vox_pts, L.vox_col, nullptr, M, L.keep_idx, kept, KPX_SELECT_GATHER, out_pts, out_col, nullptr, nullptr, L.op_ws,
                                     L.op_bytes, st));
+        // the rows are complete when the call returns, as kpx_frame_step's are (a kpx_stream hands them to the caller without another
+        // synchronisation; until round 5 pipeline.FrameStream synchronised the slot's stream behind every step)
+        KPX_SUB(frame_wait(st));
+    }
     *h_count = (int32_t)kept;
     return KPX_OK;
 }

@@ -188,7 +188,17 @@ KPX_EXPORT int kpx_stream_create(const float *xy_table, int64_t n_px, int32_t se
     S->init.assign((size_t)16 * (sensors > 1 ? sensors - 1 : 1), 0.0);
     if (sensors > 1) memcpy(S->init.data(), h_init, sizeof(double) * 16 * (size_t)(sensors - 1));
     if (S->sharded) {
-        const int rc = kpx_order_create(depth, &S->order);
+        // The collectives' issue order (kpx_order): frame f's exchange and slab all-gather go behind the master broadcast of frame
+        // f + lookahead.  Rounds 3-4 tied the lookahead to the number of slots (depth - 1): with every slot busy, frame f + depth - 1
+        // cannot START before frame f - 1 has been collected, so frame f's exchange waited for a frame that waited for its predecessor
+        // -- measured on one rank of the 8-GPU partition (bench.py --emulate-world 8): 1.9 of a frame's 3.1 ms idle in front of the
+        // exchange, 0.64 ms per frame whatever the rank computes (profiles/r05/emulate_world8_rank1_lookahead3_overlap.txt).  The
+        // lookahead is now its own number (KPX_ORDER_LOOKAHEAD, default 2: the exchange of a frame is ready ~1.3 ms after its broadcast,
+        // by when two later frames have broadcast theirs), the slots can be more (depth 6-8): no frame waits for a slot to open.
+        static const int look_env = [] { const char *e = getenv("KPX_ORDER_LOOKAHEAD"); return e ? atoi(e) : -1; }();
+        int look = look_env >= 0 ? look_env : 2;
+        if (look > depth - 1) look = depth - 1;
+        const int rc = kpx_order_create(look + 1, &S->order);
         if (rc) return rc;
     }
     // KPX_STREAM_ENGINE=1: the device's ICP engine carries the registrations of all frames in flight in one launch per tick (kpx_icp.hip,

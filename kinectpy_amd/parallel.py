@@ -295,7 +295,9 @@ class NativeComm:
             self.slot = [None] * self.world
 
     @classmethod
-    def local(cls, hub, rank):
+    def local(cls, hub, rank, record=None):
+        """record: a list that receives, per collective this rank takes part in, a device copy (uint8 tensor) of what the rank SENT
+        (None for a broadcast it only received) -- the recordings kpx_comm_create_replay plays back (bench.py --emulate-world)"""
         import ctypes as C
         from . import _lib
         L = _lib.load()
@@ -303,8 +305,15 @@ class NativeComm:
         def copy(dst, src, n, stream):
             _lib.check(L.kpx_copy_bytes(C.c_void_p(dst), C.c_void_p(src), n, C.c_void_p(stream), 1))
 
+        def keep(src, n, stream):
+            t = torch.empty(int(n), dtype=torch.uint8, device=_lib.device())
+            copy(t.data_ptr(), src, n, stream)
+            record.append(t)
+
         def bcast(user, d_buf, n, root, stream):
             copy(None, None, 0, stream)                       # everything queued before the collective has happened
+            if record is not None:
+                keep(d_buf, n, stream) if rank == root else record.append(None)
             hub.slot[rank] = d_buf
             hub.barrier.wait()
             if rank != root:
@@ -313,12 +322,37 @@ class NativeComm:
 
         def allgather(user, d_send, d_recv, n, stream):
             copy(None, None, 0, stream)
+            if record is not None:
+                keep(d_send, n, stream)
             hub.slot[rank] = d_send
             hub.barrier.wait()
             for r in range(hub.world):
                 copy(d_recv + r * n, hub.slot[r], n, stream)
             hub.barrier.wait()
         return cls._callbacks(rank, hub.world, bcast, allgather)
+
+    @classmethod
+    def replay(cls, rank, world, recordings, first_frame=0, stride=1):
+        """ONE rank of a `world`-rank job, the peers' messages played back (kpx_comm_create_replay): recordings[r] = the list
+        NativeComm.local(..., record=) filled on rank r, three entries per frame (master broadcast, cloud exchange, slab all-gather).
+        Call n of the communicator is collective n % 3 of frame (first_frame + stride * (n // 3)) % frames."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        frames = len(recordings[0]) // 3
+        n = frames * 3 * world
+        ptrs, sizes, keep = (C.c_void_p * n)(), (C.c_size_t * n)(), []
+        for f in range(frames):
+            for c in range(3):
+                for r in range(world):
+                    t = recordings[r][3 * f + c]
+                    i = (f * 3 + c) * world + r
+                    ptrs[i] = None if t is None else t.data_ptr()
+                    sizes[i] = 0 if t is None else t.numel()
+                    keep.append(t)
+        h = C.c_void_p()
+        _lib.check(L.kpx_comm_create_replay(int(rank), int(world), frames, int(first_frame), int(stride), C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), C.byref(h)))
+        return cls(h, rank, world, keep=(keep, ptrs, sizes))
 
     def close(self):
         from . import _lib

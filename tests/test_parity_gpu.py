@@ -1377,11 +1377,11 @@ def test_sensor_partition_equals_single_process_oracle(tmp_path, oracle, four_se
             assert np.array_equal(z[pk], rp) and np.array_equal(z[ck], rc), (rank, key)
 
 
-def _local_ranks(world, S, xy, depth, rgb, inits, mode, frames, slots=1, host=False):
+def _local_ranks(world, S, xy, depth, rgb, inits, mode, frames, slots=1, host=False, native_stream=False):
     """`world` in-process ranks (one thread each, all on this GPU) through the native sharded loop: -> per rank [(p, c, T, last)]"""
     import threading
     from kinectpy_amd import parallel
-    from kinectpy_amd.pipeline import FrameStream, NativeShardPipeline, PipelineParams
+    from kinectpy_amd.pipeline import FrameStream, NativeFrameStream, NativeShardPipeline, PipelineParams
     hubs = [parallel.NativeComm.LocalHub(world) for _ in range(slots)]
     results, errors = [None] * world, []
     _local_ranks.retries = [0] * world
@@ -1400,7 +1400,7 @@ def _local_ranks(world, S, xy, depth, rgb, inits, mode, frames, slots=1, host=Fa
                         p, c, Ts = pipes[0].step(*feed(f))
                         out.append((npy(p), npy(c), Ts, dict(pipes[0].last)))
                 else:
-                    fs = FrameStream(pipes)
+                    fs = NativeFrameStream(pipes) if native_stream else FrameStream(pipes)
                     for f in frames:
                         if fs.full():
                             p, c, Ts = fs.pop()
@@ -1442,6 +1442,23 @@ def test_native_sharded_loop_in_process_ranks(four_sensor_oracle, world, mode):
                 assert p.shape[0] == 0
                 continue
             assert np.array_equal(p, rp) and np.array_equal(c, rc), (r, f)
+
+
+def test_native_sharded_loop_through_the_native_stream(four_sensor_oracle):
+    """kpx_stream with communicators (pipeline.NativeFrameStream over NativeShardPipelines): the rank's frames in flight scheduled by the
+    library's worker threads, one communicator per slot, the collectives of the frames in flight in the order of the stream's own
+    kpx_order (lookahead 2, round 5) -- 2 and 4 in-process ranks with three and four frames in flight: every frame on every rank equals
+    the single-process oracle step."""
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    for world, slots in ((2, 3), (4, 4)):
+        frames = (0, 1, 1, 0, 1, 0, 0)
+        res = _local_ranks(world, 4, xy, depth, rgb, inits, "sharded", frames=frames, slots=slots, native_stream=True)
+        for r in range(world):
+            assert len(res[r]) == len(frames)
+            for (p, c, Ts, _), f in zip(res[r], frames):
+                rp, rc, rT, aux = ref[f]
+                assert np.abs(Ts - np.stack(rT)).max() < TOL_T
+                assert np.array_equal(p, rp) and np.array_equal(c, rc), (world, r, f)
 
 
 def test_native_sharded_loop_eight_ranks_eight_sensors(oracle):
