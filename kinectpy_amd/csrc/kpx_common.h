@@ -53,6 +53,21 @@ struct Arena {
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// The vendor primitives' temporary-storage queries (hipcub / rocPRIM called with a null buffer) cost tens of microseconds each when
+// several frame threads are inside the runtime, and every operator asked them again on every call while carving its workspace -- a
+// 4-sensor frame asked ~20 of them, and its stream sat idle meanwhile (profiles/r05/overlap_timeline_*.txt).  Their answers depend
+// only on (call site, element count): asked once per process and remembered.
+bool memo_bytes_lookup(unsigned site, int64_t n, size_t *bytes);
+void memo_bytes_store(unsigned site, int64_t n, size_t bytes);
+template <class F> static inline size_t memo_bytes(unsigned site, int64_t n, F &&query)
+{
+    size_t b = 0;
+    if (memo_bytes_lookup(site, n, &b)) return b;
+    b = query();
+    memo_bytes_store(site, n, b);
+    return b;
+}
+
 // 16-byte loads / stores of data that is touched once (streaming operators): non-temporal, so that a pass over a cloud does not
 // evict what other kernels of the frame keep in L2 / Infinity Cache.  -DKPX_STREAM_PLAIN: ordinary accesses (A/B switch).
 typedef unsigned int kpx_u4 __attribute__((ext_vector_type(4)));

@@ -125,10 +125,18 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     const int S = sensors;
     hipStream_t st = (hipStream_t)stream;
     BusyScope busy;                                        // (a frame in flight: see kpx_internal.h)
-    Arena a(ws, ws_bytes);
+    // (the layout is a function of (workspace, sensors, pixels): carved once per thread and slot -- the carve walks every operator's
+    // workspace query, ~100 us of host time in front of a frame's first kernel)
+    static thread_local struct { void *ws; size_t bytes; int S; int64_t n_px; FrameLayout L; size_t off; } cache = { nullptr, 0, 0, 0, {}, 0 };
     FrameLayout L;
-    frame_carve(a, S, n_px, &L);
-    KPX_ARENA_CHECK(a);
+    if (cache.ws == ws && cache.bytes == ws_bytes && cache.S == S && cache.n_px == n_px) {
+        L = cache.L;
+    } else {
+        Arena a(ws, ws_bytes);
+        frame_carve(a, S, n_px, &L);
+        KPX_ARENA_CHECK(a);
+        cache.ws = ws; cache.bytes = ws_bytes; cache.S = S; cache.n_px = n_px; cache.L = L; cache.off = a.off;
+    }
     // pinned read-back area of the calling thread: counts and ICP results.  ONE allocation (the doubles first), published only when
     // it succeeded; it lives as long as the thread's runtime context (a few KiB per host thread that ever ran a frame).
     static thread_local double *h_d = nullptr;

@@ -171,8 +171,8 @@ int grid_build(const float *pts, int64_t n, double target_per_cell, Arena &a, Gr
     int32_t *vals_in = a.get<int32_t>(nn);
     double *part = a.get<double>((size_t)kBboxBlocks * 6 + 8);
     size_t sort_bytes = 0, scan_bytes = 0;
-    (void)sort_pairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, g->sorted_idx, (int64_t)nn, 22, st);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, zero, g->cell_start, kGridMaxCells + 1, st);
+    sort_bytes = memo_bytes(2, (int64_t)nn, [&] { size_t b = 0; (void)sort_pairs(nullptr, b, keys_in, keys_out, vals_in, g->sorted_idx, (int64_t)nn, 22, st); return b; });
+    scan_bytes = memo_bytes(3, 0, [&] { size_t b = 0; (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, zero, g->cell_start, kGridMaxCells + 1, st); return b; });
     char *tmp = a.get<char>(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
     RadixScratch rx{};
     const bool own_sort = (int64_t)nn > 65536 && (int64_t)nn <= kRadixMaxPairs;     // the sort build's sizes that kpx_radix.h serves

@@ -1,10 +1,33 @@
 // kpx_misc.hip -- container operations of the Open3D surface the path touches:
 // transform, select_by_index, half-space select, slab split, bounding box.  HBM-streaming.
+#include <mutex>
+#include <unordered_map>
 #include "kpx_internal.h"
 #include "kpx_morton.h"
 #include "kpx_radix.h"
 
 namespace kpx {
+
+namespace {
+std::mutex g_memo_mu;
+std::unordered_map<unsigned long long, size_t> g_memo;
+}
+bool memo_bytes_lookup(unsigned site, int64_t n, size_t *bytes)
+{
+    const unsigned long long key = ((unsigned long long)site << 48) ^ (unsigned long long)n;
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    auto it = g_memo.find(key);
+    if (it == g_memo.end()) return false;
+    *bytes = it->second;
+    return true;
+}
+void memo_bytes_store(unsigned site, int64_t n, size_t bytes)
+{
+    const unsigned long long key = ((unsigned long long)site << 48) ^ (unsigned long long)n;
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    g_memo[key] = bytes;
+}
+
 
 struct Affine { double m[12]; };   // rows of [R | t]
 
@@ -419,8 +442,7 @@ KPX_EXPORT int kpx_fuse_skeletons(const double *skeletons, int32_t cams, int64_t
 static void sort_u32_carve(Arena &a, int64_t n, RadixScratch *rx, char **tmp, size_t *tmp_bytes)
 {
     if (n <= kRadixMaxPairs) { radix_carve(a, n, rx); return; }
-    *tmp_bytes = 0;
-    (void)sort_pairs<uint32_t>(nullptr, *tmp_bytes, nullptr, nullptr, nullptr, nullptr, n, 32, (hipStream_t) nullptr);
+    *tmp_bytes = memo_bytes(1, n, [&] { size_t b = 0; (void)sort_pairs<uint32_t>(nullptr, b, nullptr, nullptr, nullptr, nullptr, n, 32, (hipStream_t) nullptr); return b; });
     *tmp = a.get<char>(*tmp_bytes);
 }
 KPX_EXPORT size_t kpx_sort_pairs_u32_workspace_bytes(int64_t n)

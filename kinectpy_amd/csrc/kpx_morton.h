@@ -135,8 +135,7 @@ static void sort_carve(Arena &a, int64_t n, SortScratch *s)
     s->keys_in = a.get<uint32_t>(nn);
     s->keys_out = a.get<uint32_t>(nn);
     s->vals_in = a.get<int32_t>(nn);
-    s->tmp_bytes = 0;
-    (void)sort_pairs(nullptr, s->tmp_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_in, (int64_t)nn, 30, (hipStream_t) nullptr);
+    s->tmp_bytes = memo_bytes(7, (int64_t)nn, [&] { size_t b = 0; (void)sort_pairs(nullptr, b, s->keys_in, s->keys_out, s->vals_in, s->vals_in, (int64_t)nn, 30, (hipStream_t) nullptr); return b; });
     s->tmp = a.get<char>(s->tmp_bytes);
     s->bbox_part = a.get<double>((size_t)kBboxBlocks * 6);
     s->bbox = a.get<double>(8);
@@ -180,9 +179,7 @@ static void morton_batch_carve(Arena &a, int64_t total, MortonBatchScratch *s)
     s->vals_in = a.get<int32_t>(nn);
     s->vals_out = a.get<int32_t>(nn);
     s->part = a.get<double>((size_t)kMortonBatchMax * kMortonBatchBboxBlocks * 6);
-    s->tmp_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->tmp_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 34,
-                                             (hipStream_t) nullptr);
+    s->tmp_bytes = memo_bytes(8, (int64_t)nn, [&] { size_t b = 0; (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 34, (hipStream_t) nullptr); return b; });
     s->tmp = a.get<char>(s->tmp_bytes);
 }
 __device__ __forceinline__ int morton_batch_cloud(const MortonBatch &b, int64_t i)

@@ -79,9 +79,7 @@ static void sample_carve(Arena &a, int64_t n, SampleScratch *s)
     s->keys_out = a.get<uint64_t>(nn);
     s->vals_in = a.get<int32_t>(nn);
     s->vals_out = a.get<int32_t>(nn);
-    s->tmp_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->tmp_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 64,
-                                             (hipStream_t) nullptr);
+    s->tmp_bytes = memo_bytes(9, (int64_t)nn, [&] { size_t b = 0; (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 64, (hipStream_t) nullptr); return b; });
     s->tmp = a.get<char>(s->tmp_bytes);
 }
 

@@ -103,8 +103,7 @@ static int voxel_impl(const float *pts, const float *col, const float *nrm, int6
     int32_t *counts = a.get<int32_t>((size_t)compact_ws_ints(n));
     double *part = a.get<double>((size_t)kBboxBlocks * 6 + 8);
     int32_t *err = a.get<int32_t>(1);
-    size_t sort_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, vals_out, (int)nn, 0, 63, st);
+    size_t sort_bytes = memo_bytes(4, (int64_t)nn, [&] { size_t b = 0; (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, keys_in, keys_out, vals_in, vals_out, (int)nn, 0, 63, st); return b; });
     char *sort_tmp = a.get<char>(sort_bytes);
     if (a.dry) return KPX_OK;
     KPX_ARENA_CHECK(a);
@@ -444,9 +443,7 @@ static void voxel_batch_carve(Arena &a, int64_t total, VoxelBatchScratch *s)
     s->d_total = a.get<int32_t>(1);
     s->part = a.get<double>((size_t)kVoxelBatchMax * kVoxelBatchBboxBlocks * 6);
     s->bbox = a.get<double>((size_t)kVoxelBatchMax * 8);
-    s->sort_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->sort_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 64,
-                                             (hipStream_t) nullptr);
+    s->sort_bytes = memo_bytes(5, (int64_t)nn, [&] { size_t b = 0; (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 64, (hipStream_t) nullptr); return b; });
     s->sort_tmp = a.get<char>(s->sort_bytes);
     radix_carve(a, total <= kRadixMaxPairs ? total : kRadixMaxPairs, &s->rx);      // unconditional: the workspace size stays monotonic in the point count
     s->counts = a.get<int32_t>((size_t)compact_ws_ints(total));          // right behind the sort's cleared histograms: one memset for both
@@ -713,9 +710,7 @@ static void fuse_carve(Arena &a, int64_t total, FuseScratch *s)
     s->err = a.get<int32_t>(1);
     s->part = a.get<double>((size_t)kFuseMax * kFuseBboxBlocks * 6);
     s->bbox = a.get<double>(8);
-    s->sort_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s->sort_bytes, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 63,
-                                             (hipStream_t) nullptr);
+    s->sort_bytes = memo_bytes(6, (int64_t)nn, [&] { size_t b = 0; (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, s->keys_in, s->keys_out, s->vals_in, s->vals_out, (int)nn, 0, 63, (hipStream_t) nullptr); return b; });
     s->sort_tmp = a.get<char>(s->sort_bytes);
 }
 // spec_bits > 0 (frame loop): the fused cloud's keys are taken to fit `spec_bits` <= 32 bits -- the width its slot's previous frame
