@@ -524,7 +524,7 @@ def reference_stream(torch, ops, xy, depth, rgb, inits, truth, steps, gate):
             "calibration": {"ms": round(calib_ms, 1), "init_of_each_sub": how, "max_abs_error_vs_truth": [round(e, 4) for e in err]}}
 
 
-def emulate_world(torch, world, ranks, S, F, steps, depth_in_flight=4):
+def emulate_world(torch, world, ranks, S, F, steps, depth_in_flight=4, fused_filter="sharded"):
     """bench.py --emulate-world W [--emulate-ranks r,..]: what ONE rank of the W-GPU sensor partition sustains, MEASURED on one GPU.
     1. W in-process ranks (threads sharing this GPU, device-to-device transport) run the native sharded loop over the rig's F frames
        once and every rank records what it sent in each of the three collectives (fixed worst-case message capacities).
@@ -549,7 +549,7 @@ def emulate_world(torch, world, ranks, S, F, steps, depth_in_flight=4):
             torch.cuda.set_device(0)
             mine = parallel.shard_sensors(S, r, world)
             with torch.cuda.stream(torch.cuda.Stream()):
-                pipe = NativeShardPipeline(xy, S, inits, P, comm=parallel.NativeComm.local(hub, r, record=rec[r]), fused_filter="sharded")
+                pipe = NativeShardPipeline(xy, S, inits, P, comm=parallel.NativeComm.local(hub, r, record=rec[r]), fused_filter=fused_filter)
                 out = []
                 for f in range(F):
                     p, c, Ts = pipe.step(torch.as_tensor(depth_h[f][mine]).cuda(), torch.as_tensor(rgb_h[f][mine]).cuda())
@@ -562,7 +562,8 @@ def emulate_world(torch, world, ranks, S, F, steps, depth_in_flight=4):
     ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     [t.start() for t in ths]
     [t.join(timeout=900) for t in ths]
-    if errors or any(len(x) != 3 * F for x in rec):
+    per_frame = 3 if fused_filter == "sharded" else 2         # (no slab all-gather when one rank filters a frame alone)
+    if errors or any(len(x) != per_frame * F for x in rec):
         return {"error": f"recording failed: {errors or [len(x) for x in rec]}"}
     torch.cuda.synchronize()
 
@@ -588,18 +589,27 @@ def emulate_world(torch, world, ranks, S, F, steps, depth_in_flight=4):
     per_rank = {}
     for r in ranks:
         mine = parallel.shard_sensors(S, r, world)
-        comms = [parallel.NativeComm.replay(r, world, rec, first_frame=s_, stride=depth_in_flight) for s_ in range(depth_in_flight)]
-        pipes = [NativeShardPipeline(xy, S, inits, P, comm=cm, fused_filter="sharded") for cm in comms]
+        mk = lambda: [parallel.NativeComm.replay(r, world, rec, first_frame=s_, stride=depth_in_flight, per_frame=per_frame) for s_ in range(depth_in_flight)]
+        comms = mk()
+        pipes = [NativeShardPipeline(xy, S, inits, P, comm=cm, fused_filter=fused_filter) for cm in comms]
         d = [torch.as_tensor(depth_h[f][mine]).cuda() for f in range(F)]
         c = [torch.as_tensor(rgb_h[f][mine]).cuda() for f in range(F)]
         fs = NativeFrameStream(pipes, depth_in_flight)
-        # the replayed rank reproduces what it computed among its live peers (the fused, filtered frame's size)
-        fs.submit(d[0], c[0]); p0, _, _ = fs.pop()
-        # (frame 0 again on slot 1 would be frame 1 of the recording: rebuild the stream so that the timed run starts aligned)
+        # the replayed rank reproduces what it computed among its live peers: the fused, filtered frame's size, for the frames it owns
+        # (sharded: every frame; rank 0: rank 0's frames; round robin: job j on rank j mod world -- in the recording rank 0 owned them all)
+        got = []
+        for j in range(2 * F):
+            if fs.full():
+                got.append(int(fs.pop()[0].shape[0]))
+            fs.submit(d[j % F], c[j % F])
+        while fs.pending:
+            got.append(int(fs.pop()[0].shape[0]))
+        full = counts[r] if fused_filter == "sharded" else counts[0]
+        owns = lambda j: fused_filter == "sharded" or (fused_filter == "rank0" and r == 0) or (fused_filter == "round_robin" and j % world == r)
+        same = all(got[j] == (full[j % F] if owns(j) else 0) for j in range(2 * F))
         fs.close(); [cm.close() for cm in comms]
-        same = int(p0.shape[0]) == counts[r][0]
-        comms = [parallel.NativeComm.replay(r, world, rec, first_frame=s_, stride=depth_in_flight) for s_ in range(depth_in_flight)]
-        pipes = [NativeShardPipeline(xy, S, inits, P, comm=cm, fused_filter="sharded") for cm in comms]
+        comms = mk()                                         # (a fresh stream: the timed run starts aligned with the recording)
+        pipes = [NativeShardPipeline(xy, S, inits, P, comm=cm, fused_filter=fused_filter) for cm in comms]
         fs = NativeFrameStream(pipes, depth_in_flight)
         # the stream deals job j to slot j % depth; frame index = job % F; with F a multiple of the depth slot s sees frames s, s + depth, ...
         t = sustained(fs, lambda f: (d[f], c[f]))
@@ -614,7 +624,7 @@ def emulate_world(torch, world, ranks, S, F, steps, depth_in_flight=4):
     t_one = sustained(fs, lambda f: (d[f], c[f]))
     fs.close()
     slowest = max(v["ms_per_frame"] for v in per_rank.values())
-    return {"world": world, "sensors": S, "frames_in_flight": depth_in_flight, "steps": steps, "one_gpu_ms_per_frame": round(t_one * 1e3, 4),
+    return {"world": world, "sensors": S, "fused_filter": fused_filter, "frames_in_flight": depth_in_flight, "steps": steps, "one_gpu_ms_per_frame": round(t_one * 1e3, 4),
             "one_gpu_Mpoints_s": round(S * N_PX / t_one / 1e6, 1), "ranks": per_rank, "slowest_measured_rank_ms": slowest,
             "projected_factor_compute_only": round(t_one * 1e3 / slowest, 2),
             "projected_Mpoints_s_compute_only": round(S * N_PX / (slowest * 1e-3) / 1e6, 1),
@@ -631,7 +641,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--partition", choices=["sensor", "group", "frame"], default="sensor")
     ap.add_argument("--sensors", type=int, default=0, help="sensors of the rig (--partition sensor); 0 = 4, or 8 at 8 GPUs")
-    ap.add_argument("--fused-filter", choices=["sharded", "rank0"], default="sharded")
+    ap.add_argument("--fused-filter", choices=["sharded", "rank0", "round_robin"], default="round_robin",
+                    help="the fused cloud's filter on several GPUs: sharded by slab (every rank ends with the frame), on rank 0, or frame f on rank f mod world")
     ap.add_argument("--sensors-per-gpu", type=int, default=4, help="--partition group only")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic time frames cycled through")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="0 disables the cpu_baseline leg")
@@ -673,7 +684,7 @@ def main():
         W = args.emulate_world
         S_e = args.sensors or max(W, 4)
         out = emulate_world(torch, W, [int(x) for x in args.emulate_ranks.split(",") if x != ""], S_e, 8, max(20, args.steps),
-                            depth_in_flight=args.overlap if args.overlap in (1, 2, 4, 6, 8) else 4)
+                            depth_in_flight=args.overlap if args.overlap in (1, 2, 4, 6, 8) else 4, fused_filter=args.fused_filter)
         print(json.dumps({"metric": "emulated per-rank frame time, sensor partition", "emulate_world": out}))
         return
     rank, world, local = parallel.init_distributed()
@@ -716,7 +727,7 @@ def main():
         elif native:                                # one GPU: the whole frame loop is ONE native call per frame (kpx_frame_step)
             pipes = [NativeFramePipeline(xy, S, inits, P, out_ring=2) for _ in groups]     # per-slot output buffers: no allocator traffic per frame
         else:
-            pipes = [SensorShardPipeline(xy, S, inits, P, group=g, fused_filter=args.fused_filter) for g in groups]
+            pipes = [SensorShardPipeline(xy, S, inits, P, group=g, fused_filter="sharded" if args.fused_filter == "round_robin" else args.fused_filter) for g in groups]
         pipe = pipes[0]
         px_per_step = (world if frame_mode else 1) * S * N_PX      # sensor partition: whole rig, all ranks together; frame partition: a frame per rank
         local_inits = inits

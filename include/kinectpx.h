@@ -403,8 +403,8 @@ int kpx_comm_create_callbacks(int32_t rank, int32_t world, kpx_bcast_fn bcast, k
  * collective c (0 master broadcast -- root's entry only --, 1 cloud exchange, 2 slab all-gather) of recorded frame f.  Call n of the
  * communicator is collective n % 3 of frame (first_frame + stride * (n / 3)) % frames.  Message sizes must be the recording's (both
  * runs with KPX_SHARD_FIXED_CAP=1).  Replaces nothing of the reference: it prices a rank's share of preprocessing/data.py:35-61. */
-int kpx_comm_create_replay(int32_t rank, int32_t world, int32_t frames, int32_t first_frame, int32_t stride, const void *const *d_payloads,
-                           const size_t *bytes, kpx_comm **out);
+int kpx_comm_create_replay(int32_t rank, int32_t world, int32_t frames, int32_t first_frame, int32_t stride, int32_t per_frame,
+                           const void *const *d_payloads, const size_t *bytes, kpx_comm **out);      /* per_frame: 3, or 2 for frames without collective 2 */
 int kpx_comm_destroy(kpx_comm *comm);
 int kpx_comm_rank(const kpx_comm *comm);
 int kpx_comm_world(const kpx_comm *comm);
@@ -435,7 +435,8 @@ int kpx_order_log(kpx_order *order, int64_t *out, int64_t cap, int64_t *count);
 /* kpx_frame_step for the rank's share of the rig.  depth / rgb: the images of THIS rank's sensors (sensor order), on the device or
  * (host_input != 0) in host memory; h_init: the sensors - 1 initial transforms of ALL sub sensors; fused_filter 0 = the filter on
  * the fused cloud is sharded over the ranks by slabs of its grid order (every rank ends with the filtered frame, bit-identical to
- * the one-GPU filter), 1 = rank 0 filters alone (the others return *h_count = 0).  h_T f64 [sensors][16] and h_info describe the
+ * the one-GPU filter), 1 = rank 0 filters alone (the others return *h_count = 0), 2 = frame f's fused pass and filter run on rank
+ * f mod world alone (f: the kpx_order's frame number; the owner returns the frame, the others 0 rows).  h_T f64 [sensors][16] and h_info describe the
  * WHOLE rig on every rank (they travel in the exchange headers).  Message capacities adapt to the slot's previous frame; when a
  * frame outgrows one, every rank returns KPX_RETRY (1) and the caller runs the frame again (a new frame number under a kpx_order).
  * Workspace: kpx_frame_step_sharded_workspace_bytes(sensors, rank, world, n_px, host_input). */

@@ -84,7 +84,7 @@ SIGNATURES = {
     "kpx_rccl_unique_id": (C.c_int, [_vp]),
     "kpx_comm_create_rccl": (C.c_int, [_vp, _i32, _i32, _vp]),
     "kpx_comm_create_callbacks": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp]),
-    "kpx_comm_create_replay": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "kpx_comm_create_replay": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "kpx_comm_destroy": (C.c_int, [_vp]),
     "kpx_comm_rank": (C.c_int, [_vp]),
     "kpx_comm_world": (C.c_int, [_vp]),

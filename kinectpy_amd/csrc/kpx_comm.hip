@@ -61,7 +61,7 @@ struct kpx_comm {
     // replay transport (kpx_comm_create_replay): what every rank SENT in every collective of `frames` recorded frames
     std::vector<const void *> rp_ptr;
     std::vector<size_t> rp_bytes;
-    int rp_frames = 0, rp_first = 0, rp_stride = 1;
+    int rp_frames = 0, rp_first = 0, rp_stride = 1, rp_per = 3;
     long long rp_calls = 0;
     // slot memory (kpx_frame_step_sharded): rows of the master broadcast / the cloud exchange, 0 = not seen a frame yet
     int64_t cap_master = 0, cap_clouds = 0;
@@ -128,19 +128,20 @@ KPX_EXPORT int kpx_comm_create_callbacks(int32_t rank, int32_t world, kpx_bcast_
 
 // Replay transport -- a MEASUREMENT aid (bench.py --emulate-world): the collectives of ONE rank of a `world`-rank job on one GPU, the
 // peers' contributions taken from recordings of a real `world`-rank run (in-process ranks) over `frames` frames: entry
+// (per_frame = 3; 2: frames without the slab all-gather, fused_filter 1 / 2)
 // [(f * 3 + c) * world + r] = what rank r sent in collective c (0 master broadcast: root's entry only, 1 cloud exchange, 2 slab
 // all-gather) of frame f, in device memory.  The communicator counts its calls: call n is collective n % 3 of frame
 // (first_frame + stride * (n / 3)) % frames -- the frames a slot of a kpx_stream sees (slot s of depth d: first_frame = s,
 // stride = d).  The message sizes must be those of the recording: both runs use fixed worst-case capacities (KPX_SHARD_FIXED_CAP=1).
-KPX_EXPORT int kpx_comm_create_replay(int32_t rank, int32_t world, int32_t frames, int32_t first_frame, int32_t stride, const void *const *d_payloads,
-                                      const size_t *bytes, kpx_comm **out)
+KPX_EXPORT int kpx_comm_create_replay(int32_t rank, int32_t world, int32_t frames, int32_t first_frame, int32_t stride, int32_t per_frame,
+                                      const void *const *d_payloads, const size_t *bytes, kpx_comm **out)
 {
-    KPX_REQUIRE(out && d_payloads && bytes && world >= 1 && rank >= 0 && rank < world && frames >= 1 && first_frame >= 0 && stride >= 1,
-                "kpx_comm_create_replay: bad arguments");
+    KPX_REQUIRE(out && d_payloads && bytes && world >= 1 && rank >= 0 && rank < world && frames >= 1 && first_frame >= 0 && stride >= 1 &&
+                (per_frame == 2 || per_frame == 3), "kpx_comm_create_replay: bad arguments");
     kpx_comm *k = new kpx_comm();
     k->rank = rank;
     k->world = world;
-    k->rp_frames = frames; k->rp_first = first_frame; k->rp_stride = stride;
+    k->rp_frames = frames; k->rp_first = first_frame; k->rp_stride = stride; k->rp_per = per_frame;
     const size_t n = (size_t)frames * 3 * (size_t)world;
     k->rp_ptr.assign(d_payloads, d_payloads + n);
     k->rp_bytes.assign(bytes, bytes + n);
@@ -150,9 +151,9 @@ KPX_EXPORT int kpx_comm_create_replay(int32_t rank, int32_t world, int32_t frame
 static int replay_entry(kpx_comm *c, int want_c, size_t *base)
 {
     const long long n = c->rp_calls++;
-    const int col = (int)(n % 3);
+    const int col = (int)(n % c->rp_per);
     if (col != want_c) return fail(KPX_ERR_INVALID, "replay transport: call %lld is collective %d of its frame, the recording has %d there", n, want_c, col);
-    const long long f = ((long long)c->rp_first + (long long)c->rp_stride * (n / 3)) % c->rp_frames;
+    const long long f = ((long long)c->rp_first + (long long)c->rp_stride * (n / c->rp_per)) % c->rp_frames;
     *base = ((size_t)f * 3 + (size_t)col) * (size_t)c->world;
     return KPX_OK;
 }
@@ -208,7 +209,7 @@ KPX_EXPORT int kpx_comm_allgather(kpx_comm *c, const void *d_send, void *d_recv,
     }
     if (c->rp_frames) {
         size_t base;
-        const int col = (int)(c->rp_calls % 3);
+        const int col = (int)(c->rp_calls % c->rp_per);
         const int rc = replay_entry(c, col == 0 ? 1 : col, &base);
         if (rc) return rc;
         for (int r = 0; r < c->world; ++r) {

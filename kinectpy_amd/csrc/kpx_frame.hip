@@ -416,7 +416,12 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     KPX_REQUIRE(depth && rgb && xy_table && prm && out_pts && out_col && h_count && h_T && ws, "kpx_frame_step_sharded: null pointer");
     KPX_REQUIRE(S == 1 || h_init, "kpx_frame_step_sharded: initial transforms missing");
     KPX_REQUIRE(prm->icp_mode == KPX_ICP_POINT_TO_POINT || prm->icp_mode == KPX_ICP_POINT_TO_PLANE, "kpx_frame_step_sharded: bad icp_mode");
-    KPX_REQUIRE(fused_filter == 0 || fused_filter == 1, "kpx_frame_step_sharded: fused_filter is 0 (sharded) or 1 (rank 0)");
+    KPX_REQUIRE(fused_filter >= 0 && fused_filter <= 2, "kpx_frame_step_sharded: fused_filter is 0 (sharded), 1 (rank 0) or 2 (the frames' fuse + filter dealt round robin)");
+    // fused_filter 2 (round 5): frame f's fused transform + voxel + filter run on ONE rank, f mod world, the others are done behind the
+    // exchange -- the sharded form repeats the fused pass and the filter's grid on every rank (~170 us of a rank's ~790 us of kernel
+    // time per frame, bench.py --emulate-world 8); dealt round robin every rank does them for one frame in `world`.  The frame number is
+    // the kpx_order's (the same on every rank; without an order: rank 0 owns every frame).  The owner returns the frame; the others 0 rows.
+    const int owner = fused_filter == 2 ? (int)((frame < 0 ? 0 : frame) % world) : 0;
     KPX_REQUIRE(prm->filt_k <= KPX_SOR_LDS_K && prm->normals_nn <= KPX_NORMALS_LDS_NN, "kpx_frame_step_sharded: filt_k <= %d and normals_nn <= %d", KPX_SOR_LDS_K,
                 KPX_NORMALS_LDS_NN);
     hipStream_t st = (hipStream_t)stream;
@@ -487,19 +492,30 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
     int64_t &cap_m = comm_cap_master(comm);
     if (cap_m <= 0 || fixed_cap) cap_m = n_px;
     const int64_t capm = cap_m;
+    // Round 5: the normals travel again (KPX_SHARD_NORMALS=1: round 4's form) -- rank 0 estimates them once and ships them as the message's second
+    // half (cap rows xyz | cap rows normal | header).  Round 4 took them out because rank 0's ~0.1 ms in front of the broadcast was
+    // serial for every rank; with the collective order's own lookahead (kpx_stream) the broadcast of a frame is two frames ahead of the
+    // exchanges that wait, and what counts is the kernel time a rank spends per frame: the estimate (grid build + search, ~150 us) on
+    // ONE rank -- the one without a registration of its own -- instead of on all of them.  Same kernels on the same array: the same
+    // normals bit for bit either way.  Measured with bench.py --emulate-world 8.
+    static const bool normals_travel = [] { const char *e = getenv("KPX_SHARD_NORMALS"); return !(e && e[0] == '1'); }();      // 1: every rank estimates them (round 4)
+    const bool ship_n = normals_travel && plane && world > 1;
+    const size_t row_b = ship_n ? 24 : 12;
     char *msg = L.msg_master;
-    float *m_xyz = reinterpret_cast<float *>(msg);
-    double *m_hdr = reinterpret_cast<double *>(msg + (size_t)capm * 12);
+    float *m_xyz = reinterpret_cast<float *>(msg), *m_nrm = reinterpret_cast<float *>(msg + (size_t)capm * 12);
+    double *m_hdr = reinterpret_cast<double *>(msg + (size_t)capm * row_b);
     if (owns_master) {
+        if (!lerr && ship_n) lerr = kpx_estimate_normals(L.down_pts, dk[0], 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st);
         if (!lerr) {
             const size_t rows = (size_t)(dk[0] < capm ? dk[0] : capm);
             KPX_HIP(hipMemcpyAsync(m_xyz, L.down_pts, rows * 12, hipMemcpyDeviceToDevice, st));
+            if (ship_n) KPX_HIP(hipMemcpyAsync(m_nrm, L.normals, rows * 12, hipMemcpyDeviceToDevice, st));
         }
         h_d[0] = lerr ? -1.0 : (double)dk[0];                   // a negative count: rank 0 cannot provide the master (every rank returns)
         KPX_HIP(hipMemcpyAsync(m_hdr, h_d, sizeof(double), hipMemcpyHostToDevice, st));
     }
     kpx_order_turn_begin(order, frame, 0);
-    int rc = kpx_comm_broadcast(comm, msg, (size_t)capm * 12 + 256, 0, st);
+    int rc = kpx_comm_broadcast(comm, msg, (size_t)capm * row_b + 256, 0, st);
     kpx_order_turn_end(order, frame, 0);
     if (rc) return rc;
     if (owns_master && lerr) {                                 // (the message of `lerr` is the thread's last error)
@@ -532,10 +548,10 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
             subs[(size_t)j] = p_out[(size_t)i];
             ns[(size_t)j] = dk[(size_t)i];
         }
-        const float *tgt = owns_master ? L.down_pts : m_xyz, *tn = plane ? L.normals : nullptr;
+        const float *tgt = owns_master ? L.down_pts : m_xyz, *tn = plane ? ((ship_n && !owns_master) ? m_nrm : L.normals) : nullptr;
         // (a failure here is this rank's alone: it keeps its place in collective 1 with a negative count -- `lerr` -- and every rank
         // returns together; returning from here would leave the peers spinning in the all-gather)
-        if (plane) lerr = kpx_estimate_normals(tgt, m, 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st);
+        if (plane && !ship_n) lerr = kpx_estimate_normals(tgt, m, 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st);
         const int first_sub = g0 + (owns_master ? 1 : 0);      // global sensor number of subs[0]; h_init[g - 1] belongs to sensor g
         if (!lerr)
             lerr = icp_batch_ordered(n_sub, subs.data(), ns.data(), tgt, tn, m, prm->icp_max_dist, h_init + 16 * (size_t)(first_sub - 1), prm->icp_mode,
@@ -607,7 +623,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
         kpx_order_finish(order, frame);
         return KPX_RETRY;
     }
-    if (fused_filter == 1 && rank != 0) {                      // rank 0 filters alone: the others are done with this frame
+    if (fused_filter >= 1 && rank != owner) {                  // the owner filters alone: the others are done with this frame
         kpx_order_skip(order, frame, 2);
         return KPX_OK;
     }
@@ -635,7 +651,7 @@ KPX_EXPORT int kpx_frame_step_sharded(kpx_comm *comm, kpx_order *order, int64_t 
         kpx_order_skip(order, frame, 2);
         return KPX_OK;
     }
-    if (fused_filter == 1) {                                   // rank 0, alone: the one-GPU filter + selection
+    if (fused_filter >= 1) {                                   // the owner, alone: the one-GPU filter + selection
         kpx_order_skip(order, frame, 2);
         KPX_SUB(kpx_sor_select(L.vox_pts, L.vox_col, M, prm->filt_k, prm->filt_ratio, out_pts, out_col, L.keep_idx, h_i + 49, L.sor_stats, L.op_ws, L.op_bytes, st));
         KPX_SUB(frame_wait(st));

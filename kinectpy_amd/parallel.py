@@ -332,26 +332,26 @@ class NativeComm:
         return cls._callbacks(rank, hub.world, bcast, allgather)
 
     @classmethod
-    def replay(cls, rank, world, recordings, first_frame=0, stride=1):
+    def replay(cls, rank, world, recordings, first_frame=0, stride=1, per_frame=3):
         """ONE rank of a `world`-rank job, the peers' messages played back (kpx_comm_create_replay): recordings[r] = the list
         NativeComm.local(..., record=) filled on rank r, three entries per frame (master broadcast, cloud exchange, slab all-gather).
         Call n of the communicator is collective n % 3 of frame (first_frame + stride * (n // 3)) % frames."""
         import ctypes as C
         from . import _lib
         L = _lib.load()
-        frames = len(recordings[0]) // 3
+        frames = len(recordings[0]) // per_frame           # (per_frame = 2: frames without the slab all-gather -- fused_filter rank0 / round robin)
         n = frames * 3 * world
         ptrs, sizes, keep = (C.c_void_p * n)(), (C.c_size_t * n)(), []
         for f in range(frames):
             for c in range(3):
                 for r in range(world):
-                    t = recordings[r][3 * f + c]
+                    t = recordings[r][per_frame * f + c] if c < per_frame else None
                     i = (f * 3 + c) * world + r
                     ptrs[i] = None if t is None else t.data_ptr()
                     sizes[i] = 0 if t is None else t.numel()
                     keep.append(t)
         h = C.c_void_p()
-        _lib.check(L.kpx_comm_create_replay(int(rank), int(world), frames, int(first_frame), int(stride), C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), C.byref(h)))
+        _lib.check(L.kpx_comm_create_replay(int(rank), int(world), frames, int(first_frame), int(stride), int(per_frame), C.cast(ptrs, C.c_void_p), C.cast(sizes, C.c_void_p), C.byref(h)))
         return cls(h, rank, world, keep=(keep, ptrs, sizes))
 
     def close(self):

@@ -280,8 +280,8 @@ class NativeShardPipeline:
         if len(init_transforms) != self.n_sensors - 1:
             raise ValueError("init_transforms: one 4x4 per sub sensor (sensors 1 .. n-1)")
         self.init = [np.asarray(T, dtype=np.float64) for T in init_transforms]
-        if fused_filter not in ("rank0", "sharded"):
-            raise ValueError("fused_filter must be 'rank0' or 'sharded'")
+        if fused_filter not in ("rank0", "sharded", "round_robin"):
+            raise ValueError("fused_filter must be 'rank0', 'sharded' or 'round_robin'")
         self.fused_filter = fused_filter
         self.xy = ops._dev(xy_table, torch.float32).reshape(-1)
         p = self.p
@@ -308,7 +308,7 @@ class NativeShardPipeline:
         order, frame = self.order if self.order is not None else (None, None)
         while True:
             res = ops.frame_step_sharded(self.comm, order, frame, depth, rgb, self.xy, S, self.init, self._c,
-                                         1 if self.fused_filter == "rank0" else 0, out=out)
+                                         {"sharded": 0, "rank0": 1, "round_robin": 2}[self.fused_filter], out=out)
             if res is not _lib.RETRY:
                 break
             self.retries += 1
@@ -458,7 +458,7 @@ class NativeFrameStream:
         comms = None
         if self.sharded:
             comms = (C.c_void_p * self.depth)(*[getattr(p_.comm.handle, "value", p_.comm.handle) for p_ in self.pipes])
-        fused = 1 if (self.sharded and p0.fused_filter == "rank0") else 0
+        fused = {"sharded": 0, "rank0": 1, "round_robin": 2}[p0.fused_filter] if self.sharded else 0
         h = C.c_void_p()
         with torch.cuda.device(self.dev):
             torch.cuda.synchronize()                  # the table and the workspace exist before a worker's stream touches them

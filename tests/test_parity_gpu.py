@@ -1461,6 +1461,24 @@ def test_native_sharded_loop_through_the_native_stream(four_sensor_oracle):
                 assert np.array_equal(p, rp) and np.array_equal(c, rc), (world, r, f)
 
 
+def test_native_sharded_loop_round_robin_filter(four_sensor_oracle):
+    """fused_filter 2 (round 5): frame f's fused transform + voxel + filter run on rank f mod world alone -- 4 in-process ranks, three
+    frames in flight through the native stream: for every frame exactly one rank returns the oracle's frame, the others no rows, and
+    every rank reports the same transforms."""
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    frames = (0, 1, 1, 0, 1, 0)
+    res = _local_ranks(4, 4, xy, depth, rgb, inits, "round_robin", frames=frames, slots=3, native_stream=True)
+    for j, f in enumerate(frames):
+        rp, rc, rT, aux = ref[f]
+        for r in range(4):
+            p, c, Ts, _ = res[r][j]
+            assert np.abs(Ts - np.stack(rT)).max() < TOL_T
+            if r == j % 4:
+                assert np.array_equal(p, rp) and np.array_equal(c, rc), (j, r)
+            else:
+                assert p.shape[0] == 0, (j, r)
+
+
 def test_native_sharded_loop_eight_ranks_eight_sensors(oracle):
     """BASELINE configs[4]'s partition -- 8 sensors, one per rank, 8 ranks -- through the native loop (in-process ranks sharing this
     GPU): k_max = 1 headers, rank 0 owns only the master (no registration of its own), seven ranks register one sub each, the
