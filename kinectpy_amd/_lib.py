@@ -6,6 +6,7 @@ there is no CPU fallback.  PyTorch-ROCm tensors are used only as the device-memo
 """
 import ctypes as C
 import threading
+import weakref
 import os
 
 import torch
@@ -224,7 +225,26 @@ def workspace(nbytes):
         ws = _ws.get(key)
         if ws is None:
             ws = _ws[key] = Workspace()
+            if not stream:
+                # a null-stream scratch belongs to its host thread: it goes when the thread does (a pool of short-lived threads calling
+                # operators on the default stream would otherwise leave hundreds of MB per thread behind)
+                token = getattr(_tls, "token", None)
+                if token is None:
+                    token = _tls.token = _ThreadToken()
+                weakref.finalize(token, _drop_key, key)
         return ws.get(nbytes)                       # (growing under the lock: a reallocation must not race with another thread's get)
+
+
+class _ThreadToken:
+    """lives in a thread's local storage; collected when the thread ends"""
+
+
+_tls = threading.local()
+
+
+def _drop_key(key):
+    with _ws_lock:
+        _ws.pop(key, None)
 
 
 def release_workspace(stream_handle, dev=None):

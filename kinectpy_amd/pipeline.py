@@ -11,6 +11,7 @@ from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 import contextlib
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -345,7 +346,10 @@ class FrameStream:
         native = self.pipes is not None and all(getattr(p_, "native_order", False) for p_ in self.pipes)
         ordered = self.pipes is not None and self.depth > 1 and all(hasattr(p_, "order") for p_ in self.pipes) and \
             (native or parallel.collectives_on(getattr(self.pipes[0], "group", None)))
-        self.order = parallel.CollectiveOrder(self.depth, native=native) if ordered else None
+        # (round 5: the order's lookahead is its own number -- frame f's exchange goes behind the broadcast of frame f + lookahead, not
+        # f + depth - 1: with every slot busy that frame cannot start before f - 1 has been collected)
+        look = int(os.environ.get("KPX_ORDER_LOOKAHEAD", "2"))
+        self.order = parallel.CollectiveOrder(max(1, min(self.depth, look + 1)), native=native) if ordered else None
 
     def _run(self, slot, depth, rgb, frame=None):
         torch.cuda.set_device(self.device)
