@@ -308,8 +308,13 @@ def roofline_targets(torch, ops, quick=False):
     ms, hs = ev_timed(torch, lambda: ops.halfspace_select(big, [0.1, -0.9, 0.2, 300.0]))
     hbm("halfspace_select (a19)", "compact_pts_*", ms, n_big * 12 + int(hs.shape[0]) * 4, points=n_big)
     ms, (lo_, up_) = ev_timed(torch, lambda: ops.slab_split(big, 200.0))
-    hbm("slab_split (a20)", "bbox + compact_pts_*", ms, n_big * 12 + n_big * 4, points=n_big)
-    del big, idx, hs, lo_, up_
+    hbm("slab_split (a20), cold: a bounds pass for max(y), then the split", "bbox_partial_vec + compact_pts_*", ms, n_big * 12 + n_big * 4, points=n_big)
+    ms, bb_ = ev_timed(torch, lambda: ops.bounds(big))
+    hbm("bounds (get_min_bound / get_max_bound, the max(y) of floor_removal.py:65)", "bbox_partial_vec_kernel", ms, n_big * 12, points=n_big)
+    ms, (lo_, up_) = ev_timed(torch, lambda: ops.slab_split(big, 200.0, bounds=bb_))
+    hbm("slab_split (a20)", "compact_pts_* (max(y) from the bounds the producing gather left with the cloud, as remove_floor calls it)", ms,
+        n_big * 12 + n_big * 4, points=n_big)
+    del big, idx, hs, lo_, up_, bb_
     # ---- HBM: voxel_down_sample of 64 clouds of 1M points (1.5 GB with colours)
     nc = 16 if quick else 64
     c3 = torch.as_tensor(synth.filter_cloud(1_000_000)).to(dev)

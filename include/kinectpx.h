@@ -108,6 +108,16 @@ int kpx_select_by_index(const float *a0, const float *a1, const float *a2, int64
                         int64_t n_idx, int32_t invert, float *o0, float *o1, float *o2, int32_t *d_count,
                         void *ws, size_t ws_bytes, void *stream);
 
+/* The same gather (KPX_SELECT_GATHER) that also leaves the bounds of the points it wrote -- min x, y, z, max x, y, z as six doubles at
+ * d_bbox6 -- so that the selected cloud's next consumer (kpx_slab_split_bounded: floor_removal.py:64-66 takes max(y) of the cloud it just
+ * filtered) needs no pass of its own for them.  n_idx > 0; workspace: kpx_select_workspace_bytes(n). */
+int kpx_select_by_index_bounds(const float *a0, const float *a1, const float *a2, int64_t n, const int32_t *idx, int64_t n_idx,
+                               float *o0, float *o1, float *o2, double *d_bbox6, void *ws, size_t ws_bytes, void *stream);
+/* Open3D get_min_bound / get_max_bound, numpy's pcd_points[:, 1].max() (floor_removal.py:65-66): min x, y, z, max x, y, z of an
+ * (n,3) f32 cloud as six doubles in device memory.  n > 0. */
+size_t kpx_bounds_workspace_bytes(void);
+int kpx_bounds(const float *pts, int64_t n, double *d_bbox6, void *ws, size_t ws_bytes, void *stream);
+
 /* Stable sort of (key, value) pairs by the low end_bit (1..32) bits of the key -- the ordering step behind a7 / a8 / a11 (voxel keys,
  * grid cells, Morton codes; the reference gets it from Open3D's hash maps and np.argsort).  Inputs are not modified and may not
  * alias the outputs. */
@@ -122,6 +132,10 @@ int kpx_halfspace_select(const float *pts, int64_t n, const double *h_plane, int
 /* floor_removal.py:64-66: y >= max(y) - slab  -> lower indices, y < max(y) - slab -> upper indices. */
 int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t *lower_idx, int32_t *d_lower,
                    int32_t *upper_idx, int32_t *d_upper, void *ws, size_t ws_bytes, void *stream);
+/* The same split for a cloud whose bounds are already in device memory (d_bbox6 as written by kpx_bounds or
+ * kpx_select_by_index_bounds; only max y, d_bbox6[4], is read): one pass over the points instead of two. */
+int kpx_slab_split_bounded(const float *pts, int64_t n, double slab, const double *d_bbox6, int32_t *lower_idx, int32_t *d_lower,
+                           int32_t *upper_idx, int32_t *d_upper, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- filter stage ------------------------------------------------------------------------------ */
 

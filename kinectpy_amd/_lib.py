@@ -35,6 +35,10 @@ SIGNATURES = {
     "kpx_select_by_index": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_halfspace_select": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_slab_split": (C.c_int, [_vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_slab_split_bounded": (C.c_int, [_vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_select_by_index_bounds": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kpx_bounds_workspace_bytes": (C.c_size_t, []),
+    "kpx_bounds": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "kpx_voxel_workspace_bytes": (_sz, [_i64]),
     "kpx_voxel_downsample": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kpx_voxel_batch_workspace_bytes": (_sz, [_i32, _vp]),

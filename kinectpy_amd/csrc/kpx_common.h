@@ -253,10 +253,9 @@ __global__ __launch_bounds__(kCompactThreads) void compact_count_kernel(Pred pre
 // one block per frame: exclusive scan of the per-tile counts in place, total -> d_count[frame].  A round scans 8 counts
 // per thread (one 3-barrier block scan per 8 x blockDim tiles; a 64M-point selection has 31250 tiles).
 static inline int compact_scan_threads(int64_t tiles) { return tiles > 2048 ? 1024 : 256; }
-static __global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t *block_counts, int32_t nblocks, int32_t *d_count)
+static __device__ __forceinline__ void compact_scan_body(int32_t *bc, int32_t nblocks, int32_t *d_count_slot)
 {
     __shared__ int sh[1024 / 64 + 1];
-    int32_t *bc = block_counts + (int64_t)blockIdx.x * nblocks;
     int carry = 0;
     for (int32_t b0 = 0; b0 < nblocks; b0 += 8 * (int32_t)blockDim.x) {
         const int32_t b = b0 + 8 * (int32_t)threadIdx.x;
@@ -273,7 +272,17 @@ static __global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t *bloc
         carry += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && d_count) d_count[blockIdx.x] = carry;
+    if (threadIdx.x == 0 && d_count_slot) *d_count_slot = carry;
+}
+static __global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t *block_counts, int32_t nblocks, int32_t *d_count)
+{
+    compact_scan_body(block_counts + (int64_t)blockIdx.x * nblocks, nblocks, d_count ? d_count + blockIdx.x : nullptr);
+}
+// the two lists of one predicate pass (slab split) side by side: block 0 scans list A, block 1 list B
+static __global__ __launch_bounds__(1024) void compact_scan2_kernel(int32_t *counts_a, int32_t *counts_b, int32_t nblocks, int32_t *d_count_a,
+                                                                    int32_t *d_count_b)
+{
+    compact_scan_body(blockIdx.x ? counts_b : counts_a, nblocks, blockIdx.x ? d_count_b : d_count_a);
 }
 
 template <class Pred, class Emit>
@@ -357,12 +366,17 @@ __global__ __launch_bounds__(kCompactThreads) void compact_pts_flag_kernel(const
         if (TWO) counts_b[blockIdx.x] = tb;
     }
 }
+// blockIdx.y == 1: the second list of a two-list pass (*_b; NULL for one list)
 static __global__ __launch_bounds__(kCompactThreads) void compact_flags_scatter_kernel(const uint8_t *__restrict__ flag_bytes,
                                                                                        const int32_t *__restrict__ block_offsets,
-                                                                                       int32_t *__restrict__ idx)
+                                                                                       int32_t *__restrict__ idx,
+                                                                                       const uint8_t *__restrict__ flag_bytes_b = nullptr,
+                                                                                       const int32_t *__restrict__ block_offsets_b = nullptr,
+                                                                                       int32_t *__restrict__ idx_b = nullptr)
 {
     __shared__ int sh[kCompactThreads / 64 + 1];
     __shared__ int32_t si[kCompactTile];
+    if (blockIdx.y) { flag_bytes = flag_bytes_b; block_offsets = block_offsets_b; idx = idx_b; }
     const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
     const unsigned flags = flag_bytes[(int64_t)blockIdx.x * kCompactThreads + threadIdx.x];
     int tot;
@@ -525,11 +539,14 @@ int compact_points(const float *pts, int64_t n, PredXYZ pred, int32_t *idx_a, in
     else
         hipLaunchKernelGGL((compact_pts_flag_kernel<PredXYZ, false>), dim3(tiles), dim3(kCompactThreads), 0, st, pts, n, pred, aligned, s.flags[0],
                            s.counts[0], s.flags[1], s.counts[1]);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(compact_scan_threads(tiles)), 0, st, s.counts[0], tiles, d_count_a);
-    hipLaunchKernelGGL(compact_flags_scatter_kernel, dim3(tiles), dim3(kCompactThreads), 0, st, s.flags[0], s.counts[0], idx_a);
-    if (idx_b) {
-        hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(compact_scan_threads(tiles)), 0, st, s.counts[1], tiles, d_count_b);
-        hipLaunchKernelGGL(compact_flags_scatter_kernel, dim3(tiles), dim3(kCompactThreads), 0, st, s.flags[1], s.counts[1], idx_b);
+    if (idx_b) {                                        // both lists in one scan launch and one scatter launch (round 5: five launches -> three)
+        hipLaunchKernelGGL(compact_scan2_kernel, dim3(2), dim3(compact_scan_threads(tiles)), 0, st, s.counts[0], s.counts[1], tiles, d_count_a, d_count_b);
+        hipLaunchKernelGGL(compact_flags_scatter_kernel, dim3(tiles, 2), dim3(kCompactThreads), 0, st, (const uint8_t *)s.flags[0], (const int32_t *)s.counts[0], idx_a,
+                           (const uint8_t *)s.flags[1], (const int32_t *)s.counts[1], idx_b);
+    } else {
+        hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(compact_scan_threads(tiles)), 0, st, s.counts[0], tiles, d_count_a);
+        hipLaunchKernelGGL(compact_flags_scatter_kernel, dim3(tiles), dim3(kCompactThreads), 0, st, (const uint8_t *)s.flags[0], (const int32_t *)s.counts[0], idx_a,
+                           (const uint8_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr);
     }
     KPX_LAUNCH_CHECK();
     return KPX_OK;

@@ -331,6 +331,13 @@ template <int L> __device__ __forceinline__ unsigned group_max_u(unsigned v)
 #ifndef KPX_SOR_CELL_MINW
 #define KPX_SOR_CELL_MINW 4
 #endif
+constexpr int kCellBuckets = 256;             // buckets of the counting selection (round 5)
+// doubles of LDS per group of L lanes: bucket counts, selection buffer, run table (32 starts, 32 offsets), the block's points; even, so
+// that every group's region starts on 16 bytes
+__host__ __device__ constexpr size_t sor_cell_group_doubles(int kbuf, int cap)
+{
+    return ((size_t)kCellBuckets / 2 + (size_t)kbuf + 32 + (size_t)(cap * 3 + 1) / 2 + 1) & ~(size_t)1;
+}
 constexpr int kCellQueries = 16;              // consecutive cell-sorted queries per wave and trip
 constexpr int kCellTieRoom = 32;              // candidates tied with the k-th beyond k the selection buffer still holds
 template <int L, int S, int W>
@@ -343,8 +350,9 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
     // per wave and group: a selection buffer of kbuf doubles, the run table of the group's block (32 starts, 32 offsets) and the block's
     // points (CAP x 3 floats)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane / L, gl = lane % L;
-    const size_t per_group = (size_t)kbuf + 32 + (size_t)(CAP * 3 + 1) / 2;
-    double *selbuf = lds + ((size_t)wave * G + grp) * per_group;
+    const size_t per_group = sor_cell_group_doubles(kbuf, CAP);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + ((size_t)wave * G + grp) * per_group);       // 256 bucket counts (16-byte aligned)
+    double *selbuf = reinterpret_cast<double *>(hist + kCellBuckets);
     uint32_t *run_s0 = reinterpret_cast<uint32_t *>(selbuf + kbuf);
     int32_t *run_off = reinterpret_cast<int32_t *>(run_s0 + 32);
     float *cand = reinterpret_cast<float *>(selbuf + kbuf + 32);
@@ -475,6 +483,7 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
                     unsigned a = group_min_u<L>(vmin), b = group_max_u<L>(vmax);
                     bool exact = false;                          // a pivot with exactly kk patterns at or below it was met
                     bool run = ok && a < b;
+#ifdef KPX_SOR_CELL_BISECT
                     while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
                         const unsigned mid = a + ((b - a) >> 1);
                         int c1 = 0;
@@ -488,6 +497,64 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
                         }
                         run = ok && a < b;
                     }
+#else
+                    // Round 5: by COUNTING instead of bisecting (a bisection step costs 2 S + 8 instructions and the high words span
+                    // ~2^23 values: ~24 steps).  The window [a, a + range] that holds the k-th is cut into <= 256 buckets of 2^shift;
+                    // every candidate inside adds one to its bucket (LDS atomics), lane gl sums its 256 / L buckets, a scan over the
+                    // group finds the bucket of the k-th, and the next level looks inside that bucket only.  It ends when a bucket is
+                    // one value wide, or -- nearly always after two levels -- when the k-th is the LAST of its bucket: then the bucket's
+                    // upper edge is a pivot with exactly kk patterns at or below it, the bisection's `exact` case.
+                    {
+                        constexpr int BPL = kCellBuckets / L;            // buckets per lane
+                        unsigned range = b - a;
+                        int need_k = kk;                                 // rank of the k-th inside the window, 1-based
+                        while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+                            const int shift = range >= 256u ? 24 - __builtin_clz(range) : 0;      // range >> shift <= 255
+                            uint4 *hz = reinterpret_cast<uint4 *>(hist + gl * BPL);
+#pragma unroll
+                            for (int w = 0; w < BPL / 4; ++w) hz[w] = make_uint4(0u, 0u, 0u, 0u);
+                            wave_lds_fence();
+#pragma unroll
+                            for (int sl = 0; sl < S; ++sl)
+                                if (sl * L < mmax) {
+                                    const unsigned rel = hi[sl] - a;
+                                    if (run && rel <= range) __hip_atomic_fetch_add(hist + (rel >> shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                            wave_lds_fence();
+                            unsigned hv[BPL];
+#pragma unroll
+                            for (int w = 0; w < BPL / 4; ++w) { const uint4 t4 = hz[w]; hv[4 * w] = t4.x; hv[4 * w + 1] = t4.y; hv[4 * w + 2] = t4.z; hv[4 * w + 3] = t4.w; }
+                            int lsum = 0;
+#pragma unroll
+                            for (int w = 0; w < BPL; ++w) lsum += (int)hv[w];
+                            int incl = lsum;
+#pragma unroll
+                            for (int o = 1; o < L; o <<= 1) { const int t2 = __shfl_up(incl, o, L); if (gl >= o) incl += t2; }
+                            const int excl = incl - lsum;
+                            const bool mine = run && need_k > excl && need_k <= incl;
+                            int B = -1, cb = 0, hb = 0;
+                            if (mine) {
+                                int cum = excl;
+#pragma unroll
+                                for (int w = 0; w < BPL; ++w) {
+                                    if (B < 0 && need_k <= cum + (int)hv[w]) { B = gl * BPL + w; cb = cum; hb = (int)hv[w]; }
+                                    cum += (int)hv[w];
+                                }
+                            }
+                            const unsigned long long bm = __builtin_amdgcn_ballot_w64(mine);
+                            const unsigned long long gm = L == 64 ? bm : ((bm >> (grp * L)) & ((1ull << (L & 63)) - 1ull));
+                            const int owner = gm ? __builtin_ctzll(gm) : 0;
+                            B = __shfl(B, owner, L); cb = __shfl(cb, owner, L); hb = __shfl(hb, owner, L);
+                            if (run) {
+                                if (B < 0) { ok = false; run = false; }                       // cannot happen (cnt >= kk); the query would go to the lists
+                                else if (need_k - cb == hb) {                                 // the k-th is the last of its bucket
+                                    a = a + (((unsigned)B + 1u) << shift) - 1u; exact = true; run = false;
+                                } else if (shift == 0) { a = a + (unsigned)B; run = false; }  // one value wide: THE k-th high word
+                                else { need_k -= cb; a += (unsigned)B << shift; range = (1u << shift) - 1u; }
+                            }
+                        }
+                    }
+#endif
                     const unsigned P = a;
                     unsigned Q = 0xFFFFFFFFu;
                     int n_le = kk;
@@ -787,7 +854,7 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
         if (cell_on && nq > 0) {
             const int kbuf = kk + kCellTieRoom;
             const int64_t chunks = cdiv(nq, kCellQueries);
-            auto bytes = [&](int cap, int groups, int waves) { return (size_t)waves * groups * ((size_t)kbuf + 32 + (size_t)(cap * 3 + 1) / 2) * 8; };
+            auto bytes = [&](int cap, int groups, int waves) { return (size_t)waves * groups * sor_cell_group_doubles(kbuf, cap) * 8; };
 #define KPX_SOR_CELL_LAUNCH(LL, SS, WW)                                                                                          \
             hipLaunchKernelGGL((sor_cell_kernel<LL, SS, WW>), dim3((unsigned)(cdiv(chunks, WW) > 32768 ? 32768 : cdiv(chunks, WW))), dim3(64 * WW), \
                                bytes(LL * SS, 64 / LL, WW), st, g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk, kbuf, avg, fb_list0, fb_count0)

@@ -188,6 +188,58 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
         part[(int64_t)blockIdx.x * 6 + threadIdx.x] = (double)v;
     }
 }
+// The same partial boxes from lane-contiguous 16-byte loads (pts 16-byte aligned): a wave reads 3 KiB = 256 points per chunk as three
+// loads of one contiguous KiB each, two chunks in flight.  Float e of the cloud belongs to axis e mod 3, and float 4 (192 c + 64 r + lane) + j
+// has e mod 3 = (r + lane + j) mod 3 -- so a lane folds into SLOT (r + j) mod 3 (known at compile time) and turns its three slots by
+// lane mod 3 once at the end.  (The one-point-per-trip kernel above read 64M points at 2.9 TB/s.)
+__global__ __launch_bounds__(256) void bbox_partial_vec_kernel(const float *__restrict__ pts, int64_t n, double *__restrict__ part)
+{
+    __shared__ float sh[6][4];
+    const int lane = lane_id(), wave = wave_id();
+    float smn[3] = { INFINITY, INFINITY, INFINITY }, smx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    const int64_t chunks = n / 256, wstride = (int64_t)gridDim.x * 4;
+    const float4 *src = reinterpret_cast<const float4 *>(pts);
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < chunks; c += 2 * wstride) {
+        const int64_t c2 = c + wstride < chunks ? c + wstride : c;          // the odd last trip folds its chunk twice
+        float4 v[6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { v[r] = src[c * 192 + 64 * r + lane]; v[3 + r] = src[c2 * 192 + 64 * r + lane]; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const float e[4] = { v[r].x, v[r].y, v[r].z, v[r].w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sl = (r % 3 + j) % 3;
+                smn[sl] = fminf(smn[sl], e[j]); smx[sl] = fmaxf(smx[sl], e[j]);
+            }
+        }
+    }
+    // slot c of this lane is axis (c + lane) mod 3
+    const int t = lane % 3;
+    float mn[3], mx[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = t == 0 ? smn[a] : (t == 1 ? smn[(a + 2) % 3] : smn[(a + 1) % 3]);
+        mx[a] = t == 0 ? smx[a] : (t == 1 ? smx[(a + 2) % 3] : smx[(a + 1) % 3]);
+    }
+    if (blockIdx.x == 0) {                                                   // the points behind the last whole chunk
+        const int64_t i = chunks * 256 + threadIdx.x;
+        if (i < n) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float v = pts[3 * i + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+    if (lane == 0)
+        for (int a = 0; a < 3; ++a) { sh[a][wave] = mn[a]; sh[3 + a][wave] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[threadIdx.x][w]) : fmaxf(v, sh[threadIdx.x][w]);
+        part[(int64_t)blockIdx.x * 6 + threadIdx.x] = (double)v;
+    }
+}
 __global__ __launch_bounds__(256) void bbox_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ bbox)
 {
     // min / max are exact and order-independent: thread t folds the partial rows t, t+256, ..., then waves, then LDS
@@ -286,7 +338,11 @@ int bbox_f32(const float *pts, int64_t n, double *d_bbox6, double *ws_partials, 
         return KPX_OK;
     }
     int nb = (int)(cdiv(n, 256 * 8) < 1 ? 1 : (cdiv(n, 256 * 8) > kBboxBlocks ? kBboxBlocks : cdiv(n, 256 * 8)));
-    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, st, pts, n, ws_partials);
+    static const bool scalar_only = [] { const char *e = getenv("KPX_BBOX_VEC"); return e && e[0] == '0'; }();         // A/B switch
+    if (((uintptr_t)pts % 16) == 0 && !scalar_only)
+        hipLaunchKernelGGL(bbox_partial_vec_kernel, dim3(nb), dim3(256), 0, st, pts, n, ws_partials);
+    else
+        hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(256), 0, st, pts, n, ws_partials);
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, st, ws_partials, nb, d_bbox6);
     KPX_LAUNCH_CHECK();
     return KPX_OK;
@@ -303,6 +359,37 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float *__restrict__ 
         if (a0) { o0[3 * k] = a0[3 * s]; o0[3 * k + 1] = a0[3 * s + 1]; o0[3 * k + 2] = a0[3 * s + 2]; }
         if (a1) { o1[3 * k] = a1[3 * s]; o1[3 * k + 1] = a1[3 * s + 1]; o1[3 * k + 2] = a1[3 * s + 2]; }
         if (a2) { o2[3 * k] = a2[3 * s]; o2[3 * k + 1] = a2[3 * s + 1]; o2[3 * k + 2] = a2[3 * s + 2]; }
+    }
+}
+// the gather of the first attribute (the points) that also leaves the partial boxes of what it wrote (rows of six doubles, one per block,
+// folded by bbox_final_kernel): the selected cloud's bounds cost no pass of their own (kpx_select_by_index_bounds)
+constexpr int kGatherBoundsBlocks = 4096;
+__global__ __launch_bounds__(256) void gather3_bounds_kernel(const float *__restrict__ a0, const float *__restrict__ a1,
+                                                             const float *__restrict__ a2, const int32_t *__restrict__ idx,
+                                                             int64_t n_idx, float *__restrict__ o0, float *__restrict__ o1,
+                                                             float *__restrict__ o2, double *__restrict__ part)
+{
+    __shared__ float sh[6][4];
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_idx; k += (int64_t)gridDim.x * blockDim.x) {
+        int64_t s = idx[k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = a0[3 * s + a];
+            o0[3 * k + a] = v; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v);
+        }
+        if (a1) { o1[3 * k] = a1[3 * s]; o1[3 * k + 1] = a1[3 * s + 1]; o1[3 * k + 2] = a1[3 * s + 2]; }
+        if (a2) { o2[3 * k] = a2[3 * s]; o2[3 * k + 1] = a2[3 * s + 1]; o2[3 * k + 2] = a2[3 * s + 2]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+    if (lane_id() == 0)
+        for (int a = 0; a < 3; ++a) { sh[a][wave_id()] = mn[a]; sh[3 + a][wave_id()] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[threadIdx.x][w]) : fmaxf(v, sh[threadIdx.x][w]);
+        part[(int64_t)blockIdx.x * 6 + threadIdx.x] = (double)v;
     }
 }
 __global__ __launch_bounds__(256) void mark_kernel(const int32_t *__restrict__ idx, int64_t n_idx, int64_t n, uint8_t *__restrict__ flag)
@@ -480,7 +567,42 @@ KPX_EXPORT size_t kpx_select_workspace_bytes(int64_t n)
     a.get<double>((size_t)kBboxBlocks * 6 + 8);
     CompactPtsScratch cs;
     compact_pts_carve(a, n, &cs);
+    a.get<double>((size_t)kGatherBoundsBlocks * 6);              // kpx_select_by_index_bounds' partial boxes
     return a.off;
+}
+KPX_EXPORT size_t kpx_bounds_workspace_bytes(void)
+{
+    Arena a(nullptr, 0);
+    a.get<double>((size_t)kBboxBlocks * 6);
+    return a.off;
+}
+KPX_EXPORT int kpx_bounds(const float *pts, int64_t n, double *d_bbox6, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n > 0 && pts && d_bbox6 && ws, "kpx_bounds: bad arguments");
+    Arena a(ws, ws_bytes);
+    double *part = a.get<double>((size_t)kBboxBlocks * 6);
+    KPX_ARENA_CHECK(a);
+    return bbox_f32(pts, n, d_bbox6, part, (hipStream_t)stream);
+}
+KPX_EXPORT int kpx_select_by_index_bounds(const float *a0, const float *a1, const float *a2, int64_t n, const int32_t *idx, int64_t n_idx,
+                                          float *o0, float *o1, float *o2, double *d_bbox6, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n >= 0 && n_idx > 0, "kpx_select_by_index_bounds: empty selection (an empty cloud has no bounds)");
+    KPX_REQUIRE(idx && a0 && o0 && d_bbox6 && ws, "kpx_select_by_index_bounds: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    a.get<uint8_t>((size_t)(n > 0 ? n : 1));
+    a.get<int32_t>((size_t)compact_ws_ints(n));
+    a.get<double>((size_t)kBboxBlocks * 6 + 8);
+    CompactPtsScratch cs;
+    compact_pts_carve(a, n, &cs);
+    double *part = a.get<double>((size_t)kGatherBoundsBlocks * 6);
+    KPX_ARENA_CHECK(a);
+    const int nb = grid_for(n_idx, 256, kGatherBoundsBlocks);
+    hipLaunchKernelGGL(gather3_bounds_kernel, dim3(nb), dim3(256), 0, st, a0, a1, a2, idx, n_idx, o0, o1, o2, part);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, st, part, nb, d_bbox6);
+    KPX_LAUNCH_CHECK();
+    return KPX_OK;
 }
 KPX_EXPORT int kpx_select_by_index(const float *a0, const float *a1, const float *a2, int64_t n, const int32_t *idx,
                                    int64_t n_idx, int32_t invert, float *o0, float *o1, float *o2, int32_t *d_count,
@@ -524,11 +646,10 @@ KPX_EXPORT int kpx_halfspace_select(const float *pts, int64_t n, const double *h
                           (hipStream_t)stream);
 }
 
-KPX_EXPORT int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t *lower_idx, int32_t *d_lower,
-                              int32_t *upper_idx, int32_t *d_upper, void *ws, size_t ws_bytes, void *stream)
+// d_bounds != NULL: the cloud's bounds are known (kpx_bounds, kpx_select_by_index_bounds): no pass over the points for max(y)
+static int slab_split_impl(const float *pts, int64_t n, double slab, const double *d_bounds, int32_t *lower_idx, int32_t *d_lower,
+                           int32_t *upper_idx, int32_t *d_upper, void *ws, size_t ws_bytes, hipStream_t st)
 {
-    KPX_REQUIRE(n > 0 && pts && lower_idx && upper_idx && d_lower && d_upper && ws, "kpx_slab_split: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
     Arena a(ws, ws_bytes);
     a.get<uint8_t>((size_t)n);
     a.get<int32_t>((size_t)compact_ws_ints(n));
@@ -537,7 +658,21 @@ KPX_EXPORT int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t 
     compact_pts_carve(a, n, &cs);
     KPX_ARENA_CHECK(a);
     double *bbox = part + (size_t)kBboxBlocks * 6;
-    int rc = bbox_f32(pts, n, bbox, part, st);
-    if (rc) return rc;
-    return compact_points(pts, n, SlabXYZ{ bbox, slab }, lower_idx, d_lower, upper_idx, d_upper, cs, st);      // one pass feeds both lists
+    if (!d_bounds) {
+        int rc = bbox_f32(pts, n, bbox, part, st);
+        if (rc) return rc;
+    }
+    return compact_points(pts, n, SlabXYZ{ d_bounds ? d_bounds : bbox, slab }, lower_idx, d_lower, upper_idx, d_upper, cs, st);      // one pass feeds both lists
+}
+KPX_EXPORT int kpx_slab_split(const float *pts, int64_t n, double slab, int32_t *lower_idx, int32_t *d_lower,
+                              int32_t *upper_idx, int32_t *d_upper, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n > 0 && pts && lower_idx && upper_idx && d_lower && d_upper && ws, "kpx_slab_split: bad arguments");
+    return slab_split_impl(pts, n, slab, nullptr, lower_idx, d_lower, upper_idx, d_upper, ws, ws_bytes, (hipStream_t)stream);
+}
+KPX_EXPORT int kpx_slab_split_bounded(const float *pts, int64_t n, double slab, const double *d_bbox6, int32_t *lower_idx, int32_t *d_lower,
+                                      int32_t *upper_idx, int32_t *d_upper, void *ws, size_t ws_bytes, void *stream)
+{
+    KPX_REQUIRE(n > 0 && pts && d_bbox6 && lower_idx && upper_idx && d_lower && d_upper && ws, "kpx_slab_split_bounded: bad arguments");
+    return slab_split_impl(pts, n, slab, d_bbox6, lower_idx, d_lower, upper_idx, d_upper, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -33,7 +33,8 @@ def remove_floor(pcd: PointCloud, slab=200, distance_threshold=30, ransac_n=30, 
                  nb_neighbors=50, std_ratio=0.30, seed=None) -> PointCloud:
     """Body of the reference's per-file loop (floor_removal.py:61-73): split at max(y)-slab, RANSAC
     plane on the lower slab, drop its inliers, concatenate with the upper part, SOR(50, 0.30)."""
-    idx_lower, idx_upper = ops.slab_split(pcd._pts, float(slab))
+    # max(y) from the cloud's bounds: left by the gather that produced the cloud (remove_statistical_outlier, _select) or one fast pass
+    idx_lower, idx_upper = ops.slab_split(pcd._pts, float(slab), bounds=pcd._device_bounds())
     floor = pcd._select(idx_lower)
     _, inliers = floor.segment_plane(distance_threshold=distance_threshold, ransac_n=ransac_n,
                                      num_iterations=num_iterations, seed=seed)

@@ -100,10 +100,15 @@ class OrientedBoundingBox:
 
 
 class PointCloud:
+    # _bounds: the cloud's min / max as a float64[6] DEVICE tensor once some kernel has computed them (the gather that produced the
+    # cloud, or the first get_*_bound / remove_floor); dropped whenever the points change
+    _bounds = None
+
     def __init__(self, points=None):
         self._pts = Vector3dVector(points).t
         self._col = None
         self._nrm = None
+        self._bounds = None
 
     # ---- attributes ---------------------------------------------------------------------------
     @property
@@ -113,6 +118,7 @@ class PointCloud:
     @points.setter
     def points(self, v):
         self._pts = Vector3dVector(v).t
+        self._bounds = None
 
     @property
     def colors(self):
@@ -145,10 +151,16 @@ class PointCloud:
         return f"PointCloud with {self._pts.shape[0]} points."
 
     @classmethod
-    def _make(cls, pts, col=None, nrm=None):
+    def _make(cls, pts, col=None, nrm=None, bounds=None):
         pc = cls.__new__(cls)
-        pc._pts, pc._col, pc._nrm = pts, col, nrm
+        pc._pts, pc._col, pc._nrm, pc._bounds = pts, col, nrm, bounds
         return pc
+
+    def _device_bounds(self):
+        """float64[6] device tensor (min x, y, z, max x, y, z), computed once per cloud"""
+        if self._bounds is None:
+            self._bounds = ops.bounds(self._pts)
+        return self._bounds
 
     def __deepcopy__(self, memo):
         return PointCloud._make(self._pts.clone(), None if self._col is None else self._col.clone(),
@@ -161,10 +173,14 @@ class PointCloud:
 
     # ---- Open3D methods on the path -----------------------------------------------------------
     def get_min_bound(self):
-        return self._pts.min(0).values.cpu().numpy().astype(np.float64)
+        if not self.has_points():
+            return np.zeros(3)
+        return self._device_bounds()[:3].cpu().numpy()
 
     def get_max_bound(self):
-        return self._pts.max(0).values.cpu().numpy().astype(np.float64)
+        if not self.has_points():
+            return np.zeros(3)
+        return self._device_bounds()[3:].cpu().numpy()
 
     def transform(self, T):
         """in place, returns self (preprocessing/data.py:48)"""
@@ -172,6 +188,7 @@ class PointCloud:
         if T.shape != (4, 4):
             raise RuntimeError("transform: expected a 4x4 matrix")
         if self.has_points():
+            self._bounds = None
             ops.transform(self._pts, T, out=self._pts)
             if self.has_normals():
                 ops.rotate(self._nrm, T, out=self._nrm)
@@ -186,8 +203,8 @@ class PointCloud:
 
     def _select(self, idx):
         """select_by_index for an index list produced by this library (ascending, duplicate-free, in range): one gather"""
-        p, c, n = ops.select_by_index(self._attrs(), idx, False, trusted=True)
-        return PointCloud._make(p, c, n)
+        (p, c, n), bb = ops.select_by_index(self._attrs(), idx, False, trusted=True, want_bounds=True)
+        return PointCloud._make(p, c, n, bb)
 
     def voxel_down_sample(self, voxel_size):
         if not voxel_size > 0:
@@ -202,8 +219,8 @@ class PointCloud:
         if not self.has_points():
             return PointCloud(), np.zeros(0, dtype=np.int32)
         idx, _, _ = ops.sor(self._pts, int(nb_neighbors), float(std_ratio))
-        p, c, n = ops.select_by_index(self._attrs(), idx, False, trusted=True)
-        return PointCloud._make(p, c, n), idx.cpu().numpy()
+        (p, c, n), bb = ops.select_by_index(self._attrs(), idx, False, trusted=True, want_bounds=True)
+        return PointCloud._make(p, c, n, bb), idx.cpu().numpy()
 
     def segment_plane(self, distance_threshold, ransac_n, num_iterations, probability=0.99999999, seed=None):
         """seed: the reference's RANSAC is unseeded (floor_removal.py:70); ours draws from Philox with
@@ -236,7 +253,7 @@ class PointCloud:
 
     def __iadd__(self, other):
         r = self + other
-        self._pts, self._col, self._nrm = r._pts, r._col, r._nrm
+        self._pts, self._col, self._nrm, self._bounds = r._pts, r._col, r._nrm, None
         return self
 
     def clone(self):

@@ -136,7 +136,20 @@ def joints_affine(x, A, t):
     return out
 
 
-def select_by_index(attrs, idx, invert=False, trusted=False):
+def bounds(pts):
+    """min x, y, z, max x, y, z of an (n,3) f32 cloud as a float64[6] device tensor (Open3D get_min_bound / get_max_bound;
+    floor_removal.py:65-66 takes max(y))."""
+    lib = L.load()
+    pts = _dev(pts, torch.float32).reshape(-1, 3)
+    if pts.shape[0] == 0:
+        raise L.KinectPxError("bounds: empty cloud")
+    out = torch.empty(6, dtype=torch.float64, device=pts.device)
+    ws, wsz = L.workspace(lib.kpx_bounds_workspace_bytes())
+    L.check(lib.kpx_bounds(L.ptr(pts), pts.shape[0], L.ptr(out), ws, wsz, L.stream_ptr()))
+    return out
+
+
+def select_by_index(attrs, idx, invert=False, trusted=False, want_bounds=False):
     """attrs: list of up to three (n,3) f32 tensors (None allowed).  Returns list of selected tensors.
     [O3D] SelectByIndex has mask semantics: the result is in ascending original order without duplicates whatever the
     order of idx.  trusted=True is for index lists that come straight from another operator of this library (the keep
@@ -154,6 +167,16 @@ def select_by_index(attrs, idx, invert=False, trusted=False):
             raise L.KinectPxError("select_by_index: index out of range")
     # trusted lists are ascending and duplicate-free by construction: a plain gather equals Open3D's mask selection
     mode = 1 if invert else (0 if trusted else 2)
+    if want_bounds:
+        # the gather that also leaves the selected cloud's bounds (attrs[0] = the points); returns (outs, bounds or None)
+        if mode or k == 0 or attrs[0] is None:
+            return select_by_index(attrs, idx, invert, trusted), None
+        outs = [torch.empty((k, 3), dtype=torch.float32, device=ref.device) if a is not None else None for a in attrs]
+        bb = torch.empty(6, dtype=torch.float64, device=ref.device)
+        ws, wsz = L.workspace(lib.kpx_select_workspace_bytes(n))
+        L.check(lib.kpx_select_by_index_bounds(L.ptr(attrs[0]), L.ptr(attrs[1]), L.ptr(attrs[2]), n, L.ptr(idx), k,
+                                               L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(bb), ws, wsz, L.stream_ptr()))
+        return outs, bb
     m = n if mode else k
     outs = [torch.empty((m, 3), dtype=torch.float32, device=ref.device) if a is not None else None for a in attrs]
     cnt = torch.empty(1, dtype=torch.int32, device=ref.device) if mode else None        # written by the compaction's scan
@@ -179,7 +202,9 @@ def halfspace_select(pts, plane):
     return idx[:_count(cnt)[0]]
 
 
-def slab_split(pts, slab):
+def slab_split(pts, slab, bounds=None):
+    """bounds: the cloud's float64[6] device bounds when they are known (ops.bounds, select_by_index(want_bounds=True)):
+    max(y) is read from them instead of from a pass over the points."""
     lib = L.load()
     pts = _dev(pts, torch.float32).reshape(-1, 3)
     n = pts.shape[0]
@@ -187,8 +212,14 @@ def slab_split(pts, slab):
     up = torch.empty(n, dtype=torch.int32, device=pts.device)
     cnt = torch.zeros(2, dtype=torch.int32, device=pts.device)
     ws, wsz = L.workspace(lib.kpx_select_workspace_bytes(n))
-    L.check(lib.kpx_slab_split(L.ptr(pts), n, float(slab), L.ptr(lo), C.c_void_p(cnt.data_ptr()), L.ptr(up),
-                               C.c_void_p(cnt.data_ptr() + 4), ws, wsz, L.stream_ptr()))
+    if bounds is not None:
+        if bounds.dtype != torch.float64 or bounds.numel() != 6 or bounds.device != pts.device:
+            raise L.KinectPxError("slab_split: bounds must be a float64[6] tensor on the cloud's device")
+        L.check(lib.kpx_slab_split_bounded(L.ptr(pts), n, float(slab), L.ptr(bounds), L.ptr(lo), C.c_void_p(cnt.data_ptr()), L.ptr(up),
+                                           C.c_void_p(cnt.data_ptr() + 4), ws, wsz, L.stream_ptr()))
+    else:
+        L.check(lib.kpx_slab_split(L.ptr(pts), n, float(slab), L.ptr(lo), C.c_void_p(cnt.data_ptr()), L.ptr(up),
+                                   C.c_void_p(cnt.data_ptr() + 4), ws, wsz, L.stream_ptr()))
     c = _count(cnt)
     return lo[:c[0]], up[:c[1]]
 

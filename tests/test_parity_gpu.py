@@ -209,6 +209,53 @@ def test_selections_random_sizes_and_unaligned_views(ops, oracle):
         assert np.array_equal(npy(gi), p[m])
 
 
+def test_bounds_and_the_split_that_reads_them(ops):
+    """kpx_bounds (lane-contiguous 16-byte loads above 65536 points, one block below, scalar loads for unaligned views), the gather that
+    leaves the bounds of what it wrote, and kpx_slab_split_bounded: numpy's min / max, and the lists of the two-pass split"""
+    from kinectpy_amd.geometry import PointCloud
+    from kinectpy_amd.floor_removal import remove_floor
+    rng = np.random.default_rng(23)
+    for n in [1, 2, 255, 256, 257, 65536, 65537, 65536 + 255, 65536 + 256, 300_001, 1_048_576, 2_000_003]:
+        for off in ([0, 1] if n < 400_000 else [0]):
+            host = rng.normal(scale=700, size=(n + off, 3)).astype(np.float32)
+            if n > 3:                                                  # the extremes at the ends and inside a chunk
+                host[off, 0] = -9e4; host[off + n - 1, 1] = 8e4; host[off + n // 2, 2] = -7e4
+            dev = torch.as_tensor(host).cuda()[off:]
+            p = host[off:]
+            bb = ops.bounds(dev)
+            want = np.concatenate([p.min(0), p.max(0)]).astype(np.float64)
+            assert np.array_equal(npy(bb), want), (n, off)
+            slab = float(rng.uniform(1, 900))
+            lo, up = ops.slab_split(dev, slab)
+            lo2, up2 = ops.slab_split(dev, slab, bounds=bb)
+            y = p[:, 1].astype(np.float64)
+            assert np.array_equal(npy(lo), np.flatnonzero(y >= y.max() - slab)) and np.array_equal(npy(up), np.flatnonzero(y < y.max() - slab)), (n, off)
+            assert np.array_equal(npy(lo2), npy(lo)) and np.array_equal(npy(up2), npy(up)), (n, off)
+            k = int(rng.integers(1, n + 1))
+            idx = np.sort(rng.choice(n, k, replace=False)).astype(np.int32)
+            col = torch.as_tensor(rng.random((n, 3)).astype(np.float32)).cuda()
+            (g, gc, gn), gb = ops.select_by_index([dev, col, None], idx, trusted=True, want_bounds=True)
+            assert gn is None and np.array_equal(npy(g), p[idx]) and np.array_equal(npy(gc), npy(col)[idx])
+            assert np.array_equal(npy(gb), np.concatenate([p[idx].min(0), p[idx].max(0)]).astype(np.float64)), (n, off, k)
+    # the cloud object: bounds left by the producing gather, dropped when the points move
+    host = rng.normal(scale=700, size=(90_000, 3)).astype(np.float32)
+    pc = PointCloud(host)
+    assert pc._bounds is None
+    assert np.array_equal(pc.get_max_bound(), host.max(0).astype(np.float64)) and np.array_equal(pc.get_min_bound(), host.min(0).astype(np.float64))
+    assert pc._bounds is not None
+    sel = pc._select(torch.arange(0, 90_000, 3, dtype=torch.int32).cuda())
+    assert sel._bounds is not None and np.array_equal(sel.get_max_bound(), host[::3].max(0).astype(np.float64))
+    filt, keep = pc.remove_statistical_outlier(8, 1.5)
+    assert filt._bounds is not None and np.array_equal(npy(filt._bounds), np.concatenate([host[keep].min(0), host[keep].max(0)]).astype(np.float64))
+    T = np.eye(4); T[1, 3] = 1234.0
+    filt.transform(T)
+    assert filt._bounds is None
+    a = remove_floor(filt.clone(), seed=5)                             # bounds recomputed after the move ...
+    b_in = filt.clone(); b_in._device_bounds()
+    b = remove_floor(b_in, seed=5)                                     # ... or already there: the same cloud
+    assert np.array_equal(npy(a._pts), npy(b._pts)) and len(a.points) > 0
+
+
 # ---------------------------------------------------------------------------------------------- filters
 @pytest.mark.parametrize("voxel", [0.02, 10.0, 35.0, 500.0])
 def test_voxel_bit_exact(ops, oracle, base_cloud, voxel):
