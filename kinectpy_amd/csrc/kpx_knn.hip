@@ -331,6 +331,15 @@ template <int L> __device__ __forceinline__ unsigned group_max_u(unsigned v)
 #ifndef KPX_SOR_CELL_MINW
 #define KPX_SOR_CELL_MINW 4
 #endif
+#ifdef KPX_SOR_CELL_STATS
+// diagnostic build only (tools/sor_stats.py): wave clocks per phase, summed over the waves
+__device__ unsigned long long g_sor_stats[16];
+#define KPX_STAT_CLK(var) const long long var = (long long)clock64()
+#define KPX_STAT_ADD(slot, v) do { if (lane == 0) atomicAdd(&g_sor_stats[slot], (unsigned long long)(v)); } while (0)
+#else
+#define KPX_STAT_CLK(var)
+#define KPX_STAT_ADD(slot, v)
+#endif
 constexpr int kCellBuckets = 256;             // buckets of the counting selection (round 5)
 // doubles of LDS per group of L lanes: bucket counts, selection buffer, run table (32 starts, 32 offsets), the block's points; even, so
 // that every group's region starts on 16 bytes
@@ -358,6 +367,7 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
     float *cand = reinterpret_cast<float *>(selbuf + kbuf + 32);
     const GridParams g = *gp;
     const int64_t nq = q1 - q0;
+    KPX_STAT_CLK(t_wave0);
     for (int64_t chunk = (int64_t)blockIdx.x * W + wave; chunk * kCellQueries < nq; chunk += (int64_t)gridDim.x * W) {
         const int64_t base = q0 + chunk * kCellQueries;
         const int nqc = (int)(q1 - base < kCellQueries ? q1 - base : kCellQueries);
@@ -396,6 +406,7 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
             for (int rad = 1; rad <= 2; ++rad) {
                 bool active = open != 0u;
                 if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+                KPX_STAT_CLK(t_st0);
                 const int side = 2 * rad + 1, nruns = side * side;
                 // the block's runs (one per (x, y) column, ascending), two per lane where the group has fewer lanes than runs
                 uint32_t s0[2] = { 0u, 0u };
@@ -446,8 +457,11 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
                     }
                 }
                 wave_lds_fence();
+                KPX_STAT_CLK(t_st1);
+                KPX_STAT_ADD(8, t_st1 - t_st0); KPX_STAT_ADD(7, 1); KPX_STAT_ADD(6, mmax);
                 unsigned todo = active ? open : 0u;
                 while (__builtin_amdgcn_ballot_w64(todo != 0u) != 0ull) {       // one open query of every group's cell per trip
+                    KPX_STAT_CLK(t_q0);
                     const bool have = todo != 0u;
                     const int qrel = have ? __builtin_ctz(todo) : 0;
                     todo &= todo - 1u;
@@ -483,6 +497,8 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
                     unsigned a = group_min_u<L>(vmin), b = group_max_u<L>(vmax);
                     bool exact = false;                          // a pivot with exactly kk patterns at or below it was met
                     bool run = ok && a < b;
+                    KPX_STAT_CLK(t_q1);
+                    KPX_STAT_ADD(9, t_q1 - t_q0);
 #ifdef KPX_SOR_CELL_BISECT
                     while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
                         const unsigned mid = a + ((b - a) >> 1);
@@ -509,6 +525,7 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
                         unsigned range = b - a;
                         int need_k = kk;                                 // rank of the k-th inside the window, 1-based
                         while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+                            KPX_STAT_ADD(13, 1);
                             const int shift = range >= 256u ? 24 - __builtin_clz(range) : 0;      // range >> shift <= 255
                             uint4 *hz = reinterpret_cast<uint4 *>(hist + gl * BPL);
 #pragma unroll
@@ -590,6 +607,8 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
                         }
                         if (exact) n_le = kk;
                     }
+                    KPX_STAT_CLK(t_q2);
+                    KPX_STAT_ADD(10, t_q2 - t_q1);
                     // the selected patterns (all <= (P, Q)), in the block's own order -> selection buffer -> sum of square roots
                     const bool tied_out = ok && n_le > kk + kCellTieRoom;     // ties far beyond k (duplicates, lattices): the wave-per-query passes
                     if (tied_out) ok = false;
@@ -623,6 +642,9 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
                     if (ok || tied_out) open &= ~(1u << qrel);   // settled, or straight to the list
                     if (tied_out) fbbits |= 1u << qi;
                     wave_lds_fence();
+                    KPX_STAT_CLK(t_q3);
+                    KPX_STAT_ADD(11, t_q3 - t_q2);
+                    KPX_STAT_ADD(rad == 1 ? 0 : 1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && gl == 0)));
                 }
             }
             fbbits |= open << pos;                               // neither block settled them
@@ -638,6 +660,269 @@ __global__ __launch_bounds__(64 * W, (S > 16 ? 2 : (S > 8 ? 3 : KPX_SOR_CELL_MIN
             fb_base = __shfl(fb_base, 0, 64);
             if (lane < 16 && ((fbmask >> lane) & 1u)) fb_list[fb_base + __builtin_popcount(fbmask & ((1u << lane) - 1u))] = (int32_t)(base + lane);
         }
+    }
+#ifdef KPX_SOR_CELL_STATS
+    KPX_STAT_ADD(12, (long long)clock64() - t_wave0);
+#endif
+}
+
+// ---- a8 SOR, large k: a BLOCK per 64 cell-sorted queries (round 5) -------------------------------------------------------------------
+// The kernel above gives every wave its own 16 queries and its own copy of their cells' blocks: at k = 200 (filter_outliers' default,
+// preprocessing/data.py:61) that is 27 KB of LDS per wave -- five waves per CU, 247 registers -- and a cell of ~80 queries is staged by
+// five or six different waves; the phase clocks (tools/sor_stats.py) put 31 % of the wave time into staging and most of the rest into
+// dependent LDS / cross-lane round trips nothing overlaps.  Here four waves share what they can: a block takes 64 consecutive cell-sorted
+// queries, stages the 27-cell block of each CELL among them once with all 256 threads (a fixed-depth run search per point: the loads of a
+// thread's eight points are in flight together), and its waves answer the cell's queries side by side -- wave w the w-th, (w + 4)-th, ...
+// -- each from the squared distances its lanes hold in registers (lane l: candidates l, l + 64, ...).  36 KB of LDS per block at k = 200:
+// sixteen waves per CU.  The arithmetic is that of sor_cell_kernel<64, S, .>: the k-th high word by counting into 256 buckets (its window
+// starts at the smallest NON-ZERO high word and ends at the cover's), low words only for ties; the selected patterns go into the selection
+// buffer in the block's own order (a ballot per row of 64 candidates places them) and the sum of their square roots is a fixed tree --
+// every mean depends on the query's cell alone, not on how the queries were dealt out.  Queries the 3 x 3 x 3 block does not cover get the 5 x 5 x 5 block; what neither settles
+// goes to the wave-per-query passes through the list.
+constexpr int kBlkQueries = 64, kBlkWaves = 4;
+#ifndef KPX_SOR_BLOCK_MINB
+#define KPX_SOR_BLOCK_MINB 4
+#endif
+template <int S>
+__global__ __launch_bounds__(64 * kBlkWaves, KPX_SOR_BLOCK_MINB) void sor_block_kernel(
+    const GridParams *__restrict__ gp, const uint32_t *__restrict__ cell_start, const float *__restrict__ spts, const int32_t *__restrict__ sidx,
+    int64_t q0, int64_t q1, int k, int kbuf, double *__restrict__ avg, int32_t *__restrict__ fb_list, int32_t *__restrict__ fb_count)
+{
+    constexpr int CAP = 64 * S, W = kBlkWaves, T = 64 * kBlkWaves;
+    extern __shared__ __align__(16) double lds[];
+    __shared__ uint32_t run_s0[32];
+    __shared__ int32_t run_off[32];
+    __shared__ float qf[3][kBlkQueries];
+    __shared__ int32_t qc[3][kBlkQueries];
+    __shared__ int32_t qcell[kBlkQueries], qsidx[kBlkQueries];
+    __shared__ uint8_t qstate[kBlkQueries];              // 0 open, 1 settled, 2 ties beyond the buffer (straight to the list)
+    __shared__ int32_t s_m;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float *cand = reinterpret_cast<float *>(lds);                                                   // CAP x 3 floats
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + (size_t)(CAP * 3) / 2) + (size_t)wave * kCellBuckets;
+    double *selbuf = lds + (size_t)(CAP * 3) / 2 + (size_t)W * kCellBuckets / 2 + (size_t)wave * kbuf;
+    const GridParams g = *gp;
+    const int64_t nq = q1 - q0;
+    for (int64_t chunk = blockIdx.x; chunk * kBlkQueries < nq; chunk += gridDim.x) {
+        const int64_t base = q0 + chunk * kBlkQueries;
+        const int nqc = (int)(q1 - base < kBlkQueries ? q1 - base : kBlkQueries);
+        if (tid < nqc) {
+            const float *qp = spts + 3 * (base + tid);
+            int c[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float v = qp[a]; qf[a][tid] = v; c[a] = cell_coord((double)v, g.org[a], g.h, g.dim[a]); qc[a][tid] = c[a]; }
+            qcell[tid] = (int32_t)(((int64_t)c[0] * g.dim[1] + c[1]) * g.dim[2] + c[2]);
+            qsidx[tid] = sidx ? sidx[base + tid] : (int32_t)(base + tid - q0);
+            qstate[tid] = 0;
+        }
+        __syncthreads();
+        // the chunk's cells: a cell's queries are contiguous (cell-sorted); every wave derives the same mask
+        const int mycell = lane < nqc ? qcell[lane] : -1;
+        const int prevcell = __shfl_up(mycell, 1, 64);
+        unsigned long long segs = __builtin_amdgcn_ballot_w64(lane < nqc && (lane == 0 || mycell != prevcell));
+        while (segs != 0ull) {
+            const int pos = __builtin_ctzll(segs);
+            segs &= segs - 1ull;
+            const int len = (segs ? __builtin_ctzll(segs) : nqc) - pos;
+            const int cx = qc[0][pos], cy = qc[1][pos], cz = qc[2][pos];
+            for (int rad = 1; rad <= 2; ++rad) {
+                if (rad == 2 && __builtin_amdgcn_ballot_w64(lane < len && qstate[pos + lane] == 0) == 0ull) break;       // block-uniform: qstate is settled
+                const int side = 2 * rad + 1, nruns = side * side;
+                if (wave == 0) {                                 // the block's runs, one per (x, y) column, ascending
+                    uint32_t s0 = 0u;
+                    int ln = 0;
+                    if (lane < nruns) {
+                        const int x = cx + lane / side - rad, y = cy + lane % side - rad;
+                        if (x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1]) {
+                            const int64_t col = ((int64_t)x * g.dim[1] + y) * g.dim[2];
+                            const int za = cz - rad < 0 ? 0 : cz - rad, zb = cz + rad >= g.dim[2] ? g.dim[2] - 1 : cz + rad;
+                            s0 = cell_start[col + za];
+                            ln = (int)(cell_start[col + zb + 1] - s0);
+                        }
+                    }
+                    const int incl = wave_incl_scan(ln);
+                    if (lane < 32) { run_s0[lane] = s0; run_off[lane] = lane < nruns ? incl - ln : INT_MAX; }
+                    if (lane == 63) s_m = incl;
+                }
+                __syncthreads();
+                const int m = s_m;
+                if (m <= CAP) {
+                    // the block's points -> LDS: thread t brings in points t, t + 256, ...; the run of a point by a fixed-depth search
+#pragma unroll
+                    for (int tr = 0; tr < CAP / T; ++tr) {
+                        const int jn = tr * T + tid;
+                        if (jn < m) {
+                            int r = 0;
+#pragma unroll
+                            for (int st = 16; st > 0; st >>= 1) { const int cr = r + st; if (cr < nruns && run_off[cr] <= jn) r = cr; }
+                            const float *pp = spts + 3 * (int64_t)(run_s0[r] + (uint32_t)(jn - run_off[r]));
+                            cand[3 * jn] = pp[0]; cand[3 * jn + 1] = pp[1]; cand[3 * jn + 2] = pp[2];
+                        }
+                    }
+                }
+                __syncthreads();
+                if (m <= CAP) {
+                    const int c[3] = { cx, cy, cz };
+                    for (int qi = pos + wave; qi < pos + len; qi += W) {
+                        if (qstate[qi] != 0) continue;           // wave-uniform
+                        const double q[3] = { (double)qf[0][qi], (double)qf[1][qi], (double)qf[2][qi] };
+                        // inside the covered distance: at least kk candidates strictly nearer than the block's cover (the ring walk's rule);
+                        // d^2 >= 0, so the IEEE patterns order like the values
+                        const double cov2 = block_cover2(g, q, c, rad);
+                        const bool whole = cov2 == INFINITY;
+                        const unsigned ch = (unsigned)((unsigned long long)__double_as_longlong(cov2) >> 32);
+                        unsigned hi[S], lo[S];
+                        int cnt = 0, zeros = 0;                  // zeros: distances with a zero high word (the query itself, its duplicates)
+                        unsigned vmin = 0xFFFFFFFFu;             // smallest non-zero high word
+                        int vmax = -1;                           // largest high word (an empty slot's 0xFFFFFFFF is -1)
+#pragma unroll
+                        for (int sl = 0; sl < S; ++sl) {
+                            hi[sl] = 0xFFFFFFFFu; lo[sl] = 0xFFFFFFFFu;
+                            const int jn = sl * 64 + lane;
+                            if (sl * 64 < m && jn < m) {
+                                const double dx = q[0] - (double)cand[3 * jn], dy = q[1] - (double)cand[3 * jn + 1], dz = q[2] - (double)cand[3 * jn + 2];
+                                const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                                const unsigned long long pat = (unsigned long long)__double_as_longlong(d2);
+                                hi[sl] = (unsigned)(pat >> 32); lo[sl] = (unsigned)pat;
+                                cnt += d2 < cov2 ? 1 : 0;
+                                zeros += hi[sl] == 0u ? 1 : 0;
+                                const unsigned nz = hi[sl] == 0u ? 0xFFFFFFFFu : hi[sl];
+                                vmin = nz < vmin ? nz : vmin;
+                                vmax = (int)hi[sl] > vmax ? (int)hi[sl] : vmax;
+                            }
+                        }
+                        cnt = group_sum_i<64>(cnt);
+                        zeros = group_sum_i<64>(zeros);
+                        const int kk = whole ? (m < k ? m : k) : k;
+                        bool ok = cnt >= kk;                     // wave-uniform from here on
+                        // The window of the k-th high word: from the smallest NON-ZERO one (the query is its own nearest candidate: with
+                        // zero in the window the first level's buckets are eight binades wide and hold everything else in two or three
+                        // of them) up to the largest, or the cover's -- at least kk candidates lie strictly inside the cover
+                        unsigned a = group_min_u<64>(vmin);
+                        unsigned b = group_max_u<64>((unsigned)(vmax < 0 ? 0 : vmax));
+                        if (!whole && b > ch) b = ch;
+                        bool exact = false;                      // a pivot with exactly kk patterns at or below it was met
+                        {
+                            constexpr int BPL = kCellBuckets / 64;
+                            int need_k = kk - zeros;             // rank of the k-th among the candidates at or above the window's start
+                            if (need_k <= 0) a = b = 0u;         // the k-th is one of the zero distances
+                            unsigned range = b - a;
+                            bool run = ok && a < b;
+                            while (run) {
+                                const int shift = range >= 256u ? 24 - __builtin_clz(range) : 0;
+                                uint4 *hz = reinterpret_cast<uint4 *>(hist + lane * BPL);
+                                hz[0] = make_uint4(0u, 0u, 0u, 0u);
+                                wave_lds_fence();
+#pragma unroll
+                                for (int sl = 0; sl < S; ++sl)
+                                    if (sl * 64 < m) {
+                                        const unsigned rel = hi[sl] - a;
+                                        if (rel <= range) __hip_atomic_fetch_add(hist + (rel >> shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    }
+                                wave_lds_fence();
+                                const uint4 t4 = hz[0];
+                                const int hv[BPL] = { (int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w };
+                                const int lsum = hv[0] + hv[1] + hv[2] + hv[3];
+                                const int incl = wave_incl_scan(lsum), excl = incl - lsum;
+                                const bool mine = need_k > excl && need_k <= incl;
+                                int B = -1, cb = 0, hb = 0;
+                                if (mine) {
+                                    int cum = excl;
+#pragma unroll
+                                    for (int w = 0; w < BPL; ++w) {
+                                        if (B < 0 && need_k <= cum + hv[w]) { B = lane * BPL + w; cb = cum; hb = hv[w]; }
+                                        cum += hv[w];
+                                    }
+                                }
+                                const unsigned long long bm = __builtin_amdgcn_ballot_w64(mine);
+                                const int owner = bm ? __builtin_ctzll(bm) : 0;
+                                B = __shfl(B, owner, 64); cb = __shfl(cb, owner, 64); hb = __shfl(hb, owner, 64);
+                                // (the window's end may cut the last bucket -- the cover's high word at the first level: nothing beyond it was counted)
+                                const unsigned wend = a + range, bstart = a + ((unsigned)(B < 0 ? 0 : B) << shift), bspan = (1u << shift) - 1u;
+                                const unsigned bend = wend - bstart < bspan ? wend : bstart + bspan;
+                                if (B < 0) { ok = false; run = false; }                       // cannot happen (cnt >= kk)
+                                else if (need_k - cb == hb) { a = bend; exact = true; run = false; }     // the k-th is the last of its bucket
+                                else if (shift == 0) { a = bstart; run = false; }                        // one value wide: THE k-th high word
+                                else { need_k -= cb; a = bstart; range = bend - bstart; }
+                            }
+                        }
+                        const unsigned P = a;
+                        unsigned Q = 0xFFFFFFFFu;
+                        int n_le = kk;
+                        if (ok && !exact) {
+                            int c_less = 0, c_eq = 0;
+#pragma unroll
+                            for (int sl = 0; sl < S; ++sl) if (sl * 64 < m) { c_less += hi[sl] < P ? 1 : 0; c_eq += hi[sl] == P ? 1 : 0; }
+                            c_less = group_sum_i<64>(c_less); c_eq = group_sum_i<64>(c_eq);
+                            n_le = c_less + c_eq;
+                            // several candidates share the k-th high word and not all of them fit: the low words decide
+                            const int r2 = kk - c_less;
+                            if (n_le > kk) {
+                                unsigned lmin = 0xFFFFFFFFu, lmax = 0u;
+#pragma unroll
+                                for (int sl = 0; sl < S; ++sl) if (hi[sl] == P) { lmin = lo[sl] < lmin ? lo[sl] : lmin; lmax = lo[sl] > lmax ? lo[sl] : lmax; }
+                                unsigned a2 = group_min_u<64>(lmin), b2 = group_max_u<64>(lmax);
+                                while (a2 < b2) {
+                                    const unsigned mid = a2 + ((b2 - a2) >> 1);
+                                    int c2 = 0;
+#pragma unroll
+                                    for (int sl = 0; sl < S; ++sl) c2 += (hi[sl] == P && lo[sl] <= mid) ? 1 : 0;
+                                    c2 = group_sum_i<64>(c2);
+                                    if (c2 >= r2) b2 = mid; else a2 = mid + 1;
+                                }
+                                int c3 = 0;
+#pragma unroll
+                                for (int sl = 0; sl < S; ++sl) c3 += (hi[sl] == P && lo[sl] <= a2) ? 1 : 0;
+                                c3 = group_sum_i<64>(c3);
+                                Q = a2; n_le = c_less + c3;
+                            }
+                        }
+                        const bool tied_out = ok && n_le > kk + kCellTieRoom;     // ties far beyond k (duplicates, lattices): the wave-per-query passes
+                        if (tied_out) ok = false;
+                        if (ok) {
+                            // the selected patterns (all <= (P, Q)), lane by lane -> selection buffer -> sum of square roots
+                            // in the block's own order (candidate 0, 1, 2, ...): a ballot per row of 64 candidates places them
+                            int wbase = 0;
+#pragma unroll
+                            for (int sl = 0; sl < S; ++sl)
+                                if (sl * 64 < m) {
+                                    const bool sel = hi[sl] < P || (hi[sl] == P && lo[sl] <= Q);
+                                    const unsigned long long bm = __builtin_amdgcn_ballot_w64(sel);
+                                    if (sel)
+                                        selbuf[wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u))] =
+                                            __longlong_as_double((long long)(((unsigned long long)hi[sl] << 32) | lo[sl]));
+                                    wbase += __builtin_popcountll(bm);
+                                }
+                            wave_lds_fence();
+                            double acc = 0.0;
+                            for (int t = lane; t < n_le; t += 64) acc += sqrt(selbuf[t]);
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+                            if (lane == 0) {
+                                const double top = __longlong_as_double((long long)(((unsigned long long)P << 32) | Q));
+                                const double total = n_le > kk ? acc - (double)(n_le - kk) * sqrt(top) : acc;
+                                avg[qsidx[qi]] = kk > 0 ? total / (double)kk : -1.0;
+                            }
+                            wave_lds_fence();
+                        }
+                        if (lane == 0 && (ok || tied_out)) qstate[qi] = ok ? 1 : 2;
+                    }
+                }
+                __syncthreads();                                 // the states are written and the staged block may be replaced
+            }
+        }
+        // what neither block settled: ONE counter update per chunk
+        if (wave == 0) {
+            const bool fb = lane < nqc && qstate[lane] != 1;
+            const unsigned long long fm = __builtin_amdgcn_ballot_w64(fb);
+            if (fm != 0ull) {
+                int fb_base = 0;
+                if (lane == 0) fb_base = atomicAdd(fb_count, __builtin_popcountll(fm));
+                fb_base = __shfl(fb_base, 0, 64);
+                if (fb) fb_list[fb_base + __builtin_popcountll(fm & ((1ull << lane) - 1ull))] = (int32_t)(base + lane);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -859,11 +1144,27 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
             hipLaunchKernelGGL((sor_cell_kernel<LL, SS, WW>), dim3((unsigned)(cdiv(chunks, WW) > 32768 ? 32768 : cdiv(chunks, WW))), dim3(64 * WW), \
                                bytes(LL * SS, 64 / LL, WW), st, g.params, g.cell_start, g.sorted_pts, out_idx, q0, q1, kk, kbuf, avg, fb_list0, fb_count0)
             static const int small_cap = [] { const char *e = getenv("KPX_SOR_CELL_SMALL"); return e ? atoi(e) : 1; }();
-            if (kk <= 24 && small_cap) KPX_SOR_CELL_LAUNCH(16, 8, 4);
+            static const bool wave_cells = [] { const char *e = getenv("KPX_SOR_BLOCK"); return e && e[0] == '0'; }();
+            static const int block_mink = [] { const char *e = getenv("KPX_SOR_BLOCK_MINK"); return e ? atoi(e) : 33; }();
+            // a block per 64 queries, its four waves sharing the staged cell blocks (round 5), from k = block_mink on (KPX_SOR_BLOCK_MINK;
+            // KPX_SOR_BLOCK=0: never); below it the wave-per-16-queries forms
+            const int64_t bchunks = cdiv(nq, kBlkQueries);
+#define KPX_SOR_BLOCK_LAUNCH(SS)                                                                                                 \
+            hipLaunchKernelGGL(sor_block_kernel<SS>, dim3((unsigned)(bchunks > 16384 ? 16384 : bchunks)), dim3(64 * kBlkWaves),      \
+                               ((size_t)(64 * SS * 3) / 2 + (size_t)kBlkWaves * kCellBuckets / 2 + (size_t)kBlkWaves * kbuf) * 8, st, g.params, g.cell_start, \
+                               g.sorted_pts, out_idx, q0, q1, kk, kbuf, avg, fb_list0, fb_count0)
+            if (!wave_cells && kk >= block_mink) {
+                if (kk <= 32) KPX_SOR_BLOCK_LAUNCH(4);
+                else if (kk <= 64) KPX_SOR_BLOCK_LAUNCH(8);
+                else if (kk <= 128) KPX_SOR_BLOCK_LAUNCH(16);
+                else KPX_SOR_BLOCK_LAUNCH(32);
+            }
+            else if (kk <= 24 && small_cap) KPX_SOR_CELL_LAUNCH(16, 8, 4);
             else if (kk <= 32) KPX_SOR_CELL_LAUNCH(16, 16, 4);
             else if (kk <= 64) KPX_SOR_CELL_LAUNCH(32, 16, 4);
             else if (kk <= 128) KPX_SOR_CELL_LAUNCH(64, 16, 4);
             else KPX_SOR_CELL_LAUNCH(64, 32, 1);
+#undef KPX_SOR_BLOCK_LAUNCH
 #undef KPX_SOR_CELL_LAUNCH
             list0 = fb_list0; count0 = fb_count0;
         }

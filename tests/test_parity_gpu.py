@@ -332,6 +332,21 @@ def test_sor_indices_bit_exact(ops, oracle, base_cloud, n, k, ratio):
         assert np.allclose(npy(gs), rs, rtol=TOL_STATS, atol=0)
 
 
+@pytest.mark.parametrize("n,k,ratio", [(0, 200, 3.0), (100000, 129, 1.0), (150000, 400, 2.0), (200000, 1000, 2.5)])
+def test_sor_large_k_at_frame_density(ops, oracle, base_cloud, n, k, ratio):
+    """the block-per-64-queries kernel (k > 128) where it works hardest: dense clouds, whose 27-cell blocks hold up to 2048 candidates and
+    whose k-th neighbour lies near the distance the block covers (the selection window ends at the cover's high word); n = 0: the whole
+    283k-point frame cloud at filter_outliers' defaults.  Keep list equal, per-point means to 1e-14 -- a selection that takes one candidate
+    too many moves a mean by ~1e-3 of itself"""
+    rng = np.random.default_rng(n + k)
+    p = base_cloud if n == 0 else base_cloud[rng.choice(len(base_cloud), n, replace=False)]
+    gi, gs, ga = ops.sor(p, k, ratio, want_avg=True)
+    ri, rs, ra = oracle.sor(p, k, ratio)
+    assert np.array_equal(npy(gi), ri)
+    assert np.allclose(npy(ga), ra, rtol=1e-14, atol=0)
+    assert np.allclose(npy(gs), rs, rtol=TOL_STATS, atol=0)
+
+
 def test_sor_duplicates_and_errors(ops, oracle):
     from kinectpy_amd._lib import KinectPxError
     rng = np.random.default_rng(3)
