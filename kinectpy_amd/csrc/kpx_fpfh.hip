@@ -32,7 +32,8 @@ __global__ __launch_bounds__(WAVES * 64) void nbr_list_wave_kernel(const GridPar
     __shared__ int32_t run_off[WAVES][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t *posbase = reinterpret_cast<uint32_t *>(lds + (size_t)WAVES * cap);
-    const WaveKnnScratch sc{ lds + (size_t)wave * cap, posbase + (size_t)wave * cap, run_s0[wave], run_off[wave], cap };
+    __shared__ __align__(16) uint32_t knn_hist[WAVES][kKnnBuckets];
+    const WaveKnnScratch sc{ lds + (size_t)wave * cap, posbase + (size_t)wave * cap, run_s0[wave], run_off[wave], cap, knn_hist[wave] };
     const GridParams g = *gp;
     for (int64_t s = (int64_t)blockIdx.x * WAVES + wave; s < n; s += (int64_t)gridDim.x * WAVES) {
         const double q[3] = { (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2] };

@@ -188,7 +188,119 @@ struct WaveKnnScratch {        // LDS owned by one wave
     uint32_t *run_s0;          // 64
     int32_t *run_off;          // 64
     int cap;
+    uint32_t *hist;            // kKnnBuckets bucket counts of the counting selection (16-byte aligned)
 };
+constexpr int kKnnBuckets = 256;
+
+// ---- k-th smallest by COUNTING (round 5) ---------------------------------------------------------------------------------------------
+// The rank-th smallest (1-based) of the 32-bit keys key(t), t < m, that are in the set and lie in the window [a, a + range]: the window is
+// cut into <= 256 buckets of 2^shift, every key inside adds one to its bucket (LDS atomics), lane l sums its four buckets, a wave scan
+// finds the bucket of the rank-th and the next level looks inside that bucket only.  It ends with the key itself (a bucket one value wide,
+// exact = false) or -- usually after two levels -- with the upper end of a bucket whose LAST key is the rank-th: a pivot with exactly
+// `rank` window keys at or below it (exact = true).  The caller has taken the keys below the window out of `rank` and knows that none
+// above it matters.  A bisection over the same values took ~24 (high words) to ~60 (64-bit patterns) passes over the candidates.
+template <class KeyF>
+__device__ __forceinline__ unsigned wave_count_select(KeyF key, int m, unsigned a, unsigned range, int rank, uint32_t *__restrict__ hist, bool &exact)
+{
+    const int lane = threadIdx.x & 63;
+    exact = false;
+    while (range > 0u) {
+        const int shift = range >= 256u ? 24 - __builtin_clz(range) : 0;      // range >> shift <= 255
+        uint4 *hz = reinterpret_cast<uint4 *>(hist + 4 * lane);
+        hz[0] = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_fence();
+        for (int t = lane; t < m; t += 64) {
+            unsigned kv;
+            if (key(t, kv) && kv - a <= range) __hip_atomic_fetch_add(hist + ((kv - a) >> shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        wave_lds_fence();
+        const uint4 t4 = hz[0];
+        const int hv[4] = { (int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w };
+        const int lsum = hv[0] + hv[1] + hv[2] + hv[3];
+        int incl = lsum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(incl, o, 64); if (lane >= o) incl += t2; }
+        const int excl = incl - lsum;
+        const bool mine = rank > excl && rank <= incl;
+        int B = -1, cb = 0, hb = 0;
+        if (mine) {
+            int cum = excl;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (B < 0 && rank <= cum + hv[w]) { B = 4 * lane + w; cb = cum; hb = hv[w]; }
+                cum += hv[w];
+            }
+        }
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(mine);
+        if (bm == 0ull) return a;                                   // fewer than `rank` keys in the window: the caller's count is off
+        const int owner = __builtin_ctzll(bm);
+        B = __shfl(B, owner, 64); cb = __shfl(cb, owner, 64); hb = __shfl(hb, owner, 64);
+        const unsigned wend = a + range, bstart = a + ((unsigned)B << shift), bspan = (1u << shift) - 1u;
+        const unsigned bend = wend - bstart < bspan ? wend : bstart + bspan;      // the window's end may cut its last bucket
+        if (rank - cb == hb) { exact = true; return bend; }        // the rank-th is the last of its bucket
+        if (shift == 0) return bstart;                              // one value wide: THE key
+        rank -= cb; a = bstart; range = bend - bstart;
+    }
+    return a;
+}
+__device__ __forceinline__ unsigned wave_all_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_all_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_all_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// A threshold thr with { pattern <= thr } = the kk smallest of the m non-negative doubles vals[0 .. m) in LDS plus whatever ties with the
+// kk-th (1 <= kk < m): high words first (zero distances -- the query itself, its duplicates -- are counted, not bucketed: with zero in the
+// window the first level's buckets are eight binades wide), low words only among the candidates that share the kk-th high word.
+__device__ __forceinline__ unsigned long long wave_kth_pattern(const double *__restrict__ vals, int m, int kk, uint32_t *__restrict__ hist)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(vals);           // little endian: word 2 t + 1 is the high word
+    unsigned vmin = 0xFFFFFFFFu, vmax = 0u;
+    int zeros = 0;
+    for (int t = lane; t < m; t += 64) {
+        const unsigned h = w32[2 * t + 1];
+        zeros += h == 0u ? 1 : 0;
+        const unsigned nz = h == 0u ? 0xFFFFFFFFu : h;
+        vmin = nz < vmin ? nz : vmin; vmax = h > vmax ? h : vmax;
+    }
+    vmin = wave_all_min_u32(vmin); vmax = wave_all_max_u32(vmax); zeros = wave_all_sum_i32(zeros);
+    unsigned P = 0u;
+    bool exact = false;
+    if (kk > zeros) {
+        P = vmin;
+        if (vmin < vmax)
+            P = wave_count_select([&](int t, unsigned &kv) { kv = w32[2 * t + 1]; return kv != 0u; }, m, vmin, vmax - vmin, kk - zeros, hist, exact);
+        if (exact) return ((unsigned long long)P << 32) | 0xFFFFFFFFull;
+    }
+    int c_less = 0, c_eq = 0;
+    unsigned lmin = 0xFFFFFFFFu, lmax = 0u;
+    for (int t = lane; t < m; t += 64) {
+        const unsigned h = w32[2 * t + 1];
+        c_less += h < P ? 1 : 0;
+        if (h == P) { const unsigned l = w32[2 * t]; ++c_eq; lmin = l < lmin ? l : lmin; lmax = l > lmax ? l : lmax; }
+    }
+    c_less = wave_all_sum_i32(c_less); c_eq = wave_all_sum_i32(c_eq);
+    const int r2 = kk - c_less;                                                // rank of the kk-th among the candidates with high word P
+    if (r2 >= c_eq) return ((unsigned long long)P << 32) | 0xFFFFFFFFull;      // all of them are selected
+    lmin = wave_all_min_u32(lmin); lmax = wave_all_max_u32(lmax);
+    unsigned Q = lmin;
+    if (lmin < lmax)
+        Q = wave_count_select([&](int t, unsigned &kv) { kv = w32[2 * t]; return w32[2 * t + 1] == P; }, m, lmin, lmax - lmin, r2, hist, exact);
+    return ((unsigned long long)P << 32) | Q;
+}
 struct WaveKnnResult {
     int m;                     // candidates in vals / pos
     int kk;                    // neighbours selected: min(k, points within r2max)
@@ -276,26 +388,41 @@ __device__ __forceinline__ bool wave_knn_select(const GridParams &g, const uint3
             continue;
         }
         const int kk = m < k ? m : k;
-        // k-th smallest by bisection between the smallest and the largest pattern
-        unsigned long long lo = ~0ull, hi = 0ull;
-        for (int t = lane; t < m; t += 64) {
-            const unsigned long long p = (unsigned long long)__double_as_longlong(sc.vals[t]);
-            lo = p < lo ? p : lo; hi = p > hi ? p : hi;
-        }
-        lo = wave_all_min_u64(lo); hi = wave_all_max_u64(hi);
-        if (m <= k) lo = hi;                                    // everything gathered is selected: no search needed
-        if (m == 0) { lo = hi = 0ull; }
-        while (lo < hi) {
-            const unsigned long long mid = lo + ((hi - lo) >> 1);
-            int cnt = 0;
-            for (int t0 = 0; t0 < m; t0 += 64) {
-                const int t = t0 + lane;
-                const bool le = t < m && (unsigned long long)__double_as_longlong(sc.vals[t]) <= mid;
-                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
+        // the threshold of the kk smallest patterns
+        unsigned long long lo = 0ull;
+#ifdef KPX_KNN_BISECT
+        {                                                       // (until round 5: bisection between the smallest and the largest pattern)
+            unsigned long long hi = 0ull;
+            lo = ~0ull;
+            for (int t = lane; t < m; t += 64) {
+                const unsigned long long p = (unsigned long long)__double_as_longlong(sc.vals[t]);
+                lo = p < lo ? p : lo; hi = p > hi ? p : hi;
             }
-            if (cnt == kk) { lo = hi = mid; break; }           // the set is determined
-            if (cnt > kk) hi = mid; else lo = mid + 1;
+            lo = wave_all_min_u64(lo); hi = wave_all_max_u64(hi);
+            if (m <= k) lo = hi;                                // everything gathered is selected: no search needed
+            if (m == 0) { lo = hi = 0ull; }
+            while (lo < hi) {
+                const unsigned long long mid = lo + ((hi - lo) >> 1);
+                int cnt = 0;
+                for (int t0 = 0; t0 < m; t0 += 64) {
+                    const int t = t0 + lane;
+                    const bool le = t < m && (unsigned long long)__double_as_longlong(sc.vals[t]) <= mid;
+                    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
+                }
+                if (cnt == kk) { lo = hi = mid; break; }       // the set is determined
+                if (cnt > kk) hi = mid; else lo = mid + 1;
+            }
         }
+#else
+        if (m > k) lo = wave_kth_pattern(sc.vals, m, kk, sc.hist);             // by counting (above)
+        else if (m > 0) {                                       // everything gathered is selected: the largest pattern
+            for (int t = lane; t < m; t += 64) {
+                const unsigned long long p = (unsigned long long)__double_as_longlong(sc.vals[t]);
+                lo = p > lo ? p : lo;
+            }
+            lo = wave_all_max_u64(lo);
+        }
+#endif
         double top = 0.0;
         int cnt = 0;
         for (int t0 = 0; t0 < m; t0 += 64) {

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *
     __shared__ uint32_t run_s0[WAVES][64];
     __shared__ int32_t run_off[WAVES][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const WaveKnnScratch sc{ lds + (size_t)wave * cap, nullptr, run_s0[wave], run_off[wave], cap };
+    __shared__ __align__(16) uint32_t knn_hist[WAVES][kKnnBuckets];
+    const WaveKnnScratch sc{ lds + (size_t)wave * cap, nullptr, run_s0[wave], run_off[wave], cap, knn_hist[wave] };
     const GridParams g = *gp;
     const int64_t nq = in_list ? (int64_t)*in_count : q1 - q0;   // in_list: the queries an earlier pass could not hold
     for (int64_t e = (int64_t)blockIdx.x * WAVES + wave; e < nq; e += (int64_t)gridDim.x * WAVES) {
@@ -1134,7 +1135,8 @@ static int sor_impl(const float *pts, int64_t n, int k, double std_ratio, int32_
         // space (their k-th neighbour lies many cells away: the wave-per-query passes' re-gathers), and the selection itself is
         // instruction-bound either way.  So: KPX_SOR_CELL unset = the cell kernel from k > 64 on, 1 = always, 0 = never.
         static const int cell_mode = [] { const char *e = getenv("KPX_SOR_CELL"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();
-        const bool cell_on = (cell_mode == 2 || (cell_mode == 1 && kk > 64)) && kk <= 1024;       // (its largest block holds 2048 candidates)
+        // (round 5: the block-per-64-queries kernel from k > 32 on; at k <= 32 the wave-per-query pass -- now selecting by counting -- is as fast)
+        const bool cell_on = (cell_mode == 2 || (cell_mode == 1 && kk > 32)) && kk <= 1024;       // (its largest block holds 2048 candidates)
         const int32_t *list0 = nullptr, *count0 = nullptr;
         if (cell_on && nq > 0) {
             const int kbuf = kk + kCellTieRoom;
@@ -1254,7 +1256,8 @@ __global__ __launch_bounds__(WAVES * 64) void normals_wave_kernel(const GridPara
     __shared__ int32_t run_off[WAVES][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t *posbase = reinterpret_cast<uint32_t *>(lds + (size_t)WAVES * cap);
-    const WaveKnnScratch sc{ lds + (size_t)wave * cap, posbase + (size_t)wave * cap, run_s0[wave], run_off[wave], cap };
+    __shared__ __align__(16) uint32_t knn_hist[WAVES][kKnnBuckets];
+    const WaveKnnScratch sc{ lds + (size_t)wave * cap, posbase + (size_t)wave * cap, run_s0[wave], run_off[wave], cap, knn_hist[wave] };
     const GridParams g = *gp;
     for (int64_t s = (int64_t)blockIdx.x * WAVES + wave; s < n; s += (int64_t)gridDim.x * WAVES) {
         const double q[3] = { (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2] };
