@@ -312,6 +312,153 @@ __global__ __launch_bounds__(64) void median_select_kernel(uint32_t *__restrict_
     }
 }
 
+// ---- a4 exact median of a BATCH of frames: one block per frame, the whole 16-bit histogram in LDS (round 5) ---------------------------
+// The two radix passes above read every value twice and are four launches; for a batch (one block per CU has work from 64 frames on) a
+// block can hold a frame's complete histogram instead -- 32768 bins of the non-negative values, 128 KB of the CU's 160 KB of LDS -- count
+// the frame in ONE read and pick both middle ranks itself.  Negative values (depth >= 32768 mm read as int16: not a Kinect range, but the
+// contract is np.median of any int16) are only counted; if a middle rank falls among them the block reads its frame a second time with
+// the histogram over the negative half.  Same access forms as median_hist_kernel (8 values per 16-byte load, the z channel of an int16
+// XYZ image, the fused depth path's NaN mask), runs of equal neighbours added with one atomic.
+constexpr int kMedFrameBins = 32768, kMedFrameThreads = 1024;
+__global__ __launch_bounds__(kMedFrameThreads) void median_frame_kernel(const int16_t *__restrict__ v, int64_t n, int64_t stride, int64_t frame_stride,
+                                                                        double *__restrict__ d_median, const float *__restrict__ xy,
+                                                                        const uint8_t *__restrict__ nanmask)
+{
+    extern __shared__ uint32_t fh[];                                // kMedFrameBins counts
+    __shared__ int64_t wsum[kMedFrameThreads / 64 + 1];
+    __shared__ unsigned s_neg;
+    __shared__ int s_val[2];
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int16_t *p = v + (int64_t)frame * frame_stride;
+    const int64_t rank[2] = { (n - 1) / 2, n / 2 };
+    if (tid == 0) s_neg = 0u;
+    bool need_neg = false;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !need_neg) break;                          // block-uniform
+        for (int e = tid; e < kMedFrameBins / 4; e += kMedFrameThreads) reinterpret_cast<uint4 *>(fh)[e] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        // runs of equal neighbours are added with one atomic.  (A depth frame is a few surfaces -- in the bench's frame ten values hold two
+        // thirds of the pixels -- so the LDS atomics of a wave hit few addresses and serialise: ~135 us for 256 frames, where the loads
+        // alone would take ~40.  Tried: four (value, count) register pairs per thread in front of LDS -- the divergent compare chains cost
+        // more than the conflicts they avoid, 0.315 -> 0.384 ms for the whole masked extract.)
+        int run_bin = -1;
+        uint32_t run_cnt = 0, neg = 0;
+        auto flush = [&]() { if (run_cnt) atomicAdd(&fh[run_bin], run_cnt); };
+        auto take = [&](uint32_t raw) {
+            const int val = (int)(int16_t)(uint16_t)raw;
+            int bin;
+            if (pass == 0) { if (val < 0) { ++neg; return; } bin = val; }
+            else { if (val >= 0) return; bin = val + 32768; }
+            if (bin == run_bin) { ++run_cnt; return; }
+            flush();
+            run_bin = bin; run_cnt = 1;
+        };
+        const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)xy % 16 == 0);
+        if (vec) {
+            // four 16-byte loads of a thread in flight together (one per trip: 45 dependent round trips per frame, ~2 us each at one
+            // block per CU)
+            const int64_t groups = n >> 3;
+            for (int64_t g0 = tid; g0 < groups; g0 += 4 * kMedFrameThreads) {
+                union { uint4 q; uint16_t s[8]; } d[4];
+                unsigned m[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t g = g0 + (int64_t)u * kMedFrameThreads;
+                    const bool on = g < groups;
+                    d[u].q = reinterpret_cast<const uint4 *>(p)[on ? g : g0];
+                    m[u] = (xy && on) ? nanmask[g] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (g0 + (int64_t)u * kMedFrameThreads >= groups) break;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) take((m[u] & (1u << k)) ? 0u : (uint32_t)d[u].s[k]);
+                }
+            }
+        } else if (stride == 3 && (n % 8 == 0) && (frame_stride % 8 == 0)) {
+            const int64_t groups = n >> 3;
+            const int16_t *img = p - 2;                                     // frame base (x of pixel 0)
+            const bool ok = ((uintptr_t)img % 16) == 0;
+            for (int64_t g0 = tid; g0 < groups; g0 += 2 * kMedFrameThreads) {
+                if (ok) {                                                   // two groups = six 16-byte loads in flight
+                    union { uint4 q[3]; uint16_t s[24]; } d[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int64_t g = g0 + (int64_t)u * kMedFrameThreads;
+                        const uint4 *ip = reinterpret_cast<const uint4 *>(img + (g < groups ? g : g0) * 24);
+                        d[u].q[0] = ip[0]; d[u].q[1] = ip[1]; d[u].q[2] = ip[2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (g0 + (int64_t)u * kMedFrameThreads >= groups) break;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) take(d[u].s[3 * k + 2]);
+                    }
+                } else {
+                    for (int u = 0; u < 2; ++u) {
+                        const int64_t g = g0 + (int64_t)u * kMedFrameThreads;
+                        if (g >= groups) break;
+                        for (int k = 0; k < 8; ++k) take((uint32_t)(uint16_t)p[(g * 8 + k) * 3]);
+                    }
+                }
+            }
+        } else {
+            for (int64_t i = tid; i < n; i += kMedFrameThreads) {
+                uint32_t raw = (uint32_t)(uint16_t)p[i * stride];
+                if (xy && (__builtin_isnan(xy[2 * i]) || __builtin_isnan(xy[2 * i + 1]))) raw = 0;
+                take(raw);
+            }
+        }
+        flush();
+        if (pass == 0) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) neg += __shfl_xor(neg, o, 64);
+            if (lane == 0 && neg) atomicAdd(&s_neg, neg);
+        }
+        __syncthreads();
+        const int64_t negs = (int64_t)s_neg;
+        if (pass == 0) need_neg = rank[0] < negs;                       // (rank[0] <= rank[1])
+        // thread t owns bins 32 t .. 32 t + 31; exclusive prefix of the threads' sums by wave scans
+        uint32_t c[32];
+        int64_t mine = 0;
+#pragma unroll
+        for (int q4 = 0; q4 < 8; ++q4) {
+            const uint4 t4 = reinterpret_cast<const uint4 *>(fh)[tid * 8 + q4];
+            c[4 * q4] = t4.x; c[4 * q4 + 1] = t4.y; c[4 * q4 + 2] = t4.z; c[4 * q4 + 3] = t4.w;
+            mine += (int64_t)t4.x + t4.y + t4.z + t4.w;
+        }
+        int64_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int64_t t2 = __shfl_up(incl, o, 64); if (lane >= o) incl += t2; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            int64_t runs = 0;
+            for (int w = 0; w < kMedFrameThreads / 64; ++w) { const int64_t t2 = wsum[w]; wsum[w] = runs; runs += t2; }
+        }
+        __syncthreads();
+        const int64_t excl = wsum[wave] + incl - mine;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            // the rank inside this pass's histogram: pass 0 holds the values >= 0 (ranks negs ..), pass 1 the negative ones (ranks 0 .. negs - 1)
+            const bool here = pass == 0 ? rank[w] >= negs : rank[w] < negs;
+            const int64_t r = pass == 0 ? rank[w] - negs : rank[w];
+            if (here && r >= excl && r < excl + mine) {
+                int64_t cum = excl;
+                int found = -1;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+                    if (found < 0 && r < cum + (int64_t)c[q]) found = 32 * tid + q;
+                    cum += (int64_t)c[q];
+                }
+                s_val[w] = pass == 0 ? found : found - 32768;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) d_median[frame] = 0.5 * ((double)s_val[0] + (double)s_val[1]);
+}
+
 // clear_from: start of a region in FRONT of the histogram (carved just before this call) that the one memset of the histogram
 // shall cover too -- the fused depth path's tile states
 static int median_impl(const int16_t *v, int64_t n, int64_t stride, int64_t frame_stride, int32_t frames,
@@ -330,6 +477,23 @@ static int median_impl(const int16_t *v, int64_t n, int64_t stride, int64_t fram
     const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)xy % 16 == 0);
     if (xy && vec)
         hipLaunchKernelGGL(xy_nanmask_kernel, dim3((unsigned)(cdiv(n / 8, 256) > 1024 ? 1024 : cdiv(n / 8, 256))), dim3(256), 0, st, xy, n / 8, nanmask);
+    // a batch: one block per frame with the frame's whole histogram in LDS -- one read of the values, one launch (KPX_MEDIAN_FRAME=0 / 1
+    // forces either form; read at every call so that a test can cover both in one process)
+    {
+        const char *e = getenv("KPX_MEDIAN_FRAME");
+        const bool by_frame = e ? e[0] == '1' : (frames >= 64 && n >= 32768);
+        if (by_frame) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                KPX_HIP(hipFuncSetAttribute((const void *)median_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMedFrameBins * 4));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(median_frame_kernel, dim3(frames), dim3(kMedFrameThreads), (size_t)kMedFrameBins * 4, st, v, n, stride, frame_stride, d_median,
+                               xy, (const uint8_t *)(vec ? nanmask : nullptr));
+            KPX_LAUNCH_CHECK();
+            return KPX_OK;
+        }
+    }
     // values per thread: a block pays a fixed price for zeroing and folding its LDS histogram, so batches use fewer,
     // longer blocks; a handful of frames keeps many short ones to fill the chip
     const int per_thread = frames >= 64 ? 64 : (frames >= 16 ? 32 : 16);
@@ -609,14 +773,18 @@ __global__ __launch_bounds__(kCompactThreads) void depth_onepass_vec_kernel(cons
                                                                             const uint8_t *__restrict__ rgb, const double *__restrict__ median,
                                                                             int64_t n, int flags, double gate, unsigned long long *__restrict__ tile_state,
                                                                             float *__restrict__ pts, float *__restrict__ col, int32_t *__restrict__ idx,
-                                                                            int32_t *__restrict__ d_count)
+                                                                            int32_t *__restrict__ d_count, int frame_major)
 {
     __shared__ int sh[kCompactThreads / 64 + 2];
     __shared__ int16_t sp[kCompactTile * 3];
     __shared__ uint8_t sc[COL ? kCompactTile * 3 : 1];
     __shared__ int32_t si[IDX ? kCompactTile : 1];
-    const int f = blockIdx.y;
-    const int64_t base = (int64_t)blockIdx.x * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
+    // frame_major (batches): blockIdx.x is the FRAME, so that a frame's consecutive tiles are dispatched a whole row of frames apart and
+    // a tile's predecessor has usually published its count by the time it is asked for (tile-major, every block waits for the block
+    // dispatched just before it: measured 2.2 TB/s against 3.0 for count -> scan -> scatter on 256 frames)
+    const int f = frame_major ? blockIdx.x : blockIdx.y;
+    const unsigned tile = frame_major ? blockIdx.y : blockIdx.x, tiles = frame_major ? gridDim.y : gridDim.x;
+    const int64_t base = (int64_t)tile * kCompactTile + (int64_t)threadIdx.x * kCompactItems;
     Px8 p;
     p.keep = 0;
     if (base < n) load_px8(depth, xy, rgb, median, n, f, base, flags, gate, p);
@@ -631,7 +799,7 @@ __global__ __launch_bounds__(kCompactThreads) void depth_onepass_vec_kernel(cons
             ++pos;
         }
     __syncthreads();
-    const int before = lookback_exclusive(tile_state + (int64_t)f * gridDim.x, blockIdx.x, tot, sh + kCompactThreads / 64 + 1);
+    const int before = lookback_exclusive(tile_state + (int64_t)f * tiles, tile, tot, sh + kCompactThreads / 64 + 1);
     const int64_t o = (int64_t)f * n + before;
     for (int e = threadIdx.x; e < tot * 3; e += kCompactThreads) {
         pts[o * 3 + e] = (float)sp[e];
@@ -639,7 +807,7 @@ __global__ __launch_bounds__(kCompactThreads) void depth_onepass_vec_kernel(cons
     }
     if (IDX)
         for (int e = threadIdx.x; e < tot; e += kCompactThreads) idx[o + e] = si[e];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) d_count[f] = before + tot;
+    if (tile == tiles - 1 && threadIdx.x == 0) d_count[f] = before + tot;
 }
 
 // the 8-pixel kernels (xy == NULL: int16 XYZ image input).  counts: frames * compact_ws_ints(n) ints (the 64-bit tile words)
@@ -649,7 +817,12 @@ static int px8_compact(const uint16_t *depth, const float *xy, const uint8_t *rg
     const int32_t tiles = (int32_t)compact_tiles(n);
     const dim3 grid(tiles, frames), thr(kCompactThreads);
     const bool wc = col && rgb;
-    const bool onepass = use_onepass((int64_t)tiles * frames);
+    // batches beyond the one-pass limit: the one-pass kernel FRAME-major (KPX_ONEPASS_BATCH=0: count -> scan -> scatter as before)
+    static const bool batch_onepass = [] { const char *e = getenv("KPX_ONEPASS_BATCH"); return !(e && e[0] == '0'); }();
+    const bool small = use_onepass((int64_t)tiles * frames);
+    const bool frame_major = !small && batch_onepass && frames >= 8 && frames <= 65535;
+    const bool onepass = small || frame_major;
+    const dim3 ogrid = frame_major ? dim3(frames, tiles) : grid;
     unsigned long long *state = reinterpret_cast<unsigned long long *>(counts);
     if (onepass) { if (!state_is_clear) KPX_HIP(hipMemsetAsync(state, 0, (size_t)tiles * frames * sizeof(unsigned long long), st)); }
     else {
@@ -659,7 +832,8 @@ static int px8_compact(const uint16_t *depth, const float *xy, const uint8_t *rg
 #define KPX_D2C(COL, IDX)                                                                                                       \
     do {                                                                                                                        \
         if (onepass)                                                                                                            \
-            hipLaunchKernelGGL((depth_onepass_vec_kernel<COL, IDX>), grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, state, pts, col, idx, d_count); \
+            hipLaunchKernelGGL((depth_onepass_vec_kernel<COL, IDX>), ogrid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, state, pts, col, idx, d_count, \
+                               frame_major ? 1 : 0);                                                                           \
         else                                                                                                                    \
             hipLaunchKernelGGL((depth_scatter_vec_kernel<COL, IDX>), grid, thr, 0, st, depth, xy, rgb, med, n, flags, gate, counts, pts, col, idx);        \
     } while (0)

@@ -62,6 +62,26 @@ def test_median_exact(ops):
         t = torch.as_tensor(v).cuda()
         got = npy(ops.median_i16(t.reshape(-1)[2:], n, 3, 3))
         assert got.tolist() == [float(np.median(v[f, :, 2])) for f in range(3)]
+        os.environ["KPX_MEDIAN_FRAME"] = "1"          # the one-block-per-frame form (a batch's default), forced for three frames
+        try:
+            got = npy(ops.median_i16(t.reshape(-1)[2:], n, 3, 3))
+        finally:
+            del os.environ["KPX_MEDIAN_FRAME"]
+        assert got.tolist() == [float(np.median(v[f, :, 2])) for f in range(3)]
+    # a batch (>= 64 frames: one block per frame, the frame's whole histogram in LDS): Kinect-like depths, frames that are mostly
+    # negative (the second read), constant frames, odd and even sizes, contiguous values (stride 1) and the z channel of XYZ images
+    for n, stride in ((36864, 1), (36865, 1), (40000, 3), (32769, 3)):
+        F = 66
+        v = rng.integers(0, 6000, size=(F, n, stride)).astype(np.int16)
+        v[1] = rng.integers(-32768, 32767, size=(n, stride))
+        v[2] = rng.integers(-32768, -1, size=(n, stride))
+        v[3, : n // 2 + 1] = -7
+        v[4] = 0
+        v[5, ::2] = 32767
+        v[6, : n // 2] = -32768
+        t = torch.as_tensor(v).cuda()
+        got = npy(ops.median_i16(t.reshape(-1)[stride - 1:], n, stride, F))
+        assert got.tolist() == [float(np.median(v[f, :, stride - 1])) for f in range(F)], (n, stride)
 
 
 @pytest.mark.parametrize("cm,dg", [(False, False), (True, False), (False, True), (True, True)])
@@ -124,6 +144,17 @@ def test_fused_depth_to_cloud_batched_and_edge_cases(ops, oracle):
         p, c, i = res[f]
         assert np.array_equal(npy(p), rp) and np.array_equal(npy(c), rc) and np.array_equal(npy(i), ri)
     assert res[3][0].shape[0] == 0           # empty frame -> empty cloud
+    # a batch of 64 frames (the median takes its one-block-per-frame form): every frame equals its single-frame result
+    big = ops.depth_to_cloud(np.tile(deps, (16, 1)), xy, np.tile(rgbs, (16, 1, 1)), 64, True, True, want_idx=True)
+    for f in range(64):
+        for a, b in zip(big[f], res[f % 4]):
+            assert np.array_equal(npy(a), npy(b)), f
+    xyz = np.stack([oracle.unproject_u16(deps[f], xy) for f in range(4)])
+    one = ops.rgbd_compact(xyz, rgbs, 4, True, True)
+    many = ops.rgbd_compact(np.tile(xyz, (16, 1, 1)), np.tile(rgbs, (16, 1, 1)), 64, True, True)
+    for f in range(64):
+        for a, b in zip(many[f], one[f % 4]):
+            assert np.array_equal(npy(a), npy(b)), f
     # no colours, no gate, ragged size
     d = deps[0][:5001]
     (p, c, i), = ops.depth_to_cloud(d, xy[:5001], None, 1, False, False, want_idx=True)
