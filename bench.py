@@ -331,7 +331,7 @@ def roofline_targets(torch, ops, quick=False):
     ms, (keep, _, _) = ev_timed(torch, lambda: ops.sor(v1, 20, 2.0), reps=3, warm=1)
     hbm(f"remove_statistical_outlier(20, 2.0), {v1.shape[0]} points (config 3 after voxel; a8)", "sor_wave_kernel + grid build + statistics", ms,
         12 * v1.shape[0] + 16 * int(keep.shape[0]), points=int(v1.shape[0]), kept=int(keep.shape[0]),
-        Mqueries_per_s=round(v1.shape[0] / ms / 1e3, 1), binds="LDS / VALU / latency (wave per query, k-th smallest by bisection), not HBM")
+        Mqueries_per_s=round(v1.shape[0] / ms / 1e3, 1), binds="vector-instruction issue and LDS round trips (wave per query, k-th smallest by counting into LDS buckets), not HBM: profiles/*/pmc_sor_k20.csv")
     vb = clouds                                              # the raw 1M-point clouds: 64 x 12 MB = 0.77 GB of points
     def sor_many():
         return [ops.sor(v, 20, 2.0)[0] for v in vb]
@@ -342,10 +342,10 @@ def roofline_targets(torch, ops, quick=False):
     fused = synth.frame_cloud()                              # a fused 4-sensor person cloud, millimetres: filter_outliers' defaults on it
     fv = ops.voxel_downsample(torch.as_tensor(fused).to(dev), 10.0)[0]
     ms, (keep, _, _) = ev_timed(torch, lambda: ops.sor(fv, 200, 3.0), reps=3, warm=1)
-    hbm(f"remove_statistical_outlier(200, 3.0) (filter_outliers' defaults, filtering.py:12), {fv.shape[0]} points", "sor_cell_kernel<64, 32, 1> (k > 64: a cell's queries together) + sor_wave_kernel passes for what it leaves + grid build + statistics", ms,
+    hbm(f"remove_statistical_outlier(200, 3.0) (filter_outliers' defaults, filtering.py:12), {fv.shape[0]} points", "sor_block_kernel<32> (k > 32: a block per 64 cell-sorted queries, four waves share the staged cell blocks) + sor_wave_kernel passes for what it leaves + grid build + statistics", ms,
         12 * fv.shape[0] + 16 * int(keep.shape[0]), points=int(fv.shape[0]), kept=int(keep.shape[0]),
         Mqueries_per_s=round(fv.shape[0] / ms / 1e3, 2),
-        binds="vector ALU on LDS-resident candidates (distances + bisection on the high words: ~1500 wave-instructions per query at k = 200), not HBM")
+        binds="vector-instruction issue on LDS-resident candidates (fp64 distances, the k-th high word by counting into 256 LDS buckets, ballot emit, sqrt sum), not HBM: instruction count and issue fraction in profiles/*/pmc_sor_k200.csv")
     del keeps, vb
 
     # segment_plane: the (point, hypothesis) distances are a K = 4 fp64 GEMM on the matrix cores (8 flop per pair); the row
