@@ -378,6 +378,40 @@ def test_sor_large_k_at_frame_density(ops, oracle, base_cloud, n, k, ratio):
     assert np.allclose(npy(gs), rs, rtol=TOL_STATS, atol=0)
 
 
+def test_sor_block_kernel_fuzz_ties_duplicates_clusters(ops, oracle):
+    """random (cloud, k) pairs for the block-per-64-queries kernel (k > 32) and the counting selection behind every form: integer
+    lattices (many candidates AT the k-th distance: the low-word phase, ties beyond the selection buffer's room), clouds with blocks of
+    coincident points (zero distances: the window starts above them, or the k-th is one of them), tight clusters in empty space (the
+    second block radius, the leftovers' list), tiny clouds (k >= n).  Keep list equal, means to 1e-13."""
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        kind = case % 4
+        if kind == 0:                                   # lattice, integer coordinates, permuted
+            a, b, c = (int(v) for v in rng.integers(6, 22, size=3))
+            step = float(rng.choice([1.0, 3.0, 10.0]))
+            gx, gy, gz = np.arange(a, dtype=np.float32), np.arange(b, dtype=np.float32), np.arange(c, dtype=np.float32)
+            p = np.stack(np.meshgrid(gx, gy, gz, indexing="ij"), -1).reshape(-1, 3) * step
+        elif kind == 1:                                 # smooth sheet with blocks of coincident points
+            n = int(rng.integers(3000, 30000))
+            p = np.stack([rng.uniform(0, 2000, n), rng.uniform(0, 1500, n), np.zeros(n)], 1).astype(np.float32)
+            p[:, 2] = 1500 + 40 * np.sin(p[:, 0] / 300) + rng.normal(scale=2.0, size=n)
+            for _ in range(int(rng.integers(1, 6))):
+                i0, m = int(rng.integers(0, n - 400)), int(rng.integers(2, 400))
+                p[i0:i0 + m] = p[i0]
+        elif kind == 2:                                 # tight clusters far apart + a few isolated points
+            cl = [rng.normal(loc=rng.uniform(-3000, 3000, 3), scale=rng.uniform(3, 60), size=(int(rng.integers(50, 4000)), 3)) for _ in range(6)]
+            p = np.concatenate(cl + [rng.uniform(-5000, 5000, size=(20, 3))]).astype(np.float32)
+        else:                                           # tiny
+            p = rng.normal(scale=100, size=(int(rng.integers(2, 200)), 3)).astype(np.float32)
+        p = np.ascontiguousarray(p[rng.permutation(len(p))], dtype=np.float32)
+        k = int(rng.choice([33, 40, 64, 65, 100, 128, 129, 200, 288, 400, 700])) if kind != 3 else int(rng.integers(1, 300))
+        ratio = float(rng.choice([0.3, 1.0, 2.0, 3.0]))
+        gi, gs, ga = ops.sor(p, k, ratio, want_avg=True)
+        ri, rs, ra = oracle.sor(p, k, ratio)
+        assert np.array_equal(npy(gi), ri), (case, kind, len(p), k, ratio)
+        assert np.allclose(npy(ga), ra, rtol=1e-13, atol=0), (case, kind, len(p), k, ratio)
+
+
 def test_sor_duplicates_and_errors(ops, oracle):
     from kinectpy_amd._lib import KinectPxError
     rng = np.random.default_rng(3)
