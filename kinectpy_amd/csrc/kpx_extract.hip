@@ -312,146 +312,188 @@ __global__ __launch_bounds__(64) void median_select_kernel(uint32_t *__restrict_
     }
 }
 
-// ---- a4 exact median of a BATCH of frames: one block per frame, the whole 16-bit histogram in LDS (round 5) ---------------------------
+// ---- a4 exact median of a BATCH of frames: one block per frame, the frame's histogram in LDS (round 5) ---------------------------------
 // The two radix passes above read every value twice and are four launches; for a batch (one block per CU has work from 64 frames on) a
-// block can hold a frame's complete histogram instead -- 32768 bins of the non-negative values, 128 KB of the CU's 160 KB of LDS -- count
-// the frame in ONE read and pick both middle ranks itself.  Negative values (depth >= 32768 mm read as int16: not a Kinect range, but the
-// contract is np.median of any int16) are only counted; if a middle rank falls among them the block reads its frame a second time with
-// the histogram over the negative half.  Same access forms as median_hist_kernel (8 values per 16-byte load, the z channel of an int16
-// XYZ image, the fused depth path's NaN mask), runs of equal neighbours added with one atomic.
-constexpr int kMedFrameBins = 32768, kMedFrameThreads = 1024;
+// block can hold a frame's fine histogram instead, count the frame in ONE read and pick both middle ranks itself.  A depth frame is a
+// few surfaces -- in the bench's frame ten values hold two thirds of the pixels -- so a wave's LDS atomics hit few addresses and
+// serialise; the histogram therefore covers the Kinect's own range, 0 .. 8191 mm, in FOUR copies (lane & 3; 4 x 32 KB), and everything
+// else -- negative values, depths beyond 8 m: not a Kinect range, but the contract is np.median of any int16 -- is counted by its top
+// byte only (256 coarse bins).  A middle rank that falls outside the window is found by a second read of the frame with the fine
+// histogram over the 256 values of its coarse bin.  Same access forms as median_hist_kernel (8 values per 16-byte load, the z channel of
+// an int16 XYZ image, the fused depth path's NaN mask), four loads of a thread in flight, runs of equal neighbours added with one atomic.
+// (Tried: ONE copy of 32768 bins -- 135 us for 256 frames where the loads alone take ~40, against ~100 with the four copies; four (value,
+// count) register pairs per thread in front of it -- the divergent compare chains cost more than the conflicts they avoid; the zeros,
+// a fifth of a frame, counted in a register -- no change.)
+constexpr int kMedWin = 8192, kMedCopies = 4, kMedFrameThreads = 1024;
+template <class Take>
+__device__ __forceinline__ void median_frame_scan(const int16_t *__restrict__ p, int64_t n, int64_t stride, int64_t frame_stride, bool vec, const float *__restrict__ xy,
+                                                  const uint8_t *__restrict__ nanmask, Take take)
+{
+    const int tid = threadIdx.x;
+    if (vec) {
+        const int64_t groups = n >> 3;
+        for (int64_t g0 = tid; g0 < groups; g0 += 4 * kMedFrameThreads) {
+            union { uint4 q; uint16_t s[8]; } d[4];
+            unsigned m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + (int64_t)u * kMedFrameThreads;
+                const bool on = g < groups;
+                d[u].q = reinterpret_cast<const uint4 *>(p)[on ? g : g0];
+                m[u] = (xy && on) ? nanmask[g] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (g0 + (int64_t)u * kMedFrameThreads >= groups) break;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) take((m[u] & (1u << k)) ? 0u : (uint32_t)d[u].s[k]);
+            }
+        }
+    } else if (stride == 3 && (n % 8 == 0) && (frame_stride % 8 == 0)) {
+        const int64_t groups = n >> 3;
+        const int16_t *img = p - 2;                                     // frame base (x of pixel 0)
+        const bool ok = ((uintptr_t)img % 16) == 0;
+        for (int64_t g0 = tid; g0 < groups; g0 += 2 * kMedFrameThreads) {
+            if (ok) {                                                   // two groups = six 16-byte loads in flight
+                union { uint4 q[3]; uint16_t s[24]; } d[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t g = g0 + (int64_t)u * kMedFrameThreads;
+                    const uint4 *ip = reinterpret_cast<const uint4 *>(img + (g < groups ? g : g0) * 24);
+                    d[u].q[0] = ip[0]; d[u].q[1] = ip[1]; d[u].q[2] = ip[2];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (g0 + (int64_t)u * kMedFrameThreads >= groups) break;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) take(d[u].s[3 * k + 2]);
+                }
+            } else {
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t g = g0 + (int64_t)u * kMedFrameThreads;
+                    if (g >= groups) break;
+                    for (int k = 0; k < 8; ++k) take((uint32_t)(uint16_t)p[(g * 8 + k) * 3]);
+                }
+            }
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += kMedFrameThreads) {
+            uint32_t raw = (uint32_t)(uint16_t)p[i * stride];
+            if (xy && (__builtin_isnan(xy[2 * i]) || __builtin_isnan(xy[2 * i + 1]))) raw = 0;
+            take(raw);
+        }
+    }
+}
 __global__ __launch_bounds__(kMedFrameThreads) void median_frame_kernel(const int16_t *__restrict__ v, int64_t n, int64_t stride, int64_t frame_stride,
                                                                         double *__restrict__ d_median, const float *__restrict__ xy,
                                                                         const uint8_t *__restrict__ nanmask)
 {
-    extern __shared__ uint32_t fh[];                                // kMedFrameBins counts
+    extern __shared__ uint32_t fh[];                                // kMedCopies x kMedWin counts (copy-major)
+    __shared__ uint32_t coarse[256];                                // out-of-window values by the top byte of their order key (v ^ 0x8000)
     __shared__ int64_t wsum[kMedFrameThreads / 64 + 1];
-    __shared__ unsigned s_neg;
-    __shared__ int s_val[2];
+    __shared__ int s_val[2], s_bin[2];
+    __shared__ int64_t s_rank[2];
     const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int16_t *p = v + (int64_t)frame * frame_stride;
+    const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)xy % 16 == 0);
     const int64_t rank[2] = { (n - 1) / 2, n / 2 };
-    if (tid == 0) s_neg = 0u;
-    bool need_neg = false;
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && !need_neg) break;                          // block-uniform
-        for (int e = tid; e < kMedFrameBins / 4; e += kMedFrameThreads) reinterpret_cast<uint4 *>(fh)[e] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
-        // runs of equal neighbours are added with one atomic.  (A depth frame is a few surfaces -- in the bench's frame ten values hold two
-        // thirds of the pixels -- so the LDS atomics of a wave hit few addresses and serialise: ~135 us for 256 frames, where the loads
-        // alone would take ~40.  Tried: four (value, count) register pairs per thread in front of LDS -- the divergent compare chains cost
-        // more than the conflicts they avoid, 0.315 -> 0.384 ms for the whole masked extract.)
+    for (int e = tid; e < kMedCopies * kMedWin / 4; e += kMedFrameThreads) reinterpret_cast<uint4 *>(fh)[e] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 256) coarse[tid] = 0u;
+    if (tid < 2) s_bin[tid] = -1;
+    __syncthreads();
+    {
+        uint32_t *mine = fh + (size_t)(lane & (kMedCopies - 1)) * kMedWin;
         int run_bin = -1;
-        uint32_t run_cnt = 0, neg = 0;
-        auto flush = [&]() { if (run_cnt) atomicAdd(&fh[run_bin], run_cnt); };
-        auto take = [&](uint32_t raw) {
-            const int val = (int)(int16_t)(uint16_t)raw;
-            int bin;
-            if (pass == 0) { if (val < 0) { ++neg; return; } bin = val; }
-            else { if (val >= 0) return; bin = val + 32768; }
-            if (bin == run_bin) { ++run_cnt; return; }
-            flush();
-            run_bin = bin; run_cnt = 1;
-        };
-        const bool vec = stride == 1 && (n % 8 == 0) && (frame_stride % 8 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)xy % 16 == 0);
-        if (vec) {
-            // four 16-byte loads of a thread in flight together (one per trip: 45 dependent round trips per frame, ~2 us each at one
-            // block per CU)
-            const int64_t groups = n >> 3;
-            for (int64_t g0 = tid; g0 < groups; g0 += 4 * kMedFrameThreads) {
-                union { uint4 q; uint16_t s[8]; } d[4];
-                unsigned m[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t g = g0 + (int64_t)u * kMedFrameThreads;
-                    const bool on = g < groups;
-                    d[u].q = reinterpret_cast<const uint4 *>(p)[on ? g : g0];
-                    m[u] = (xy && on) ? nanmask[g] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (g0 + (int64_t)u * kMedFrameThreads >= groups) break;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) take((m[u] & (1u << k)) ? 0u : (uint32_t)d[u].s[k]);
-                }
+        uint32_t run_cnt = 0;
+        median_frame_scan(p, n, stride, frame_stride, vec, xy, nanmask, [&](uint32_t raw) {
+            const unsigned val = raw & 0xFFFFu;
+            if (val < (unsigned)kMedWin) {
+                if ((int)val == run_bin) { ++run_cnt; return; }
+                if (run_cnt) atomicAdd(&mine[run_bin], run_cnt);
+                run_bin = (int)val; run_cnt = 1;
+            } else {
+                atomicAdd(&coarse[(val ^ 0x8000u) >> 8], 1u);
             }
-        } else if (stride == 3 && (n % 8 == 0) && (frame_stride % 8 == 0)) {
-            const int64_t groups = n >> 3;
-            const int16_t *img = p - 2;                                     // frame base (x of pixel 0)
-            const bool ok = ((uintptr_t)img % 16) == 0;
-            for (int64_t g0 = tid; g0 < groups; g0 += 2 * kMedFrameThreads) {
-                if (ok) {                                                   // two groups = six 16-byte loads in flight
-                    union { uint4 q[3]; uint16_t s[24]; } d[2];
+        });
+        if (run_cnt) atomicAdd(&mine[run_bin], run_cnt);
+    }
+    __syncthreads();
+    // order: coarse bins 0 .. 127 (negative values), the window (keys 0x8000 .. 0x9FFF = coarse bins 128 .. 159, counted fine), coarse bins
+    // 160 .. 255.  Thread t owns the window's values 8 t .. 8 t + 7 (the four copies folded).
+    uint32_t c[8];
+    int64_t mine_sum = 0;
+    {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int64_t g = g0 + (int64_t)u * kMedFrameThreads;
-                        const uint4 *ip = reinterpret_cast<const uint4 *>(img + (g < groups ? g : g0) * 24);
-                        d[u].q[0] = ip[0]; d[u].q[1] = ip[1]; d[u].q[2] = ip[2];
-                    }
+        for (int q = 0; q < 8; ++q) c[q] = 0u;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (g0 + (int64_t)u * kMedFrameThreads >= groups) break;
+        for (int cp = 0; cp < kMedCopies; ++cp) {
+            const uint4 a4 = reinterpret_cast<const uint4 *>(fh + (size_t)cp * kMedWin)[2 * tid], b4 = reinterpret_cast<const uint4 *>(fh + (size_t)cp * kMedWin)[2 * tid + 1];
+            c[0] += a4.x; c[1] += a4.y; c[2] += a4.z; c[3] += a4.w; c[4] += b4.x; c[5] += b4.y; c[6] += b4.z; c[7] += b4.w;
+        }
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) take(d[u].s[3 * k + 2]);
-                    }
-                } else {
-                    for (int u = 0; u < 2; ++u) {
-                        const int64_t g = g0 + (int64_t)u * kMedFrameThreads;
-                        if (g >= groups) break;
-                        for (int k = 0; k < 8; ++k) take((uint32_t)(uint16_t)p[(g * 8 + k) * 3]);
-                    }
-                }
-            }
-        } else {
-            for (int64_t i = tid; i < n; i += kMedFrameThreads) {
-                uint32_t raw = (uint32_t)(uint16_t)p[i * stride];
-                if (xy && (__builtin_isnan(xy[2 * i]) || __builtin_isnan(xy[2 * i + 1]))) raw = 0;
-                take(raw);
+        for (int q = 0; q < 8; ++q) mine_sum += (int64_t)c[q];
+    }
+    int64_t incl = mine_sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int64_t t2 = __shfl_up(incl, o, 64); if (lane >= o) incl += t2; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t runs = 0;
+        for (int w = 0; w < kMedFrameThreads / 64; ++w) { const int64_t t2 = wsum[w]; wsum[w] = runs; runs += t2; }
+        wsum[kMedFrameThreads / 64] = runs;                                 // values inside the window
+        // the ranks that fall outside the window: which coarse bin, which rank inside it
+        int64_t below = 0;
+        for (int b = 0; b < 128; ++b) below += (int64_t)coarse[b];
+        const int64_t inwin = runs;
+        for (int w = 0; w < 2; ++w) {
+            const int64_t r = rank[w];
+            if (r < below) {
+                int64_t cum = 0;
+                for (int b = 0; b < 128; ++b) { if (r < cum + (int64_t)coarse[b]) { s_bin[w] = b; s_rank[w] = r - cum; break; } cum += (int64_t)coarse[b]; }
+            } else if (r >= below + inwin) {
+                int64_t cum = below + inwin;
+                for (int b = 160; b < 256; ++b) { if (r < cum + (int64_t)coarse[b]) { s_bin[w] = b; s_rank[w] = r - cum; break; } cum += (int64_t)coarse[b]; }
+            } else {
+                s_rank[w] = r - below;                                      // rank inside the window
             }
         }
-        flush();
-        if (pass == 0) {
+    }
+    __syncthreads();
+    const int64_t excl = wsum[wave] + incl - mine_sum;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) neg += __shfl_xor(neg, o, 64);
-            if (lane == 0 && neg) atomicAdd(&s_neg, neg);
+    for (int w = 0; w < 2; ++w) {
+        const int64_t r = s_rank[w];
+        if (s_bin[w] < 0 && r >= excl && r < excl + mine_sum) {
+            int64_t cum = excl;
+            int found = -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (found < 0 && r < cum + (int64_t)c[q]) found = 8 * tid + q;
+                cum += (int64_t)c[q];
+            }
+            s_val[w] = found;
         }
+    }
+    __syncthreads();
+    // the rare second read: a middle rank among the values the window does not hold -- the 256 values of its coarse bin, counted fine
+    for (int w = 0; w < 2; ++w) {
+        const int b = s_bin[w];                                             // block-uniform
+        if (b < 0) continue;
+        if (w == 1 && s_bin[0] == b && s_rank[0] == s_rank[1]) { if (tid == 0) s_val[1] = s_val[0]; __syncthreads(); continue; }
+        if (tid < 256) fh[tid] = 0u;
         __syncthreads();
-        const int64_t negs = (int64_t)s_neg;
-        if (pass == 0) need_neg = rank[0] < negs;                       // (rank[0] <= rank[1])
-        // thread t owns bins 32 t .. 32 t + 31; exclusive prefix of the threads' sums by wave scans
-        uint32_t c[32];
-        int64_t mine = 0;
-#pragma unroll
-        for (int q4 = 0; q4 < 8; ++q4) {
-            const uint4 t4 = reinterpret_cast<const uint4 *>(fh)[tid * 8 + q4];
-            c[4 * q4] = t4.x; c[4 * q4 + 1] = t4.y; c[4 * q4 + 2] = t4.z; c[4 * q4 + 3] = t4.w;
-            mine += (int64_t)t4.x + t4.y + t4.z + t4.w;
-        }
-        int64_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int64_t t2 = __shfl_up(incl, o, 64); if (lane >= o) incl += t2; }
-        if (lane == 63) wsum[wave] = incl;
+        median_frame_scan(p, n, stride, frame_stride, vec, xy, nanmask, [&](uint32_t raw) {
+            const unsigned key = (raw & 0xFFFFu) ^ 0x8000u;
+            if ((int)(key >> 8) == b) atomicAdd(&fh[key & 255u], 1u);
+        });
         __syncthreads();
         if (tid == 0) {
-            int64_t runs = 0;
-            for (int w = 0; w < kMedFrameThreads / 64; ++w) { const int64_t t2 = wsum[w]; wsum[w] = runs; runs += t2; }
-        }
-        __syncthreads();
-        const int64_t excl = wsum[wave] + incl - mine;
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            // the rank inside this pass's histogram: pass 0 holds the values >= 0 (ranks negs ..), pass 1 the negative ones (ranks 0 .. negs - 1)
-            const bool here = pass == 0 ? rank[w] >= negs : rank[w] < negs;
-            const int64_t r = pass == 0 ? rank[w] - negs : rank[w];
-            if (here && r >= excl && r < excl + mine) {
-                int64_t cum = excl;
-                int found = -1;
-#pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    if (found < 0 && r < cum + (int64_t)c[q]) found = 32 * tid + q;
-                    cum += (int64_t)c[q];
-                }
-                s_val[w] = pass == 0 ? found : found - 32768;
+            int64_t cum = 0;
+            const int64_t r = s_rank[w];
+            for (int q = 0; q < 256; ++q) {
+                if (r < cum + (int64_t)fh[q]) { s_val[w] = (int)(int16_t)(uint16_t)((((unsigned)b << 8) | (unsigned)q) ^ 0x8000u); break; }
+                cum += (int64_t)fh[q];
             }
         }
         __syncthreads();
@@ -485,10 +527,10 @@ static int median_impl(const int16_t *v, int64_t n, int64_t stride, int64_t fram
         if (by_frame) {
             static bool attr_set = false;
             if (!attr_set) {
-                KPX_HIP(hipFuncSetAttribute((const void *)median_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMedFrameBins * 4));
+                KPX_HIP(hipFuncSetAttribute((const void *)median_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMedCopies * kMedWin * 4));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(median_frame_kernel, dim3(frames), dim3(kMedFrameThreads), (size_t)kMedFrameBins * 4, st, v, n, stride, frame_stride, d_median,
+            hipLaunchKernelGGL(median_frame_kernel, dim3(frames), dim3(kMedFrameThreads), (size_t)kMedCopies * kMedWin * 4, st, v, n, stride, frame_stride, d_median,
                                xy, (const uint8_t *)(vec ? nanmask : nullptr));
             KPX_LAUNCH_CHECK();
             return KPX_OK;
