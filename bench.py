@@ -322,8 +322,18 @@ def roofline_targets(torch, ops, quick=False):
     cols = [torch.rand_like(c3) for _ in range(nc)]
     ms, outs = ev_timed(torch, lambda: ops.voxel_downsample_batch(clouds, 10.0, cols), reps=2, warm=1)
     m_tot = sum(int(o[0].shape[0]) for o in outs)
-    hbm(f"voxel_down_sample, {nc} x 1M points, 10 mm, colours (a7)", "voxel_*", ms, 24 * nc * c3.shape[0] + 24 * m_tot, clouds=nc, voxels=m_tot)
-    del cols
+    hbm(f"voxel_down_sample, {nc} x 1M points, 10 mm, colours (a7)", "voxel_*", ms, 24 * nc * c3.shape[0] + 24 * m_tot, clouds=nc, voxels=m_tot,
+        order="the synthetic cloud's: a random permutation (every per-voxel gather is a random 12-byte access)")
+    # the same clouds in the order a sensor delivers them -- rows (5 mm of y), ascending x inside a row: neighbours in memory are neighbours in
+    # space, as in the reference's clouds (utils/io.py: one record per pixel, row by row) -- beside the random permutation above
+    c3h = c3.cpu().numpy()
+    scan = torch.as_tensor(c3h[np.lexsort((c3h[:, 0], np.floor(c3h[:, 1] / 5.0)))]).to(dev)
+    clouds_s = [(scan + float(k)).contiguous() for k in range(nc)]
+    ms_s, outs_s = ev_timed(torch, lambda: ops.voxel_downsample_batch(clouds_s, 10.0, cols), reps=2, warm=1)
+    m_s = sum(int(o[0].shape[0]) for o in outs_s)
+    hbm(f"voxel_down_sample, {nc} x 1M points in scan order, 10 mm, colours (a7)", "voxel_*", ms_s, 24 * nc * c3.shape[0] + 24 * m_s, clouds=nc, voxels=m_s,
+        order="rows of 5 mm in y, ascending x inside a row", same_voxel_count=bool(m_s == m_tot))
+    del cols, clouds_s, outs_s, scan
     # ---- statistical-outlier removal (a8) and RANSAC plane scoring (a21): BASELINE config 3 sizes, one cloud and a >= 0.75 GB batch.
     # Neither is an HBM kernel (SURVEY 8d "Neither (LDS/VALU/latency)"): the HBM fraction of 12 N + 16 K is reported because the
     # survey asks for it, beside the roof that binds them (the wave-per-query search: LDS/VALU; plane scoring: fp64 VALU).
