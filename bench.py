@@ -530,12 +530,48 @@ def reference_stream(torch, ops, xy, depth, rgb, inits, truth, steps, gate):
     flight = (_t.perf_counter() - t0) / steps
     fs.close()
     px = S * N_PX
+    # -- the same loop with the host side of the frame inside the library (round 5): kpx_frame_step with icp_mode KPX_ICP_FIXED -- no
+    #    registration in the frame, the transforms of frame 0 -- scheduled by kpx_stream like the headline's loop
+    from kinectpy_amd.pipeline import NativeFramePipeline, NativeFrameStream, PipelineParams
+    natp = NativeFramePipeline(xy, S, Ts[1:], PipelineParams(icp_mode="fixed", filt_voxel=0.02, filt_k=200, filt_ratio=3.0, gate=gate), out_ring=2)
+    for k in range(5):
+        natp.step(depth[k % F], rgb[k % F])
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    for k in range(steps):
+        natp.step(depth[k % F], rgb[k % F])
+    torch.cuda.synchronize()
+    nat_serial = (_t.perf_counter() - t0) / steps
+    nat_out = natp.last.get("n_out")
+    a_p, a_c, _ = pipe.step(depth[0], rgb[0])               # the two legs on the same frame: the same cloud
+    b_p, b_c, _ = natp.step(depth[0], rgb[0])
+    same = bool(a_p.shape == b_p.shape and torch.equal(a_p, b_p) and torch.equal(a_c, b_c))
+    nfs = NativeFrameStream(NativeFramePipeline(xy, S, Ts[1:], natp.p), 4)
+    def nrun(n):
+        for k in range(n):
+            if nfs.full():
+                nfs.pop()
+            nfs.submit(depth[k % F], rgb[k % F])
+        while nfs.pending:
+            nfs.pop()
+    nrun(8)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    nrun(steps)
+    torch.cuda.synchronize()
+    nat_flight = (_t.perf_counter() - t0) / steps
+    nfs.close()
     return {"workload": "the reference's own frame loop (preprocessing/data.py:31-61): registration once on frame 0 (execute_global_registration + "
                         "execute_point_to_plane_registration, data.py:156-157), then per frame extract -> person mask + depth gate -> "
                         "transform + vstack -> filter_outliers() DEFAULTS (voxel 0.02, remove_statistical_outlier(200, 3.0))",
-            "value": round(px / flight / 1e6, 1), "unit": "Mpoints/s", "ms_per_frame": round(flight * 1e3, 3), "frames_in_flight": 4,
-            "one_frame_at_a_time": {"value": round(px / serial / 1e6, 1), "ms_per_frame": round(serial * 1e3, 3)}, "steps": steps,
-            "fused_points": pipe.last.get("n_fused"), "kept_points": pipe.last.get("n_out"),
+            "value": round(px / nat_flight / 1e6, 1), "unit": "Mpoints/s", "ms_per_frame": round(nat_flight * 1e3, 3), "frames_in_flight": 4,
+            "frame_loop": "native: kpx_frame_step with icp_mode KPX_ICP_FIXED (the transforms of frame 0), four frames in flight through kpx_stream",
+            "one_frame_at_a_time": {"value": round(px / nat_serial / 1e6, 1), "ms_per_frame": round(nat_serial * 1e3, 3)},
+            "through_the_python_operators": {"value": round(px / flight / 1e6, 1), "ms_per_frame": round(flight * 1e3, 3), "frames_in_flight": 4,
+                                             "one_frame_at_a_time": {"value": round(px / serial / 1e6, 1), "ms_per_frame": round(serial * 1e3, 3)},
+                                             "note": "rounds 3-4's leg: one Python call per operator, frames in flight on interpreter threads -- host-bound and noisy from box to box"},
+            "steps": steps, "fused_points": pipe.last.get("n_fused"), "kept_points": pipe.last.get("n_out"), "kept_points_native": nat_out,
+            "native_equals_python_operators_on_frame_0": same,
             "calibration": {"ms": round(calib_ms, 1), "init_of_each_sub": how, "max_abs_error_vs_truth": [round(e, 4) for e in err]}}
 
 

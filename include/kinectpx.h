@@ -246,6 +246,11 @@ int kpx_kabsch(const float *src, const float *tgt, const int32_t *corr, int64_t 
  * p iterations (one 4-byte copy + stream sync) and stops enqueuing. */
 #define KPX_ICP_POINT_TO_POINT 0
 #define KPX_ICP_POINT_TO_PLANE 1
+/* kpx_frame_params.icp_mode only (round 5): no registration inside the frame -- the reference registers on its first frame only
+ * (preprocessing/data.py:35-41: `if i == 0: ...register...`, every later frame reuses registration_transformations): h_init ARE the
+ * transforms, the frame is extract (mask + gate + colour) -> transform + vstack + voxel -> remove_statistical_outlier.  Not taken by
+ * kpx_frame_step_sharded. */
+#define KPX_ICP_FIXED 2
 size_t kpx_icp_workspace_bytes(int64_t n_src, int64_t n_tgt);
 int kpx_icp(const float *src, int64_t n_src, const float *tgt, const float *tgt_normals, int64_t n_tgt,
             double max_dist, const double *h_init, int32_t mode, int32_t max_iteration, double relative_fitness,

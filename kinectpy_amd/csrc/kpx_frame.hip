@@ -119,7 +119,10 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     KPX_REQUIRE(sensors >= 1 && sensors <= 16 && n_px > 0 && n_px < ((int64_t)1 << 31) / 16, "kpx_frame_step: 1 .. 16 sensors of at most 2^27 pixels");
     KPX_REQUIRE(depth && rgb && xy_table && prm && out_pts && out_col && h_count && h_T && ws, "kpx_frame_step: null pointer");
     KPX_REQUIRE(sensors == 1 || h_init, "kpx_frame_step: initial transforms missing");
-    KPX_REQUIRE(prm->icp_mode == KPX_ICP_POINT_TO_POINT || prm->icp_mode == KPX_ICP_POINT_TO_PLANE, "kpx_frame_step: bad icp_mode");
+    KPX_REQUIRE(prm->icp_mode == KPX_ICP_POINT_TO_POINT || prm->icp_mode == KPX_ICP_POINT_TO_PLANE || prm->icp_mode == KPX_ICP_FIXED, "kpx_frame_step: bad icp_mode");
+    // KPX_ICP_FIXED: the reference's loop after its first frame (preprocessing/data.py:35-41 registers `if i == 0`, every later frame reuses
+    // registration_transformations): no registration in the frame, h_init ARE the transforms
+    const bool fixed = prm->icp_mode == KPX_ICP_FIXED;
     KPX_REQUIRE(prm->filt_k <= KPX_SOR_LDS_K && prm->normals_nn <= KPX_NORMALS_LDS_NN, "kpx_frame_step: filt_k <= %d and normals_nn <= %d (the frame's scratch is "
                 "sized for the LDS forms; kpx_sor / kpx_estimate_normals take larger values)", KPX_SOR_LDS_K, KPX_NORMALS_LDS_NN);
     const int S = sensors;
@@ -154,7 +157,8 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     // Counts that only the HOST reads next are written by the kernels straight into the thread's pinned area (device-visible host
     // memory): every D2H copy of a few bytes is a dispatch of its own (~5 us) in front of the read-back it serves.  Counts that
     // later kernels read (the fused cloud's, the registrations' results) stay in device memory and are copied.
-    KPX_SUB(kpx_depth_to_cloud(depth, xy_table, nullptr, n_px, S, 0, prm->gate, L.full_pts, nullptr, nullptr, h_i, L.op_ws, L.op_bytes, st));
+    if (!fixed) KPX_SUB(kpx_depth_to_cloud(depth, xy_table, nullptr, n_px, S, 0, prm->gate, L.full_pts, nullptr, nullptr, h_i, L.op_ws, L.op_bytes, st));
+    else for (int i = 0; i < S; ++i) h_i[i] = 0;
     // (every operator runs on `st`: stream order alone makes the shared scratch region safe)
     KPX_SUB(kpx_depth_to_cloud(depth, xy_table, rgb, n_px, S, KPX_COMPACT_COLOR_MASK | KPX_COMPACT_DEPTH_GATE, prm->gate, L.mask_pts, L.mask_col, nullptr,
                                h_i + 16, L.op_ws, L.op_bytes, st));
@@ -179,7 +183,8 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     static thread_local int spec_bits = 0;
     static const bool speculate = [] { const char *e = getenv("KPX_FRAME_SPECULATE"); return !(e && e[0] == '0'); }();      // A/B switch
     if (!speculate) spec_bits = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int i = 0; i < S; ++i) h_i[32 + i] = 0;
+    for (int attempt = 0; attempt < 2 && !fixed; ++attempt) {
         KPX_SUB(voxel_downsample_batch_spec(S, p_in.data(), nullptr, fk.data(), prm->reg_voxel, p_out.data(), nullptr, h_i + 32, L.op_ws, L.op_bytes, st,
                                             attempt == 0 ? spec_bits : 0, h_i + 50, zorder));
         KPX_SUB(frame_wait(st));
@@ -192,7 +197,10 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     for (int i = 0; i < S; ++i) dk[(size_t)i] = h_i[32 + i];
     for (int q = 0; q < 16; ++q) h_T[q] = (q % 5 == 0) ? 1.0 : 0.0;
     if (h_info) for (int i = 0; i < S; ++i) { h_info[i] = (int32_t)dk[(size_t)i]; h_info[16 + i] = (int32_t)mk[(size_t)i]; h_info[32 + i] = 0; }
-    if (S > 1) {
+    if (fixed)
+        for (int i = 1; i < S; ++i)
+            for (int q = 0; q < 16; ++q) h_T[16 * i + q] = h_init[16 * (i - 1) + q];
+    if (S > 1 && !fixed) {
         const bool plane = prm->icp_mode == KPX_ICP_POINT_TO_PLANE;
         if (plane) KPX_SUB(kpx_estimate_normals(L.down_pts, dk[0], 2.0 * prm->reg_voxel, prm->normals_nn, L.normals, L.op_ws, L.op_bytes, st));
         std::vector<const float *> subs((size_t)S - 1);
@@ -208,7 +216,7 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
     std::vector<const double *> dT((size_t)S, nullptr);
     for (int i = 0; i < S; ++i) {
         p_in[(size_t)i] = L.mask_pts + (size_t)i * n_px * 3; c_in[(size_t)i] = L.mask_col + (size_t)i * n_px * 3;
-        if (i > 0) dT[(size_t)i] = L.icp_res + 20 * (size_t)(i - 1);
+        if (i > 0 && !fixed) dT[(size_t)i] = L.icp_res + 20 * (size_t)(i - 1);
     }
     // The fused cloud's sort-key width is speculated from this thread's previous frame, like the registration grids' above: <= 32 bits,
     // the library's own radix sort; a frame that needs more is seen at the read-back below and fused again the careful way.
@@ -226,13 +234,13 @@ KPX_EXPORT int kpx_frame_step(const uint16_t *depth, const uint8_t *rgb, const f
         if (!narrow) break;
     }
     h_i[48] = *reinterpret_cast<const int32_t *>(h_d + (size_t)S * 20);
-    for (int i = 1; i < S; ++i)                            // (a one-launch ICP chain that lost its race for residency: its results are NaN)
+    for (int i = 1; i < S && !fixed; ++i)                  // (a one-launch ICP chain that lost its race for residency: its results are NaN)
         if (h_d[20 * (i - 1) + 16] != h_d[20 * (i - 1) + 16]) {
             (void)icp_chain_abort_take();
             return fail(KPX_ERR_HIP, "kpx_frame_step: the one-launch ICP chain of sensor %d gave up waiting for its blocks to become resident; KPX_ICP_CHAIN=0 "
                                      "selects the launch-per-iteration form", i);
         }
-    for (int i = 1; i < S; ++i) {
+    for (int i = 1; i < S && !fixed; ++i) {
         for (int q = 0; q < 16; ++q) h_T[16 * i + q] = h_d[20 * (i - 1) + q];
         if (h_info) h_info[32 + i] = (int32_t)h_d[20 * (i - 1) + 18];
     }

@@ -20,6 +20,11 @@ import torch
 from . import ops, parallel
 
 
+# kpx_frame_params.icp_mode; "fixed" (round 5): no registration inside the frame -- the reference registers on its first frame only
+# (preprocessing/data.py:35-41) and every later frame reuses the transforms: the pipeline's init_transforms ARE the transforms
+ICP_MODES = {"p2p": 0, "p2plane": 1, "fixed": 2}
+
+
 @dataclass
 class PipelineParams:
     reg_voxel: float = 35.0          # preprocessing/registration.py:35,69
@@ -51,15 +56,21 @@ class SensorGroupPipeline:
         S = depth.shape[0]
         # both extractions are queued before the first count is read back; the person clouds are only needed after the
         # registration, so their counts are fetched then (no stall)
-        fp, _, _, fcnt = ops.depth_to_cloud(depth, self.xy, None, S, False, False, sync=False)                 # registration input
+        fixed = p.icp_mode == "fixed"
+        if not fixed:
+            fp, _, _, fcnt = ops.depth_to_cloud(depth, self.xy, None, S, False, False, sync=False)             # registration input
         mp, mc, _, mcnt = ops.depth_to_cloud(depth, self.xy, rgb, S, True, True, gate=p.gate, sync=False)     # person clouds
-        fk = ops._count(fcnt)
-        # -- registration: every sub onto the master, exactly execute_point_to_plane_registration
-        downs = [d[0] for d in ops.voxel_downsample_batch([fp[i, :fk[i]] for i in range(S)], p.reg_voxel)]
-        tn = ops.estimate_normals(downs[0], 2.0 * p.reg_voxel, p.normals_nn) if p.icp_mode == "p2plane" else None
         Ts = [np.eye(4)]
         stats = []
-        if S > 1:
+        downs = []
+        if fixed:                                           # data.py:44-61 after the first frame: the stored transforms
+            Ts += [np.asarray(T, dtype=np.float64) for T in self.init]
+        else:
+            fk = ops._count(fcnt)
+            # -- registration: every sub onto the master, exactly execute_point_to_plane_registration
+            downs = [d[0] for d in ops.voxel_downsample_batch([fp[i, :fk[i]] for i in range(S)], p.reg_voxel)]
+            tn = ops.estimate_normals(downs[0], 2.0 * p.reg_voxel, p.normals_nn) if p.icp_mode == "p2plane" else None
+        if S > 1 and not fixed:
             rs = ops.icp_batch(downs[1:], downs[0], p.icp_max_dist, self.init, p.icp_mode, tn, p.icp_max_iteration)
             for r in rs:
                 Ts.append(r["transformation"])
@@ -241,7 +252,7 @@ class NativeFramePipeline:
         self.xy = ops._dev(xy_table, torch.float32).reshape(-1)
         p = self.p
         self._c = ops.FrameParams(p.reg_voxel, p.icp_max_dist, p.filt_voxel, p.filt_ratio, p.gate, p.normals_nn,
-                                  {"p2p": 0, "p2plane": 1}[p.icp_mode], p.icp_max_iteration, p.filt_k)
+                                  ICP_MODES[p.icp_mode], p.icp_max_iteration, p.filt_k)
         self.last = {}
 
     def step(self, depth: torch.Tensor, rgb: torch.Tensor):
@@ -287,7 +298,7 @@ class NativeShardPipeline:
         self.xy = ops._dev(xy_table, torch.float32).reshape(-1)
         p = self.p
         self._c = ops.FrameParams(p.reg_voxel, p.icp_max_dist, p.filt_voxel, p.filt_ratio, p.gate, p.normals_nn,
-                                  {"p2p": 0, "p2plane": 1}[p.icp_mode], p.icp_max_iteration, p.filt_k)
+                                  ICP_MODES[p.icp_mode], p.icp_max_iteration, p.filt_k)
         self._ring, self._ring_n, self._ring_k = [], int(out_ring), 0
         self.order = None                 # (parallel.NativeCollectiveOrder, frame number) while a FrameStream runs this step
         self.native_order = True

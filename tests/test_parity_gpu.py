@@ -2267,6 +2267,49 @@ def test_native_frame_stream_equals_serial_steps_and_oracle(four_sensor_oracle):
     fs.close()
 
 
+def test_frame_step_with_fixed_transforms_equals_oracle(oracle, four_sensor_oracle):
+    """KPX_ICP_FIXED (PipelineParams(icp_mode="fixed")): the reference's loop after its first frame (preprocessing/data.py:35-61 registers
+    `if i == 0` and reuses the transforms): extract (mask + gate + colours) -> transform + vstack + voxel -> remove_statistical_outlier with
+    GIVEN transforms.  The native step, the same step from pinned host memory, four frames in flight through kpx_stream and the Python
+    operators all equal the oracle's pieces bit for bit, at the bench's filter (20, 2.0) and at filter_outliers' defaults (200, 3.0)."""
+    from kinectpy_amd.pipeline import NativeFramePipeline, NativeFrameStream, PipelineParams, SensorGroupPipeline
+    xy, depth, rgb, inits, truth, ref = four_sensor_oracle
+    dd, cd = torch.as_tensor(depth).cuda(), torch.as_tensor(rgb).cuda()
+    dh, ch = torch.as_tensor(depth).pin_memory(), torch.as_tensor(rgb).pin_memory()
+    Ts = [np.asarray(T, dtype=np.float64) for T in ref[0][2][1:]]               # the registered transforms of frame 0
+    for k, ratio in ((20, 2.0), (200, 3.0)):
+        P = PipelineParams(icp_mode="fixed", filt_k=k, filt_ratio=ratio)
+        want = []
+        for f in range(2):
+            clouds, cols = [], []
+            for i in range(4):
+                r = oracle.unproject_u16(depth[f][i], xy)
+                p_, c_, _ = oracle.rgbd_compact(r, rgb[f][i], True, True, oracle.median_z(r) + P.gate)
+                clouds.append(p_); cols.append(c_)
+            vp, vc = oracle.fuse_voxel_downsample(clouds, cols, [np.eye(4)] + Ts, P.filt_voxel)
+            keep = oracle.sor(vp, k, ratio)[0]
+            want.append((vp[keep], vc[keep]))
+        nat = NativeFramePipeline(xy, 4, Ts, P)
+        py = SensorGroupPipeline(xy, Ts, P)
+        for f in range(2):
+            for step, a, b in ((nat.step, dd[f], cd[f]), (nat.step, dh[f], ch[f]), (py.step, dd[f], cd[f])):
+                gp, gc, gT = step(a, b)
+                assert np.array_equal(npy(gp), want[f][0]) and np.array_equal(npy(gc), want[f][1]), (k, f)
+                assert np.array_equal(np.asarray(gT)[1:], np.stack(Ts)) and np.array_equal(np.asarray(gT)[0], np.eye(4))
+        fs = NativeFrameStream(nat, 4)
+        got = []
+        for j in range(10):
+            if fs.full():
+                got.append([npy(t) if isinstance(t, torch.Tensor) else t.copy() for t in fs.pop()])
+            fs.submit(dh[j % 2], ch[j % 2]) if j % 3 == 1 else fs.submit(dd[j % 2], cd[j % 2])
+        while fs.pending:
+            got.append([npy(t) if isinstance(t, torch.Tensor) else t.copy() for t in fs.pop()])
+        fs.close()
+        assert len(got) == 10
+        for j, (gp, gc, gT) in enumerate(got):
+            assert np.array_equal(gp, want[j % 2][0]) and np.array_equal(gc, want[j % 2][1]), (k, j)
+
+
 def test_native_frame_step_ten_sensors_equals_oracle(oracle):
     """ten sensors: nine registrations = two launch chains side by side on the library's lanes (each with its own update-in-the-
     last-block tickets and skip keys), the voxel batch in two groups (row-major clouds: the ICP batch sorts them itself)"""
