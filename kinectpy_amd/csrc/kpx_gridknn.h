@@ -311,7 +311,7 @@ struct WaveKnnResult {
 // Returns false when the query does not fit the buffer (the caller hands it to the next pass).
 template <bool POS>
 __device__ __forceinline__ bool wave_knn_select(const GridParams &g, const uint32_t *__restrict__ cell_start, const float *__restrict__ spts,
-                                                const double q[3], int k, double r2max, const WaveKnnScratch &sc, WaveKnnResult &out, int r_start = 1)
+                                                const double q[3], int k, double r2max, const WaveKnnScratch &sc, WaveKnnResult &out)
 {
     const int lane = threadIdx.x & 63;
     int c[3];
@@ -324,12 +324,7 @@ __device__ __forceinline__ bool wave_knn_select(const GridParams &g, const uint3
         const int xa = c[0] - r < 0 ? 0 : c[0] - r, xb = c[0] + r >= g.dim[0] ? g.dim[0] - 1 : c[0] + r;
         const int ya = c[1] - r < 0 ? 0 : c[1] - r, yb = c[1] + r >= g.dim[1] ? g.dim[1] - 1 : c[1] + r;
         const int za = c[2] - r < 0 ? 0 : c[2] - r, zb = c[2] + r >= g.dim[2] ? g.dim[2] - 1 : c[2] + r;
-        // Round 5: a block that spans the grid's whole z extent -- the far walks of an outlier, the points this filter exists to find: a
-        // block of radius 30 is 3721 columns, one dependent round trip per 64 of them -- is a run per x ROW (cells are numbered
-        // (x dim1 + y) dim2 + z: the columns y = ya .. yb of a row are contiguous); same candidates in the same order.
-        const int ny = yb - ya + 1;
-        const bool rows = za == 0 && zb == g.dim[2] - 1 && ny > 1;
-        const int ncols = rows ? xb - xa + 1 : (xb - xa + 1) * ny;
+        const int ny = yb - ya + 1, ncols = (xb - xa + 1) * ny;
         int m = 0;
         truncated = false;
         for (int c0 = 0; c0 < ncols && !truncated; c0 += 64) {
@@ -337,12 +332,10 @@ __device__ __forceinline__ bool wave_knn_select(const GridParams &g, const uint3
             uint32_t s0 = 0;
             int len = 0;
             if (lane < nruns) {
-                // (cell numbers fit 32 bits: the grid has at most kGridMaxCells = 2^22 cells)
-                const int ci = c0 + lane;
-                const int x = rows ? xa + ci : xa + ci / ny, y0 = rows ? ya : ya + ci % ny, y1 = rows ? yb + 1 : y0;
-                const int i_lo = (x * g.dim[1] + y0) * g.dim[2] + (rows ? 0 : za), i_hi = (x * g.dim[1] + y1) * g.dim[2] + (rows ? 0 : zb + 1);
-                s0 = cell_start[i_lo];
-                len = (int)(cell_start[i_hi] - s0);
+                const int x = xa + (c0 + lane) / ny, y = ya + (c0 + lane) % ny;
+                const int64_t col = ((int64_t)x * g.dim[1] + y) * g.dim[2];
+                s0 = cell_start[col + za];
+                len = (int)(cell_start[col + zb + 1] - s0);
             }
             const int incl = wave_incl_scan(len);
             const int mc = __shfl(incl, 63, 64);
@@ -381,16 +374,14 @@ __device__ __forceinline__ bool wave_knn_select(const GridParams &g, const uint3
     };
 
     double tau = INFINITY;
-    int r = r_start < 1 ? 1 : (r_start > maxr ? maxr : r_start);
+    int r = 1;
     for (int round = 0; round <= 24; ++round) {                // safety net: past it the query goes to the next pass
         const int m = gather_block(r, tau);
         wave_lds_fence();
         const double cov2 = block_cover2(g, q, c, r);
         const bool whole = cov2 == INFINITY || cov2 >= r2max;   // the block holds everything that may be selected
         if (!truncated && m < k && !whole) {                    // too few candidates: grow by the density seen so far
-            // (round 5: the clouds of the path are SURFACES -- the count grows with the square of the radius, and the cube root took a
-            // round more to get there; a volume is overshot by a block that is somewhat larger than needed)
-            const double f = sqrt((double)(k + 1) / (double)(m > 0 ? m : 1));
+            const double f = cbrt((double)(k + 1) / (double)(m > 0 ? m : 1));
             int rn = (int)((double)r * (f < 4.0 ? f : 4.0)) + 1;
             r = rn > r ? rn : r + 1;
             if (r > maxr) r = maxr;

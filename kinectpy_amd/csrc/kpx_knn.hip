@@ -253,8 +253,7 @@ __global__ __launch_bounds__(WAVES * 64) void sor_wave_kernel(const GridParams *
         const int64_t s = in_list ? (int64_t)in_list[e] : q0 + e;
         const double q[3] = { (double)spts[3 * s], (double)spts[3 * s + 1], (double)spts[3 * s + 2] };
         WaveKnnResult res;
-        // (in_list: what a cell / block kernel could not settle -- the 27-cell block has been tried)
-        if (!wave_knn_select<false>(g, cell_start, spts, q, k, INFINITY, sc, res, in_list ? 2 : 1)) {
+        if (!wave_knn_select<false>(g, cell_start, spts, q, k, INFINITY, sc, res)) {
             if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = (int32_t)s;
             continue;
         }
