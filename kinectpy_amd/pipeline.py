@@ -124,6 +124,8 @@ class SensorShardPipeline:
                  group=None, fused_filter: str = "sharded", cloud_capacity: int = 64 * 1024, ops_module=None, rank=None, world=None):
         self.ops = ops_module or ops
         self.p = params or PipelineParams()
+        if self.p.icp_mode == "fixed":
+            raise ValueError('icp_mode "fixed" (no registration in the frame) is a one-GPU form: SensorGroupPipeline / NativeFramePipeline')
         self.group = group
         self.world = parallel.world_size(group) if world is None else world
         self.rank = (torch.distributed.get_rank() if torch.distributed.is_initialized() else 0) if rank is None else rank
@@ -284,6 +286,8 @@ class NativeShardPipeline:
         if comm is None:
             raise ValueError("NativeShardPipeline needs a communicator (parallel.NativeComm.rccl / staged / local)")
         self.p = params or PipelineParams()
+        if self.p.icp_mode == "fixed":
+            raise ValueError('icp_mode "fixed" (no registration in the frame) is a one-GPU form: SensorGroupPipeline / NativeFramePipeline')
         self.comm = comm
         self.n_sensors = int(n_sensors)
         if comm.world > self.n_sensors:
