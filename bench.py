@@ -173,7 +173,10 @@ def quiet_kernel_roofline(torch, ops, xy, pair_depth, init, P):
     dur = ms / launches * 1e-3
     issued = flops / launches
     dense = 8.0 * n * m
-    roof = {"kernel": KERNEL_OF[kname], "bound": "latency", "achieved": round(issued / dur / 1e12, 4), "peak": peak, "unit": "TFLOP/s",
+    # "bound": the roof SURVEY 8(d) prices this kernel against (the contract's "hbm" | "mfma"); what actually limits it is in `limited_by`
+    roof = {"kernel": KERNEL_OF[kname], "bound": "mfma", "limited_by": "latency (dependent round trips: vector instructions issue in 0.12 of the dispatch's SIMD-cycles, "
+                                                                       "profiles/r05/pmc_frame_valu.csv; matrix pipe busy 0.024)",
+            "achieved": round(issued / dur / 1e12, 4), "peak": peak, "unit": "TFLOP/s",
             "frac": round(issued / dur / 1e12 / peak, 5), "mfma_dtype": "f32" if kname == "nn_screen" else "f64",
             "avg_launch_us": round(dur * 1e6, 2), "launches_timed": launches, "launches_per_registration": round(launches / reps, 1),
             "issued_flop_per_launch": round(issued), "source_points": n, "target_points": m,
